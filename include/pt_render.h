@@ -1,0 +1,283 @@
+/*
+ * pt_render.h — C-ABI drop-in boundary of the MI355X-native render() hot path.
+ *
+ * What it replaces (all citations are into the reference tree, triSYCL/path_tracer):
+ *
+ *   render<width,height,samples>(sycl::queue&, sycl::buffer<color,2>&,
+ *                                std::vector<hittable_t>&, camera&)      include/render.hpp:141-160
+ *
+ * The reference has no FFI/plugin layer; its boundary is that one C++ function
+ * template plus a hidden third input, the process-global image-texture atlas
+ * (include/texture.hpp:71,126-131,157).  This header states the same boundary as a
+ * plain C ABI (pointers + sizes, no C++/torch types) so any host — the C++20
+ * facade in path_tracer_amd/include/pt/, the Python ctypes mirror in
+ * path_tracer_amd/, or the reference's own main.cpp with a one-line include swap —
+ * can bind it.
+ *
+ * The scene crosses the boundary as three small tables (hittables, materials,
+ * textures) + the RGB8 atlas; tags keep the reference's std::variant index order
+ * (render.hpp:22-23, material.hpp:133-135, texture.hpp:154, rectangle.hpp:130,
+ * constant_medium.hpp:10) so dumps are debuggable against the reference.
+ * pt_scene_create() flattens those tables into per-kind 16-byte-aligned record
+ * arrays + an order-preserving run table in HBM (see DESIGN.md "Data layout").
+ *
+ * All floating point is IEEE binary32, no contraction; RNG is xorshift32
+ * (include/xorshift.hpp:72-74) seeded with the pixel's linear id (render.hpp:130-132).
+ */
+#ifndef PT_RENDER_H
+#define PT_RENDER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PT_ABI_VERSION 1
+
+/* ---- tags: same numbering as the reference's variant alternatives ---------- */
+
+/* hittable_t = variant<sphere, xy_rect, triangle, box, constant_medium>  render.hpp:22-23 */
+enum {
+  PT_HIT_SPHERE = 0,          /* sphere.hpp:26-117 (static + moving)             */
+  PT_HIT_XY_RECT = 1,         /* rectangle.hpp:16-52                              */
+  PT_HIT_TRIANGLE = 2,        /* triangle.hpp:58-122 (Moller-Trumbore strategy)   */
+  PT_HIT_BOX = 3,             /* box.hpp:10-56                                    */
+  PT_HIT_CONSTANT_MEDIUM = 4, /* constant_medium.hpp:16-83                        */
+  /* Extension: classes exist (rectangle.hpp:54,92) but are not hittable_t
+   * alternatives in the reference; offered as top-level hittables here.        */
+  PT_HIT_XZ_RECT = 5,
+  PT_HIT_YZ_RECT = 6,
+  PT_HIT_KIND_COUNT = 7
+};
+
+/* material_t = variant<lambertian, metal, dielectric, lightsource, isotropic>  material.hpp:133-135 */
+enum {
+  PT_MAT_LAMBERTIAN = 0,
+  PT_MAT_METAL = 1,
+  PT_MAT_DIELECTRIC = 2,
+  PT_MAT_LIGHTSOURCE = 3,
+  PT_MAT_ISOTROPIC = 4
+};
+
+/* texture_t = variant<checker_texture, solid_texture, image_texture>  texture.hpp:154 */
+enum { PT_TEX_CHECKER = 0, PT_TEX_SOLID = 1, PT_TEX_IMAGE = 2 };
+
+/* ---- scene description tables (host memory, caller-owned, read-only) ------- */
+
+/* One hittable, 64 bytes.  f[] by kind:
+ *  SPHERE           f[0..2]=center0 f[3..5]=center1 f[6]=radius f[7]=time0 f[8]=time1
+ *                   (static sphere: center1=center0, time0=time1=0  sphere.hpp:30-36)
+ *  XY_RECT          f[0]=x0 f[1]=x1 f[2]=y0 f[3]=y1 f[4]=k          rectangle.hpp:21
+ *  XZ_RECT          f[0]=x0 f[1]=x1 f[2]=z0 f[3]=z1 f[4]=k          rectangle.hpp:59
+ *  YZ_RECT          f[0]=y0 f[1]=y1 f[2]=z0 f[3]=z1 f[4]=k          rectangle.hpp:97
+ *  TRIANGLE         f[0..2]=v0 f[3..5]=v1 f[6..8]=v2                triangle.hpp:107
+ *  BOX              f[0..2]=p0 (min) f[3..5]=p1 (max)               box.hpp:15
+ *  CONSTANT_MEDIUM  f[0..8]=boundary in SPHERE or BOX layout (boundary_kind),
+ *                   f[9]=neg_inv_density (= -1/d, constant_medium.hpp:20);
+ *                   material = the isotropic phase function         constant_medium.hpp:21
+ */
+typedef struct PtHittable {
+  int32_t kind;
+  int32_t material;      /* index into PtSceneDesc.materials */
+  int32_t boundary_kind; /* CONSTANT_MEDIUM only: PT_HIT_SPHERE or PT_HIT_BOX */
+  int32_t reserved;
+  float f[12];
+} PtHittable;
+
+/* One material, 32 bytes.
+ *  LAMBERTIAN   texture = albedo                              material.hpp:11-31
+ *  METAL        color = albedo, param = fuzz (already clamped to [0,1], material.hpp:37)
+ *  DIELECTRIC   color = albedo, param = ref_idx               material.hpp:55-95
+ *  LIGHTSOURCE  texture = emit                                material.hpp:97-111
+ *  ISOTROPIC    texture = albedo                              material.hpp:113-131
+ */
+typedef struct PtMaterial {
+  int32_t kind;
+  int32_t texture; /* index into PtSceneDesc.textures, or -1 */
+  float color[3];
+  float param;
+  int32_t reserved[2];
+} PtMaterial;
+
+/* One texture, 48 bytes.
+ *  SOLID    color0                                            texture.hpp:18-29
+ *  CHECKER  color0 = odd (sines < 0), color1 = even           texture.hpp:32-52
+ *  IMAGE    width,height,offset (in texels into the atlas),freq  texture.hpp:67-152
+ */
+typedef struct PtTexture {
+  int32_t kind;
+  float color0[3];
+  float color1[3];
+  uint32_t width, height;
+  uint32_t offset;
+  float freq;
+  int32_t reserved;
+} PtTexture;
+
+typedef struct PtSceneDesc {
+  const PtHittable* hittables; /* list order == traversal order (render.hpp:37) */
+  int32_t n_hittables;
+  const PtMaterial* materials;
+  int32_t n_materials;
+  const PtTexture* textures;
+  int32_t n_textures;
+  int32_t reserved;
+  /* RGB8 atlas, rows top-down; texel 0 is the {0,0,1} load-failure fallback
+   * (texture.hpp:157).  May be NULL/0 when no image texture is used.          */
+  const uint8_t* atlas;
+  uint64_t atlas_bytes;
+} PtSceneDesc;
+
+/* camera, 96 bytes: the private fields of camera.hpp:23-51 in declaration order.
+ * pt_camera_init() is the 9-argument constructor camera.hpp:67-87.             */
+typedef struct PtCamera {
+  float origin[3];
+  float lower_left_corner[3];
+  float horizontal[3];
+  float vertical[3];
+  float u[3], v[3], w[3];
+  float lens_radius;
+  float time0, time1;
+} PtCamera;
+
+/* Pixels are grouped into 8x8 tiles (one 64-lane wavefront per tile).  Tile g =
+ * ty*tiles_x + tx belongs to shard g % shard_count, local index g / shard_count. */
+#define PT_TILE 8
+#define PT_TILE_PIXELS 64
+
+enum {
+  PT_FLAG_NONE = 0,
+  PT_FLAG_NO_LDS = 1u << 0, /* A/B switch: fetch primitives with scalar loads instead of LDS */
+};
+
+typedef struct PtRenderParams {
+  int32_t width, height; /* template args of render<> (render.hpp:141)           */
+  int32_t samples;       /* spp, template arg                                    */
+  int32_t depth;         /* 50 in the reference (render.hpp:144)                 */
+  int32_t shard_index;   /* this GPU's shard, 0 <= shard_index < shard_count     */
+  int32_t shard_count;   /* 1 = whole frame                                      */
+  uint32_t flags;
+  int32_t reserved;
+} PtRenderParams;
+
+typedef struct PtScene PtScene; /* opaque: device-resident flattened scene */
+
+/* ---- error codes (the reference returns void and asserts; we return codes) -- */
+enum {
+  PT_OK = 0,
+  PT_ERR_INVALID_ARG = 1,
+  PT_ERR_BAD_SCENE = 2,   /* tag / index out of range in the tables */
+  PT_ERR_HIP = 3,         /* a HIP runtime call failed; see pt_last_error() */
+  PT_ERR_NO_DEVICE = 4,
+  PT_ERR_TOO_LARGE = 5
+};
+
+int pt_abi_version(void);
+const char* pt_error_string(int code);
+const char* pt_last_error(void); /* thread-local detail of the last failure */
+
+/* camera(look_from, look_at, vup, vfov_deg, aspect, aperture, focus_dist, t0, t1)
+ * camera.hpp:67-87.  Host-side arithmetic only.                                 */
+int pt_camera_init(PtCamera* cam, const float look_from[3], const float look_at[3],
+                   const float vup[3], float vfov_deg, float aspect_ratio,
+                   float aperture, float focus_dist, float time0, float time1);
+
+/* Validate + flatten + upload to the current HIP device.  Replaces the
+ * sycl::buffer wrapping of hittables and image_texture::freeze()
+ * (render.hpp:146-148).  Unlike freeze() it may be called any number of times. */
+int pt_scene_create(const PtSceneDesc* desc, PtScene** out_scene);
+void pt_scene_destroy(PtScene* scene);
+
+/* Number of floats the caller must provide to pt_render for these params:
+ * shard_count==1: height*width*3 laid out [y][x][rgb], y=0 = bottom scan-line
+ * (render.hpp:105, main.cpp:41).  shard_count>1: pt_shard_tiles()*64*3 laid
+ * out [local_tile][ly*8+lx][rgb].                                              */
+int64_t pt_framebuffer_floats(const PtRenderParams* p);
+int32_t pt_shard_tiles(const PtRenderParams* p); /* ceil(n_tiles / shard_count) */
+
+/* The hot path.  Asynchronous on `stream` (a hipStream_t, or NULL for the
+ * default stream) like queue.submit (render.hpp:151); fb_device is device
+ * memory, fully overwritten (discard_write, render.hpp:152).                    */
+int pt_render(const PtScene* scene, const PtCamera* cam, const PtRenderParams* p,
+              float* fb_device, void* stream);
+
+/* Same, timed: brackets the kernel launch with HIP events recorded on `stream`
+ * and returns the kernel's duration (blocks until done).                        */
+int pt_render_timed(const PtScene* scene, const PtCamera* cam, const PtRenderParams* p,
+                    float* fb_device, void* stream, float* kernel_ms);
+
+/* Convenience: render into host memory (allocates, renders, copies back, syncs). */
+int pt_render_host(const PtScene* scene, const PtCamera* cam, const PtRenderParams* p,
+                   float* fb_host);
+
+/* Root-side un-interleave after the RCCL gather: gathered is
+ * [shard_count][pt_shard_tiles][64][3] device floats -> fb [height][width][3].  */
+int pt_unshard_tiles(const float* gathered_device, const PtRenderParams* p,
+                     float* fb_device, void* stream);
+
+/* Output stage of main.cpp:33-59: sqrt gamma, clamp [0,0.999], *256 -> u8,
+ * vertical flip; rgb8_device is [height][width][3], row 0 = top.               */
+int pt_tonemap_rgb8(const float* fb_device, int32_t width, int32_t height,
+                    uint8_t* rgb8_device, void* stream);
+
+/* ---- function-level probes (parity tests call these; not used by render) ---- */
+
+/* One iteration of the bounce loop render.hpp:58-89 per record: hit_world,
+ * emitted, scatter (or sky).  n records in, n out; host pointers.              */
+typedef struct PtBounceIn {
+  float origin[3];
+  float dir[3];
+  float time;
+  uint32_t rng_state;
+  float attenuation[3];
+} PtBounceIn;
+
+enum { PT_BOUNCE_MISS = 0, PT_BOUNCE_SCATTERED = 1, PT_BOUNCE_ABSORBED = 2 };
+
+typedef struct PtBounceOut {
+  int32_t status;     /* PT_BOUNCE_* */
+  int32_t hittable;   /* index of the nearest hittable, -1 on miss */
+  int32_t material;   /* material index of the hit, -1 on miss */
+  int32_t front_face;
+  float t;
+  float p[3];
+  float normal[3];
+  float u, v;         /* 0 unless the scene has an image texture */
+  float color[3];     /* MISS: attenuation*sky; ABSORBED: emitted; SCATTERED: new attenuation */
+  float sc_origin[3]; /* scattered ray (SCATTERED only) */
+  float sc_dir[3];
+  float sc_time;
+  uint32_t rng_state; /* generator state after the bounce */
+} PtBounceOut;
+
+int pt_debug_bounce(const PtScene* scene, const PtBounceIn* in, PtBounceOut* out, int32_t n);
+
+/* First camera ray of a pixel: render.hpp:96-99 + camera.hpp:93-100.
+ * rng_state in/out; ray out.                                                   */
+typedef struct PtCameraRay {
+  float origin[3];
+  float dir[3];
+  float time;
+  uint32_t rng_state;
+} PtCameraRay;
+int pt_debug_camera_rays(const PtCamera* cam, int32_t width, int32_t height,
+                         const int32_t* xy /*[n][2]*/, const uint32_t* rng_in,
+                         PtCameraRay* out, int32_t n);
+
+/* Host-only view of what pt_scene_create() uploads (no GPU needed): the flattened blob
+ * ([n_runs run headers (device kind, first record offset, count, first hittable)] then the
+ * per-kind 16-byte records) and the material table (4 x 16 bytes each, texture inlined).
+ * Pass NULL buffers to query the sizes.  flags_out: bit0 = has image texture, bit1 = has medium. */
+int pt_debug_flatten(const PtSceneDesc* desc, float* blob_out, int64_t blob_cap_f4, int32_t* n_blob_f4,
+                     int32_t* n_runs, float* mats_out, int64_t mats_cap_f4, int32_t* flags_out);
+
+/* Device math used by the kernel, elementwise over host arrays.
+ * op: 0 sin 1 cos 2 log 3 pow5 4 atan2(a,b) 5 asin 6 fmod(a,b) 7 sqrt 8 div(a,b) */
+int pt_debug_math(int32_t op, const float* a, const float* b, float* out, int64_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PT_RENDER_H */

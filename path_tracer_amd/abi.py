@@ -1,0 +1,160 @@
+"""ctypes mirror of include/pt_render.h — the C-ABI drop-in boundary of render().
+
+The structs are declared field-for-field as in the header; `load_library()` opens the
+in-tree `libpt_render.so` built by `__graft_entry__.build()` (hipcc, gfx950) and fails
+loudly when it is missing: there is no CPU fallback in the product path.
+
+Reference boundary being replaced: `render<W,H,S>(queue, frame_buf, hittables, cam)`
+(/root/reference include/render.hpp:141-160).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+PT_ABI_VERSION = 1
+
+# tags — same numbering as the reference's std::variant alternatives
+PT_HIT_SPHERE, PT_HIT_XY_RECT, PT_HIT_TRIANGLE, PT_HIT_BOX, PT_HIT_CONSTANT_MEDIUM = 0, 1, 2, 3, 4
+PT_HIT_XZ_RECT, PT_HIT_YZ_RECT = 5, 6  # extension (rectangle.hpp:54,92 exist but are not hittable_t members)
+PT_HIT_KIND_COUNT = 7
+PT_MAT_LAMBERTIAN, PT_MAT_METAL, PT_MAT_DIELECTRIC, PT_MAT_LIGHTSOURCE, PT_MAT_ISOTROPIC = 0, 1, 2, 3, 4
+PT_TEX_CHECKER, PT_TEX_SOLID, PT_TEX_IMAGE = 0, 1, 2
+
+PT_TILE = 8
+PT_TILE_PIXELS = 64
+PT_FLAG_NONE = 0
+PT_FLAG_NO_LDS = 1
+
+PT_OK, PT_ERR_INVALID_ARG, PT_ERR_BAD_SCENE, PT_ERR_HIP, PT_ERR_NO_DEVICE, PT_ERR_TOO_LARGE = range(6)
+PT_BOUNCE_MISS, PT_BOUNCE_SCATTERED, PT_BOUNCE_ABSORBED = 0, 1, 2
+
+
+class PtHittable(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("material", C.c_int32), ("boundary_kind", C.c_int32),
+                ("reserved", C.c_int32), ("f", C.c_float * 12)]
+
+
+class PtMaterial(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("texture", C.c_int32), ("color", C.c_float * 3),
+                ("param", C.c_float), ("reserved", C.c_int32 * 2)]
+
+
+class PtTexture(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("color0", C.c_float * 3), ("color1", C.c_float * 3),
+                ("width", C.c_uint32), ("height", C.c_uint32), ("offset", C.c_uint32),
+                ("freq", C.c_float), ("reserved", C.c_int32)]
+
+
+class PtSceneDesc(C.Structure):
+    _fields_ = [("hittables", C.POINTER(PtHittable)), ("n_hittables", C.c_int32),
+                ("materials", C.POINTER(PtMaterial)), ("n_materials", C.c_int32),
+                ("textures", C.POINTER(PtTexture)), ("n_textures", C.c_int32),
+                ("reserved", C.c_int32),
+                ("atlas", C.POINTER(C.c_uint8)), ("atlas_bytes", C.c_uint64)]
+
+
+class PtCamera(C.Structure):
+    _fields_ = [("origin", C.c_float * 3), ("lower_left_corner", C.c_float * 3),
+                ("horizontal", C.c_float * 3), ("vertical", C.c_float * 3),
+                ("u", C.c_float * 3), ("v", C.c_float * 3), ("w", C.c_float * 3),
+                ("lens_radius", C.c_float), ("time0", C.c_float), ("time1", C.c_float)]
+
+
+class PtRenderParams(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("samples", C.c_int32), ("depth", C.c_int32),
+                ("shard_index", C.c_int32), ("shard_count", C.c_int32), ("flags", C.c_uint32),
+                ("reserved", C.c_int32)]
+
+
+class PtBounceIn(C.Structure):
+    _fields_ = [("origin", C.c_float * 3), ("dir", C.c_float * 3), ("time", C.c_float),
+                ("rng_state", C.c_uint32), ("attenuation", C.c_float * 3)]
+
+
+class PtBounceOut(C.Structure):
+    _fields_ = [("status", C.c_int32), ("hittable", C.c_int32), ("material", C.c_int32), ("front_face", C.c_int32),
+                ("t", C.c_float), ("p", C.c_float * 3), ("normal", C.c_float * 3), ("u", C.c_float), ("v", C.c_float),
+                ("color", C.c_float * 3), ("sc_origin", C.c_float * 3), ("sc_dir", C.c_float * 3),
+                ("sc_time", C.c_float), ("rng_state", C.c_uint32)]
+
+
+class PtCameraRay(C.Structure):
+    _fields_ = [("origin", C.c_float * 3), ("dir", C.c_float * 3), ("time", C.c_float), ("rng_state", C.c_uint32)]
+
+
+assert C.sizeof(PtHittable) == 64 and C.sizeof(PtMaterial) == 32 and C.sizeof(PtTexture) == 48
+assert C.sizeof(PtCamera) == 96 and C.sizeof(PtRenderParams) == 32
+
+_FP = C.POINTER(C.c_float)
+_SCENE_P = C.c_void_p
+
+# name -> (restype, argtypes): every entry point include/pt_render.h declares
+SIGNATURES = {
+    "pt_abi_version": (C.c_int, []),
+    "pt_error_string": (C.c_char_p, [C.c_int]),
+    "pt_last_error": (C.c_char_p, []),
+    "pt_camera_init": (C.c_int, [C.POINTER(PtCamera), _FP, _FP, _FP, C.c_float, C.c_float, C.c_float, C.c_float,
+                                 C.c_float, C.c_float]),
+    "pt_scene_create": (C.c_int, [C.POINTER(PtSceneDesc), C.POINTER(_SCENE_P)]),
+    "pt_scene_destroy": (None, [_SCENE_P]),
+    "pt_framebuffer_floats": (C.c_int64, [C.POINTER(PtRenderParams)]),
+    "pt_shard_tiles": (C.c_int32, [C.POINTER(PtRenderParams)]),
+    "pt_render": (C.c_int, [_SCENE_P, C.POINTER(PtCamera), C.POINTER(PtRenderParams), C.c_void_p, C.c_void_p]),
+    "pt_render_timed": (C.c_int, [_SCENE_P, C.POINTER(PtCamera), C.POINTER(PtRenderParams), C.c_void_p, C.c_void_p,
+                                  C.POINTER(C.c_float)]),
+    "pt_render_host": (C.c_int, [_SCENE_P, C.POINTER(PtCamera), C.POINTER(PtRenderParams), _FP]),
+    "pt_unshard_tiles": (C.c_int, [C.c_void_p, C.POINTER(PtRenderParams), C.c_void_p, C.c_void_p]),
+    "pt_tonemap_rgb8": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "pt_debug_bounce": (C.c_int, [_SCENE_P, C.POINTER(PtBounceIn), C.POINTER(PtBounceOut), C.c_int32]),
+    "pt_debug_camera_rays": (C.c_int, [C.POINTER(PtCamera), C.c_int32, C.c_int32, C.POINTER(C.c_int32),
+                                       C.POINTER(C.c_uint32), C.POINTER(PtCameraRay), C.c_int32]),
+    "pt_debug_flatten": (C.c_int, [C.POINTER(PtSceneDesc), _FP, C.c_int64, C.POINTER(C.c_int32),
+                                   C.POINTER(C.c_int32), _FP, C.c_int64, C.POINTER(C.c_int32)]),
+    "pt_debug_math": (C.c_int, [C.c_int32, _FP, _FP, _FP, C.c_int64]),
+}
+
+LIB_NAME = "libpt_render.so"
+_lib = None
+
+
+class PtError(RuntimeError):
+    """A pt_* entry point returned a non-zero code (the reference's `void` + asserts, made explicit)."""
+
+    def __init__(self, code: int, where: str, detail: str = ""):
+        self.code = code
+        super().__init__(f"{where}: error {code}" + (f" ({detail})" if detail else ""))
+
+
+def library_path() -> Path:
+    override = os.environ.get("PT_RENDER_LIB")
+    return Path(override) if override else Path(__file__).resolve().parent / LIB_NAME
+
+
+def load_library() -> C.CDLL:
+    """Open the HIP extension.  Fails loudly: the product has no CPU path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not path.exists():
+        raise ImportError(
+            f"{path} is missing: the gfx950 HIP extension has not been built. "
+            "Run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc cross-compiles without a GPU).")
+    lib = C.CDLL(str(path))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export what the header declares
+        fn.restype = res
+        fn.argtypes = args
+    if lib.pt_abi_version() != PT_ABI_VERSION:
+        raise ImportError(f"{path}: ABI version {lib.pt_abi_version()} != {PT_ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(code: int, where: str) -> None:
+    if code != PT_OK:
+        lib = load_library()
+        detail = lib.pt_last_error().decode() or lib.pt_error_string(code).decode()
+        raise PtError(code, where, detail)

@@ -1,0 +1,481 @@
+// pt_device.hpp — device functions of the render() hot path for gfx950 (CDNA4).
+//
+// What is computed follows the reference line by line (citations below are into
+// /root/reference/include); how it is computed does not:
+//
+//  * the std::variant<hittable> list (render.hpp:22-23, 624 B per element) is a
+//    flattened blob of 16-byte records grouped in order-preserving RUNS of one
+//    kind; the blob lives in LDS (or is fetched with scalar loads), the primitive
+//    index is wave-uniform, so every primitive fetch is an LDS broadcast / SGPR
+//    operand and every kind dispatch is a scalar branch (visit.hpp:51-67 becomes
+//    s_cbranch);
+//  * the traversal keeps only (closest t, hit id [, u, v]) per lane; hit_record
+//    (hitable.hpp:8-24) is materialised once per ray for the final nearest hit —
+//    a pure function of (ray, primitive, t), so deferring it cannot change a bit;
+//  * uniform sub-expressions are hoisted or precomputed at flatten time
+//    (dot(d,d), radius^2, triangle edges) — same IEEE operations on the same
+//    operands, so same bits.
+//
+// Compiled with -ffp-contract=off: no fused multiply-add except the explicit
+// sycl::fma of vec.hpp:12.  Division and sqrt are the correctly rounded forms.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pt_math.hpp"
+
+namespace ptd {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef int i4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(3))) f4* lds_f4p; // LDS-resident blob
+typedef const __attribute__((address_space(4))) f4* cst_f4p; // global blob via scalar (SMEM) loads
+
+// device kinds of a run / hit id (not the ABI tags: the three rect axes share one kind)
+enum { DK_SPHERE = 0, DK_RECT = 1, DK_TRI = 2, DK_BOX = 3, DK_MEDIUM = 4 };
+
+// record sizes in f4 units
+enum { SZ_SPHERE = 3, SZ_RECT = 2, SZ_TRI = 3, SZ_BOX = 2, SZ_MEDIUM = 4, SZ_MATERIAL = 4 };
+
+// hit id: [23:0] record offset in the blob (f4 units), [26:24] box side, [29:27] device kind; -1 = none
+__device__ __forceinline__ int hit_pack(int kind, int side, int off) { return (kind << 27) | (side << 24) | off; }
+__device__ __forceinline__ int hit_kind(int h) { return (h >> 27) & 7; }
+__device__ __forceinline__ int hit_side(int h) { return (h >> 24) & 7; }
+__device__ __forceinline__ int hit_off(int h) { return h & 0xffffff; }
+
+__device__ __forceinline__ float as_f(int i) { return __int_as_float(i); }
+__device__ __forceinline__ int as_i(float f) { return __float_as_int(f); }
+
+#define PT_INF (__builtin_inff())
+#define PT_PI 3.1415926535897932385f /* rtweekend.hpp:22 */
+#define PT_TMIN 0.001f               /* render.hpp:40 */
+
+struct V3 {
+  float x, y, z;
+};
+__device__ __forceinline__ V3 mk(float x, float y, float z) { return V3{x, y, z}; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ V3 operator*(float s, V3 a) { return mk(s * a.x, s * a.y, s * a.z); }
+__device__ __forceinline__ V3 operator/(V3 a, float s) { return mk(a.x / s, a.y / s, a.z / s); }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) {
+  return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ V3 xyz(f4 v) { return mk(v.x, v.y, v.z); }
+// vec.hpp:11-13 (explicit fma)
+__device__ __forceinline__ float length_squared(V3 v) {
+  return __builtin_fmaf(v.x, v.x, __builtin_fmaf(v.y, v.y, v.z * v.z));
+}
+__device__ __forceinline__ float sqrt_rn(float x) { return __fsqrt_rn(x); }
+
+struct Ray {
+  V3 o, d;
+  float tm;
+};
+
+// ---- RNG: xorshift.hpp:72-74 + rtweekend.hpp:39-88 -------------------------------------
+__device__ __forceinline__ float rng_float(uint32_t& s) {
+  s ^= s >> 7;
+  s ^= s << 1;
+  s ^= s >> 9;
+  return (float)s * 2.3283064365386963e-10f; // v_cvt_f32_u32 (RNE) * 2^-32
+}
+__device__ __forceinline__ float rng_float(uint32_t& s, float mn, float mx) { return mn + (mx - mn) * rng_float(s); }
+
+__device__ __forceinline__ V3 rng_unit_vec(uint32_t& s) {
+  float x = rng_float(s, -1.0f, 1.0f);
+  float maxy = sqrt_rn(1.0f - x * x);
+  float y = rng_float(s, -maxy, maxy);
+  float absz = sqrt_rn(maxy * maxy - y * y);
+  float z = (rng_float(s) > 0.5f) ? absz : -absz;
+  return mk(x, y, z);
+}
+__device__ __forceinline__ V3 rng_in_unit_ball(uint32_t& s) {
+  float r = rng_float(s);
+  float theta = rng_float(s, 0.0f, 2.0f * PT_PI);
+  float phi = rng_float(s, 0.0f, PT_PI);
+  float plan_seed = r * ptm::sinf_(phi);
+  float z = r * ptm::cosf_(phi);
+  return mk(plan_seed * ptm::cosf_(theta), plan_seed * ptm::sinf_(theta), z);
+}
+
+// ---- camera: render.hpp:96-99 + camera.hpp:93-100 ----------------------------------------
+struct Cam { // PtCamera, passed by value in the kernarg segment (SGPRs)
+  float origin[3], llc[3], horizontal[3], vertical[3], u[3], v[3], w[3];
+  float lens_radius, time0, time1;
+};
+
+__device__ __forceinline__ Ray camera_ray(const Cam& c, int x, int y, int width, int height, uint32_t& rng) {
+  const float su = ((float)x + rng_float(rng)) / (float)width;
+  const float sv = ((float)y + rng_float(rng)) / (float)height;
+  // in_unit_disk rtweekend.hpp:83-88
+  float dx = rng_float(rng, -1.0f, 1.0f);
+  float maxy = sqrt_rn(1.0f - dx * dx);
+  float dy = rng_float(rng, -maxy, maxy);
+  V3 rd = c.lens_radius * mk(dx, dy, 0.0f);
+  V3 U = mk(c.u[0], c.u[1], c.u[2]), Vv = mk(c.v[0], c.v[1], c.v[2]);
+  V3 offset = rd.x * U + rd.y * Vv;
+  V3 origin = mk(c.origin[0], c.origin[1], c.origin[2]);
+  Ray r;
+  r.o = origin + offset;
+  r.d = mk(c.llc[0], c.llc[1], c.llc[2]) + su * mk(c.horizontal[0], c.horizontal[1], c.horizontal[2]) +
+        sv * mk(c.vertical[0], c.vertical[1], c.vertical[2]) - origin - offset;
+  r.tm = rng_float(rng, c.time0, c.time1);
+  return r;
+}
+
+// ---- sphere.hpp -----------------------------------------------------------------------------
+// record: R0 = (c0.xyz, radius^2)  R1 = (radius, mat, time0, time1)  R2 = (c1.xyz, hittable index)
+
+// sphere.hpp:51-56
+__device__ __forceinline__ V3 sphere_center(f4 R0, f4 R1, f4 R2, float time) {
+  V3 c0 = xyz(R0);
+  if (R1.z == R1.w) return c0; // wave-uniform
+  return c0 + ((time - R1.z) / (R1.w - R1.z)) * (xyz(R2) - c0);
+}
+
+// sphere.hpp:13-24
+__device__ __forceinline__ void mercator(V3 p, float& u, float& v) {
+  float phi = ptm::atan2f_(p.z, p.x);
+  float theta = ptm::asinf_(p.y);
+  u = 1.0f - (phi + PT_PI) / (2.0f * PT_PI);
+  v = (theta + PT_PI / 2.0f) / PT_PI;
+}
+
+// Roots of sphere.hpp:68-93; returns true and t if one lies in (mn, mx).  a = dot(d,d) hoisted.
+template <typename P>
+__device__ __forceinline__ bool sphere_t(P blob, int off, const Ray& r, float a, float mn, float mx, float& t) {
+  f4 R0 = blob[off];
+  V3 center = xyz(R0);
+  f4 R1 = blob[off + 1];
+  if (R1.z != R1.w) center = sphere_center(R0, R1, blob[off + 2], r.tm);
+  V3 oc = r.o - center;
+  float b = dot(oc, r.d);
+  float c = dot(oc, oc) - R0.w;
+  float discriminant = b * b - a * c;
+  if (discriminant > 0) {
+    float sq = sqrt_rn(discriminant);
+    float temp = (-b - sq) / a;
+    if (temp < mx && temp > mn) { t = temp; return true; }
+    temp = (-b + sq) / a;
+    if (temp < mx && temp > mn) { t = temp; return true; }
+  }
+  return false;
+}
+
+// ---- rectangle.hpp:31-49,69-87,107-125 --------------------------------------------------------
+// record: R0 = (a0, a1, b0, b1)  R1 = (k, mat, axis, hittable index); axis 0 xy, 1 xz, 2 yz
+__device__ __forceinline__ bool rect_t(int axis, float a0, float a1, float b0, float b1, float k, const Ray& r,
+                                       float mn, float mx, float& t_out, float& a_out, float& b_out) {
+  float ok, dk, oa, da, ob, db;
+  if (axis == 0)      { ok = r.o.z; dk = r.d.z; oa = r.o.x; da = r.d.x; ob = r.o.y; db = r.d.y; }
+  else if (axis == 1) { ok = r.o.y; dk = r.d.y; oa = r.o.x; da = r.d.x; ob = r.o.z; db = r.d.z; }
+  else                { ok = r.o.x; dk = r.d.x; oa = r.o.y; da = r.d.y; ob = r.o.z; db = r.d.z; }
+  float t = (k - ok) / dk;
+  if (t < mn || t > mx) return false;
+  float a = oa + t * da;
+  float b = ob + t * db;
+  if (a < a0 || a > a1 || b < b0 || b > b1) return false;
+  t_out = t; a_out = a; b_out = b;
+  return true;
+}
+
+// ---- box.hpp:29-50: nearest of the six sides in constructor order (box.hpp:20-25) ---------------
+// record: R0 = (x0,y0,z0, mat)  R1 = (x1,y1,z1, hittable index)
+template <bool UV>
+__device__ __forceinline__ bool box_t(f4 R0, f4 R1, const Ray& r, float mn, float mx, float& t_out, int& side_out,
+                                      float& u_out, float& v_out) {
+  bool hit = false;
+  float closest = mx;
+  float t, a, b;
+#define PT_BOX_SIDE(S, AX, A0, A1, B0, B1, K)                          \
+  if (rect_t(AX, A0, A1, B0, B1, K, r, mn, closest, t, a, b)) {        \
+    hit = true; closest = t; side_out = S;                             \
+    if (UV) { u_out = (a - (A0)) / ((A1) - (A0)); v_out = (b - (B0)) / ((B1) - (B0)); } \
+  }
+  PT_BOX_SIDE(0, 0, R0.x, R1.x, R0.y, R1.y, R1.z)
+  PT_BOX_SIDE(1, 0, R0.x, R1.x, R0.y, R1.y, R0.z)
+  PT_BOX_SIDE(2, 1, R0.x, R1.x, R0.z, R1.z, R1.y)
+  PT_BOX_SIDE(3, 1, R0.x, R1.x, R0.z, R1.z, R0.y)
+  PT_BOX_SIDE(4, 2, R0.y, R1.y, R0.z, R1.z, R1.x)
+  PT_BOX_SIDE(5, 2, R0.y, R1.y, R0.z, R1.z, R0.x)
+#undef PT_BOX_SIDE
+  t_out = closest;
+  return hit;
+}
+
+// ---- triangle.hpp:58-100 (Moller-Trumbore) ---------------------------------------------------------
+// record: R0 = (v0.xyz, mat)  R1 = (edge1.xyz, hittable index)  R2 = (edge2.xyz, 0); edges = v1-v0, v2-v0
+__device__ __forceinline__ bool tri_t(f4 R0, f4 R1, f4 R2, const Ray& r, float mn, float mx, float& t_out) {
+  const float epsilon = 0.0000001f;
+  V3 edge1 = xyz(R1), edge2 = xyz(R2);
+  V3 h = cross(r.d, edge2);
+  float a = dot(edge1, h);
+  float a_abs = __builtin_fabsf(a);
+  if (a_abs < epsilon) return false;
+  bool a_pos = a > 0.0f;
+  V3 s = r.o - xyz(R0);
+  float u = dot(s, h);
+  bool u_pos = u > 0.0f;
+  if ((u_pos != a_pos) || __builtin_fabsf(u) > a_abs) return false;
+  V3 q = cross(s, edge1);
+  float v = dot(r.d, q);
+  bool v_pos = v > 0.0f;
+  if ((v_pos != a_pos) || (__builtin_fabsf(u + v) > a_abs)) return false;
+  float length = dot(edge2, q) / a;
+  if (length < mn || length > mx) return false;
+  t_out = length;
+  return true;
+}
+
+// ---- constant_medium.hpp:28-78 -------------------------------------------------------------------------
+// record: R0 = (boundary kind, neg_inv_density, mat, hittable index)  R1.. = boundary (sphere 3 f4 | box 2 f4)
+template <typename P>
+__device__ __forceinline__ bool boundary_t(P blob, int off, int bkind, const Ray& r, float a, float mn, float mx,
+                                           float& t) {
+  if (bkind == DK_SPHERE) return sphere_t(blob, off, r, a, mn, mx, t);
+  int side; float u, v;
+  return box_t<false>(blob[off], blob[off + 1], r, mn, mx, t, side, u, v);
+}
+
+template <typename P>
+__device__ __forceinline__ bool medium_t(P blob, int off, const Ray& r, float a, float mn, float mx, uint32_t& rng,
+                                         float& t_out) {
+  f4 R0 = blob[off];
+  int bkind = as_i(R0.x);
+  float t1, t2;
+  if (!boundary_t(blob, off + 1, bkind, r, a, -PT_INF, PT_INF, t1)) return false;
+  if (!boundary_t(blob, off + 1, bkind, r, a, t1 + 0.0001f, PT_INF, t2)) return false;
+  if (t1 < mn) t1 = mn;
+  if (t2 > mx) t2 = mx;
+  if (t1 >= t2) return false;
+  if (t1 < 0) t1 = 0;
+  const float ray_length = sqrt_rn(a); // sycl::length(r.direction()), a = dot(d,d)
+  const float distance_inside_boundary = (t2 - t1) * ray_length;
+  const float hit_distance = R0.y * ptm::logf_(rng_float(rng)); // the in-traversal draw (:65)
+  if (hit_distance > distance_inside_boundary) return false;
+  t_out = t1 + hit_distance / ray_length;
+  return true;
+}
+
+// ---- hit_world: render.hpp:30-51 --------------------------------------------------------------------------
+// blob = [n_runs x (kind, first record offset, count, 0)] [records...]
+// IMG: the scene has an image texture, so u,v of every accepted candidate are tracked exactly as the
+// reference's temp_rec does (incl. the stale values triangles/media leave behind); otherwise u,v are dead.
+template <bool IMG, typename P>
+__device__ __forceinline__ void hit_world(P blob, int n_runs, const Ray& r, uint32_t& rng, float& closest, int& hit,
+                                          float& hu, float& hv) {
+  closest = PT_INF;
+  hit = -1;
+  hu = 0.0f; hv = 0.0f;
+  const float a = dot(r.d, r.d);
+  for (int ri = 0; ri < n_runs; ++ri) {
+    f4 runf = blob[ri];
+    const int kind = as_i(runf.x);
+    int off = as_i(runf.y);
+    const int cnt = as_i(runf.z);
+    if (kind == DK_SPHERE) {
+      for (int i = 0; i < cnt; ++i, off += SZ_SPHERE) {
+        float t;
+        if (sphere_t(blob, off, r, a, PT_TMIN, closest, t)) {
+          closest = t;
+          hit = hit_pack(DK_SPHERE, 0, off);
+          if (IMG) {
+            f4 R0 = blob[off], R1 = blob[off + 1], R2 = blob[off + 2];
+            V3 p = r.o + t * r.d;
+            V3 n = (p - sphere_center(R0, R1, R2, r.tm)) / R1.x;
+            bool ff = dot(r.d, n) < 0;
+            V3 nn = ff ? n : mk(0.0f, 0.0f, 0.0f) - n;
+            mercator(nn, hu, hv);
+          }
+        }
+      }
+    } else if (kind == DK_RECT) {
+      for (int i = 0; i < cnt; ++i, off += SZ_RECT) {
+        f4 R0 = blob[off], R1 = blob[off + 1];
+        float t, ca, cb;
+        if (rect_t(as_i(R1.z), R0.x, R0.y, R0.z, R0.w, R1.x, r, PT_TMIN, closest, t, ca, cb)) {
+          closest = t;
+          hit = hit_pack(DK_RECT, 0, off);
+          if (IMG) { hu = (ca - R0.x) / (R0.y - R0.x); hv = (cb - R0.z) / (R0.w - R0.z); }
+        }
+      }
+    } else if (kind == DK_TRI) {
+      for (int i = 0; i < cnt; ++i, off += SZ_TRI) {
+        float t;
+        if (tri_t(blob[off], blob[off + 1], blob[off + 2], r, PT_TMIN, closest, t)) {
+          closest = t;
+          hit = hit_pack(DK_TRI, 0, off);
+        }
+      }
+    } else if (kind == DK_BOX) {
+      for (int i = 0; i < cnt; ++i, off += SZ_BOX) {
+        float t, bu = 0.0f, bv = 0.0f;
+        int side = 0;
+        if (box_t<IMG>(blob[off], blob[off + 1], r, PT_TMIN, closest, t, side, bu, bv)) {
+          closest = t;
+          hit = hit_pack(DK_BOX, side, off);
+          if (IMG) { hu = bu; hv = bv; }
+        }
+      }
+    } else {
+      for (int i = 0; i < cnt; ++i, off += SZ_MEDIUM) {
+        float t;
+        if (medium_t(blob, off, r, a, PT_TMIN, closest, rng, t)) {
+          closest = t;
+          hit = hit_pack(DK_MEDIUM, 0, off);
+        }
+      }
+    }
+  }
+}
+
+// ---- hit_record of the final nearest hit (hitable.hpp:8-24) ---------------------------------------------------
+struct Rec {
+  V3 p, normal;
+  bool front_face;
+  int mat;
+  int hittable;
+};
+
+__device__ __forceinline__ void set_face_normal(Rec& rec, const Ray& r, V3 n) {
+  rec.front_face = dot(r.d, n) < 0;
+  rec.normal = rec.front_face ? n : mk(0.0f, 0.0f, 0.0f) - n;
+}
+
+template <typename P>
+__device__ __forceinline__ Rec resolve_hit(P blob, int hit, const Ray& r, float t) {
+  Rec rec;
+  rec.p = r.o + t * r.d; // ray::at ray.hpp:21
+  const int off = hit_off(hit);
+  const int kind = hit_kind(hit);
+  f4 R0 = blob[off], R1 = blob[off + 1];
+  if (kind == DK_SPHERE) {
+    f4 R2 = blob[off + 2];
+    V3 n = (rec.p - sphere_center(R0, R1, R2, r.tm)) / R1.x;
+    set_face_normal(rec, r, n);
+    rec.mat = as_i(R1.y);
+    rec.hittable = as_i(R2.w);
+  } else if (kind == DK_RECT || kind == DK_BOX) {
+    int axis;
+    if (kind == DK_RECT) { axis = as_i(R1.z); rec.mat = as_i(R1.y); rec.hittable = as_i(R1.w); }
+    else { axis = hit_side(hit) >> 1; rec.mat = as_i(R0.w); rec.hittable = as_i(R1.w); }
+    V3 n = axis == 0 ? mk(0, 0, 1) : axis == 1 ? mk(0, 1, 0) : mk(1, 0, 0);
+    set_face_normal(rec, r, n);
+  } else if (kind == DK_TRI) {
+    f4 R2 = blob[off + 2];
+    set_face_normal(rec, r, cross(xyz(R1), xyz(R2))); // not normalised, triangle.hpp:96
+    rec.mat = as_i(R0.w);
+    rec.hittable = as_i(R1.w);
+  } else {
+    rec.normal = mk(1, 0, 0); // constant_medium.hpp:75-76
+    rec.front_face = true;
+    rec.mat = as_i(R0.z);
+    rec.hittable = as_i(R0.w);
+  }
+  return rec;
+}
+
+// ---- textures: texture.hpp:25, 42-49, 135-151 -------------------------------------------------------------------
+// material record (global memory, 4 f4): M0 = (mat kind, tex kind, param, freq)  M1 = (color0.xyz, width)
+//                                        M2 = (color1.xyz, height)  M3 = (atlas offset, 0, 0, 0)
+__device__ __forceinline__ uint32_t texel_index(float f, uint32_t maxv) {
+  if (!(f > 0.0f)) return 0;
+  if (f >= (float)maxv) return maxv;
+  return (uint32_t)f;
+}
+
+__device__ __forceinline__ V3 texture_value(f4 M0, f4 M1, f4 M2, f4 M3, V3 p, float u, float v,
+                                            const uint8_t* __restrict__ atlas) {
+  const int tk = as_i(M0.y);
+  if (tk == 1) return xyz(M1); // solid
+  if (tk == 0) {               // checker
+    float sines = ptm::sinf_(10.0f * p.x) * ptm::sinf_(10.0f * p.y) * ptm::sinf_(10.0f * p.z);
+    return (sines < 0) ? xyz(M1) : xyz(M2);
+  }
+  const uint32_t w = (uint32_t)as_i(M1.w), h = (uint32_t)as_i(M2.w), offset = (uint32_t)as_i(M3.x);
+  uint32_t i = texel_index(ptm::fmod1f_(u * M0.w) * (float)(w - 1), w - 1);
+  uint32_t j = texel_index((1.0f - ptm::fmod1f_(v * M0.w)) * (float)(h - 1), h - 1);
+  uint64_t pix = (uint64_t)j * w + i + offset;
+  const float scale = 1.0f / 255;
+  return mk((float)atlas[pix * 3] * scale, (float)atlas[pix * 3 + 1] * scale, (float)atlas[pix * 3 + 2] * scale);
+}
+
+// vec.hpp:26
+__device__ __forceinline__ V3 reflect(V3 v, V3 n) { return v - (2.0f * dot(v, n)) * n; }
+// vec.hpp:29-35
+__device__ __forceinline__ V3 refract(V3 uv, V3 n, float etai_over_etat) {
+  float cos_theta = __builtin_fminf(-dot(uv, n), 1.0f);
+  V3 r_out_perp = etai_over_etat * (uv + cos_theta * n);
+  V3 r_out_parallel = (-sqrt_rn(__builtin_fabsf(1.0f - length_squared(r_out_perp)))) * n;
+  return r_out_perp + r_out_parallel;
+}
+// material.hpp:62-66
+__device__ __forceinline__ float reflectance(float cosine, float ref_idx) {
+  float r0 = (1.0f - ref_idx) / (1.0f + ref_idx);
+  r0 *= r0;
+  return r0 + (1.0f - r0) * ptm::pow5f_(1.0f - cosine);
+}
+
+// render.hpp:83-87
+__device__ __forceinline__ V3 sky_color(const Ray& r, V3 att) {
+  V3 ud = r.d / sqrt_rn(dot(r.d, r.d));
+  float hit_pt = 0.5f * (ud.y + 1.0f);
+  V3 c = (1.0f - hit_pt) * mk(1.0f, 1.0f, 1.0f) + hit_pt * mk(0.5f, 0.7f, 1.0f);
+  return att * c;
+}
+
+// One iteration of the bounce loop render.hpp:58-89 after hit_world: emitted + scatter.
+// Returns true if the path continues (ray/att updated); false if it ended with `out`.
+__device__ __forceinline__ bool shade(const f4* __restrict__ mats, const uint8_t* __restrict__ atlas, const Rec& rec,
+                                      float hu, float hv, Ray& ray, V3& att, uint32_t& rng, V3& out) {
+  const f4* M = mats + rec.mat * SZ_MATERIAL;
+  f4 M0 = M[0], M1 = M[1];
+  const int mk_ = as_i(M0.x);
+  if (mk_ == 0) { // lambertian material.hpp:18-28
+    V3 dir = rec.normal + rng_unit_vec(rng);
+    V3 tv = texture_value(M0, M1, M[2], M[3], rec.p, hu, hv, atlas);
+    ray.o = rec.p; ray.d = dir;
+    att = att * tv;
+    return true;
+  }
+  if (mk_ == 1) { // metal material.hpp:39-48
+    V3 ud = ray.d / sqrt_rn(dot(ray.d, ray.d));
+    V3 reflected = reflect(ud, rec.normal);
+    V3 ball = rng_in_unit_ball(rng);
+    V3 dir = reflected + M0.z * ball;
+    ray.o = rec.p; ray.d = dir;
+    att = att * xyz(M1);
+    if (dot(dir, rec.normal) > 0) return true;
+    out = mk(0.0f, 0.0f, 0.0f); // emitted of a non-light (material.hpp:50)
+    return false;
+  }
+  if (mk_ == 2) { // dielectric material.hpp:68-88
+    att = att * xyz(M1);
+    float ref_idx = M0.z;
+    float ratio = rec.front_face ? (1.0f / ref_idx) : ref_idx;
+    V3 ud = ray.d / sqrt_rn(dot(ray.d, ray.d));
+    float cos_theta = __builtin_fminf(-dot(ud, rec.normal), 1.0f);
+    float sin_theta = sqrt_rn(1.0f - cos_theta * cos_theta);
+    bool cannot_refract = ratio * sin_theta > 1.0f;
+    V3 dir;
+    if (cannot_refract || reflectance(cos_theta, ratio) > rng_float(rng)) dir = reflect(ud, rec.normal);
+    else dir = refract(ud, rec.normal, ratio);
+    ray.o = rec.p; ray.d = dir;
+    return true;
+  }
+  if (mk_ == 3) { // lightsource material.hpp:104-108; returned un-attenuated (render.hpp:73)
+    out = texture_value(M0, M1, M[2], M[3], rec.p, hu, hv, atlas);
+    return false;
+  }
+  // isotropic material.hpp:119-126
+  V3 ball = rng_in_unit_ball(rng);
+  V3 tv = texture_value(M0, M1, M[2], M[3], rec.p, hu, hv, atlas);
+  ray.o = rec.p; ray.d = ball;
+  att = att * tv;
+  return true;
+}
+
+} // namespace ptd

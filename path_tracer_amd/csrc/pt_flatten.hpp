@@ -1,0 +1,163 @@
+// pt_flatten.hpp — host side of pt_scene_create(): validate the ABI tables and flatten
+// them into the device blob the kernels read (layout documented in pt_device.hpp and
+// DESIGN.md "Data layout in HBM").  Pure host C++ (no HIP), so it is unit-testable on a
+// machine without a GPU through pt_debug_flatten().
+//
+// Replaces: the AoS sycl::buffer<hittable_t> of 624-byte variants (render.hpp:146-147).
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/pt_render.h"
+
+namespace ptf {
+
+struct F4 {
+  float x, y, z, w;
+};
+static_assert(sizeof(F4) == 16);
+
+inline float as_f(int32_t i) { float f; std::memcpy(&f, &i, 4); return f; }
+
+enum { DK_SPHERE = 0, DK_RECT = 1, DK_TRI = 2, DK_BOX = 3, DK_MEDIUM = 4 };
+
+struct Flat {
+  std::vector<F4> blob; // [n_runs run headers][records]
+  std::vector<F4> mats; // 4 F4 per material, texture inlined
+  int32_t n_runs = 0;
+  bool has_image = false;
+  bool has_medium = false;
+};
+
+inline int device_kind(int32_t k) {
+  switch (k) {
+    case PT_HIT_SPHERE: return DK_SPHERE;
+    case PT_HIT_XY_RECT: case PT_HIT_XZ_RECT: case PT_HIT_YZ_RECT: return DK_RECT;
+    case PT_HIT_TRIANGLE: return DK_TRI;
+    case PT_HIT_BOX: return DK_BOX;
+    case PT_HIT_CONSTANT_MEDIUM: return DK_MEDIUM;
+    default: return -1;
+  }
+}
+
+inline int record_size(int dk) {
+  switch (dk) { case DK_SPHERE: return 3; case DK_RECT: return 2; case DK_TRI: return 3; case DK_BOX: return 2; default: return 4; }
+}
+
+inline int validate(const PtSceneDesc* sc, std::string& err) {
+  if (!sc) { err = "scene description is NULL"; return PT_ERR_INVALID_ARG; }
+  if (sc->n_hittables < 0 || sc->n_materials < 0 || sc->n_textures < 0) { err = "negative table size"; return PT_ERR_INVALID_ARG; }
+  if ((sc->n_hittables && !sc->hittables) || (sc->n_materials && !sc->materials) || (sc->n_textures && !sc->textures)) {
+    err = "table pointer is NULL"; return PT_ERR_INVALID_ARG;
+  }
+  for (int i = 0; i < sc->n_textures; i++) {
+    const PtTexture& t = sc->textures[i];
+    if (t.kind < 0 || t.kind > PT_TEX_IMAGE) { err = "texture " + std::to_string(i) + ": bad kind"; return PT_ERR_BAD_SCENE; }
+    if (t.kind == PT_TEX_IMAGE) {
+      if (t.width < 1 || t.height < 1) { err = "texture " + std::to_string(i) + ": empty image"; return PT_ERR_BAD_SCENE; }
+      if (!sc->atlas || ((uint64_t)t.offset + (uint64_t)t.width * t.height) * 3 > sc->atlas_bytes) {
+        err = "texture " + std::to_string(i) + ": image outside the atlas"; return PT_ERR_BAD_SCENE;
+      }
+    }
+  }
+  for (int i = 0; i < sc->n_materials; i++) {
+    const PtMaterial& m = sc->materials[i];
+    if (m.kind < 0 || m.kind > PT_MAT_ISOTROPIC) { err = "material " + std::to_string(i) + ": bad kind"; return PT_ERR_BAD_SCENE; }
+    bool needs_tex = m.kind == PT_MAT_LAMBERTIAN || m.kind == PT_MAT_LIGHTSOURCE || m.kind == PT_MAT_ISOTROPIC;
+    if (needs_tex && (m.texture < 0 || m.texture >= sc->n_textures)) {
+      err = "material " + std::to_string(i) + ": texture index out of range"; return PT_ERR_BAD_SCENE;
+    }
+  }
+  for (int i = 0; i < sc->n_hittables; i++) {
+    const PtHittable& h = sc->hittables[i];
+    if (device_kind(h.kind) < 0) { err = "hittable " + std::to_string(i) + ": bad kind"; return PT_ERR_BAD_SCENE; }
+    if (h.material < 0 || h.material >= sc->n_materials) { err = "hittable " + std::to_string(i) + ": material index out of range"; return PT_ERR_BAD_SCENE; }
+    if (h.kind == PT_HIT_CONSTANT_MEDIUM && h.boundary_kind != PT_HIT_SPHERE && h.boundary_kind != PT_HIT_BOX) {
+      err = "hittable " + std::to_string(i) + ": constant_medium boundary must be a sphere or a box"; return PT_ERR_BAD_SCENE;
+    }
+  }
+  return PT_OK;
+}
+
+inline void put_sphere(std::vector<F4>& b, const float* f, int32_t mat, int32_t hidx) {
+  b.push_back({f[0], f[1], f[2], f[6] * f[6]});          // c0, radius^2 (sphere.hpp:71)
+  b.push_back({f[6], as_f(mat), f[7], f[8]});            // radius, material, time0, time1
+  b.push_back({f[3], f[4], f[5], as_f(hidx)});           // c1
+}
+inline void put_box(std::vector<F4>& b, const float* f, int32_t mat, int32_t hidx) {
+  b.push_back({f[0], f[1], f[2], as_f(mat)});
+  b.push_back({f[3], f[4], f[5], as_f(hidx)});
+}
+
+inline int flatten(const PtSceneDesc* sc, Flat& out, std::string& err) {
+  int rc = validate(sc, err);
+  if (rc) return rc;
+  out = Flat();
+  // materials with their texture inlined
+  out.mats.reserve((size_t)sc->n_materials * 4);
+  for (int i = 0; i < sc->n_materials; i++) {
+    const PtMaterial& m = sc->materials[i];
+    F4 M0{as_f(m.kind), as_f(PT_TEX_SOLID), m.param, 1.0f}, M1{m.color[0], m.color[1], m.color[2], as_f(1)},
+        M2{0, 0, 0, as_f(1)}, M3{as_f(0), 0, 0, 0};
+    if (m.kind == PT_MAT_LAMBERTIAN || m.kind == PT_MAT_LIGHTSOURCE || m.kind == PT_MAT_ISOTROPIC) {
+      const PtTexture& t = sc->textures[m.texture];
+      M0.y = as_f(t.kind);
+      M0.w = t.freq;
+      M1 = {t.color0[0], t.color0[1], t.color0[2], as_f((int32_t)t.width)};
+      M2 = {t.color1[0], t.color1[1], t.color1[2], as_f((int32_t)t.height)};
+      M3.x = as_f((int32_t)t.offset);
+      if (t.kind == PT_TEX_IMAGE) out.has_image = true;
+    }
+    out.mats.push_back(M0); out.mats.push_back(M1); out.mats.push_back(M2); out.mats.push_back(M3);
+  }
+  // runs: maximal stretches of one device kind, in list order (traversal order is semantics:
+  // constant_medium draws RNG against the current closest hit, ties resolve by position)
+  struct Run { int kind, first, count; };
+  std::vector<Run> runs;
+  for (int i = 0; i < sc->n_hittables; i++) {
+    int dk = device_kind(sc->hittables[i].kind);
+    if (runs.empty() || runs.back().kind != dk) runs.push_back({dk, i, 0});
+    runs.back().count++;
+  }
+  out.n_runs = (int32_t)runs.size();
+  std::vector<F4>& b = out.blob;
+  b.resize(runs.size());
+  for (size_t ri = 0; ri < runs.size(); ri++) {
+    const Run& run = runs[ri];
+    b[ri] = {as_f(run.kind), as_f((int32_t)b.size()), as_f(run.count), as_f(run.first)};
+    for (int i = run.first; i < run.first + run.count; i++) {
+      const PtHittable& h = sc->hittables[i];
+      const float* f = h.f;
+      switch (h.kind) {
+        case PT_HIT_SPHERE: put_sphere(b, f, h.material, i); break;
+        case PT_HIT_XY_RECT: case PT_HIT_XZ_RECT: case PT_HIT_YZ_RECT: {
+          int axis = h.kind == PT_HIT_XY_RECT ? 0 : h.kind == PT_HIT_XZ_RECT ? 1 : 2;
+          b.push_back({f[0], f[1], f[2], f[3]});
+          b.push_back({f[4], as_f(h.material), as_f(axis), as_f(i)});
+          break;
+        }
+        case PT_HIT_TRIANGLE:
+          b.push_back({f[0], f[1], f[2], as_f(h.material)});
+          b.push_back({f[3] - f[0], f[4] - f[1], f[5] - f[2], as_f(i)}); // edge1 (triangle.hpp:65)
+          b.push_back({f[6] - f[0], f[7] - f[1], f[8] - f[2], 0.0f});    // edge2 (triangle.hpp:66)
+          break;
+        case PT_HIT_BOX: put_box(b, f, h.material, i); break;
+        default: { // constant_medium
+          out.has_medium = true;
+          int bk = h.boundary_kind == PT_HIT_SPHERE ? DK_SPHERE : DK_BOX;
+          b.push_back({as_f(bk), f[9], as_f(h.material), as_f(i)});
+          size_t before = b.size();
+          if (bk == DK_SPHERE) put_sphere(b, f, h.material, i); else put_box(b, f, h.material, i);
+          while (b.size() < before + 3) b.push_back({0, 0, 0, 0});
+          break;
+        }
+      }
+    }
+  }
+  if (b.size() >= (1u << 24)) { err = "scene too large for 24-bit record offsets"; return PT_ERR_TOO_LARGE; }
+  return PT_OK;
+}
+
+} // namespace ptf

@@ -1,0 +1,545 @@
+// pt_render.hip — kernels + C ABI (include/pt_render.h) of the MI355X-native render() hot path.
+//
+// Replaces render<W,H,S>() / executor() / render_pixel()  (reference include/render.hpp:25-160).
+//
+// Mapping (DESIGN.md "Kernel"): one 64-lane wavefront owns one 8x8 pixel tile, one lane owns one
+// pixel for ALL of its samples — the reference's single xorshift32 stream per pixel, consumed
+// sequentially across samples (render.hpp:95-101,130-133), leaves no other bit-exact choice.  Each
+// lane runs a persistent "regenerate in place" loop: a lane whose path ended starts its next
+// sample in the same iteration, so the wave-uniform primitive loop always runs with all lanes
+// live (what ballot/prefix compaction would buy, without moving state between lanes).  The wave
+// leaves the loop when a ballot of the live lanes is empty.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/pt_render.h"
+#include "pt_device.hpp"
+#include "pt_flatten.hpp"
+
+using namespace ptd;
+
+static_assert(sizeof(PtHittable) == 64 && sizeof(PtMaterial) == 32 && sizeof(PtTexture) == 48 && sizeof(PtCamera) == 96);
+static_assert(sizeof(Cam) == sizeof(PtCamera));
+
+namespace {
+
+constexpr int kBlock = 256;                 // 4 wavefronts = 4 tiles per workgroup
+constexpr int kWavesPerBlock = kBlock / 64;
+constexpr size_t kMaxLdsBlob = 64 * 1024;   // blob staged in LDS when it fits
+
+struct KArgs {
+  Cam cam;
+  const f4* blob;
+  const f4* mats;
+  const uint8_t* atlas;
+  float* fb;
+  int n_runs, blob_f4;
+  int width, height, samples, depth;
+  int shard_index, shard_count;
+  int tiles_x, n_tiles;
+};
+
+template <bool IMG, bool LDS>
+__global__ __launch_bounds__(kBlock) void render_kernel(KArgs a) {
+  extern __shared__ f4 smem[];
+  if (LDS) {
+    for (int i = threadIdx.x; i < a.blob_f4; i += kBlock) smem[i] = a.blob[i];
+    __syncthreads();
+  }
+  const int lane = threadIdx.x & 63;
+  const int l = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6); // local tile of this wave
+  const long long g = (long long)l * a.shard_count + a.shard_index;
+  if (g >= a.n_tiles) return; // no barrier below this point
+  const int tx = (int)(g % a.tiles_x), ty = (int)(g / a.tiles_x);
+  const int x = tx * PT_TILE + (lane & 7), y = ty * PT_TILE + (lane >> 3);
+  const bool valid = x < a.width && y < a.height;
+
+  // render.hpp:130-132: seed = linear id, truncated to 32 bits
+  uint32_t rng = (uint32_t)((unsigned long long)y * (unsigned long long)a.width + (unsigned long long)x);
+  V3 acc = mk(0.0f, 0.0f, 0.0f);
+  V3 att = mk(1.0f, 1.0f, 1.0f);
+  Ray ray;
+  ray.o = mk(0.0f, 0.0f, 0.0f); ray.d = mk(0.0f, 0.0f, 0.0f); ray.tm = 0.0f;
+  int s = 0, b = 0;
+  bool done = !valid || a.depth <= 0; // depth 0: every sample returns black (render.hpp:58,91)
+  bool need_new = true;
+
+  for (;;) {
+    if (!done && need_new) {
+      if (s == a.samples) done = true;
+      else {
+        ray = camera_ray(a.cam, x, y, a.width, a.height, rng);
+        att = mk(1.0f, 1.0f, 1.0f);
+        b = 0;
+        need_new = false;
+      }
+    }
+    if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
+
+    float closest, hu, hv;
+    int hit;
+    if constexpr (LDS) hit_world<IMG>((lds_f4p)smem, a.n_runs, ray, rng, closest, hit, hu, hv);
+    else hit_world<IMG>((cst_f4p)a.blob, a.n_runs, ray, rng, closest, hit, hu, hv);
+
+    if (!done) {
+      V3 out = mk(0.0f, 0.0f, 0.0f);
+      bool cont;
+      if (hit < 0) {
+        out = sky_color(ray, att);
+        cont = false;
+      } else {
+        Rec rec;
+        if constexpr (LDS) rec = resolve_hit((lds_f4p)smem, hit, ray, closest);
+        else rec = resolve_hit((const f4*)a.blob, hit, ray, closest);
+        cont = shade(a.mats, a.atlas, rec, hu, hv, ray, att, rng, out);
+        if (cont && ++b >= a.depth) { // bounce loop exhausted: black (render.hpp:91)
+          out = mk(0.0f, 0.0f, 0.0f);
+          cont = false;
+        }
+      }
+      if (!cont) {
+        acc = acc + out; // final_color += get_color(r)  render.hpp:100
+        s++;
+        need_new = true;
+      }
+    }
+  }
+
+  if (valid) {
+    acc = acc / (float)a.samples; // render.hpp:102
+    long long idx;
+    if (a.shard_count == 1) idx = ((long long)y * a.width + x) * 3;
+    else idx = ((long long)l * PT_TILE_PIXELS + lane) * 3;
+    a.fb[idx] = acc.x; a.fb[idx + 1] = acc.y; a.fb[idx + 2] = acc.z;
+  }
+}
+
+// ---- probes ---------------------------------------------------------------------------------
+template <bool IMG>
+__global__ void bounce_kernel(const f4* __restrict__ blob, int n_runs, const f4* __restrict__ mats,
+                              const uint8_t* __restrict__ atlas, const PtBounceIn* __restrict__ in,
+                              PtBounceOut* __restrict__ outp, int n) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  PtBounceIn I = in[k];
+  Ray ray;
+  ray.o = mk(I.origin[0], I.origin[1], I.origin[2]);
+  ray.d = mk(I.dir[0], I.dir[1], I.dir[2]);
+  ray.tm = I.time;
+  uint32_t rng = I.rng_state;
+  V3 att = mk(I.attenuation[0], I.attenuation[1], I.attenuation[2]);
+  PtBounceOut O;
+  memset(&O, 0, sizeof O);
+  float closest, hu, hv;
+  int hit;
+  hit_world<IMG>(blob, n_runs, ray, rng, closest, hit, hu, hv);
+  if (hit < 0) {
+    V3 c = sky_color(ray, att);
+    O.status = PT_BOUNCE_MISS; O.hittable = -1; O.material = -1;
+    O.color[0] = c.x; O.color[1] = c.y; O.color[2] = c.z;
+  } else {
+    Rec rec = resolve_hit(blob, hit, ray, closest);
+    O.hittable = rec.hittable; O.material = rec.mat; O.front_face = rec.front_face ? 1 : 0;
+    O.t = closest;
+    O.p[0] = rec.p.x; O.p[1] = rec.p.y; O.p[2] = rec.p.z;
+    O.normal[0] = rec.normal.x; O.normal[1] = rec.normal.y; O.normal[2] = rec.normal.z;
+    O.u = hu; O.v = hv;
+    V3 out = mk(0.0f, 0.0f, 0.0f);
+    if (shade(mats, atlas, rec, hu, hv, ray, att, rng, out)) {
+      O.status = PT_BOUNCE_SCATTERED;
+      O.color[0] = att.x; O.color[1] = att.y; O.color[2] = att.z;
+      O.sc_origin[0] = ray.o.x; O.sc_origin[1] = ray.o.y; O.sc_origin[2] = ray.o.z;
+      O.sc_dir[0] = ray.d.x; O.sc_dir[1] = ray.d.y; O.sc_dir[2] = ray.d.z;
+      O.sc_time = ray.tm;
+    } else {
+      O.status = PT_BOUNCE_ABSORBED;
+      O.color[0] = out.x; O.color[1] = out.y; O.color[2] = out.z;
+    }
+  }
+  O.rng_state = rng;
+  outp[k] = O;
+}
+
+__global__ void camera_rays_kernel(Cam cam, int width, int height, const int* __restrict__ xy,
+                                   const uint32_t* __restrict__ rng_in, PtCameraRay* __restrict__ out, int n) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  uint32_t rng = rng_in[k];
+  Ray r = camera_ray(cam, xy[2 * k], xy[2 * k + 1], width, height, rng);
+  PtCameraRay o;
+  o.origin[0] = r.o.x; o.origin[1] = r.o.y; o.origin[2] = r.o.z;
+  o.dir[0] = r.d.x; o.dir[1] = r.d.y; o.dir[2] = r.d.z;
+  o.time = r.tm; o.rng_state = rng;
+  out[k] = o;
+}
+
+__global__ void math_kernel(int op, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                            long long n) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float x = a[i], y = b ? b[i] : 0.0f, r;
+  switch (op) {
+    case 0: r = ptm::sinf_(x); break;
+    case 1: r = ptm::cosf_(x); break;
+    case 2: r = ptm::logf_(x); break;
+    case 3: r = ptm::pow5f_(x); break;
+    case 4: r = ptm::atan2f_(x, y); break;
+    case 5: r = ptm::asinf_(x); break;
+    case 6: r = ptm::fmod1f_(x); break;
+    case 7: r = sqrt_rn(x); break;
+    default: r = x / y; break;
+  }
+  out[i] = r;
+}
+
+// Root-side un-interleave of the gathered shard tiles -> [y][x][rgb].
+__global__ void unshard_kernel(const float* __restrict__ gathered, float* __restrict__ fb, int width, int height,
+                               int tiles_x, int shard_count, int tiles_per_shard) {
+  int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= width) return;
+  int g = (y / PT_TILE) * tiles_x + (x / PT_TILE);
+  long long src = (((long long)(g % shard_count) * tiles_per_shard + g / shard_count) * PT_TILE_PIXELS +
+                   (y % PT_TILE) * PT_TILE + (x % PT_TILE)) * 3;
+  long long dst = ((long long)y * width + x) * 3;
+  fb[dst] = gathered[src]; fb[dst + 1] = gathered[src + 1]; fb[dst + 2] = gathered[src + 2];
+}
+
+// main.cpp:33-59 — sqrt gamma, clamp [0,0.999], *256, truncate, vertical flip.
+__global__ void tonemap_kernel(const float* __restrict__ fb, uint8_t* __restrict__ rgb8, int width, int height) {
+  int x = blockIdx.x * blockDim.x + threadIdx.x, row = blockIdx.y; // row 0 = top
+  if (x >= width) return;
+  int j = height - 1 - row;
+  for (int ch = 0; ch < 3; ch++) {
+    float s = sqrt_rn(fb[((long long)j * width + x) * 3 + ch]);
+    float cl = (s < 0.0f) ? 0.0f : (0.999f < s) ? 0.999f : s; // std::clamp
+    float sc = 256.0f * cl;
+    int v = (sc == sc) ? (int)sc : 0; // int(NaN) is UB in the reference; defined as 0
+    rgb8[((long long)row * width + x) * 3 + ch] = (uint8_t)v;
+  }
+}
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+
+#define PT_HIP(expr)                                                                             \
+  do {                                                                                           \
+    hipError_t e_ = (expr);                                                                      \
+    if (e_ != hipSuccess) return fail(PT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t n) { return hipMalloc((void**)&p, std::max<size_t>(n, 1) * sizeof(T)); }
+};
+
+} // namespace
+
+struct PtScene {
+  f4* blob = nullptr;
+  f4* mats = nullptr;
+  uint8_t* atlas = nullptr;
+  int n_runs = 0, blob_f4 = 0;
+  bool has_image = false;
+  int device = 0;
+};
+
+extern "C" {
+
+int pt_abi_version(void) { return PT_ABI_VERSION; }
+
+const char* pt_error_string(int code) {
+  switch (code) {
+    case PT_OK: return "ok";
+    case PT_ERR_INVALID_ARG: return "invalid argument";
+    case PT_ERR_BAD_SCENE: return "malformed scene tables";
+    case PT_ERR_HIP: return "HIP runtime error";
+    case PT_ERR_NO_DEVICE: return "no HIP device";
+    case PT_ERR_TOO_LARGE: return "scene too large";
+    default: return "unknown error";
+  }
+}
+
+const char* pt_last_error(void) { return g_last_error.c_str(); }
+
+// camera.hpp:67-87 (host arithmetic, binary32, no contraction)
+int pt_camera_init(PtCamera* cam, const float look_from[3], const float look_at[3], const float vup[3],
+                   float vfov_deg, float aspect_ratio, float aperture, float focus_dist, float time0, float time1) {
+  if (!cam || !look_from || !look_at || !vup) return fail(PT_ERR_INVALID_ARG, "pt_camera_init: NULL argument");
+  struct H3 { float x, y, z; };
+  auto sub = [](H3 a, H3 b) { return H3{a.x - b.x, a.y - b.y, a.z - b.z}; };
+  auto scale = [](float s, H3 a) { return H3{s * a.x, s * a.y, s * a.z}; };
+  auto divs = [](H3 a, float s) { return H3{a.x / s, a.y / s, a.z / s}; };
+  auto dot3 = [](H3 a, H3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; };
+  auto cross3 = [](H3 a, H3 b) { return H3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; };
+  auto unit = [&](H3 a) { return divs(a, std::sqrt(dot3(a, a))); };
+  const float pi = 3.1415926535897932385f;
+  H3 origin{look_from[0], look_from[1], look_from[2]}, at{look_at[0], look_at[1], look_at[2]}, up{vup[0], vup[1], vup[2]};
+  float theta = vfov_deg * pi / 180.0f; // rtweekend.hpp:31
+  float h = std::tan(theta / 2.0f);
+  float viewport_height = 2.0f * h;
+  float viewport_width = aspect_ratio * viewport_height;
+  H3 w = unit(sub(origin, at));
+  H3 u = unit(cross3(up, w));
+  H3 v = cross3(w, u);
+  H3 horizontal = scale(focus_dist * viewport_width, u);
+  H3 vertical = scale(focus_dist * viewport_height, v);
+  H3 llc = sub(sub(sub(origin, divs(horizontal, 2.0f)), divs(vertical, 2.0f)), scale(focus_dist, w));
+  auto st = [](float* d, H3 a) { d[0] = a.x; d[1] = a.y; d[2] = a.z; };
+  st(cam->origin, origin); st(cam->lower_left_corner, llc); st(cam->horizontal, horizontal); st(cam->vertical, vertical);
+  st(cam->u, u); st(cam->v, v); st(cam->w, w);
+  cam->lens_radius = aperture / 2.0f;
+  cam->time0 = time0;
+  cam->time1 = time1;
+  return PT_OK;
+}
+
+// Host-only view of the flattening (no GPU needed): blob_out/mats_out may be NULL to query sizes.
+int pt_debug_flatten(const PtSceneDesc* desc, float* blob_out, int64_t blob_cap_f4, int32_t* n_blob_f4,
+                     int32_t* n_runs, float* mats_out, int64_t mats_cap_f4, int32_t* flags_out) {
+  ptf::Flat flat;
+  std::string err;
+  int rc = ptf::flatten(desc, flat, err);
+  if (rc) return fail(rc, err);
+  if (n_blob_f4) *n_blob_f4 = (int32_t)flat.blob.size();
+  if (n_runs) *n_runs = flat.n_runs;
+  if (flags_out) *flags_out = (flat.has_image ? 1 : 0) | (flat.has_medium ? 2 : 0);
+  if (blob_out) {
+    if (blob_cap_f4 < (int64_t)flat.blob.size()) return fail(PT_ERR_INVALID_ARG, "blob buffer too small");
+    std::memcpy(blob_out, flat.blob.data(), flat.blob.size() * 16);
+  }
+  if (mats_out) {
+    if (mats_cap_f4 < (int64_t)flat.mats.size()) return fail(PT_ERR_INVALID_ARG, "material buffer too small");
+    std::memcpy(mats_out, flat.mats.data(), flat.mats.size() * 16);
+  }
+  return PT_OK;
+}
+
+int pt_scene_create(const PtSceneDesc* desc, PtScene** out_scene) {
+  if (!out_scene) return fail(PT_ERR_INVALID_ARG, "pt_scene_create: out_scene is NULL");
+  *out_scene = nullptr;
+  ptf::Flat flat;
+  std::string err;
+  int rc = ptf::flatten(desc, flat, err);
+  if (rc) return fail(rc, err);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(PT_ERR_NO_DEVICE, "no HIP device visible");
+  PtScene* s = new PtScene();
+  auto cleanup = [&]() { pt_scene_destroy(s); };
+  hipError_t e;
+#define PT_TRY(expr) if ((e = (expr)) != hipSuccess) { cleanup(); return fail(PT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e)); }
+  PT_TRY(hipGetDevice(&s->device));
+  s->n_runs = flat.n_runs;
+  s->blob_f4 = (int)flat.blob.size();
+  s->has_image = flat.has_image;
+  size_t blob_bytes = std::max<size_t>(flat.blob.size(), 1) * 16, mats_bytes = std::max<size_t>(flat.mats.size(), 1) * 16;
+  PT_TRY(hipMalloc((void**)&s->blob, blob_bytes));
+  PT_TRY(hipMalloc((void**)&s->mats, mats_bytes));
+  if (!flat.blob.empty()) PT_TRY(hipMemcpy(s->blob, flat.blob.data(), flat.blob.size() * 16, hipMemcpyHostToDevice));
+  if (!flat.mats.empty()) PT_TRY(hipMemcpy(s->mats, flat.mats.data(), flat.mats.size() * 16, hipMemcpyHostToDevice));
+  size_t atlas_bytes = flat.has_image ? (size_t)desc->atlas_bytes : 0;
+  PT_TRY(hipMalloc((void**)&s->atlas, std::max<size_t>(atlas_bytes, 16)));
+  if (atlas_bytes) PT_TRY(hipMemcpy(s->atlas, desc->atlas, atlas_bytes, hipMemcpyHostToDevice));
+#undef PT_TRY
+  *out_scene = s;
+  return PT_OK;
+}
+
+void pt_scene_destroy(PtScene* s) {
+  if (!s) return;
+  if (s->blob) (void)hipFree(s->blob);
+  if (s->mats) (void)hipFree(s->mats);
+  if (s->atlas) (void)hipFree(s->atlas);
+  delete s;
+}
+
+static int check_params(const PtRenderParams* p) {
+  if (!p) return fail(PT_ERR_INVALID_ARG, "render params are NULL");
+  if (p->width <= 0 || p->height <= 0 || p->samples <= 0 || p->depth < 0)
+    return fail(PT_ERR_INVALID_ARG, "width, height, samples must be > 0 and depth >= 0");
+  if (p->shard_count < 1 || p->shard_index < 0 || p->shard_index >= p->shard_count)
+    return fail(PT_ERR_INVALID_ARG, "need 0 <= shard_index < shard_count");
+  return PT_OK;
+}
+
+static int n_tiles_of(const PtRenderParams* p, int* tiles_x) {
+  int tx = (p->width + PT_TILE - 1) / PT_TILE, ty = (p->height + PT_TILE - 1) / PT_TILE;
+  if (tiles_x) *tiles_x = tx;
+  return tx * ty;
+}
+
+int32_t pt_shard_tiles(const PtRenderParams* p) {
+  if (check_params(p)) return -1;
+  int n = n_tiles_of(p, nullptr);
+  return (n + p->shard_count - 1) / p->shard_count;
+}
+
+int64_t pt_framebuffer_floats(const PtRenderParams* p) {
+  if (check_params(p)) return -1;
+  if (p->shard_count == 1) return (int64_t)p->width * p->height * 3;
+  return (int64_t)pt_shard_tiles(p) * PT_TILE_PIXELS * 3;
+}
+
+static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderParams* p, float* fb, hipStream_t st) {
+  KArgs a;
+  std::memcpy(&a.cam, cam, sizeof(Cam));
+  a.blob = s->blob; a.mats = s->mats; a.atlas = s->atlas; a.fb = fb;
+  a.n_runs = s->n_runs; a.blob_f4 = s->blob_f4;
+  a.width = p->width; a.height = p->height; a.samples = p->samples; a.depth = p->depth;
+  a.shard_index = p->shard_index; a.shard_count = p->shard_count;
+  a.n_tiles = n_tiles_of(p, &a.tiles_x);
+  const int local_tiles = (a.n_tiles - p->shard_index + p->shard_count - 1) / p->shard_count; // tiles this shard owns
+  // pixels no lane owns (edge tiles, padded last tile, depth 0) read as 0
+  PT_HIP(hipMemsetAsync(fb, 0, (size_t)pt_framebuffer_floats(p) * sizeof(float), st));
+  if (local_tiles <= 0) return PT_OK;
+  const size_t blob_bytes = (size_t)s->blob_f4 * 16;
+  const bool lds = !(p->flags & PT_FLAG_NO_LDS) && blob_bytes <= kMaxLdsBlob;
+  dim3 grid((local_tiles + kWavesPerBlock - 1) / kWavesPerBlock), block(kBlock);
+  size_t shmem = lds ? blob_bytes : 0;
+  if (s->has_image) {
+    if (lds) hipLaunchKernelGGL((render_kernel<true, true>), grid, block, shmem, st, a);
+    else hipLaunchKernelGGL((render_kernel<true, false>), grid, block, 0, st, a);
+  } else {
+    if (lds) hipLaunchKernelGGL((render_kernel<false, true>), grid, block, shmem, st, a);
+    else hipLaunchKernelGGL((render_kernel<false, false>), grid, block, 0, st, a);
+  }
+  PT_HIP(hipGetLastError());
+  return PT_OK;
+}
+
+int pt_render(const PtScene* scene, const PtCamera* cam, const PtRenderParams* p, float* fb_device, void* stream) {
+  if (!scene || !cam || !fb_device) return fail(PT_ERR_INVALID_ARG, "pt_render: NULL argument");
+  int rc = check_params(p);
+  if (rc) return rc;
+  return launch_render(scene, cam, p, fb_device, (hipStream_t)stream);
+}
+
+int pt_render_timed(const PtScene* scene, const PtCamera* cam, const PtRenderParams* p, float* fb_device, void* stream,
+                    float* kernel_ms) {
+  if (!scene || !cam || !fb_device || !kernel_ms) return fail(PT_ERR_INVALID_ARG, "pt_render_timed: NULL argument");
+  int rc = check_params(p);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  hipEvent_t e0, e1;
+  PT_HIP(hipEventCreate(&e0));
+  PT_HIP(hipEventCreate(&e1));
+  PT_HIP(hipEventRecord(e0, st));
+  rc = launch_render(scene, cam, p, fb_device, st);
+  if (rc == PT_OK) {
+    PT_HIP(hipEventRecord(e1, st));
+    PT_HIP(hipEventSynchronize(e1));
+    PT_HIP(hipEventElapsedTime(kernel_ms, e0, e1));
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return rc;
+}
+
+int pt_render_host(const PtScene* scene, const PtCamera* cam, const PtRenderParams* p, float* fb_host) {
+  if (!scene || !cam || !fb_host) return fail(PT_ERR_INVALID_ARG, "pt_render_host: NULL argument");
+  int rc = check_params(p);
+  if (rc) return rc;
+  size_t bytes = (size_t)pt_framebuffer_floats(p) * sizeof(float);
+  float* d = nullptr;
+  PT_HIP(hipMalloc((void**)&d, bytes));
+  rc = launch_render(scene, cam, p, d, nullptr);
+  if (rc == PT_OK) {
+    hipError_t e = hipMemcpy(fb_host, d, bytes, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = fail(PT_ERR_HIP, std::string("hipMemcpy D2H: ") + hipGetErrorString(e));
+  }
+  (void)hipFree(d);
+  return rc;
+}
+
+int pt_unshard_tiles(const float* gathered_device, const PtRenderParams* p, float* fb_device, void* stream) {
+  if (!gathered_device || !fb_device) return fail(PT_ERR_INVALID_ARG, "pt_unshard_tiles: NULL argument");
+  int rc = check_params(p);
+  if (rc) return rc;
+  int tiles_x;
+  int n_tiles = n_tiles_of(p, &tiles_x);
+  int per = (n_tiles + p->shard_count - 1) / p->shard_count;
+  dim3 block(256), grid((p->width + 255) / 256, p->height);
+  hipLaunchKernelGGL(unshard_kernel, grid, block, 0, (hipStream_t)stream, gathered_device, fb_device, p->width, p->height,
+                     tiles_x, p->shard_count, per);
+  PT_HIP(hipGetLastError());
+  return PT_OK;
+}
+
+int pt_tonemap_rgb8(const float* fb_device, int32_t width, int32_t height, uint8_t* rgb8_device, void* stream) {
+  if (!fb_device || !rgb8_device || width <= 0 || height <= 0) return fail(PT_ERR_INVALID_ARG, "pt_tonemap_rgb8: bad argument");
+  dim3 block(256), grid((width + 255) / 256, height);
+  hipLaunchKernelGGL(tonemap_kernel, grid, block, 0, (hipStream_t)stream, fb_device, rgb8_device, width, height);
+  PT_HIP(hipGetLastError());
+  return PT_OK;
+}
+
+// ---- probes: host arrays in/out ------------------------------------------------------------------------
+
+int pt_debug_bounce(const PtScene* scene, const PtBounceIn* in, PtBounceOut* out, int32_t n) {
+  if (!scene || !in || !out || n < 0) return fail(PT_ERR_INVALID_ARG, "pt_debug_bounce: bad argument");
+  if (n == 0) return PT_OK;
+  DevBuf<PtBounceIn> din;
+  DevBuf<PtBounceOut> dout;
+  PT_HIP(din.alloc(n));
+  PT_HIP(dout.alloc(n));
+  PT_HIP(hipMemcpy(din.p, in, (size_t)n * sizeof(PtBounceIn), hipMemcpyHostToDevice));
+  dim3 block(64), grid((n + 63) / 64);
+  if (scene->has_image)
+    hipLaunchKernelGGL(bounce_kernel<true>, grid, block, 0, nullptr, scene->blob, scene->n_runs, scene->mats, scene->atlas, din.p, dout.p, n);
+  else
+    hipLaunchKernelGGL(bounce_kernel<false>, grid, block, 0, nullptr, scene->blob, scene->n_runs, scene->mats, scene->atlas, din.p, dout.p, n);
+  PT_HIP(hipGetLastError());
+  PT_HIP(hipMemcpy(out, dout.p, (size_t)n * sizeof(PtBounceOut), hipMemcpyDeviceToHost));
+  return PT_OK;
+}
+
+int pt_debug_camera_rays(const PtCamera* cam, int32_t width, int32_t height, const int32_t* xy, const uint32_t* rng_in,
+                         PtCameraRay* out, int32_t n) {
+  if (!cam || !xy || !rng_in || !out || n < 0 || width <= 0 || height <= 0)
+    return fail(PT_ERR_INVALID_ARG, "pt_debug_camera_rays: bad argument");
+  if (n == 0) return PT_OK;
+  DevBuf<int32_t> dxy;
+  DevBuf<uint32_t> drng;
+  DevBuf<PtCameraRay> dout;
+  PT_HIP(dxy.alloc((size_t)n * 2));
+  PT_HIP(drng.alloc(n));
+  PT_HIP(dout.alloc(n));
+  PT_HIP(hipMemcpy(dxy.p, xy, (size_t)n * 2 * sizeof(int32_t), hipMemcpyHostToDevice));
+  PT_HIP(hipMemcpy(drng.p, rng_in, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice));
+  Cam c;
+  std::memcpy(&c, cam, sizeof c);
+  hipLaunchKernelGGL(camera_rays_kernel, dim3((n + 63) / 64), dim3(64), 0, nullptr, c, width, height, dxy.p, drng.p, dout.p, n);
+  PT_HIP(hipGetLastError());
+  PT_HIP(hipMemcpy(out, dout.p, (size_t)n * sizeof(PtCameraRay), hipMemcpyDeviceToHost));
+  return PT_OK;
+}
+
+int pt_debug_math(int32_t op, const float* a, const float* b, float* out, int64_t n) {
+  if (!a || !out || n < 0 || op < 0 || op > 8) return fail(PT_ERR_INVALID_ARG, "pt_debug_math: bad argument");
+  if ((op == 4 || op == 8) && !b) return fail(PT_ERR_INVALID_ARG, "pt_debug_math: op needs two operands");
+  if (n == 0) return PT_OK;
+  DevBuf<float> da, db, dout;
+  PT_HIP(da.alloc(n));
+  PT_HIP(dout.alloc(n));
+  PT_HIP(hipMemcpy(da.p, a, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+  if (b) {
+    PT_HIP(db.alloc(n));
+    PT_HIP(hipMemcpy(db.p, b, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+  }
+  hipLaunchKernelGGL(math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, op, da.p, b ? db.p : nullptr, dout.p, (long long)n);
+  PT_HIP(hipGetLastError());
+  PT_HIP(hipMemcpy(out, dout.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+  return PT_OK;
+}
+
+} // extern "C"

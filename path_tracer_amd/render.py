@@ -1,0 +1,153 @@
+"""render() — the host-side mirror of the reference's hot-path entry point, over the C ABI.
+
+Reference: `render<width,height,samples>(queue, frame_buf, hittables, cam)` include/render.hpp:141-160.
+Here:      `render(width, height, samples, scene, cam, depth=50, ...) -> torch.Tensor [H][W][3]` on the GPU.
+
+PyTorch is plumbing only: it owns the device framebuffer, the current HIP stream and (for N GPUs)
+the RCCL process group.  All arithmetic happens in the hand-written gfx950 kernels of
+`csrc/pt_render.hip`, reached through `include/pt_render.h`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from . import abi
+from .scene import PackedScene, camera, pack
+
+
+class DeviceScene:
+    """The flattened, HBM-resident scene (pt_scene_create).  Replaces the sycl::buffer wrapping of the
+    hittable vector and image_texture::freeze() (render.hpp:146-148); may be reused across renders."""
+
+    def __init__(self, scene: PackedScene):
+        self.lib = abi.load_library()
+        self.handle = C.c_void_p()
+        self._packed = scene  # keep the host tables alive
+        abi.check(self.lib.pt_scene_create(C.byref(scene.desc), C.byref(self.handle)), "pt_scene_create")
+
+    def close(self):
+        if self.handle:
+            self.lib.pt_scene_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
+
+
+def _params(width, height, samples, depth, shard_index=0, shard_count=1, flags=0) -> abi.PtRenderParams:
+    return abi.PtRenderParams(int(width), int(height), int(samples), int(depth), int(shard_index), int(shard_count),
+                              int(flags), 0)
+
+
+def _as_device_scene(scene) -> DeviceScene:
+    if isinstance(scene, DeviceScene):
+        return scene
+    if isinstance(scene, PackedScene):
+        return DeviceScene(scene)
+    return DeviceScene(pack(scene))  # a list of hittables, like std::vector<hittable_t>
+
+
+def _stream_ptr(torch) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def render(width: int, height: int, samples: int, scene, cam: camera, depth: int = 50, *, flags: int = 0,
+           out=None, shard_index: int = 0, shard_count: int = 1, timed: bool = False):
+    """Launch the render kernel on torch's current device/stream; asynchronous like queue.submit
+    (render.hpp:151) unless `timed`.  Returns the framebuffer tensor — [H][W][3] float32, y=0 bottom
+    row — or, for shard_count>1, this shard's tiles [tiles][64][3].  With `timed`, returns
+    (tensor, kernel_ms) measured with HIP events on the launch stream."""
+    import torch
+
+    if not torch.cuda.is_available():
+        raise RuntimeError("path_tracer_amd.render needs a HIP device: there is no CPU path in the product")
+    lib = abi.load_library()
+    ds = _as_device_scene(scene)
+    p = _params(width, height, samples, depth, shard_index, shard_count, flags)
+    n = lib.pt_framebuffer_floats(C.byref(p))
+    if n < 0:
+        abi.check(abi.PT_ERR_INVALID_ARG, "pt_framebuffer_floats")
+    shape = (height, width, 3) if shard_count == 1 else (n // (abi.PT_TILE_PIXELS * 3), abi.PT_TILE_PIXELS, 3)
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float32, device="cuda")
+    elif out.numel() != n or out.dtype != torch.float32 or not out.is_cuda or not out.is_contiguous():
+        raise ValueError("out must be a contiguous float32 CUDA tensor of pt_framebuffer_floats() elements")
+    if timed:
+        ms = C.c_float()
+        abi.check(lib.pt_render_timed(ds.handle, C.byref(cam.c), C.byref(p), C.c_void_p(out.data_ptr()),
+                                      _stream_ptr(torch), C.byref(ms)), "pt_render_timed")
+        return out, float(ms.value)
+    abi.check(lib.pt_render(ds.handle, C.byref(cam.c), C.byref(p), C.c_void_p(out.data_ptr()), _stream_ptr(torch)),
+              "pt_render")
+    return out
+
+
+def render_host(width: int, height: int, samples: int, scene, cam: camera, depth: int = 50, *, flags: int = 0,
+                shard_index: int = 0, shard_count: int = 1) -> np.ndarray:
+    """Torch-free path: pt_render_host renders into a numpy array (allocates, copies back, syncs)."""
+    lib = abi.load_library()
+    ds = _as_device_scene(scene)
+    p = _params(width, height, samples, depth, shard_index, shard_count, flags)
+    n = lib.pt_framebuffer_floats(C.byref(p))
+    if n < 0:
+        abi.check(abi.PT_ERR_INVALID_ARG, "pt_framebuffer_floats")
+    fb = np.empty(n, dtype=np.float32)
+    abi.check(lib.pt_render_host(ds.handle, C.byref(cam.c), C.byref(p), fb.ctypes.data_as(C.POINTER(C.c_float))),
+              "pt_render_host")
+    return fb.reshape((height, width, 3) if shard_count == 1 else (-1, abi.PT_TILE_PIXELS, 3))
+
+
+def unshard(gathered, width: int, height: int, shard_count: int):
+    """[shard_count][tiles_per_shard][64][3] (the RCCL-gathered buffer) -> [H][W][3] on the root GPU."""
+    import torch
+
+    lib = abi.load_library()
+    p = _params(width, height, 1, 1, 0, shard_count)
+    fb = torch.empty((height, width, 3), dtype=torch.float32, device=gathered.device)
+    abi.check(lib.pt_unshard_tiles(C.c_void_p(gathered.data_ptr()), C.byref(p), C.c_void_p(fb.data_ptr()),
+                                   _stream_ptr(torch)), "pt_unshard_tiles")
+    return fb
+
+
+def render_distributed(width: int, height: int, samples: int, scene, cam: camera, depth: int = 50, *,
+                       flags: int = 0, group=None, gather: bool = True):
+    """One process per GPU (torch.distributed, backend nccl == RCCL).  Tiles are dealt round-robin to
+    ranks (tile g -> rank g % world), each rank renders its tiles with the pixels' GLOBAL seeds
+    (render.hpp:130-131), so the assembled frame is bit-identical to a single-GPU render.  One RCCL
+    gather of the float tiles to rank 0 over xGMI, then a device-side un-interleave.
+    Returns (frame on rank 0 | None elsewhere, local tiles)."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if world == 1:
+        fb = render(width, height, samples, scene, cam, depth, flags=flags)
+        return fb, fb
+    local = render(width, height, samples, scene, cam, depth, flags=flags, shard_index=rank, shard_count=world)
+    if not gather:
+        return None, local
+    bufs = [torch.empty_like(local) for _ in range(world)] if rank == 0 else None
+    dist.gather(local, bufs, dst=0, group=group)
+    if rank != 0:
+        return None, local
+    return unshard(torch.stack(bufs), width, height, world), local
+
+
+def tonemap_rgb8(fb):
+    """Output stage of main.cpp:33-59 on the device: sqrt gamma, clamp [0,0.999], x256 -> u8, rows flipped
+    (row 0 = top).  Returns a uint8 tensor [H][W][3]."""
+    import torch
+
+    lib = abi.load_library()
+    h, w, _ = fb.shape
+    out = torch.empty((h, w, 3), dtype=torch.uint8, device=fb.device)
+    abi.check(lib.pt_tonemap_rgb8(C.c_void_p(fb.data_ptr()), w, h, C.c_void_p(out.data_ptr()), _stream_ptr(torch)),
+              "pt_tonemap_rgb8")
+    return out
