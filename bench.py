@@ -1,0 +1,170 @@
+"""bench.py — Msamples/s of the render() hot path on BASELINE.json's headline config.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (config.workload): configs[1] — Cornell-style scene (7 box + 1 xy_rect, diffuse light),
+1920x1080, 1024 spp, depth 50.  One step = one full render of that frame: N=1 the whole frame on one
+GPU; N>1 the frame's 8x8 tiles dealt round-robin to the ranks, one RCCL gather of the float tiles to
+rank 0 over xGMI and a device-side un-interleave (inside the timed step).  Total work is fixed as N
+grows -> "strong".  The scene is resident in HBM before the timed region (it is ~1 KB; the boundary
+hands over host tables, and uploading them costs microseconds — see DESIGN.md).
+
+Extra objects on the JSON line:
+  roofline      bound = VALU issue (not HBM, not MFMA).  achieved = algorithmic
+                lane-ops/sample (oracle event counters x the per-event op costs of SURVEY.md §8d)
+                x samples/s of the render kernel, measured with HIP events on the launch stream.
+  cpu_baseline  the CPU oracle (kind "port": the reference itself needs triSYCL and cannot be built)
+                timed on this host's cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12  # 78.6 T lane-ops/s: 256 CU x 4 SIMD-32 x 2.4 GHz (MI355X_MICROARCH.md)
+
+# per-event algorithmic op costs as written in the reference (1 op = one fp32
+# add/sub/mul/div/cmp/sqrt/cvt or int32 shift/xor; a transcendental call counts 4)
+OPS = dict(rng_draw=8, sphere_miss=25, sphere_accept=58 + 2 * 4, rect_test=12, rect_accept=33, tri_test=40,
+           tri_accept=84, medium_extra=25 + 4, camera=91 - 5 * 8, sky=24, lambertian=46 - 3 * 8, metal=71 + 16 - 3 * 8,
+           dielectric=60 + 4, isotropic=41 + 16 - 3 * 8, light=4)
+
+
+def ops_per_sample(ctr: dict) -> float:
+    """Algorithmic lane-ops per sample from the oracle's event counters."""
+    n = ctr["samples"]
+    acc = ctr["accepts"]
+    sphere_acc = acc[0]
+    rect_acc = acc[1] + acc[5] + acc[6] + acc[3]  # top-level rects + one accepted side per accepted box (lower bound)
+    total = (ctr["rng_draws"] * OPS["rng_draw"]
+             + (ctr["sphere_tests"] - sphere_acc) * OPS["sphere_miss"] + sphere_acc * OPS["sphere_accept"]
+             + (ctr["rect_tests"] - rect_acc) * OPS["rect_test"] + rect_acc * OPS["rect_accept"]
+             + (ctr["tests"][2] - acc[2]) * OPS["tri_test"] + acc[2] * OPS["tri_accept"]
+             + ctr["tests"][4] * OPS["medium_extra"]
+             + n * OPS["camera"] + ctr["end_sky"] * OPS["sky"]
+             + ctr["scatters"][0] * OPS["lambertian"] + ctr["scatters"][1] * OPS["metal"]
+             + ctr["scatters"][2] * OPS["dielectric"] + ctr["scatters"][3] * OPS["light"]
+             + ctr["scatters"][4] * OPS["isotropic"])
+    return total / n
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scene", default="cornell", choices=["cornell", "smoke", "triangles"])
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=1024)
+    ap.add_argument("--depth", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--flags", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from path_tracer_amd import render as R
+    from path_tracer_amd import scenes
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    W, H, SPP, DEPTH = args.width, args.height, args.spp, args.depth
+    kw = {"n_triangles": 100_000} if args.scene == "triangles" else {}
+    packed, cam_args = scenes.build(args.scene, **kw)
+    cam = scenes.make_camera(cam_args, W, H)
+    ds = R.DeviceScene(packed)  # scene resident in HBM before the timed region
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    kernel_ms = []
+
+    def step():
+        if world == 1:
+            fb, ms = R.render(W, H, SPP, ds, cam, DEPTH, flags=args.flags, timed=True)
+            kernel_ms.append(ms)
+            return fb
+        local, ms = R.render(W, H, SPP, ds, cam, DEPTH, flags=args.flags, shard_index=rank, shard_count=world, timed=True)
+        kernel_ms.append(ms)
+        bufs = [torch.empty_like(local) for _ in range(world)] if rank == 0 else None
+        dist.gather(local, bufs, dst=0)
+        return R.unshard(torch.stack(bufs), W, H, world) if rank == 0 else None
+
+    for _ in range(args.warmup):
+        step()
+    kernel_ms.clear()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        fb = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed, sum(kernel_ms) / max(1, len(kernel_ms))], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, kern_ms = float(t[0]), float(t[1])
+    else:
+        kern_ms = sum(kernel_ms) / max(1, len(kernel_ms))
+
+    if rank == 0:
+        samples_per_step = W * H * SPP
+        value = samples_per_step * args.steps / elapsed / 1e6
+        # --- checker-side numbers (oracle: test infrastructure, used here only for counters + CPU baseline)
+        from oracle import binding as orc
+        orc.set_math(True)
+        cw, ch, cs = (480, 270, 4) if args.scene != "triangles" else (96, 54, 1)
+        _, ctr = orc.render(packed, scenes.make_camera(cam_args, cw, ch).c, cw, ch, cs, DEPTH, counters=True)
+        ops = ops_per_sample(ctr.as_dict())
+        kernel_samples_per_s = (samples_per_step / world) / (kern_ms * 1e-3) * world if world > 1 else samples_per_step / (kern_ms * 1e-3)
+        achieved = ops * kernel_samples_per_s / 1e12 / world  # per GPU
+        line = {
+            "metric": "Msamples/s (W x H x spp / s) at 1080p 1024spp", "value": round(value, 2), "unit": "Msamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.scene}: " + ("Cornell-style 7 box + 1 xy_rect + diffuse light" if args.scene == "cornell" else args.scene)
+                       + f", {W}x{H}, {SPP} spp, depth {DEPTH}, seed = pixel linear id",
+                       "hittables": packed.n_hittables, "sharding": "whole frame" if world == 1 else f"8x8 tiles round-robin over {world} ranks + RCCL gather"},
+            "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": round(PEAK_TLANEOPS, 1), "unit": "Tlaneop/s",
+                         "frac": round(achieved / PEAK_TLANEOPS, 4), "traffic": None,
+                         "kernel": "render_kernel", "kernel_ms": round(kern_ms, 3),
+                         "algorithmic_ops_per_sample": round(ops, 1),
+                         "kernel_msamples_per_s_per_gpu": round(kernel_samples_per_s / world / 1e6, 2),
+                         "hbm_algorithmic_bytes": W * H * 12 // world},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            bw, bh, bs = W, H, (8 if args.scene == "cornell" else 1)
+            if args.scene == "triangles":
+                bw, bh, bs = 240, 135, 1
+            bcam = scenes.make_camera(cam_args, bw, bh)
+            t1 = time.perf_counter()
+            orc.render(packed, bcam.c, bw, bh, bs, DEPTH)
+            dt = time.perf_counter() - t1
+            line["cpu_baseline"] = {"value": round(bw * bh * bs / dt / 1e6, 3), "unit": "Msamples/s",
+                                    "cores": orc.load().orc_max_threads(), "kind": "port",
+                                    "sample": f"same scene, {bw}x{bh}, {bs} spp, depth {DEPTH} ({bw * bh * bs / 1e6:.1f} Msamples, {dt:.1f} s), OpenMP CPU oracle, portable math"}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -61,6 +61,8 @@ def load() -> C.CDLL:
                                _FP, C.POINTER(OrcCounters)]
     lib.orc_render_rows.argtypes = [C.POINTER(abi.PtSceneDesc), C.POINTER(abi.PtCamera),
                                     C.POINTER(abi.PtRenderParams), C.c_int32, C.c_int32, _FP, C.POINTER(OrcCounters)]
+    lib.orc_render_pixels.argtypes = [C.POINTER(abi.PtSceneDesc), C.POINTER(abi.PtCamera),
+                                      C.POINTER(abi.PtRenderParams), C.POINTER(C.c_int32), C.c_int32, _FP]
     lib.orc_bounce.argtypes = [C.POINTER(abi.PtSceneDesc), C.POINTER(abi.PtBounceIn), C.POINTER(abi.PtBounceOut),
                                C.c_int32, C.c_int32]
     lib.orc_camera_rays.argtypes = [C.POINTER(abi.PtCamera), C.c_int32, C.c_int32, C.POINTER(C.c_int32),
@@ -119,6 +121,18 @@ def render_rows(packed, cam: abi.PtCamera, width, height, samples, y0, y1, depth
     if rc:
         raise RuntimeError(f"orc_render_rows: error {rc}")
     return (fb, ctr) if counters else fb
+
+
+def render_pixels(packed, cam: abi.PtCamera, width, height, samples, xy: np.ndarray, depth=50) -> np.ndarray:
+    lib = load()
+    p = params(width, height, samples, depth)
+    xy = np.ascontiguousarray(xy, dtype=np.int32)
+    out = np.zeros((len(xy), 3), dtype=np.float32)
+    rc = lib.orc_render_pixels(C.byref(packed.desc), C.byref(cam), C.byref(p), xy.ctypes.data_as(C.POINTER(C.c_int32)),
+                               len(xy), _fp(out))
+    if rc:
+        raise RuntimeError(f"orc_render_pixels: error {rc}")
+    return out
 
 
 def bounce(packed, recs_in):

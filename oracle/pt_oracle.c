@@ -612,6 +612,19 @@ int orc_render_rows(const PtSceneDesc* sc, const PtCamera* cam, const PtRenderPa
   return render_rows(sc, cam, p, y0, y1, fb_rows, (int64_t)y0 * p->width * 3, counters);
 }
 
+/* Arbitrary pixels of the frame (full spp each): lets a test check a 1080p x 1024 spp GPU frame at
+ * sampled positions in seconds. xy = [n][2], out = [n][3].                                            */
+int orc_render_pixels(const PtSceneDesc* sc, const PtCamera* cam, const PtRenderParams* p, const int32_t* xy,
+                      int32_t n, float* out) {
+  int rc = validate(sc);
+  if (rc) return rc;
+  if (!cam || !p || !xy || !out || p->width <= 0 || p->height <= 0 || p->samples <= 0 || p->depth < 0)
+    return PT_ERR_INVALID_ARG;
+#pragma omp parallel for schedule(dynamic, 4)
+  for (int32_t k = 0; k < n; k++) render_pixel(sc, cam, p, xy[2 * k], xy[2 * k + 1], out + 3 * (int64_t)k, NULL);
+  return PT_OK;
+}
+
 /* ---- function-level probes ---------------------------------------------------------------------------- */
 
 int orc_bounce(const PtSceneDesc* sc, const PtBounceIn* in, PtBounceOut* out, int32_t n, int32_t depth_unused) {

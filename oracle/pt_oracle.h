@@ -64,6 +64,10 @@ int orc_render(const PtSceneDesc* scene, const PtCamera* cam, const PtRenderPara
 int orc_render_rows(const PtSceneDesc* scene, const PtCamera* cam, const PtRenderParams* p,
                     int32_t y0, int32_t y1, float* fb_rows, OrcCounters* counters);
 
+/* Arbitrary pixels (full spp each) of the frame: xy = [n][2] -> out [n][3].    */
+int orc_render_pixels(const PtSceneDesc* scene, const PtCamera* cam, const PtRenderParams* p,
+                      const int32_t* xy, int32_t n, float* out);
+
 int orc_bounce(const PtSceneDesc* scene, const PtBounceIn* in, PtBounceOut* out, int32_t n,
                int32_t depth_unused);
 

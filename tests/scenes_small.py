@@ -1,0 +1,105 @@
+"""Small scenes shared by the CPU and GPU tests: every hittable kind, every material, every texture,
+the edge cases the reference's semantics make interesting (ties, nested media, moving spheres, stale UV)."""
+import numpy as np
+
+from path_tracer_amd import scenes
+from path_tracer_amd.scene import (TextureAtlas, box, checker_texture, constant_medium, dielectric_material,
+                                   image_texture, lambertian_material, lightsource_material, metal_material, pack,
+                                   sphere, triangle, xy_rect, xz_rect, yz_rect)
+
+
+def _atlas_image(atlas, w=37, h=23, freq=1.0):
+    y, x = np.mgrid[0:h, 0:w]
+    rgb = np.stack([(x * 7 + y * 3) % 256, (x * 5 + 11 * y) % 256, (x * y) % 256], axis=-1).astype(np.uint8)
+    return image_texture.from_array(rgb, freq, atlas)
+
+
+def mixed_scene():
+    """All seven hittable kinds, five materials, three textures, both medium boundaries, in an order that
+    interleaves kinds (many short runs)."""
+    atlas = TextureAtlas()
+    img = _atlas_image(atlas)
+    img5 = _atlas_image(atlas, 16, 9, 5.0)
+    hs = [
+        sphere((0, -100.5, -1), 100, lambertian_material(checker_texture((0.2, 0.3, 0.1), (0.9, 0.9, 0.9)))),
+        sphere((0, 0, -1), 0.5, lambertian_material((0.7, 0.3, 0.3))),
+        xy_rect(-2, -1, -0.5, 1, -1.5, lambertian_material(img)),
+        sphere((1, 0, -1), 0.5, metal_material((0.8, 0.6, 0.2), 0.3)),
+        sphere((-1, 0, -1), 0.5, dielectric_material(1.5, (1, 1, 1))),
+        sphere((-1, 0, -1), -0.45, dielectric_material(1.5, (1.0, 0.9, 0.9))),  # negative radius: hollow glass
+        triangle((-0.5, 0.6, -1.2), (0.5, 0.6, -1.2), (0, 1.3, -0.9), lambertian_material(img5)),  # stale-UV path
+        box((1.2, -0.5, -2.5), (1.8, 0.7, -1.9), metal_material((0.7, 0.6, 0.5), 0.0)),
+        sphere((0.3, 0.1, -0.2), (0.3, 0.3, -0.2), 0.0, 1.0, 0.12, lambertian_material(img)),  # moving + image
+        constant_medium(sphere((0.8, 0.9, -1.2), 0.4, lambertian_material((1, 1, 1))), 3.0, (0.9, 0.9, 1.0)),
+        xz_rect(-1, 1, -2, 0, 2.5, lightsource_material((4, 4, 4))),
+        yz_rect(-0.5, 1.5, -2.5, -0.5, -2.2, lambertian_material((0.2, 0.8, 0.2))),
+        constant_medium(box((-1.9, -0.5, -0.9), (-1.3, 0.2, -0.3), lambertian_material((1, 1, 1))), 5.0,
+                        checker_texture((0.1, 0.1, 0.1), (0.9, 0.2, 0.2))),
+        sphere((0, 0.2, 0.6), 0.15, lightsource_material(img5)),
+    ]
+    cam = dict(look_from=(0.3, 0.6, 2.5), look_at=(0, 0.2, -1), vup=(0, 1, 0), vfov=50.0, aperture=0.1,
+               focus_dist=3.4, time0=0.0, time1=1.0)
+    return pack(hs, atlas), cam
+
+
+def spheres_scene():
+    """No image texture, no medium: spheres (static + moving), all scattering materials, checker."""
+    hs = [sphere((0, -1000, 0), 1000, lambertian_material(checker_texture((0.2, 0.3, 0.1), (0.9, 0.9, 0.9))))]
+    rng = scenes.HostRNG(4242)
+    for a in range(-3, 3):
+        for b in range(-3, 3):
+            c = (a + 0.9 * float(rng.float_t()), 0.2, b + 0.9 * float(rng.float_t()))
+            m = float(rng.float_t())
+            if m < 0.3:
+                hs.append(sphere(c, 0.2, lambertian_material(tuple(rng.vec_t()))))
+            elif m < 0.6:
+                c2 = (c[0], c[1] + 0.3 * float(rng.float_t()), c[2])
+                hs.append(sphere(c, c2, 0.0, 1.0, 0.2, lambertian_material(tuple(rng.vec_t()))))
+            elif m < 0.8:
+                hs.append(sphere(c, 0.2, metal_material(tuple(rng.vec_t(0.5, 1)), float(rng.float_t(0, 0.5)))))
+            else:
+                hs.append(sphere(c, 0.2, dielectric_material(1.5, (1, 1, 1))))
+    hs.append(sphere((0, 1, 0), 1.0, dielectric_material(1.5, (1.0, 0.5, 0.5))))
+    hs.append(sphere((4, 1, 0), 0.2, lightsource_material((10, 0, 10))))
+    cam = dict(look_from=(6, 2, 3), look_at=(0, 0.5, 0), vup=(0, 1, 0), vfov=40.0, aperture=0.05, focus_dist=7.0,
+               time0=0.0, time1=1.0)
+    return pack(hs), cam
+
+
+def triangles_scene(n=300):
+    return scenes.triangle_mesh_scene(n, seed=7, n_colors=8)
+
+
+def ties_scene():
+    """Coplanar / touching surfaces: equal-t ties resolve by list position (rects accept t == max,
+    spheres need t < max: rectangle.hpp:36 vs sphere.hpp:77)."""
+    white = lambertian_material((0.8, 0.8, 0.8))
+    red = lambertian_material((0.9, 0.1, 0.1))
+    blue = lambertian_material((0.1, 0.1, 0.9))
+    hs = [
+        xy_rect(-1, 1, -1, 1, -2, red),
+        xy_rect(-0.5, 1.5, -0.5, 1.5, -2, blue),          # same plane, later in the list: wins the overlap
+        box((-2, -1.5, -3), (2, -1, -1), white),
+        box((-2, -1.5, -3), (0, -1, -1), red),            # shares faces with the previous box
+        sphere((0, 0, -2), 0.5, white),
+        sphere((0, 0, -2), 0.5, blue),                    # identical sphere later: loses (strict <)
+        triangle((-1.5, 1, -2), (-0.5, 1, -2), (-1, 1.8, -2), red),
+        triangle((-1.5, 1, -2), (-0.5, 1, -2), (-1, 1.8, -2), blue),
+    ]
+    cam = dict(look_from=(0, 0, 1), look_at=(0, 0, -2), vup=(0, 1, 0), vfov=70.0, aperture=0.0, focus_dist=3.0,
+               time0=0.0, time1=0.0)
+    return pack(hs), cam
+
+
+def empty_scene():
+    cam = dict(look_from=(0, 0, 1), look_at=(0, 0, -1), vup=(0, 1, 0), vfov=60.0, aperture=0.0, focus_dist=1.0,
+               time0=0.0, time1=0.0)
+    return pack([]), cam
+
+
+def cornell_scene():
+    return scenes.build("cornell")
+
+
+ALL = {"cornell": cornell_scene, "mixed": mixed_scene, "spheres": spheres_scene, "triangles": triangles_scene,
+       "ties": ties_scene, "empty": empty_scene}

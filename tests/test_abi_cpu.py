@@ -1,0 +1,182 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads without a GPU, exports every symbol
+include/pt_render.h declares, agrees with the header on struct sizes, flattens scenes as documented,
+and reports malformed input through error codes (no compute calls: those need the GPU)."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import scenes_small as S
+from path_tracer_amd import abi, scenes
+from path_tracer_amd.scene import (box, camera, constant_medium, lambertian_material, metal_material, pack, sphere,
+                                   triangle, xy_rect, xz_rect)
+
+HEADER = Path(__file__).resolve().parent.parent / "include" / "pt_render.h"
+
+
+def declared_functions():
+    text = re.sub(r"/\*.*?\*/", "", HEADER.read_text(), flags=re.S)
+    return sorted(set(re.findall(r"\b(pt_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(lib):
+    names = declared_functions()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), f"libpt_render.so does not export {n}"
+    assert set(names) == set(abi.SIGNATURES), "abi.py and pt_render.h disagree on the entry points"
+
+
+def test_abi_version_and_errors(lib):
+    assert lib.pt_abi_version() == abi.PT_ABI_VERSION
+    assert lib.pt_error_string(abi.PT_OK) == b"ok"
+    assert b"scene" in lib.pt_error_string(abi.PT_ERR_BAD_SCENE)
+
+
+def test_struct_sizes_match_header():
+    text = HEADER.read_text()
+    for name, size in (("PtHittable", 64), ("PtMaterial", 32), ("PtTexture", 48), ("PtCamera", 96)):
+        assert f"typedef struct {name}" in text
+        assert C.sizeof(getattr(abi, name)) == size
+
+
+def test_camera_matches_oracle(orc):
+    for args in [((13, 3, 3), (0, -1, 0), (0, 1, 0), 40, 400 / 225, 0.04, 13.928, 0, 1),
+                 ((278, 278, -800), (278, 278, 0), (0, 1, 0), 40, 16 / 9, 0, 800, 0, 1),
+                 ((1, 2, 3), (-4, 0.5, 2), (0.1, 1, 0.2), 75.5, 1.25, 0.5, 3.3, 0.25, 0.75)]:
+        a = camera(*args)
+        b = orc.camera_init(*args)
+        assert bytes(a.c) == bytes(b)
+
+
+def test_framebuffer_sizes(lib):
+    p = abi.PtRenderParams(1920, 1080, 1, 50, 0, 1, 0, 0)
+    assert lib.pt_framebuffer_floats(C.byref(p)) == 1920 * 1080 * 3
+    p = abi.PtRenderParams(1920, 1080, 1, 50, 3, 8, 0, 0)
+    assert lib.pt_shard_tiles(C.byref(p)) == 240 * 135 // 8
+    assert lib.pt_framebuffer_floats(C.byref(p)) == 240 * 135 // 8 * 64 * 3
+    p = abi.PtRenderParams(21, 13, 1, 50, 0, 4, 0, 0)  # 3x2 tiles, padded to 2 per shard
+    assert lib.pt_shard_tiles(C.byref(p)) == 2
+    for bad in (abi.PtRenderParams(0, 8, 1, 1, 0, 1, 0, 0), abi.PtRenderParams(8, 8, 0, 1, 0, 1, 0, 0),
+                abi.PtRenderParams(8, 8, 1, 1, 2, 2, 0, 0), abi.PtRenderParams(8, 8, 1, -1, 0, 1, 0, 0)):
+        assert lib.pt_framebuffer_floats(C.byref(bad)) == -1
+
+
+def flatten(lib, ps):
+    n_f4, n_runs, flags = C.c_int32(), C.c_int32(), C.c_int32()
+    rc = lib.pt_debug_flatten(C.byref(ps.desc), None, 0, C.byref(n_f4), C.byref(n_runs), None, 0, C.byref(flags))
+    if rc:
+        return rc, None, None, None, None
+    blob = np.zeros((n_f4.value, 4), np.float32)
+    mats = np.zeros((ps.n_materials * 4, 4), np.float32)
+    FP = C.POINTER(C.c_float)
+    rc = lib.pt_debug_flatten(C.byref(ps.desc), blob.ctypes.data_as(FP), len(blob), None, None,
+                              mats.ctypes.data_as(FP), len(mats), None)
+    return rc, blob, mats, n_runs.value, flags.value
+
+
+def test_flatten_preserves_list_order(lib):
+    """Traversal order is semantics (constant_medium's in-traversal RNG draw, equal-t ties): runs are
+    maximal stretches of one kind in list order, and record i of a run is hittable first+i."""
+    m = lambertian_material((0.5, 0.5, 0.5))
+    hs = [sphere((0, 0, 0), 1, m), sphere((1, 0, 0), 2, m), xy_rect(0, 1, 0, 1, 5, m), xz_rect(0, 1, 0, 1, 6, m),
+          sphere((2, 0, 0), 3, m), box((0, 0, 0), (1, 1, 1), m), triangle((0, 0, 0), (1, 0, 0), (0, 1, 0), m),
+          triangle((0, 0, 1), (1, 0, 1), (0, 1, 1), m), constant_medium(sphere((0, 0, 0), 1, m), 2.0, (1, 1, 1)),
+          sphere((3, 0, 0), 4, m)]
+    ps = pack(hs)
+    rc, blob, mats, n_runs, flags = flatten(lib, ps)
+    assert rc == 0 and n_runs == 7 and flags == 2
+    runs = blob[:n_runs].view(np.int32)
+    assert runs[:, 0].tolist() == [0, 1, 0, 3, 2, 4, 0]       # device kinds: sphere, rect, sphere, box, tri, medium, sphere
+    assert runs[:, 2].tolist() == [2, 2, 1, 1, 2, 1, 1]        # counts
+    assert runs[:, 3].tolist() == [0, 2, 4, 5, 6, 8, 9]        # first hittable of each run
+    sizes = {0: 3, 1: 2, 2: 3, 3: 2, 4: 4}
+    off = n_runs
+    for kind, first, count, _ in runs:
+        assert first == off
+        off += sizes[int(kind)] * int(count)
+    assert off == len(blob)
+    # sphere record: (c0, r^2) (r, mat, t0, t1) (c1, hittable index)
+    s1 = blob[runs[0, 1] + 3: runs[0, 1] + 6]
+    assert s1[0].tolist() == [1, 0, 0, 4] and s1[1, 0] == 2 and s1[2].view(np.int32)[3] == 1
+    # rect record carries its axis (xy=0, xz=1)
+    r = blob[runs[1, 1]: runs[1, 1] + 4]
+    assert r[1].view(np.int32)[2] == 0 and r[3].view(np.int32)[2] == 1 and r[1, 0] == 5 and r[3, 0] == 6
+    # triangle record stores edges v1-v0, v2-v0
+    t = blob[runs[4, 1]: runs[4, 1] + 3]
+    assert t[1, :3].tolist() == [1, 0, 0] and t[2, :3].tolist() == [0, 1, 0]
+    # medium record: boundary kind, neg_inv_density = -1/2
+    md = blob[runs[5, 1]]
+    assert md.view(np.int32)[0] == 0 and md[1] == np.float32(-0.5)
+
+
+def test_flatten_flags_and_materials(lib):
+    ps, _ = S.mixed_scene()
+    rc, blob, mats, n_runs, flags = flatten(lib, ps)
+    assert rc == 0 and flags == 3  # image texture + medium
+    ps, _ = S.cornell_scene()
+    rc, blob, mats, n_runs, flags = flatten(lib, ps)
+    assert rc == 0 and flags == 0 and n_runs == 3  # boxes, xy_rect, boxes
+    kinds = mats[0::4].view(np.int32)[:, 0].tolist()
+    assert kinds == [abi.PT_MAT_LAMBERTIAN, abi.PT_MAT_LAMBERTIAN, abi.PT_MAT_LIGHTSOURCE, abi.PT_MAT_LAMBERTIAN]
+    assert mats[2 * 4 + 1, :3].tolist() == [15, 15, 15]  # light colour inlined from its solid texture
+
+
+@pytest.mark.parametrize("mutate,code", [
+    (lambda ps: setattr(ps.hittables[0], "kind", 9), abi.PT_ERR_BAD_SCENE),
+    (lambda ps: setattr(ps.hittables[1], "material", -1), abi.PT_ERR_BAD_SCENE),
+    (lambda ps: setattr(ps.materials[0], "kind", 7), abi.PT_ERR_BAD_SCENE),
+    (lambda ps: setattr(ps.materials[0], "texture", 1000), abi.PT_ERR_BAD_SCENE),
+    (lambda ps: setattr(ps.textures[0], "kind", 3), abi.PT_ERR_BAD_SCENE),
+])
+def test_malformed_scene_is_an_error_code(lib, mutate, code):
+    ps, _ = S.cornell_scene()
+    mutate(ps)
+    rc, *_ = flatten(lib, ps)
+    assert rc == code
+    assert lib.pt_last_error() != b""
+
+
+def test_image_outside_atlas_rejected(lib):
+    ps, _ = S.mixed_scene()
+    for i in range(ps.n_textures):
+        if ps.textures[i].kind == abi.PT_TEX_IMAGE:
+            ps.textures[i].offset = 10 ** 7
+    assert flatten(lib, ps)[0] == abi.PT_ERR_BAD_SCENE
+
+
+def test_constructor_semantics():
+    assert metal_material((1, 1, 1), 7.0).fuzz == 1.0 and metal_material((1, 1, 1), -1).fuzz == 0.0  # material.hpp:37
+    s = sphere((1, 2, 3), 0.5, lambertian_material((1, 1, 1)))
+    assert s.center0 == s.center1 and s.time0 == s.time1 == 0.0  # sphere.hpp:30-36
+    cm = constant_medium(s, 4, (1, 1, 1))
+    assert cm.neg_inv_density == -0.25
+    with pytest.raises(TypeError):
+        constant_medium(xy_rect(0, 1, 0, 1, 0, lambertian_material((1, 1, 1))), 1, (1, 1, 1))
+    ps = pack([s, s, cm])
+    assert ps.n_materials == 2 and ps.n_textures == 1  # value-equal materials/textures are shared
+
+
+def test_scene_generators_are_deterministic():
+    a, _ = scenes.build("smoke")
+    b, _ = scenes.build("smoke")
+    assert bytes(a.hittables) == bytes(b.hittables) and a.n_hittables > 480
+    kinds = a.kinds()
+    assert kinds[0] == abi.PT_HIT_SPHERE and kinds[-1] == abi.PT_HIT_CONSTANT_MEDIUM and kinds.count(abi.PT_HIT_TRIANGLE) == 4
+    t, _ = scenes.triangle_mesh_scene(1000)
+    assert t.n_hittables == 1002
+    f = np.frombuffer(bytes(t.hittables), dtype=scenes.hittable_dtype)
+    tri = f[1:-1]["f"]
+    assert np.abs(tri[:, 3:6] - tri[:, 0:3]).max() <= 0.15 + 1e-6
+
+
+def test_no_gpu_is_reported_not_crashed(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    ps, _ = S.cornell_scene()
+    h = C.c_void_p()
+    rc = lib.pt_scene_create(C.byref(ps.desc), C.byref(h))
+    assert rc in (abi.PT_ERR_NO_DEVICE, abi.PT_ERR_HIP) and not h.value

@@ -1,0 +1,78 @@
+"""The pinned transcendental set (oracle copy, oracle/ptm_portable.h) against glibc: how far the project's
+definition of sin/cos/log/pow5/atan2/asin/fmod1 sits from the platform libm the reference would call."""
+import numpy as np
+import pytest
+
+from conftest import bits
+
+SIN, COS, LOG, POW5, ATAN2, ASIN, FMOD1, SQRT, DIV = range(9)
+
+
+def ulp_diff(a, b):
+    ia = bits(a).astype(np.int64)
+    ib = bits(b).astype(np.int64)
+    ia = np.where(ia < 0x80000000, ia, 0x80000000 - ia)
+    ib = np.where(ib < 0x80000000, ib, 0x80000000 - ib)
+    return np.abs(ia - ib)
+
+
+def both(orc, op, a, b=None):
+    orc.set_math(True)
+    p = orc.math(op, a, b)
+    orc.set_math(False)
+    g = orc.math(op, a, b)
+    return p, g
+
+
+def inputs(rng, n):
+    u = rng.random(n, dtype=np.float32)
+    return {
+        SIN: np.concatenate([u * np.float32(2 * np.pi), (u - 0.5) * 2e4, (u - 0.5) * 2e-3, np.float32([0, -0.0, 1e-30, 1e5, -3e6, 1e8])]).astype(np.float32),
+        LOG: np.concatenate([u, u * 1e-6, np.float32([1.0, 2.0 ** -32, 0.5, 1e-38, 3e-39])]).astype(np.float32),
+        POW5: np.concatenate([u * 2, np.float32([0, 1, 2, 1e-8, 1e-10, -0.5])]).astype(np.float32),
+        ASIN: np.concatenate([u * 2 - 1, np.float32([0, 1, -1, 1e-8, 0.99999994])]).astype(np.float32),
+    }
+
+
+# measured here (glibc 2.35, 200k inputs): identical bits sin .991 cos .991 log .996 pow5 .9994 asin .926
+# atan2 .839 (glibc's float atan2f/asinf are the less accurate side); max distance 1 ulp everywhere
+@pytest.mark.parametrize("op,name,bound,same", [(SIN, "sin", 1, .97), (COS, "cos", 1, .97), (LOG, "log", 1, .97),
+                                                (POW5, "pow5", 1, .97), (ASIN, "asin", 1, .85)])
+def test_within_one_ulp_of_glibc(orc, op, name, bound, same):
+    rng = np.random.default_rng(op + 1)
+    a = inputs(rng, 200_000)[SIN if op == COS else op]
+    p, g = both(orc, op, a)
+    d = ulp_diff(p, g)
+    assert d.max() <= bound, f"{name}: max {d.max()} ulp at {a[d.argmax()]!r}"
+    # the two agree bit-for-bit on the vast majority of inputs (both are near-correctly-rounded)
+    assert (d == 0).mean() > same, f"{name}: only {(d == 0).mean():.4f} identical"
+
+
+def test_atan2_within_one_ulp(orc):
+    rng = np.random.default_rng(9)
+    y = (rng.random(200_000, dtype=np.float32) * 2 - 1).astype(np.float32)
+    x = (rng.random(200_000, dtype=np.float32) * 2 - 1).astype(np.float32)
+    p, g = both(orc, ATAN2, y, x)
+    d = ulp_diff(p, g)
+    assert d.max() <= 1 and (d == 0).mean() > 0.75
+
+
+def test_special_values(orc):
+    orc.set_math(True)
+    inf, nan = np.float32(np.inf), np.float32(np.nan)
+    assert np.isnan(orc.math(SIN, np.float32([inf, -inf, nan]))).all()
+    assert np.isnan(orc.math(COS, np.float32([inf, nan]))).all()
+    lg = orc.math(LOG, np.float32([0.0, 1.0, inf, -1.0, nan]))
+    assert lg[0] == -inf and lg[1] == 0 and lg[2] == inf and np.isnan(lg[3]) and np.isnan(lg[4])
+    assert orc.math(POW5, np.float32([2.0, -2.0, 0.0])).tolist() == [32.0, -32.0, 0.0]
+    at = orc.math(ATAN2, np.float32([0.0, 0.0, 1.0, -1.0, -0.0]), np.float32([1.0, -1.0, 0.0, 0.0, -1.0]))
+    np.testing.assert_array_equal(at, np.float32([0.0, np.pi, np.pi / 2, -np.pi / 2, -np.pi]))
+    asn = orc.math(ASIN, np.float32([1.0, -1.0, 0.0, 1.5]))
+    assert asn[0] == np.float32(np.pi / 2) and asn[1] == np.float32(-np.pi / 2) and asn[2] == 0 and np.isnan(asn[3])
+
+
+def test_fmod1_is_exact(orc):
+    rng = np.random.default_rng(3)
+    a = np.concatenate([(rng.random(100_000, dtype=np.float32) - 0.5) * 50, np.float32([0, -0.0, 1, -1, 2.5, -2.5, 1e10, 8388608.5])]).astype(np.float32)
+    p, g = both(orc, FMOD1, a)
+    np.testing.assert_array_equal(bits(p), bits(g))
