@@ -142,6 +142,14 @@ def load_library() -> C.CDLL:
         raise ImportError(
             f"{path} is missing: the gfx950 HIP extension has not been built. "
             "Run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc cross-compiles without a GPU).")
+    # PyTorch ships its own copy of the HIP runtime (torch/lib/libamdhip64.so, SONAME libamdhip64.so.7).  Two
+    # HIP runtimes in one process cannot both see the GPU, and torch asks for its copy by file name, so the
+    # order matters: with torch loaded first the loader binds this library's libamdhip64.so.7 dependency to
+    # torch's copy by SONAME; loaded the other way round the process would end up with two runtimes.
+    try:
+        import torch  # noqa: F401  (plumbing: device memory, streams, RCCL)
+    except ImportError:
+        pass  # torch-free hosts bind to /opt/rocm/lib through the library's RUNPATH
     lib = C.CDLL(str(path))
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export what the header declares
