@@ -68,7 +68,9 @@ __device__ __forceinline__ V3 xyz(f4 v) { return mk(v.x, v.y, v.z); }
 __device__ __forceinline__ float length_squared(V3 v) {
   return __builtin_fmaf(v.x, v.x, __builtin_fmaf(v.y, v.y, v.z * v.z));
 }
-__device__ __forceinline__ float sqrt_rn(float x) { return __fsqrt_rn(x); }
+// Correctly rounded fp32 sqrt: __builtin_sqrtf under -fhip-fp32-correctly-rounded-divide-sqrt (the HIP header's
+// __fsqrt_rn is the 1-ulp native v_sqrt_f32 unless OCML_BASIC_ROUNDED_OPERATIONS is defined).
+__device__ __forceinline__ float sqrt_rn(float x) { return __builtin_sqrtf(x); }
 
 struct Ray {
   V3 o, d;
