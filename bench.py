@@ -104,9 +104,7 @@ def main() -> None:
             return fb
         local, ms = R.render(W, H, SPP, ds, cam, DEPTH, flags=args.flags, shard_index=rank, shard_count=world, timed=True)
         kernel_ms.append(ms)
-        bufs = [torch.empty_like(local) for _ in range(world)] if rank == 0 else None
-        dist.gather(local, bufs, dst=0)
-        return R.unshard(torch.stack(bufs), W, H, world) if rank == 0 else None
+        return R.gather_frame(local, W, H)  # one RCCL gather of the float tiles to rank 0 + un-interleave
 
     for _ in range(args.warmup):
         step()
@@ -151,10 +149,13 @@ def main() -> None:
                          "hbm_algorithmic_bytes": W * H * 12 // world},
         }
         if world == 1 and not args.no_cpu_baseline:
-            bw, bh, bs = W, H, (8 if args.scene == "cornell" else 1)
-            if args.scene == "triangles":
-                bw, bh, bs = 240, 135, 1
+            # bounded sample of the same workload, sized for ~15 s of CPU work from a 1-spp probe
+            bw, bh = (W, H) if args.scene != "triangles" else (240, 135)
             bcam = scenes.make_camera(cam_args, bw, bh)
+            t1 = time.perf_counter()
+            orc.render(packed, bcam.c, bw, bh, 1, DEPTH)
+            probe = time.perf_counter() - t1
+            bs = int(max(1, min(SPP, round(15.0 / max(probe, 1e-3)))))
             t1 = time.perf_counter()
             orc.render(packed, bcam.c, bw, bh, bs, DEPTH)
             dt = time.perf_counter() - t1

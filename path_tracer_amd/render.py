@@ -115,14 +115,28 @@ def unshard(gathered, width: int, height: int, shard_count: int):
     return fb
 
 
+def gather_frame(local, width: int, height: int, group=None, unshard_fn=None):
+    """The exchange step of the N-GPU path: ONE gather of every rank's float tiles to rank 0 (RCCL over xGMI
+    with the nccl backend; gloo in the CPU tests), then the un-interleave on the root.  `local` is this rank's
+    [tiles_per_shard][64][3] tensor.  Returns the [H][W][3] frame on rank 0, None elsewhere."""
+    import torch
+    import torch.distributed as dist
+
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    bufs = [torch.empty_like(local) for _ in range(world)] if rank == 0 else None
+    dist.gather(local, bufs, dst=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    if rank != 0:
+        return None
+    return (unshard_fn or unshard)(torch.stack(bufs), width, height, world)
+
+
 def render_distributed(width: int, height: int, samples: int, scene, cam: camera, depth: int = 50, *,
                        flags: int = 0, group=None, gather: bool = True):
     """One process per GPU (torch.distributed, backend nccl == RCCL).  Tiles are dealt round-robin to
     ranks (tile g -> rank g % world), each rank renders its tiles with the pixels' GLOBAL seeds
-    (render.hpp:130-131), so the assembled frame is bit-identical to a single-GPU render.  One RCCL
-    gather of the float tiles to rank 0 over xGMI, then a device-side un-interleave.
+    (render.hpp:130-131), so the assembled frame is bit-identical to a single-GPU render.  No collective
+    inside the render; one gather of the framebuffer at the end (gather_frame).
     Returns (frame on rank 0 | None elsewhere, local tiles)."""
-    import torch
     import torch.distributed as dist
 
     world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -133,11 +147,7 @@ def render_distributed(width: int, height: int, samples: int, scene, cam: camera
     local = render(width, height, samples, scene, cam, depth, flags=flags, shard_index=rank, shard_count=world)
     if not gather:
         return None, local
-    bufs = [torch.empty_like(local) for _ in range(world)] if rank == 0 else None
-    dist.gather(local, bufs, dst=0, group=group)
-    if rank != 0:
-        return None, local
-    return unshard(torch.stack(bufs), width, height, world), local
+    return gather_frame(local, width, height, group), local
 
 
 def tonemap_rgb8(fb):

@@ -1,0 +1,97 @@
+"""The C++20 host facade (path_tracer_amd/include/pt/path_tracer.hpp): scenes built with the reference-shaped
+C++ constructors flatten to the same C-ABI tables as the Python mirror (CPU), and render to the same
+framebuffer through pt_render_host (GPU)."""
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import scenes_small as S
+from conftest import assert_bit_identical
+from path_tracer_amd import abi, scenes
+from path_tracer_amd.scene import (box, checker_texture, constant_medium, dielectric_material, lambertian_material,
+                                   lightsource_material, metal_material, pack, sphere, triangle, xy_rect, xz_rect,
+                                   yz_rect, camera)
+
+ROOT = Path(__file__).resolve().parent.parent
+SRC = ROOT / "tests" / "cpp" / "facade_main.cpp"
+
+
+@pytest.fixture(scope="module")
+def facade_bin(tmp_path_factory, lib):
+    out = tmp_path_factory.mktemp("facade") / "facade_main"
+    libdir = ROOT / "path_tracer_amd"
+    subprocess.run(["g++", "-std=c++20", "-O1", "-ffp-contract=off", f"-I{ROOT / 'path_tracer_amd' / 'include'}",
+                    str(SRC), "-o", str(out), f"-L{libdir}", "-lpt_render", f"-Wl,-rpath,{libdir}",
+                    "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    return out
+
+
+def zoo_py():
+    checker = checker_texture((0.2, 0.3, 0.1), (0.9, 0.9, 0.9))
+    hs = [
+        sphere((0, -100.5, -1), 100, lambertian_material(checker)),
+        sphere((0, 0, -1), 0.5, lambertian_material((0.7, 0.3, 0.3))),
+        sphere((1, 0, -1), 0.5, metal_material((0.8, 0.6, 0.2), 0.3)),
+        sphere((-1, 0, -1), 0.5, dielectric_material(1.5, (1, 1, 1))),
+        sphere((0.3, 0.1, -0.2), (0.3, 0.3, -0.2), 0.0, 1.0, 0.12, lambertian_material((0.7, 0.3, 0.3))),
+        triangle((-0.5, 0.6, -1.2), (0.5, 0.6, -1.2), (0, 1.3, -0.9), lambertian_material((0.1, 0.2, 0.9))),
+        box((1.2, -0.5, -2.5), (1.8, 0.7, -1.9), metal_material((0.7, 0.6, 0.5), 7.0)),
+        constant_medium(sphere((0.8, 0.9, -1.2), 0.4, lambertian_material((1, 1, 1))), 3.0, (0.9, 0.9, 1.0)),
+        xz_rect(-1, 1, -2, 0, 2.5, lightsource_material((4, 4, 4))),
+        yz_rect(-0.5, 1.5, -2.5, -0.5, -2.2, lambertian_material((0.2, 0.8, 0.2))),
+        xy_rect(-2, -1, -0.5, 1, -1.5, lambertian_material((0.7, 0.3, 0.3))),
+        constant_medium(box((-1.9, -0.5, -0.9), (-1.3, 0.2, -0.3), lambertian_material((1, 1, 1))), 5.0, checker),
+    ]
+    cam = dict(look_from=(0.3, 0.6, 2.5), look_at=(0, 0.2, -1), vup=(0, 1, 0), vfov=50.0, aperture=0.1,
+               focus_dist=3.4, time0=0.0, time1=1.0)
+    return pack(hs), cam
+
+
+def read_dump(path):
+    raw = Path(path).read_bytes()
+    n = np.frombuffer(raw[:12], dtype=np.int32)
+    off = 12
+    sizes = (n[0] * 64, n[1] * 32, n[2] * 48, 96)
+    parts = []
+    for s in sizes:
+        parts.append(raw[off:off + s])
+        off += s
+    assert off == len(raw)
+    return n.tolist(), parts
+
+
+@pytest.mark.parametrize("name", ["cornell", "zoo"])
+def test_cpp_tables_match_python_packer(facade_bin, tmp_path, name):
+    out = tmp_path / f"{name}.bin"
+    subprocess.run([str(facade_bin), "dump", name, str(out)], check=True)
+    n, (hb, mb, tb, cb) = read_dump(out)
+    if name == "cornell":
+        ps, cam = S.cornell_scene()
+        c = camera(cam["look_from"], cam["look_at"], cam["vup"], cam["vfov"], np.float32(64) / np.float32(36),
+                   cam["aperture"], cam["focus_dist"], cam["time0"], cam["time1"])
+    else:
+        ps, cam = zoo_py()
+        c = camera(cam["look_from"], cam["look_at"], cam["vup"], cam["vfov"], 1.5, cam["aperture"], cam["focus_dist"],
+                   cam["time0"], cam["time1"])
+    assert n == [ps.n_hittables, ps.n_materials, ps.n_textures]
+    assert hb == bytes(ps.hittables)[:len(hb)]
+    assert mb == bytes(ps.materials)[:len(mb)]
+    assert tb == bytes(ps.textures)[:len(tb)]
+    assert cb == bytes(c.c)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["cornell", "zoo"])
+def test_cpp_render_matches_python_render(facade_bin, tmp_path, orc, name):
+    from path_tracer_amd import render as R
+    w, h, spp = 64, 40, 6
+    out = tmp_path / f"{name}.f32"
+    subprocess.run([str(facade_bin), "render", name, str(w), str(h), str(spp), str(out)], check=True)
+    fb = np.fromfile(out, dtype=np.float32).reshape(h, w, 3)
+    ps, cam = S.cornell_scene() if name == "cornell" else zoo_py()
+    c = scenes.make_camera(cam, w, h)
+    assert_bit_identical(fb, R.render_host(w, h, spp, ps, c), f"C++ facade vs Python host: {name}")
+    orc.set_math(True)
+    assert_bit_identical(fb, orc.render(ps, c.c, w, h, spp), f"C++ facade vs oracle: {name}")
