@@ -55,6 +55,20 @@ def ops_per_sample(ctr: dict) -> float:
     return total / n
 
 
+def pmc_traffic(scene: str, w: int, h: int, spp: int):
+    """HBM bytes per launch of the render kernel from the newest committed rocprofv3 PMC summary of the same
+    workload (FETCH_SIZE and WRITE_SIZE are collected in their own --pmc passes: tools/pmc_summary.py)."""
+    best = None
+    for f in sorted((ROOT / "profiles").glob("r*_pmc_summary.json")):
+        try:
+            d = json.loads(f.read_text())
+        except Exception:  # noqa: BLE001
+            continue
+        if d.get("workload") == f"{w}x{h}x{spp}" and d.get("scene", "cornell") == scene and "hbm_bytes_per_launch" in d.get("derived", {}):
+            best = (d["derived"]["hbm_bytes_per_launch"], f.name)
+    return best
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -142,7 +156,9 @@ def main() -> None:
                        + f", {W}x{H}, {SPP} spp, depth {DEPTH}, seed = pixel linear id",
                        "hittables": packed.n_hittables, "sharding": "whole frame" if world == 1 else f"8x8 tiles round-robin over {world} ranks + RCCL gather"},
             "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": round(PEAK_TLANEOPS, 1), "unit": "Tlaneop/s",
-                         "frac": round(achieved / PEAK_TLANEOPS, 4), "traffic": None,
+                         "frac": round(achieved / PEAK_TLANEOPS, 4),
+                         "traffic": (pmc_traffic(args.scene, W, H, SPP) or (None, None))[0] if world == 1 else None,
+                         "traffic_source": (pmc_traffic(args.scene, W, H, SPP) or (None, None))[1] if world == 1 else None,
                          "kernel": "render_kernel", "kernel_ms": round(kern_ms, 3),
                          "algorithmic_ops_per_sample": round(ops, 1),
                          "kernel_msamples_per_s_per_gpu": round(kernel_samples_per_s / world / 1e6, 2),

@@ -1,0 +1,48 @@
+"""Aggregate rocprofv3 --pmc counter_collection CSVs (one pass per CSV) into one JSON summary for the
+render kernel: per-launch counter sums plus the derived figures DESIGN.md quotes.
+
+  python tools/pmc_summary.py profiles/r01 1920 1080 1024 profiles/r01_pmc_*.csv > profiles/r01_pmc_summary.json
+"""
+import collections
+import csv
+import json
+import sys
+
+
+def main():
+    tag, w, h, spp = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+    sums, launches = collections.defaultdict(float), collections.defaultdict(set)
+    meta = {}
+    for path in sys.argv[5:]:
+        for r in csv.DictReader(open(path)):
+            if "render_kernel" not in r["Kernel_Name"]:
+                continue
+            sums[r["Counter_Name"]] += float(r["Counter_Value"])
+            launches[r["Counter_Name"]].add(r["Dispatch_Id"])
+            meta = {k: r[k] for k in ("Kernel_Name", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Grid_Size", "Workgroup_Size")}
+    per = {k: v / max(1, len(launches[k])) for k, v in sums.items()}
+    samples = w * h * spp
+    out = {"tag": tag, "workload": f"{w}x{h}x{spp}", "kernel": meta, "per_launch": per, "derived": {}}
+    d = out["derived"]
+    if "GRBM_GUI_ACTIVE" in per:
+        cyc = per["GRBM_GUI_ACTIVE"] / 8  # summed over the 8 XCDs
+        d["cycles_per_xcd"] = cyc
+        if "SQ_INSTS_VALU" in per:
+            d["valu_lane_instr_per_sample"] = per["SQ_INSTS_VALU"] * 64 / samples
+            d["valu_issue_occupancy"] = per["SQ_INSTS_VALU"] * 2 / (1024 * cyc)  # wave64 on SIMD-32: 2 cycles per instruction
+        if "SQ_WAVE_CYCLES" in per:
+            d["mean_waves_per_simd"] = per["SQ_WAVE_CYCLES"] * 4 / (1024 * cyc)  # SQ_WAVE_CYCLES counts quad-cycles
+    if "SQ_THREAD_CYCLES_VALU" in per and "SQ_ACTIVE_INST_VALU" in sums:
+        pass
+    if "FETCH_SIZE" in per or "WRITE_SIZE" in per:
+        # KiB units. The guide's gfx950 x2 FETCH_SIZE correction is calibrated for 16 B/lane streaming reads only;
+        # this kernel's reads are scalar/LDS-staged (uncalibrated), so both readings are reported.
+        f, wr = per.get("FETCH_SIZE", 0.0) * 1024, per.get("WRITE_SIZE", 0.0) * 1024
+        d["hbm_bytes_per_launch"] = f + wr
+        d["hbm_bytes_per_launch_fetch_x2"] = 2 * f + wr
+        d["algorithmic_bytes_per_launch"] = w * h * 12
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
