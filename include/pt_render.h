@@ -149,7 +149,9 @@ typedef struct PtCamera {
 
 enum {
   PT_FLAG_NONE = 0,
-  PT_FLAG_NO_LDS = 1u << 0, /* A/B switch: fetch primitives with scalar loads instead of LDS */
+  PT_FLAG_NO_LDS = 1u << 0,       /* A/B switch: fetch primitives with scalar loads instead of LDS */
+  PT_FLAG_FORCE_STREAM = 1u << 1, /* use the LDS-tile streaming kernel even when the scene fits in LDS */
+  PT_FLAG_NO_FASTDIV = 1u << 2,   /* plain IEEE division for every rect/box side (no shared reciprocal) */
 };
 
 typedef struct PtRenderParams {
@@ -274,7 +276,8 @@ int pt_debug_flatten(const PtSceneDesc* desc, float* blob_out, int64_t blob_cap_
                      int32_t* n_runs, float* mats_out, int64_t mats_cap_f4, int32_t* flags_out);
 
 /* Device math used by the kernel, elementwise over host arrays.
- * op: 0 sin 1 cos 2 log 3 pow5 4 atan2(a,b) 5 asin 6 fmod(a,b) 7 sqrt 8 div(a,b) */
+ * op: 0 sin 1 cos 2 log 3 pow5 4 atan2(a,b) 5 asin 6 fmod(a,1) 7 sqrt 8 div(a,b)
+ *     9 the shared-reciprocal exact quotient a/b used for rect/box sides (pt_device.hpp: div_exact) */
 int pt_debug_math(int32_t op, const float* a, const float* b, float* out, int64_t n);
 
 #ifdef __cplusplus

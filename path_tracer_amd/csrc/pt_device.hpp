@@ -128,6 +128,49 @@ __device__ __forceinline__ Ray camera_ray(const Cam& c, int x, int y, int width,
   return r;
 }
 
+// ---- per-ray context ------------------------------------------------------------------------------
+// Everything the primitive loop needs that is constant for one ray.
+//
+// Exact division without dividing (rect/box sides, 43 per ray in the Cornell-style scene): the
+// reference computes t = (k - o_c) / d_c per side (rectangle.hpp:34,72,110).  For a "regular" ray
+// (o, d finite, 2^-40 <= |d_c| <= 2^40, |o_c| <= 2^60, scene coordinates <= 2^60) the correctly rounded
+// quotient is obtained from ONE correctly rounded reciprocal per axis, y = RN(1/d_c), shared by all sides:
+//     q0 = RN(n*y); r0 = fma(-d,q0,n); q1 = fma(r0,y,q0); r1 = fma(-d,q1,n); t = fma(r1,y,q1)
+// — the Markstein-style correction the compiler's own fdiv expansion ends with, with a better y and no
+// scaling needed inside the guarded range (no overflow / denormal intermediate).  Checked exhaustively-ish:
+// 3.2e9 random + adversarial (n, d) pairs, zero mismatches vs n/d, and on the GPU by
+// tests/test_gpu_parity.py::test_fast_division_is_exact.  The reference's comparisons are then applied to
+// that t unchanged, as straight-line predicated code (rect_fast/box_fast).  A wave with any irregular live
+// ray (axis-parallel, NaN, huge) takes the plain-division path for that iteration (wave-uniform branch).
+struct RayCtx {
+  Ray r;
+  float a;          // dot(d,d), hoisted (sphere.hpp:69)
+  float yx, yy, yz; // RN(1/d_c) for regular rays
+  bool reg;
+};
+
+__device__ __forceinline__ RayCtx make_ctx(const Ray& r, bool scene_fast_ok) {
+  RayCtx c;
+  c.r = r;
+  c.a = dot(r.d, r.d);
+  const float lo = 9.094947017729282e-13f, hi = 1.099511627776e12f, ohi = 1.152921504606846976e18f; // 2^-40 2^40 2^60
+  float ax = __builtin_fabsf(r.d.x), ay = __builtin_fabsf(r.d.y), az = __builtin_fabsf(r.d.z);
+  c.reg = scene_fast_ok && ax >= lo && ax <= hi && ay >= lo && ay <= hi && az >= lo && az <= hi &&
+          __builtin_fabsf(r.o.x) <= ohi && __builtin_fabsf(r.o.y) <= ohi && __builtin_fabsf(r.o.z) <= ohi;
+  c.yx = 1.0f / r.d.x;
+  c.yy = 1.0f / r.d.y;
+  c.yz = 1.0f / r.d.z;
+  return c;
+}
+
+// n / d for a regular ray axis; y = RN(1/d).  Bit-identical to the IEEE quotient inside the guarded range.
+__device__ __forceinline__ float div_exact(float n, float d, float y, float q0) {
+  float r0 = __builtin_fmaf(-d, q0, n);
+  float q1 = __builtin_fmaf(r0, y, q0);
+  float r1 = __builtin_fmaf(-d, q1, n);
+  return __builtin_fmaf(r1, y, q1);
+}
+
 // ---- sphere.hpp -----------------------------------------------------------------------------
 // record: R0 = (c0.xyz, radius^2)  R1 = (radius, mat, time0, time1)  R2 = (c1.xyz, hittable index)
 
@@ -146,22 +189,23 @@ __device__ __forceinline__ void mercator(V3 p, float& u, float& v) {
   v = (theta + PT_PI / 2.0f) / PT_PI;
 }
 
-// Roots of sphere.hpp:68-93; returns true and t if one lies in (mn, mx).  a = dot(d,d) hoisted.
+// Roots of sphere.hpp:68-93; returns true and t if one lies in (mn, mx).
 template <typename P>
-__device__ __forceinline__ bool sphere_t(P blob, int off, const Ray& r, float a, float mn, float mx, float& t) {
-  f4 R0 = blob[off];
+__device__ __forceinline__ bool sphere_t(P recs, int off, const RayCtx& c, float mn, float mx, float& t) {
+  const Ray& r = c.r;
+  f4 R0 = recs[off];
   V3 center = xyz(R0);
-  f4 R1 = blob[off + 1];
-  if (R1.z != R1.w) center = sphere_center(R0, R1, blob[off + 2], r.tm);
+  f4 R1 = recs[off + 1];
+  if (R1.z != R1.w) center = sphere_center(R0, R1, recs[off + 2], r.tm);
   V3 oc = r.o - center;
   float b = dot(oc, r.d);
-  float c = dot(oc, oc) - R0.w;
-  float discriminant = b * b - a * c;
+  float cc = dot(oc, oc) - R0.w;
+  float discriminant = b * b - c.a * cc;
   if (discriminant > 0) {
     float sq = sqrt_rn(discriminant);
-    float temp = (-b - sq) / a;
+    float temp = (-b - sq) / c.a;
     if (temp < mx && temp > mn) { t = temp; return true; }
-    temp = (-b + sq) / a;
+    temp = (-b + sq) / c.a;
     if (temp < mx && temp > mn) { t = temp; return true; }
   }
   return false;
@@ -169,40 +213,124 @@ __device__ __forceinline__ bool sphere_t(P blob, int off, const Ray& r, float a,
 
 // ---- rectangle.hpp:31-49,69-87,107-125 --------------------------------------------------------
 // record: R0 = (a0, a1, b0, b1)  R1 = (k, mat, axis, hittable index); axis 0 xy, 1 xz, 2 yz
-__device__ __forceinline__ bool rect_t(int axis, float a0, float a1, float b0, float b1, float k, const Ray& r,
-                                       float mn, float mx, float& t_out, float& a_out, float& b_out) {
-  float ok, dk, oa, da, ob, db;
-  if (axis == 0)      { ok = r.o.z; dk = r.d.z; oa = r.o.x; da = r.d.x; ob = r.o.y; db = r.d.y; }
-  else if (axis == 1) { ok = r.o.y; dk = r.d.y; oa = r.o.x; da = r.d.x; ob = r.o.z; db = r.d.z; }
-  else                { ok = r.o.x; dk = r.d.x; oa = r.o.y; da = r.d.y; ob = r.o.z; db = r.d.z; }
-  float t = (k - ok) / dk;
+// AX is a compile-time constant so the operand selection costs nothing (a run-time axis index into the ray
+// puts the seven selected floats in scratch memory).
+template <int AX> struct AxisSel;
+template <> struct AxisSel<0> { // xy_rect: plane z = k
+  static __device__ __forceinline__ float ok(const RayCtx& c) { return c.r.o.z; }
+  static __device__ __forceinline__ float dk(const RayCtx& c) { return c.r.d.z; }
+  static __device__ __forceinline__ float yk(const RayCtx& c) { return c.yz; }
+  static __device__ __forceinline__ float oa(const RayCtx& c) { return c.r.o.x; }
+  static __device__ __forceinline__ float da(const RayCtx& c) { return c.r.d.x; }
+  static __device__ __forceinline__ float ob(const RayCtx& c) { return c.r.o.y; }
+  static __device__ __forceinline__ float db(const RayCtx& c) { return c.r.d.y; }
+};
+template <> struct AxisSel<1> { // xz_rect: plane y = k
+  static __device__ __forceinline__ float ok(const RayCtx& c) { return c.r.o.y; }
+  static __device__ __forceinline__ float dk(const RayCtx& c) { return c.r.d.y; }
+  static __device__ __forceinline__ float yk(const RayCtx& c) { return c.yy; }
+  static __device__ __forceinline__ float oa(const RayCtx& c) { return c.r.o.x; }
+  static __device__ __forceinline__ float da(const RayCtx& c) { return c.r.d.x; }
+  static __device__ __forceinline__ float ob(const RayCtx& c) { return c.r.o.z; }
+  static __device__ __forceinline__ float db(const RayCtx& c) { return c.r.d.z; }
+};
+template <> struct AxisSel<2> { // yz_rect: plane x = k
+  static __device__ __forceinline__ float ok(const RayCtx& c) { return c.r.o.x; }
+  static __device__ __forceinline__ float dk(const RayCtx& c) { return c.r.d.x; }
+  static __device__ __forceinline__ float yk(const RayCtx& c) { return c.yx; }
+  static __device__ __forceinline__ float oa(const RayCtx& c) { return c.r.o.y; }
+  static __device__ __forceinline__ float da(const RayCtx& c) { return c.r.d.y; }
+  static __device__ __forceinline__ float ob(const RayCtx& c) { return c.r.o.z; }
+  static __device__ __forceinline__ float db(const RayCtx& c) { return c.r.d.z; }
+};
+
+// The reference's test as written, with the IEEE division.  Used for irregular rays and for
+// constant_medium boundaries (min = -inf: tiny/zero quotients matter there).
+template <int AX>
+__device__ __forceinline__ bool rect_plain(float a0, float a1, float b0, float b1, float k, const RayCtx& c,
+                                           float mn, float mx, float& t_out, float& a_out, float& b_out) {
+  typedef AxisSel<AX> S;
+  float t = (k - S::ok(c)) / S::dk(c);
   if (t < mn || t > mx) return false;
-  float a = oa + t * da;
-  float b = ob + t * db;
+  float a = S::oa(c) + t * S::da(c);
+  float b = S::ob(c) + t * S::db(c);
   if (a < a0 || a > a1 || b < b0 || b > b1) return false;
   t_out = t; a_out = a; b_out = b;
   return true;
 }
 
+// Same predicate, straight-line, for a wave whose live rays are all regular and min = PT_TMIN > 0:
+// t comes from the shared reciprocal (div_exact) — identical bits whenever |t| >= 2^-60; below that both
+// the exact and the computed t are < min, so the decision is the same.  No branch: with 64 incoherent rays
+// per wave some lane passes almost every sub-test, so early-outs only add exec-mask bookkeeping.
+template <int AX>
+__device__ __forceinline__ bool rect_fast(float a0, float a1, float b0, float b1, float k, const RayCtx& c,
+                                          float mx, float& t_out, float& a_out, float& b_out) {
+  typedef AxisSel<AX> S;
+  const float n = k - S::ok(c);
+  const float t = div_exact(n, S::dk(c), S::yk(c), n * S::yk(c));
+  const float a = S::oa(c) + t * S::da(c);
+  const float b = S::ob(c) + t * S::db(c);
+  t_out = t; a_out = a; b_out = b;
+  // !(t < min || t > max) && !(a < a0 || a > a1 || b < b0 || b > b1), NaN-for-NaN as the reference
+  return (!(t < PT_TMIN)) & (!(t > mx)) & (!(a < a0)) & (!(a > a1)) & (!(b < b0)) & (!(b > b1));
+}
+
+// run-time axis (top-level rect records): wave-uniform dispatch to the three instantiations
+__device__ __forceinline__ bool rect_any(bool fast, int axis, float a0, float a1, float b0, float b1, float k,
+                                         const RayCtx& c, float mx, float& t, float& a, float& b) {
+  if (fast) {
+    if (axis == 0) return rect_fast<0>(a0, a1, b0, b1, k, c, mx, t, a, b);
+    if (axis == 1) return rect_fast<1>(a0, a1, b0, b1, k, c, mx, t, a, b);
+    return rect_fast<2>(a0, a1, b0, b1, k, c, mx, t, a, b);
+  }
+  if (axis == 0) return rect_plain<0>(a0, a1, b0, b1, k, c, PT_TMIN, mx, t, a, b);
+  if (axis == 1) return rect_plain<1>(a0, a1, b0, b1, k, c, PT_TMIN, mx, t, a, b);
+  return rect_plain<2>(a0, a1, b0, b1, k, c, PT_TMIN, mx, t, a, b);
+}
+
 // ---- box.hpp:29-50: nearest of the six sides in constructor order (box.hpp:20-25) ---------------
 // record: R0 = (x0,y0,z0, mat)  R1 = (x1,y1,z1, hittable index)
+#define PT_BOX_SIDES(R0, R1)                          \
+  PT_BOX_SIDE(0, 0, R0.x, R1.x, R0.y, R1.y, R1.z)     \
+  PT_BOX_SIDE(1, 0, R0.x, R1.x, R0.y, R1.y, R0.z)     \
+  PT_BOX_SIDE(2, 1, R0.x, R1.x, R0.z, R1.z, R1.y)     \
+  PT_BOX_SIDE(3, 1, R0.x, R1.x, R0.z, R1.z, R0.y)     \
+  PT_BOX_SIDE(4, 2, R0.y, R1.y, R0.z, R1.z, R1.x)     \
+  PT_BOX_SIDE(5, 2, R0.y, R1.y, R0.z, R1.z, R0.x)
+
 template <bool UV>
-__device__ __forceinline__ bool box_t(f4 R0, f4 R1, const Ray& r, float mn, float mx, float& t_out, int& side_out,
-                                      float& u_out, float& v_out) {
+__device__ __forceinline__ bool box_plain(f4 R0, f4 R1, const RayCtx& c, float mn, float mx, float& t_out, int& side_out,
+                                          float& u_out, float& v_out) {
   bool hit = false;
   float closest = mx;
   float t, a, b;
 #define PT_BOX_SIDE(S, AX, A0, A1, B0, B1, K)                          \
-  if (rect_t(AX, A0, A1, B0, B1, K, r, mn, closest, t, a, b)) {        \
+  if (rect_plain<AX>(A0, A1, B0, B1, K, c, mn, closest, t, a, b)) {    \
     hit = true; closest = t; side_out = S;                             \
     if (UV) { u_out = (a - (A0)) / ((A1) - (A0)); v_out = (b - (B0)) / ((B1) - (B0)); } \
   }
-  PT_BOX_SIDE(0, 0, R0.x, R1.x, R0.y, R1.y, R1.z)
-  PT_BOX_SIDE(1, 0, R0.x, R1.x, R0.y, R1.y, R0.z)
-  PT_BOX_SIDE(2, 1, R0.x, R1.x, R0.z, R1.z, R1.y)
-  PT_BOX_SIDE(3, 1, R0.x, R1.x, R0.z, R1.z, R0.y)
-  PT_BOX_SIDE(4, 2, R0.y, R1.y, R0.z, R1.z, R1.x)
-  PT_BOX_SIDE(5, 2, R0.y, R1.y, R0.z, R1.z, R0.x)
+  PT_BOX_SIDES(R0, R1)
+#undef PT_BOX_SIDE
+  t_out = closest;
+  return hit;
+}
+
+template <bool UV>
+__device__ __forceinline__ bool box_fast(f4 R0, f4 R1, const RayCtx& c, float mx, float& t_out, int& side_out,
+                                         float& u_out, float& v_out) {
+  bool hit = false;
+  float closest = mx;
+  float t, a, b;
+#define PT_BOX_SIDE(S, AX, A0, A1, B0, B1, K)                          \
+  {                                                                    \
+    const bool acc = rect_fast<AX>(A0, A1, B0, B1, K, c, closest, t, a, b); \
+    hit |= acc;                                                        \
+    closest = acc ? t : closest;                                       \
+    side_out = acc ? S : side_out;                                     \
+    if (UV) { if (acc) { u_out = (a - (A0)) / ((A1) - (A0)); v_out = (b - (B0)) / ((B1) - (B0)); } } \
+  }
+  PT_BOX_SIDES(R0, R1)
 #undef PT_BOX_SIDE
   t_out = closest;
   return hit;
@@ -235,26 +363,25 @@ __device__ __forceinline__ bool tri_t(f4 R0, f4 R1, f4 R2, const Ray& r, float m
 // ---- constant_medium.hpp:28-78 -------------------------------------------------------------------------
 // record: R0 = (boundary kind, neg_inv_density, mat, hittable index)  R1.. = boundary (sphere 3 f4 | box 2 f4)
 template <typename P>
-__device__ __forceinline__ bool boundary_t(P blob, int off, int bkind, const Ray& r, float a, float mn, float mx,
-                                           float& t) {
-  if (bkind == DK_SPHERE) return sphere_t(blob, off, r, a, mn, mx, t);
+__device__ __forceinline__ bool boundary_t(P recs, int off, int bkind, const RayCtx& c, float mn, float mx, float& t) {
+  if (bkind == DK_SPHERE) return sphere_t(recs, off, c, mn, mx, t);
   int side; float u, v;
-  return box_t<false>(blob[off], blob[off + 1], r, mn, mx, t, side, u, v);
+  return box_plain<false>(recs[off], recs[off + 1], c, mn, mx, t, side, u, v);
 }
 
 template <typename P>
-__device__ __forceinline__ bool medium_t(P blob, int off, const Ray& r, float a, float mn, float mx, uint32_t& rng,
+__device__ __forceinline__ bool medium_t(P recs, int off, const RayCtx& c, float mn, float mx, uint32_t& rng,
                                          float& t_out) {
-  f4 R0 = blob[off];
+  f4 R0 = recs[off];
   int bkind = as_i(R0.x);
   float t1, t2;
-  if (!boundary_t(blob, off + 1, bkind, r, a, -PT_INF, PT_INF, t1)) return false;
-  if (!boundary_t(blob, off + 1, bkind, r, a, t1 + 0.0001f, PT_INF, t2)) return false;
+  if (!boundary_t(recs, off + 1, bkind, c, -PT_INF, PT_INF, t1)) return false;
+  if (!boundary_t(recs, off + 1, bkind, c, t1 + 0.0001f, PT_INF, t2)) return false;
   if (t1 < mn) t1 = mn;
   if (t2 > mx) t2 = mx;
   if (t1 >= t2) return false;
   if (t1 < 0) t1 = 0;
-  const float ray_length = sqrt_rn(a); // sycl::length(r.direction()), a = dot(d,d)
+  const float ray_length = sqrt_rn(c.a); // sycl::length(r.direction())
   const float distance_inside_boundary = (t2 - t1) * ray_length;
   const float hit_distance = R0.y * ptm::logf_(rng_float(rng)); // the in-traversal draw (:65)
   if (hit_distance > distance_inside_boundary) return false;
@@ -263,75 +390,107 @@ __device__ __forceinline__ bool medium_t(P blob, int off, const Ray& r, float a,
 }
 
 // ---- hit_world: render.hpp:30-51 --------------------------------------------------------------------------
-// blob = [n_runs x (kind, first record offset, count, 0)] [records...]
-// IMG: the scene has an image texture, so u,v of every accepted candidate are tracked exactly as the
-// reference's temp_rec does (incl. the stale values triangles/media leave behind); otherwise u,v are dead.
+// Per-lane traversal state.  IMG: the scene has an image texture, so u,v of every accepted candidate are
+// tracked exactly as the reference's temp_rec does (incl. the stale values triangles/media leave behind).
+struct HitState {
+  float closest;
+  int hit;
+  float u, v;
+};
+__device__ __forceinline__ void hit_begin(HitState& h) { h.closest = PT_INF; h.hit = -1; h.u = 0.0f; h.v = 0.0f; }
+
+// n records of one kind at recs[0..): record i is blob offset goff + i*size.  `recs` is either the resident
+// blob (LDS or scalar-cached) advanced to the run, or an LDS tile of a streamed run.
 template <bool IMG, typename P>
-__device__ __forceinline__ void hit_world(P blob, int n_runs, const Ray& r, uint32_t& rng, float& closest, int& hit,
-                                          float& hu, float& hv) {
-  closest = PT_INF;
-  hit = -1;
-  hu = 0.0f; hv = 0.0f;
-  const float a = dot(r.d, r.d);
-  for (int ri = 0; ri < n_runs; ++ri) {
-    f4 runf = blob[ri];
-    const int kind = as_i(runf.x);
-    int off = as_i(runf.y);
-    const int cnt = as_i(runf.z);
-    if (kind == DK_SPHERE) {
-      for (int i = 0; i < cnt; ++i, off += SZ_SPHERE) {
-        float t;
-        if (sphere_t(blob, off, r, a, PT_TMIN, closest, t)) {
-          closest = t;
-          hit = hit_pack(DK_SPHERE, 0, off);
-          if (IMG) {
-            f4 R0 = blob[off], R1 = blob[off + 1], R2 = blob[off + 2];
-            V3 p = r.o + t * r.d;
-            V3 n = (p - sphere_center(R0, R1, R2, r.tm)) / R1.x;
-            bool ff = dot(r.d, n) < 0;
-            V3 nn = ff ? n : mk(0.0f, 0.0f, 0.0f) - n;
-            mercator(nn, hu, hv);
-          }
-        }
-      }
-    } else if (kind == DK_RECT) {
-      for (int i = 0; i < cnt; ++i, off += SZ_RECT) {
-        f4 R0 = blob[off], R1 = blob[off + 1];
-        float t, ca, cb;
-        if (rect_t(as_i(R1.z), R0.x, R0.y, R0.z, R0.w, R1.x, r, PT_TMIN, closest, t, ca, cb)) {
-          closest = t;
-          hit = hit_pack(DK_RECT, 0, off);
-          if (IMG) { hu = (ca - R0.x) / (R0.y - R0.x); hv = (cb - R0.z) / (R0.w - R0.z); }
-        }
-      }
-    } else if (kind == DK_TRI) {
-      for (int i = 0; i < cnt; ++i, off += SZ_TRI) {
-        float t;
-        if (tri_t(blob[off], blob[off + 1], blob[off + 2], r, PT_TMIN, closest, t)) {
-          closest = t;
-          hit = hit_pack(DK_TRI, 0, off);
-        }
-      }
-    } else if (kind == DK_BOX) {
-      for (int i = 0; i < cnt; ++i, off += SZ_BOX) {
-        float t, bu = 0.0f, bv = 0.0f;
-        int side = 0;
-        if (box_t<IMG>(blob[off], blob[off + 1], r, PT_TMIN, closest, t, side, bu, bv)) {
-          closest = t;
-          hit = hit_pack(DK_BOX, side, off);
-          if (IMG) { hu = bu; hv = bv; }
-        }
-      }
-    } else {
-      for (int i = 0; i < cnt; ++i, off += SZ_MEDIUM) {
-        float t;
-        if (medium_t(blob, off, r, a, PT_TMIN, closest, rng, t)) {
-          closest = t;
-          hit = hit_pack(DK_MEDIUM, 0, off);
+__device__ __forceinline__ void hit_records(P recs, int kind, int n, int goff, const RayCtx& c, bool fast,
+                                            uint32_t& rng, HitState& h) {
+  const Ray& r = c.r;
+  int off = 0;
+  if (kind == DK_SPHERE) {
+    for (int i = 0; i < n; ++i, off += SZ_SPHERE) {
+      float t;
+      if (sphere_t(recs, off, c, PT_TMIN, h.closest, t)) {
+        h.closest = t;
+        h.hit = hit_pack(DK_SPHERE, 0, goff + off);
+        if (IMG) {
+          f4 R0 = recs[off], R1 = recs[off + 1], R2 = recs[off + 2];
+          V3 p = r.o + t * r.d;
+          V3 n_ = (p - sphere_center(R0, R1, R2, r.tm)) / R1.x;
+          bool ff = dot(r.d, n_) < 0;
+          V3 nn = ff ? n_ : mk(0.0f, 0.0f, 0.0f) - n_;
+          mercator(nn, h.u, h.v);
         }
       }
     }
+  } else if (kind == DK_RECT) {
+    for (int i = 0; i < n; ++i, off += SZ_RECT) {
+      f4 R0 = recs[off], R1 = recs[off + 1];
+      float t, ca, cb;
+      const bool acc = rect_any(fast, as_i(R1.z), R0.x, R0.y, R0.z, R0.w, R1.x, c, h.closest, t, ca, cb);
+      if (acc) {
+        h.closest = t;
+        h.hit = hit_pack(DK_RECT, 0, goff + off);
+        if (IMG) { h.u = (ca - R0.x) / (R0.y - R0.x); h.v = (cb - R0.z) / (R0.w - R0.z); }
+      }
+    }
+  } else if (kind == DK_TRI) {
+    for (int i = 0; i < n; ++i, off += SZ_TRI) {
+      float t;
+      if (tri_t(recs[off], recs[off + 1], recs[off + 2], r, PT_TMIN, h.closest, t)) {
+        h.closest = t;
+        h.hit = hit_pack(DK_TRI, 0, goff + off);
+      }
+    }
+  } else if (kind == DK_BOX) {
+    if (fast) {
+      for (int i = 0; i < n; ++i, off += SZ_BOX) {
+        float t, bu = 0.0f, bv = 0.0f;
+        int side = 0;
+        const bool acc = box_fast<IMG>(recs[off], recs[off + 1], c, h.closest, t, side, bu, bv);
+        h.closest = acc ? t : h.closest;
+        h.hit = acc ? hit_pack(DK_BOX, side, goff + off) : h.hit;
+        if (IMG) { if (acc) { h.u = bu; h.v = bv; } }
+      }
+    } else {
+      for (int i = 0; i < n; ++i, off += SZ_BOX) {
+        float t, bu = 0.0f, bv = 0.0f;
+        int side = 0;
+        if (box_plain<IMG>(recs[off], recs[off + 1], c, PT_TMIN, h.closest, t, side, bu, bv)) {
+          h.closest = t;
+          h.hit = hit_pack(DK_BOX, side, goff + off);
+          if (IMG) { h.u = bu; h.v = bv; }
+        }
+      }
+    }
+  } else {
+    for (int i = 0; i < n; ++i, off += SZ_MEDIUM) {
+      float t;
+      if (medium_t(recs, off, c, PT_TMIN, h.closest, rng, t)) {
+        h.closest = t;
+        h.hit = hit_pack(DK_MEDIUM, 0, goff + off);
+      }
+    }
   }
+}
+
+__device__ __forceinline__ int record_size(int kind) {
+  return kind == DK_SPHERE ? SZ_SPHERE : kind == DK_RECT ? SZ_RECT : kind == DK_TRI ? SZ_TRI : kind == DK_BOX ? SZ_BOX : SZ_MEDIUM;
+}
+
+// Whole list, blob resident (LDS or scalar cache): blob = [n_runs x (kind, first record offset, count, -)] [records]
+template <bool IMG, typename P>
+__device__ __forceinline__ void hit_world(P blob, int n_runs, const RayCtx& c, bool fast, uint32_t& rng, HitState& h) {
+  hit_begin(h);
+  for (int ri = 0; ri < n_runs; ++ri) {
+    f4 runf = blob[ri];
+    const int off = as_i(runf.y);
+    hit_records<IMG>(blob + off, as_i(runf.x), as_i(runf.z), off, c, fast, rng, h);
+  }
+}
+
+// Wave-uniform switch: the straight-line rect/box path is used only when every live lane's ray is regular.
+__device__ __forceinline__ bool wave_all_regular(const RayCtx& c, bool live) {
+  return __builtin_amdgcn_ballot_w64(live && !c.reg) == 0;
 }
 
 // ---- hit_record of the final nearest hit (hitable.hpp:8-24) ---------------------------------------------------

@@ -5,6 +5,7 @@
 //
 // Replaces: the AoS sycl::buffer<hittable_t> of 624-byte variants (render.hpp:146-147).
 #pragma once
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <string>
@@ -29,6 +30,7 @@ struct Flat {
   int32_t n_runs = 0;
   bool has_image = false;
   bool has_medium = false;
+  bool fast_ok = true; // all rect/box coordinates finite with |v| <= 2^60 (pt_device.hpp: RayCtx)
 };
 
 inline int device_kind(int32_t k) {
@@ -120,6 +122,15 @@ inline int flatten(const PtSceneDesc* sc, Flat& out, std::string& err) {
     int dk = device_kind(sc->hittables[i].kind);
     if (runs.empty() || runs.back().kind != dk) runs.push_back({dk, i, 0});
     runs.back().count++;
+  }
+  for (int i = 0; i < sc->n_hittables; i++) {
+    const PtHittable& h = sc->hittables[i];
+    bool rectish = h.kind == PT_HIT_XY_RECT || h.kind == PT_HIT_XZ_RECT || h.kind == PT_HIT_YZ_RECT || h.kind == PT_HIT_BOX ||
+                   (h.kind == PT_HIT_CONSTANT_MEDIUM && h.boundary_kind == PT_HIT_BOX);
+    if (!rectish) continue;
+    int nf = (h.kind == PT_HIT_BOX || h.kind == PT_HIT_CONSTANT_MEDIUM) ? 6 : 5;
+    for (int k = 0; k < nf; k++)
+      if (!(std::fabs(h.f[k]) <= 1.152921504606846976e18f)) out.fast_ok = false; // also false for NaN
   }
   out.n_runs = (int32_t)runs.size();
   std::vector<F4>& b = out.blob;

@@ -42,8 +42,74 @@ struct KArgs {
   int width, height, samples, depth;
   int shard_index, shard_count;
   int tiles_x, n_tiles;
+  int fast_ok; // every rect/box coordinate finite and <= 2^60: rays may use the shared-reciprocal division
 };
 
+// Per-lane path state of the persistent loop.
+struct Lane {
+  uint32_t rng;
+  V3 acc, att;
+  Ray ray;
+  int s, b;
+  bool done, need_new;
+};
+
+__device__ __forceinline__ void lane_init(Lane& L, const KArgs& a, int x, int y, bool valid) {
+  // render.hpp:130-132: seed = linear id, truncated to 32 bits
+  L.rng = (uint32_t)((unsigned long long)y * (unsigned long long)a.width + (unsigned long long)x);
+  L.acc = mk(0.0f, 0.0f, 0.0f);
+  L.att = mk(1.0f, 1.0f, 1.0f);
+  L.ray.o = mk(0.0f, 0.0f, 0.0f); L.ray.d = mk(0.0f, 0.0f, 0.0f); L.ray.tm = 0.0f;
+  L.s = 0; L.b = 0;
+  L.done = !valid || a.depth <= 0; // depth 0: every sample returns black (render.hpp:58,91)
+  L.need_new = true;
+}
+
+// Start the next sample of a lane whose path ended (render.hpp:95-99), or retire the lane.
+__device__ __forceinline__ void lane_regenerate(Lane& L, const KArgs& a, int x, int y) {
+  if (!L.done && L.need_new) {
+    if (L.s == a.samples) L.done = true;
+    else {
+      L.ray = camera_ray(a.cam, x, y, a.width, a.height, L.rng);
+      L.att = mk(1.0f, 1.0f, 1.0f);
+      L.b = 0;
+      L.need_new = false;
+    }
+  }
+}
+
+// emitted / scatter / sky for the nearest hit (render.hpp:60-88) and the sample bookkeeping (:100).
+__device__ __forceinline__ void lane_shade(Lane& L, const KArgs& a, const HitState& h) {
+  if (L.done) return;
+  V3 out = mk(0.0f, 0.0f, 0.0f);
+  bool cont;
+  if (h.hit < 0) {
+    out = sky_color(L.ray, L.att);
+    cont = false;
+  } else {
+    Rec rec = resolve_hit(a.blob, h.hit, L.ray, h.closest); // per-lane gather of the one record that was hit
+    cont = shade(a.mats, a.atlas, rec, h.u, h.v, L.ray, L.att, L.rng, out);
+    if (cont && ++L.b >= a.depth) { // bounce loop exhausted: black (render.hpp:91)
+      out = mk(0.0f, 0.0f, 0.0f);
+      cont = false;
+    }
+  }
+  if (!cont) {
+    L.acc = L.acc + out; // final_color += get_color(r)  render.hpp:100
+    L.s++;
+    L.need_new = true;
+  }
+}
+
+__device__ __forceinline__ void lane_store(const Lane& L, const KArgs& a, int x, int y, int l, int lane) {
+  V3 acc = L.acc / (float)a.samples; // render.hpp:102
+  long long idx;
+  if (a.shard_count == 1) idx = ((long long)y * a.width + x) * 3;
+  else idx = ((long long)l * PT_TILE_PIXELS + lane) * 3;
+  a.fb[idx] = acc.x; a.fb[idx + 1] = acc.y; a.fb[idx + 2] = acc.z;
+}
+
+// Scene blob resident for the whole kernel: staged once into LDS (LDS=true) or read through the scalar cache.
 template <bool IMG, bool LDS>
 __global__ __launch_bounds__(kBlock) void render_kernel(KArgs a) {
   extern __shared__ f4 smem[];
@@ -58,72 +124,76 @@ __global__ __launch_bounds__(kBlock) void render_kernel(KArgs a) {
   const int tx = (int)(g % a.tiles_x), ty = (int)(g / a.tiles_x);
   const int x = tx * PT_TILE + (lane & 7), y = ty * PT_TILE + (lane >> 3);
   const bool valid = x < a.width && y < a.height;
-
-  // render.hpp:130-132: seed = linear id, truncated to 32 bits
-  uint32_t rng = (uint32_t)((unsigned long long)y * (unsigned long long)a.width + (unsigned long long)x);
-  V3 acc = mk(0.0f, 0.0f, 0.0f);
-  V3 att = mk(1.0f, 1.0f, 1.0f);
-  Ray ray;
-  ray.o = mk(0.0f, 0.0f, 0.0f); ray.d = mk(0.0f, 0.0f, 0.0f); ray.tm = 0.0f;
-  int s = 0, b = 0;
-  bool done = !valid || a.depth <= 0; // depth 0: every sample returns black (render.hpp:58,91)
-  bool need_new = true;
-
+  Lane L;
+  lane_init(L, a, x, y, valid);
   for (;;) {
-    if (!done && need_new) {
-      if (s == a.samples) done = true;
-      else {
-        ray = camera_ray(a.cam, x, y, a.width, a.height, rng);
-        att = mk(1.0f, 1.0f, 1.0f);
-        b = 0;
-        need_new = false;
+    lane_regenerate(L, a, x, y);
+    if (__builtin_amdgcn_ballot_w64(!L.done) == 0) break;
+    RayCtx c = make_ctx(L.ray, a.fast_ok != 0);
+    const bool fast = wave_all_regular(c, !L.done);
+    HitState h;
+    if constexpr (LDS) hit_world<IMG>((lds_f4p)smem, a.n_runs, c, fast, L.rng, h);
+    else hit_world<IMG>((cst_f4p)a.blob, a.n_runs, c, fast, L.rng, h);
+    lane_shade(L, a, h);
+  }
+  if (valid) lane_store(L, a, x, y, l, lane);
+}
+
+// Scene blob larger than LDS (100 k triangles = 4.8 MB): the workgroup walks the list in lock-step and streams
+// each run through one LDS tile — cooperative 16 B/lane copy, barrier, every wave tests its 64 rays against the
+// tile's records by LDS broadcast, barrier.  Arithmetic intensity is ~200 lane-ops per streamed byte
+// (256 rays x ~40 ops per 48-byte triangle), so the stream needs < 0.4 TB/s chip-wide: compute-bound by design.
+constexpr int kTileF4 = 2040;      // 32,640 B; a multiple of every record size (2, 3, 4 f4)
+constexpr int kSmallRunF4 = 48;    // runs this short are read through the scalar cache instead (no barriers)
+
+template <bool IMG>
+__global__ __launch_bounds__(kBlock) void render_kernel_stream(KArgs a) {
+  __shared__ f4 tile[kTileF4];
+  const int lane = threadIdx.x & 63;
+  const int l = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const long long g = (long long)l * a.shard_count + a.shard_index;
+  const bool wave_valid = g < a.n_tiles; // a wave without a tile still joins every barrier
+  const int tx = wave_valid ? (int)(g % a.tiles_x) : 0, ty = wave_valid ? (int)(g / a.tiles_x) : 0;
+  const int x = tx * PT_TILE + (lane & 7), y = ty * PT_TILE + (lane >> 3);
+  const bool valid = wave_valid && x < a.width && y < a.height;
+  Lane L;
+  lane_init(L, a, x, y, valid);
+  const cst_f4p cblob = (cst_f4p)a.blob;
+  for (;;) {
+    lane_regenerate(L, a, x, y);
+    if (!__syncthreads_or(!L.done)) break;
+    RayCtx c = make_ctx(L.ray, a.fast_ok != 0);
+    const bool fast = wave_all_regular(c, !L.done);
+    HitState h;
+    hit_begin(h);
+    for (int ri = 0; ri < a.n_runs; ++ri) {
+      f4 runf = cblob[ri];
+      const int kind = as_i(runf.x), off = as_i(runf.y), cnt = as_i(runf.z);
+      const int sz = record_size(kind);
+      if (cnt * sz <= kSmallRunF4) {
+        hit_records<IMG>(cblob + off, kind, cnt, off, c, fast, L.rng, h);
+        continue;
+      }
+      const int per_tile = kTileF4 / sz;
+      for (int first = 0; first < cnt; first += per_tile) {
+        const int n = min(per_tile, cnt - first);
+        const int nf4 = n * sz, base = off + first * sz;
+        for (int i = threadIdx.x; i < nf4; i += kBlock) tile[i] = a.blob[base + i];
+        __syncthreads();
+        hit_records<IMG>((lds_f4p)tile, kind, n, base, c, fast, L.rng, h);
+        __syncthreads();
       }
     }
-    if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
-
-    float closest, hu, hv;
-    int hit;
-    if constexpr (LDS) hit_world<IMG>((lds_f4p)smem, a.n_runs, ray, rng, closest, hit, hu, hv);
-    else hit_world<IMG>((cst_f4p)a.blob, a.n_runs, ray, rng, closest, hit, hu, hv);
-
-    if (!done) {
-      V3 out = mk(0.0f, 0.0f, 0.0f);
-      bool cont;
-      if (hit < 0) {
-        out = sky_color(ray, att);
-        cont = false;
-      } else {
-        Rec rec;
-        if constexpr (LDS) rec = resolve_hit((lds_f4p)smem, hit, ray, closest);
-        else rec = resolve_hit((const f4*)a.blob, hit, ray, closest);
-        cont = shade(a.mats, a.atlas, rec, hu, hv, ray, att, rng, out);
-        if (cont && ++b >= a.depth) { // bounce loop exhausted: black (render.hpp:91)
-          out = mk(0.0f, 0.0f, 0.0f);
-          cont = false;
-        }
-      }
-      if (!cont) {
-        acc = acc + out; // final_color += get_color(r)  render.hpp:100
-        s++;
-        need_new = true;
-      }
-    }
+    lane_shade(L, a, h);
   }
-
-  if (valid) {
-    acc = acc / (float)a.samples; // render.hpp:102
-    long long idx;
-    if (a.shard_count == 1) idx = ((long long)y * a.width + x) * 3;
-    else idx = ((long long)l * PT_TILE_PIXELS + lane) * 3;
-    a.fb[idx] = acc.x; a.fb[idx + 1] = acc.y; a.fb[idx + 2] = acc.z;
-  }
+  if (valid) lane_store(L, a, x, y, l, lane);
 }
 
 // ---- probes ---------------------------------------------------------------------------------
 template <bool IMG>
 __global__ void bounce_kernel(const f4* __restrict__ blob, int n_runs, const f4* __restrict__ mats,
                               const uint8_t* __restrict__ atlas, const PtBounceIn* __restrict__ in,
-                              PtBounceOut* __restrict__ outp, int n) {
+                              PtBounceOut* __restrict__ outp, int n, int fast_ok) {
   int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
   PtBounceIn I = in[k];
@@ -135,9 +205,11 @@ __global__ void bounce_kernel(const f4* __restrict__ blob, int n_runs, const f4*
   V3 att = mk(I.attenuation[0], I.attenuation[1], I.attenuation[2]);
   PtBounceOut O;
   memset(&O, 0, sizeof O);
-  float closest, hu, hv;
-  int hit;
-  hit_world<IMG>(blob, n_runs, ray, rng, closest, hit, hu, hv);
+  RayCtx c = make_ctx(ray, fast_ok != 0);
+  HitState h;
+  hit_world<IMG>(blob, n_runs, c, wave_all_regular(c, true), rng, h);
+  const float closest = h.closest, hu = h.u, hv = h.v;
+  const int hit = h.hit;
   if (hit < 0) {
     V3 c = sky_color(ray, att);
     O.status = PT_BOUNCE_MISS; O.hittable = -1; O.material = -1;
@@ -192,6 +264,7 @@ __global__ void math_kernel(int op, const float* __restrict__ a, const float* __
     case 5: r = ptm::asinf_(x); break;
     case 6: r = ptm::fmod1f_(x); break;
     case 7: r = sqrt_rn(x); break;
+    case 9: { float yy = 1.0f / y; r = div_exact(x, y, yy, x * yy); break; } // the shared-reciprocal quotient (|q| >= 2^-60)
     default: r = x / y; break;
   }
   out[i] = r;
@@ -251,6 +324,8 @@ struct PtScene {
   uint8_t* atlas = nullptr;
   int n_runs = 0, blob_f4 = 0;
   bool has_image = false;
+  bool fast_ok = false;
+  size_t blob_bytes = 0;
   int device = 0;
 };
 
@@ -342,6 +417,8 @@ int pt_scene_create(const PtSceneDesc* desc, PtScene** out_scene) {
   s->n_runs = flat.n_runs;
   s->blob_f4 = (int)flat.blob.size();
   s->has_image = flat.has_image;
+  s->fast_ok = flat.fast_ok;
+  s->blob_bytes = flat.blob.size() * 16;
   size_t blob_bytes = std::max<size_t>(flat.blob.size(), 1) * 16, mats_bytes = std::max<size_t>(flat.mats.size(), 1) * 16;
   PT_TRY(hipMalloc((void**)&s->blob, blob_bytes));
   PT_TRY(hipMalloc((void**)&s->mats, mats_bytes));
@@ -402,11 +479,16 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
   // pixels no lane owns (edge tiles, padded last tile, depth 0) read as 0
   PT_HIP(hipMemsetAsync(fb, 0, (size_t)pt_framebuffer_floats(p) * sizeof(float), st));
   if (local_tiles <= 0) return PT_OK;
+  a.fast_ok = (s->fast_ok && !(p->flags & PT_FLAG_NO_FASTDIV)) ? 1 : 0;
   const size_t blob_bytes = (size_t)s->blob_f4 * 16;
-  const bool lds = !(p->flags & PT_FLAG_NO_LDS) && blob_bytes <= kMaxLdsBlob;
+  const bool resident = (blob_bytes <= kMaxLdsBlob || (p->flags & PT_FLAG_NO_LDS)) && !(p->flags & PT_FLAG_FORCE_STREAM);
+  const bool lds = resident && !(p->flags & PT_FLAG_NO_LDS);
   dim3 grid((local_tiles + kWavesPerBlock - 1) / kWavesPerBlock), block(kBlock);
   size_t shmem = lds ? blob_bytes : 0;
-  if (s->has_image) {
+  if (!resident) { // stream the list through LDS tiles
+    if (s->has_image) hipLaunchKernelGGL((render_kernel_stream<true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((render_kernel_stream<false>), grid, block, 0, st, a);
+  } else if (s->has_image) {
     if (lds) hipLaunchKernelGGL((render_kernel<true, true>), grid, block, shmem, st, a);
     else hipLaunchKernelGGL((render_kernel<true, false>), grid, block, 0, st, a);
   } else {
@@ -495,9 +577,9 @@ int pt_debug_bounce(const PtScene* scene, const PtBounceIn* in, PtBounceOut* out
   PT_HIP(hipMemcpy(din.p, in, (size_t)n * sizeof(PtBounceIn), hipMemcpyHostToDevice));
   dim3 block(64), grid((n + 63) / 64);
   if (scene->has_image)
-    hipLaunchKernelGGL(bounce_kernel<true>, grid, block, 0, nullptr, scene->blob, scene->n_runs, scene->mats, scene->atlas, din.p, dout.p, n);
+    hipLaunchKernelGGL(bounce_kernel<true>, grid, block, 0, nullptr, scene->blob, scene->n_runs, scene->mats, scene->atlas, din.p, dout.p, n, scene->fast_ok ? 1 : 0);
   else
-    hipLaunchKernelGGL(bounce_kernel<false>, grid, block, 0, nullptr, scene->blob, scene->n_runs, scene->mats, scene->atlas, din.p, dout.p, n);
+    hipLaunchKernelGGL(bounce_kernel<false>, grid, block, 0, nullptr, scene->blob, scene->n_runs, scene->mats, scene->atlas, din.p, dout.p, n, scene->fast_ok ? 1 : 0);
   PT_HIP(hipGetLastError());
   PT_HIP(hipMemcpy(out, dout.p, (size_t)n * sizeof(PtBounceOut), hipMemcpyDeviceToHost));
   return PT_OK;
@@ -525,8 +607,8 @@ int pt_debug_camera_rays(const PtCamera* cam, int32_t width, int32_t height, con
 }
 
 int pt_debug_math(int32_t op, const float* a, const float* b, float* out, int64_t n) {
-  if (!a || !out || n < 0 || op < 0 || op > 8) return fail(PT_ERR_INVALID_ARG, "pt_debug_math: bad argument");
-  if ((op == 4 || op == 8) && !b) return fail(PT_ERR_INVALID_ARG, "pt_debug_math: op needs two operands");
+  if (!a || !out || n < 0 || op < 0 || op > 9) return fail(PT_ERR_INVALID_ARG, "pt_debug_math: bad argument");
+  if ((op == 4 || op == 8 || op == 9) && !b) return fail(PT_ERR_INVALID_ARG, "pt_debug_math: op needs two operands");
   if (n == 0) return PT_OK;
   DevBuf<float> da, db, dout;
   PT_HIP(da.alloc(n));

@@ -86,6 +86,32 @@ def test_ieee_sqrt_and_div(lib):
         assert_bit_identical(gpu_math(lib, 8, x, y), x / y, "div")
 
 
+def test_fast_division_is_exact(lib):
+    """The shared-reciprocal quotient used for rect/box sides (pt_device.hpp: div_exact) equals the IEEE quotient
+    bit for bit over its guarded range: |d| in [2^-40, 2^40], n = 0 or |n| in [2^-100, 2^61], incl. all-ones /
+    all-zeros significands."""
+    rng = np.random.default_rng(77)
+    n_ = 4_000_000
+    md = rng.integers(0, 2 ** 23, n_, dtype=np.uint32)
+    mn = rng.integers(0, 2 ** 23, n_, dtype=np.uint32)
+    md[::5] = 0x7FFFFF - rng.integers(0, 256, len(md[::5]), dtype=np.uint32)
+    md[1::5] = rng.integers(0, 256, len(md[1::5]), dtype=np.uint32)
+    mn[2::7] = 0x7FFFFF - rng.integers(0, 4, len(mn[2::7]), dtype=np.uint32)
+    ed = rng.integers(-40, 41, n_).astype(np.uint32) + 127
+    en = rng.integers(-100, 62, n_).astype(np.uint32) + 127
+    sd = rng.integers(0, 2, n_, dtype=np.uint32) << 31
+    sn = rng.integers(0, 2, n_, dtype=np.uint32) << 31
+    d = ((ed << 23) | md | sd).astype(np.uint32).view(np.float32)
+    n = ((en << 23) | mn | sn).astype(np.uint32).view(np.float32)
+    with np.errstate(all="ignore"):
+        assert_bit_identical(gpu_math(lib, 9, n, d), n / d, "shared-reciprocal division")
+    # n = +-0: the quotient is a zero whose sign may differ from IEEE's; any |t| < 2^-60 is below the rect
+    # test's min = 0.001 and rejected either way (pt_device.hpp: rect_fast)
+    z = np.zeros(2000, np.float32)
+    z[1000:] = -0.0
+    assert (gpu_math(lib, 9, z, d[:2000]) == 0).all()
+
+
 def test_camera_rays_bit_exact(lib, orc):
     rng = np.random.default_rng(11)
     for cam_args, (w, h) in [(S.cornell_scene()[1], (1920, 1080)), (S.mixed_scene()[1], (400, 225))]:
@@ -227,6 +253,56 @@ def test_lds_and_scalar_fetch_agree(name):
     a = R.render_host(64, 40, 8, ps, c)
     b = R.render_host(64, 40, 8, ps, c, flags=abi.PT_FLAG_NO_LDS)
     assert_bit_identical(a, b, name)
+
+
+@pytest.mark.parametrize("name", ["cornell", "mixed", "triangles", "spheres", "ties"])
+def test_streaming_kernel_agrees(name):
+    """The LDS-tile streaming kernel (used when the scene exceeds LDS) gives the resident kernel's frame."""
+    ps, cam = S.ALL[name]()
+    c = scenes.make_camera(cam, 64, 40)
+    a = R.render_host(64, 40, 8, ps, c)
+    b = R.render_host(64, 40, 8, ps, c, flags=abi.PT_FLAG_FORCE_STREAM)
+    assert_bit_identical(a, b, name)
+
+
+def test_streaming_kernel_many_tiles(orc):
+    """3 000 triangles = 9 000 records: several LDS tiles per run, partial last tile, small runs either side."""
+    ps, cam = S.triangles_scene(3000)
+    c = scenes.make_camera(cam, 48, 27)
+    fb = R.render_host(48, 27, 3, ps, c, flags=abi.PT_FLAG_FORCE_STREAM)
+    orc.set_math(True)
+    assert_bit_identical(fb, orc.render(ps, c.c, 48, 27, 3), "streamed 3000 triangles")
+    assert_bit_identical(fb, R.render_host(48, 27, 3, ps, c, flags=abi.PT_FLAG_NO_LDS), "stream vs scalar")
+
+
+@pytest.mark.parametrize("name", ["cornell", "mixed", "ties"])
+def test_plain_division_path_agrees(name):
+    ps, cam = S.ALL[name]()
+    c = scenes.make_camera(cam, 64, 40)
+    assert_bit_identical(R.render_host(64, 40, 8, ps, c), R.render_host(64, 40, 8, ps, c, flags=abi.PT_FLAG_NO_FASTDIV), name)
+
+
+def test_irregular_rays_take_the_plain_division(lib, orc):
+    """Axis-parallel / zero / huge directions are not 'regular': they must still match the oracle bit for bit."""
+    ps, _ = S.cornell_scene()
+    ds = R.DeviceScene(ps)
+    dirs = [(0, 0, 1), (0, 1, 0), (1, 0, 0), (0, 0, -1), (1e-30, 0.5, 1), (1e30, 1, 1), (0, 0, 0), (np.nan, 0, 1),
+            (np.inf, 1, 1), (1, 1, 1e-45), (0.0, -0.0, 1.0), (1e-41, 1e-41, 1e-41)]
+    origins = [(278, 278, -800), (278, 278, 278), (0, 0, 0), (555, 555, 555), (278, 0, 278), (1e20, 0, 0)]
+    recs = (abi.PtBounceIn * (len(dirs) * len(origins)))()
+    k = 0
+    for o in origins:
+        for d in dirs:
+            recs[k].origin[:] = [float(np.float32(v)) for v in o]
+            recs[k].dir[:] = [float(np.float32(v)) for v in d]
+            recs[k].time = 0.5
+            recs[k].rng_state = 12345 + k
+            recs[k].attenuation[:] = [1.0, 1.0, 1.0]
+            k += 1
+    out = (abi.PtBounceOut * k)()
+    abi.check(lib.pt_debug_bounce(ds.handle, recs, out, k), "pt_debug_bounce")
+    orc.set_math(True)
+    compare_bounce(out, orc.bounce(ps, recs), k, "irregular", False)
 
 
 @pytest.mark.parametrize("shards", [2, 3, 8])
