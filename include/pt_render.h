@@ -152,6 +152,7 @@ enum {
   PT_FLAG_NO_LDS = 1u << 0,       /* A/B switch: fetch primitives with scalar loads instead of LDS */
   PT_FLAG_FORCE_STREAM = 1u << 1, /* use the LDS-tile streaming kernel even when the scene fits in LDS */
   PT_FLAG_NO_FASTDIV = 1u << 2,   /* plain IEEE division for every rect/box side (no shared reciprocal) */
+  PT_FLAG_TILE_GRANULAR = 1u << 3, /* A/B switch: waves dequeue whole 8x8 tiles instead of single pixels */
 };
 
 typedef struct PtRenderParams {

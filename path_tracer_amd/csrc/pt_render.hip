@@ -13,6 +13,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -31,6 +32,7 @@ namespace {
 constexpr int kBlock = 256;                 // 4 wavefronts = 4 tiles per workgroup
 constexpr int kWavesPerBlock = kBlock / 64;
 constexpr size_t kMaxLdsBlob = 64 * 1024;   // blob staged in LDS when it fits
+constexpr unsigned kQueueRing = 256;        // launches in flight on one scene may not exceed this
 
 struct KArgs {
   Cam cam;
@@ -42,35 +44,83 @@ struct KArgs {
   int width, height, samples, depth;
   int shard_index, shard_count;
   int tiles_x, n_tiles;
+  int n_local_pixels;  // 64 x the tiles this shard owns (incl. padding pixels of edge tiles)
+  unsigned int* queue; // per-launch dequeue counter, zeroed on the stream before the kernel
+  int tile_granular;   // PT_FLAG_TILE_GRANULAR
   int fast_ok; // every rect/box coordinate finite and <= 2^60: rays may use the shared-reciprocal division
 };
 
-// Per-lane path state of the persistent loop.
+// Per-lane state of the persistent loop.  A lane owns ONE pixel at a time, for all of its samples (the
+// reference's single RNG stream per pixel, render.hpp:130-133, forbids splitting a pixel), but lanes are not
+// tied to a tile: a lane that has finished its pixel pulls the next one from a per-launch queue, so every lane
+// of the chip stays busy until the frame's pixels run out.
 struct Lane {
   uint32_t rng;
   V3 acc, att;
   Ray ray;
   int s, b;
-  bool done, need_new;
+  int pix;       // local pixel index = local_tile * 64 + lane-in-tile; -1 = none
+  int x, y;
+  bool live;     // owns a pixel with samples left
+  bool retired;  // the queue is empty for this lane
+  bool need_new; // next iteration starts a new sample
 };
 
-__device__ __forceinline__ void lane_init(Lane& L, const KArgs& a, int x, int y, bool valid) {
-  // render.hpp:130-132: seed = linear id, truncated to 32 bits
-  L.rng = (uint32_t)((unsigned long long)y * (unsigned long long)a.width + (unsigned long long)x);
+__device__ __forceinline__ void lane_reset(Lane& L) {
+  L.rng = 0;
   L.acc = mk(0.0f, 0.0f, 0.0f);
   L.att = mk(1.0f, 1.0f, 1.0f);
-  L.ray.o = mk(0.0f, 0.0f, 0.0f); L.ray.d = mk(0.0f, 0.0f, 0.0f); L.ray.tm = 0.0f;
-  L.s = 0; L.b = 0;
-  L.done = !valid || a.depth <= 0; // depth 0: every sample returns black (render.hpp:58,91)
+  L.ray.o = mk(0.0f, 0.0f, 0.0f); L.ray.d = mk(0.0f, 0.0f, 1.0f); L.ray.tm = 0.0f;
+  L.s = 0; L.b = 0; L.pix = -1; L.x = 0; L.y = 0;
+  L.live = false; L.retired = false; L.need_new = true;
+}
+
+// Wave-aggregated dequeue: one atomicAdd per wave for all lanes that need a pixel (ballot + prefix count),
+// pixels handed out in tile order so a fresh wave starts on one coherent 8x8 tile.
+__device__ __forceinline__ void lane_acquire(Lane& L, const KArgs& a) {
+  const bool want = !L.live && !L.retired;
+  const unsigned long long mask = __builtin_amdgcn_ballot_w64(want);
+  if (mask == 0) return;
+  // tile-granular mode (A/B switch): a wave takes its next 64 pixels only when all of its lanes are idle
+  if (a.tile_granular && __builtin_amdgcn_ballot_w64(L.live) != 0) return;
+  unsigned int base = 0;
+  const int lane = threadIdx.x & 63;
+  const int leader = __builtin_ctzll(mask);
+  if (lane == leader) base = atomicAdd(a.queue, (unsigned int)__builtin_popcountll(mask));
+  base = __builtin_amdgcn_readlane(base, leader);
+  if (!want) return;
+  const unsigned int rank = __builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mask, 0u));
+  const unsigned int i = base + rank;
+  if (i >= (unsigned int)a.n_local_pixels) { L.retired = true; return; }
+  const int l = (int)(i >> 6), in_tile = (int)(i & 63);
+  const long long g = (long long)l * a.shard_count + a.shard_index; // global tile (pt_render.h: round-robin shards)
+  const int tx = (int)(g % a.tiles_x), ty = (int)(g / a.tiles_x);
+  const int x = tx * PT_TILE + (in_tile & 7), y = ty * PT_TILE + (in_tile >> 3);
+  if (g >= a.n_tiles || x >= a.width || y >= a.height) return; // padding pixel: stays 0, ask again next iteration
+  L.pix = (int)i; L.x = x; L.y = y;
+  // render.hpp:130-132: seed = linear id of the pixel in the WHOLE frame, truncated to 32 bits
+  L.rng = (uint32_t)((unsigned long long)y * (unsigned long long)a.width + (unsigned long long)x);
+  L.acc = mk(0.0f, 0.0f, 0.0f);
+  L.s = 0;
+  L.live = true;
   L.need_new = true;
 }
 
-// Start the next sample of a lane whose path ended (render.hpp:95-99), or retire the lane.
-__device__ __forceinline__ void lane_regenerate(Lane& L, const KArgs& a, int x, int y) {
-  if (!L.done && L.need_new) {
-    if (L.s == a.samples) L.done = true;
+__device__ __forceinline__ void lane_store(Lane& L, const KArgs& a) {
+  V3 acc = L.acc / (float)a.samples; // render.hpp:102
+  long long idx;
+  if (a.shard_count == 1) idx = ((long long)L.y * a.width + L.x) * 3;
+  else idx = (long long)L.pix * 3;
+  a.fb[idx] = acc.x; a.fb[idx + 1] = acc.y; a.fb[idx + 2] = acc.z;
+  L.live = false;
+}
+
+// Start the next sample of a lane whose path ended (render.hpp:95-99), or finish the pixel.
+__device__ __forceinline__ void lane_regenerate(Lane& L, const KArgs& a) {
+  if (L.live && L.need_new) {
+    if (L.s == a.samples) lane_store(L, a);
     else {
-      L.ray = camera_ray(a.cam, x, y, a.width, a.height, L.rng);
+      L.ray = camera_ray(a.cam, L.x, L.y, a.width, a.height, L.rng);
       L.att = mk(1.0f, 1.0f, 1.0f);
       L.b = 0;
       L.need_new = false;
@@ -80,7 +130,7 @@ __device__ __forceinline__ void lane_regenerate(Lane& L, const KArgs& a, int x, 
 
 // emitted / scatter / sky for the nearest hit (render.hpp:60-88) and the sample bookkeeping (:100).
 __device__ __forceinline__ void lane_shade(Lane& L, const KArgs& a, const HitState& h) {
-  if (L.done) return;
+  if (!L.live) return;
   V3 out = mk(0.0f, 0.0f, 0.0f);
   bool cont;
   if (h.hit < 0) {
@@ -101,12 +151,12 @@ __device__ __forceinline__ void lane_shade(Lane& L, const KArgs& a, const HitSta
   }
 }
 
-__device__ __forceinline__ void lane_store(const Lane& L, const KArgs& a, int x, int y, int l, int lane) {
-  V3 acc = L.acc / (float)a.samples; // render.hpp:102
-  long long idx;
-  if (a.shard_count == 1) idx = ((long long)y * a.width + x) * 3;
-  else idx = ((long long)l * PT_TILE_PIXELS + lane) * 3;
-  a.fb[idx] = acc.x; a.fb[idx + 1] = acc.y; a.fb[idx + 2] = acc.z;
+// One turn of the crank before tracing: finish/advance pixels, pull new ones, start new samples.
+// Returns false when this lane has nothing to trace this iteration.
+__device__ __forceinline__ void lane_prepare(Lane& L, const KArgs& a) {
+  lane_regenerate(L, a); // may finish the pixel (store) ...
+  lane_acquire(L, a);    // ... in which case a new one is pulled in the same iteration
+  lane_regenerate(L, a); // and its first camera ray generated
 }
 
 // Scene blob resident for the whole kernel: staged once into LDS (LDS=true) or read through the scalar cache.
@@ -117,26 +167,22 @@ __global__ __launch_bounds__(kBlock) void render_kernel(KArgs a) {
     for (int i = threadIdx.x; i < a.blob_f4; i += kBlock) smem[i] = a.blob[i];
     __syncthreads();
   }
-  const int lane = threadIdx.x & 63;
-  const int l = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6); // local tile of this wave
-  const long long g = (long long)l * a.shard_count + a.shard_index;
-  if (g >= a.n_tiles) return; // no barrier below this point
-  const int tx = (int)(g % a.tiles_x), ty = (int)(g / a.tiles_x);
-  const int x = tx * PT_TILE + (lane & 7), y = ty * PT_TILE + (lane >> 3);
-  const bool valid = x < a.width && y < a.height;
   Lane L;
-  lane_init(L, a, x, y, valid);
+  lane_reset(L);
+  if (a.depth <= 0) return; // depth 0: every sample returns black (render.hpp:58,91); the frame is pre-zeroed
   for (;;) {
-    lane_regenerate(L, a, x, y);
-    if (__builtin_amdgcn_ballot_w64(!L.done) == 0) break;
+    lane_prepare(L, a);
+    if (__builtin_amdgcn_ballot_w64(L.live) == 0) {
+      if (__builtin_amdgcn_ballot_w64(!L.retired) == 0) break; // queue drained for the whole wave
+      continue;                                                 // only padding pixels this time: pull again
+    }
     RayCtx c = make_ctx(L.ray, a.fast_ok != 0);
-    const bool fast = wave_all_regular(c, !L.done);
+    const bool fast = wave_all_regular(c, L.live);
     HitState h;
     if constexpr (LDS) hit_world<IMG>((lds_f4p)smem, a.n_runs, c, fast, L.rng, h);
     else hit_world<IMG>((cst_f4p)a.blob, a.n_runs, c, fast, L.rng, h);
     lane_shade(L, a, h);
   }
-  if (valid) lane_store(L, a, x, y, l, lane);
 }
 
 // Scene blob larger than LDS (100 k triangles = 4.8 MB): the workgroup walks the list in lock-step and streams
@@ -149,21 +195,18 @@ constexpr int kSmallRunF4 = 48;    // runs this short are read through the scala
 template <bool IMG>
 __global__ __launch_bounds__(kBlock) void render_kernel_stream(KArgs a) {
   __shared__ f4 tile[kTileF4];
-  const int lane = threadIdx.x & 63;
-  const int l = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-  const long long g = (long long)l * a.shard_count + a.shard_index;
-  const bool wave_valid = g < a.n_tiles; // a wave without a tile still joins every barrier
-  const int tx = wave_valid ? (int)(g % a.tiles_x) : 0, ty = wave_valid ? (int)(g / a.tiles_x) : 0;
-  const int x = tx * PT_TILE + (lane & 7), y = ty * PT_TILE + (lane >> 3);
-  const bool valid = wave_valid && x < a.width && y < a.height;
   Lane L;
-  lane_init(L, a, x, y, valid);
+  lane_reset(L);
+  if (a.depth <= 0) return;
   const cst_f4p cblob = (cst_f4p)a.blob;
   for (;;) {
-    lane_regenerate(L, a, x, y);
-    if (!__syncthreads_or(!L.done)) break;
+    lane_prepare(L, a);
+    if (!__syncthreads_or(L.live)) {
+      if (!__syncthreads_or(!L.retired)) break;
+      continue;
+    }
     RayCtx c = make_ctx(L.ray, a.fast_ok != 0);
-    const bool fast = wave_all_regular(c, !L.done);
+    const bool fast = wave_all_regular(c, L.live);
     HitState h;
     hit_begin(h);
     for (int ri = 0; ri < a.n_runs; ++ri) {
@@ -186,7 +229,6 @@ __global__ __launch_bounds__(kBlock) void render_kernel_stream(KArgs a) {
     }
     lane_shade(L, a, h);
   }
-  if (valid) lane_store(L, a, x, y, l, lane);
 }
 
 // ---- probes ---------------------------------------------------------------------------------
@@ -326,6 +368,9 @@ struct PtScene {
   bool has_image = false;
   bool fast_ok = false;
   size_t blob_bytes = 0;
+  int num_cus = 256;
+  unsigned int* queues = nullptr; // ring of per-launch pixel-queue counters
+  mutable unsigned int next_queue = 0;
   int device = 0;
 };
 
@@ -414,6 +459,11 @@ int pt_scene_create(const PtSceneDesc* desc, PtScene** out_scene) {
   hipError_t e;
 #define PT_TRY(expr) if ((e = (expr)) != hipSuccess) { cleanup(); return fail(PT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e)); }
   PT_TRY(hipGetDevice(&s->device));
+  {
+    hipDeviceProp_t prop;
+    PT_TRY(hipGetDeviceProperties(&prop, s->device));
+    s->num_cus = prop.multiProcessorCount;
+  }
   s->n_runs = flat.n_runs;
   s->blob_f4 = (int)flat.blob.size();
   s->has_image = flat.has_image;
@@ -427,6 +477,7 @@ int pt_scene_create(const PtSceneDesc* desc, PtScene** out_scene) {
   size_t atlas_bytes = flat.has_image ? (size_t)desc->atlas_bytes : 0;
   PT_TRY(hipMalloc((void**)&s->atlas, std::max<size_t>(atlas_bytes, 16)));
   if (atlas_bytes) PT_TRY(hipMemcpy(s->atlas, desc->atlas, atlas_bytes, hipMemcpyHostToDevice));
+  PT_TRY(hipMalloc((void**)&s->queues, kQueueRing * sizeof(unsigned int)));
 #undef PT_TRY
   *out_scene = s;
   return PT_OK;
@@ -437,6 +488,7 @@ void pt_scene_destroy(PtScene* s) {
   if (s->blob) (void)hipFree(s->blob);
   if (s->mats) (void)hipFree(s->mats);
   if (s->atlas) (void)hipFree(s->atlas);
+  if (s->queues) (void)hipFree(s->queues);
   delete s;
 }
 
@@ -483,18 +535,30 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
   const size_t blob_bytes = (size_t)s->blob_f4 * 16;
   const bool resident = (blob_bytes <= kMaxLdsBlob || (p->flags & PT_FLAG_NO_LDS)) && !(p->flags & PT_FLAG_FORCE_STREAM);
   const bool lds = resident && !(p->flags & PT_FLAG_NO_LDS);
-  dim3 grid((local_tiles + kWavesPerBlock - 1) / kWavesPerBlock), block(kBlock);
-  size_t shmem = lds ? blob_bytes : 0;
+  a.n_local_pixels = local_tiles * PT_TILE_PIXELS;
+  a.tile_granular = (p->flags & PT_FLAG_TILE_GRANULAR) ? 1 : 0;
+  a.queue = s->queues + (s->next_queue++ % kQueueRing);
+  PT_HIP(hipMemsetAsync(a.queue, 0, sizeof(unsigned int), st));
+  const size_t shmem = lds ? blob_bytes : 0;
+  // Persistent grid: no more workgroups than the chip holds at once; lanes pull pixels from the queue.
+  auto launch = [&](auto kernel) -> int {
+    int per_cu = 0;
+    PT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, shmem));
+    if (const char* e = std::getenv("PT_BLOCKS_PER_CU")) per_cu = std::min(per_cu, std::max(1, std::atoi(e))); // tuning knob
+    const int resident = std::max(1, per_cu) * std::max(1, s->num_cus);
+    dim3 grid(std::min((local_tiles + kWavesPerBlock - 1) / kWavesPerBlock, resident)), block(kBlock);
+    hipLaunchKernelGGL(kernel, grid, block, shmem, st, a);
+    return PT_OK;
+  };
+  int rc;
   if (!resident) { // stream the list through LDS tiles
-    if (s->has_image) hipLaunchKernelGGL((render_kernel_stream<true>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((render_kernel_stream<false>), grid, block, 0, st, a);
+    rc = s->has_image ? launch(render_kernel_stream<true>) : launch(render_kernel_stream<false>);
   } else if (s->has_image) {
-    if (lds) hipLaunchKernelGGL((render_kernel<true, true>), grid, block, shmem, st, a);
-    else hipLaunchKernelGGL((render_kernel<true, false>), grid, block, 0, st, a);
+    rc = lds ? launch(render_kernel<true, true>) : launch(render_kernel<true, false>);
   } else {
-    if (lds) hipLaunchKernelGGL((render_kernel<false, true>), grid, block, shmem, st, a);
-    else hipLaunchKernelGGL((render_kernel<false, false>), grid, block, 0, st, a);
+    rc = lds ? launch(render_kernel<false, true>) : launch(render_kernel<false, false>);
   }
+  if (rc) return rc;
   PT_HIP(hipGetLastError());
   return PT_OK;
 }
