@@ -172,7 +172,7 @@ __device__ __forceinline__ float div_exact(float n, float d, float y, float q0) 
 }
 
 // ---- sphere.hpp -----------------------------------------------------------------------------
-// record: R0 = (c0.xyz, radius^2)  R1 = (radius, mat, time0, time1)  R2 = (c1.xyz, hittable index)
+// record: R0 = (c0.xyz, +-radius^2: sign bit set = moving)  R1 = (radius, mat, time0, time1)  R2 = (c1.xyz, hittable index)
 
 // sphere.hpp:51-56
 __device__ __forceinline__ V3 sphere_center(f4 R0, f4 R1, f4 R2, float time) {
@@ -193,13 +193,15 @@ __device__ __forceinline__ void mercator(V3 p, float& u, float& v) {
 template <typename P>
 __device__ __forceinline__ bool sphere_t(P recs, int off, const RayCtx& c, float mn, float mx, float& t) {
   const Ray& r = c.r;
-  f4 R0 = recs[off];
+  f4 R0 = recs[off]; // the only read on the miss path of a static sphere
   V3 center = xyz(R0);
-  f4 R1 = recs[off + 1];
-  if (R1.z != R1.w) center = sphere_center(R0, R1, recs[off + 2], r.tm);
+  if (as_i(R0.w) < 0) { // moving (flatten stores -(radius^2) when time0 != time1): wave-uniform
+    f4 R1 = recs[off + 1];
+    center = sphere_center(R0, R1, recs[off + 2], r.tm);
+  }
   V3 oc = r.o - center;
   float b = dot(oc, r.d);
-  float cc = dot(oc, oc) - R0.w;
+  float cc = dot(oc, oc) - __builtin_fabsf(R0.w);
   float discriminant = b * b - c.a * cc;
   if (discriminant > 0) {
     float sq = sqrt_rn(discriminant);
@@ -344,16 +346,16 @@ __device__ __forceinline__ bool tri_t(f4 R0, f4 R1, f4 R2, const Ray& r, float m
   V3 h = cross(r.d, edge2);
   float a = dot(edge1, h);
   float a_abs = __builtin_fabsf(a);
-  if (a_abs < epsilon) return false;
   bool a_pos = a > 0.0f;
   V3 s = r.o - xyz(R0);
   float u = dot(s, h);
   bool u_pos = u > 0.0f;
-  if ((u_pos != a_pos) || __builtin_fabsf(u) > a_abs) return false;
+  // the first two rejections of triangle.hpp:71-81 evaluated together (both are pure): one exec-mask branch
+  if ((a_abs < epsilon) | (u_pos != a_pos) | (__builtin_fabsf(u) > a_abs)) return false;
   V3 q = cross(s, edge1);
   float v = dot(r.d, q);
   bool v_pos = v > 0.0f;
-  if ((v_pos != a_pos) || (__builtin_fabsf(u + v) > a_abs)) return false;
+  if ((v_pos != a_pos) | (__builtin_fabsf(u + v) > a_abs)) return false;
   float length = dot(edge2, q) / a;
   if (length < mn || length > mx) return false;
   t_out = length;
@@ -590,9 +592,10 @@ __device__ __forceinline__ V3 sky_color(const Ray& r, V3 att) {
 
 // One iteration of the bounce loop render.hpp:58-89 after hit_world: emitted + scatter.
 // Returns true if the path continues (ray/att updated); false if it ended with `out`.
-__device__ __forceinline__ bool shade(const f4* __restrict__ mats, const uint8_t* __restrict__ atlas, const Rec& rec,
+template <typename PM>
+__device__ __forceinline__ bool shade(PM mats, const uint8_t* __restrict__ atlas, const Rec& rec,
                                       float hu, float hv, Ray& ray, V3& att, uint32_t& rng, V3& out) {
-  const f4* M = mats + rec.mat * SZ_MATERIAL;
+  PM M = mats + rec.mat * SZ_MATERIAL;
   f4 M0 = M[0], M1 = M[1];
   const int mk_ = as_i(M0.x);
   if (mk_ == 0) { // lambertian material.hpp:18-28

@@ -32,6 +32,7 @@ namespace {
 constexpr int kBlock = 256;                 // 4 wavefronts = 4 tiles per workgroup
 constexpr int kWavesPerBlock = kBlock / 64;
 constexpr size_t kMaxLdsBlob = 64 * 1024;   // blob staged in LDS when it fits
+constexpr size_t kMaxLdsWithMaterials = 16 * 1024; // stage the material table too when records + materials are this small
 constexpr unsigned kQueueRing = 256;        // launches in flight on one scene may not exceed this
 
 struct KArgs {
@@ -40,12 +41,14 @@ struct KArgs {
   const f4* mats;
   const uint8_t* atlas;
   float* fb;
-  int n_runs, blob_f4;
+  int n_runs, blob_f4, mats_f4;
   int width, height, samples, depth;
   int shard_index, shard_count;
   int tiles_x, n_tiles;
   int n_local_pixels;  // 64 x the tiles this shard owns (incl. padding pixels of edge tiles)
   unsigned int* queue; // per-launch dequeue counter, zeroed on the stream before the kernel
+  unsigned int* cost;  // non-NULL: cost-probe pass, per local tile ray counts (nothing is written to fb)
+  const int* order;    // non-NULL: queue position -> local tile, heaviest first
   int tile_granular;   // PT_FLAG_TILE_GRANULAR
   int fast_ok; // every rect/box coordinate finite and <= 2^60: rays may use the shared-reciprocal division
 };
@@ -59,6 +62,7 @@ struct Lane {
   V3 acc, att;
   Ray ray;
   int s, b;
+  unsigned int iters; // rays traced for the current pixel (cost probe)
   int pix;       // local pixel index = local_tile * 64 + lane-in-tile; -1 = none
   int x, y;
   bool live;     // owns a pixel with samples left
@@ -71,7 +75,7 @@ __device__ __forceinline__ void lane_reset(Lane& L) {
   L.acc = mk(0.0f, 0.0f, 0.0f);
   L.att = mk(1.0f, 1.0f, 1.0f);
   L.ray.o = mk(0.0f, 0.0f, 0.0f); L.ray.d = mk(0.0f, 0.0f, 1.0f); L.ray.tm = 0.0f;
-  L.s = 0; L.b = 0; L.pix = -1; L.x = 0; L.y = 0;
+  L.s = 0; L.b = 0; L.iters = 0; L.pix = -1; L.x = 0; L.y = 0;
   L.live = false; L.retired = false; L.need_new = true;
 }
 
@@ -92,27 +96,33 @@ __device__ __forceinline__ void lane_acquire(Lane& L, const KArgs& a) {
   const unsigned int rank = __builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mask, 0u));
   const unsigned int i = base + rank;
   if (i >= (unsigned int)a.n_local_pixels) { L.retired = true; return; }
-  const int l = (int)(i >> 6), in_tile = (int)(i & 63);
+  // queue position -> local tile: identity, or the cost-sorted order of the probe pass (heaviest tiles first)
+  const int l = a.order ? a.order[i >> 6] : (int)(i >> 6), in_tile = (int)(i & 63);
   const long long g = (long long)l * a.shard_count + a.shard_index; // global tile (pt_render.h: round-robin shards)
   const int tx = (int)(g % a.tiles_x), ty = (int)(g / a.tiles_x);
   const int x = tx * PT_TILE + (in_tile & 7), y = ty * PT_TILE + (in_tile >> 3);
   if (g >= a.n_tiles || x >= a.width || y >= a.height) return; // padding pixel: stays 0, ask again next iteration
-  L.pix = (int)i; L.x = x; L.y = y;
+  L.pix = l * PT_TILE_PIXELS + in_tile; L.x = x; L.y = y;
   // render.hpp:130-132: seed = linear id of the pixel in the WHOLE frame, truncated to 32 bits
   L.rng = (uint32_t)((unsigned long long)y * (unsigned long long)a.width + (unsigned long long)x);
   L.acc = mk(0.0f, 0.0f, 0.0f);
   L.s = 0;
+  L.iters = 0;
   L.live = true;
   L.need_new = true;
 }
 
 __device__ __forceinline__ void lane_store(Lane& L, const KArgs& a) {
+  L.live = false;
+  if (a.cost) { // cost-probe pass: only the tile's ray count is kept
+    atomicAdd(&a.cost[L.pix >> 6], L.iters);
+    return;
+  }
   V3 acc = L.acc / (float)a.samples; // render.hpp:102
   long long idx;
   if (a.shard_count == 1) idx = ((long long)L.y * a.width + L.x) * 3;
   else idx = (long long)L.pix * 3;
   a.fb[idx] = acc.x; a.fb[idx + 1] = acc.y; a.fb[idx + 2] = acc.z;
-  L.live = false;
 }
 
 // Start the next sample of a lane whose path ended (render.hpp:95-99), or finish the pixel.
@@ -129,16 +139,18 @@ __device__ __forceinline__ void lane_regenerate(Lane& L, const KArgs& a) {
 }
 
 // emitted / scatter / sky for the nearest hit (render.hpp:60-88) and the sample bookkeeping (:100).
-__device__ __forceinline__ void lane_shade(Lane& L, const KArgs& a, const HitState& h) {
+template <typename PB, typename PM>
+__device__ __forceinline__ void lane_shade(Lane& L, const KArgs& a, const HitState& h, PB recs, PM mats) {
   if (!L.live) return;
+  L.iters++;
   V3 out = mk(0.0f, 0.0f, 0.0f);
   bool cont;
   if (h.hit < 0) {
     out = sky_color(L.ray, L.att);
     cont = false;
   } else {
-    Rec rec = resolve_hit(a.blob, h.hit, L.ray, h.closest); // per-lane gather of the one record that was hit
-    cont = shade(a.mats, a.atlas, rec, h.u, h.v, L.ray, L.att, L.rng, out);
+    Rec rec = resolve_hit(recs, h.hit, L.ray, h.closest); // per-lane gather of the one record that was hit
+    cont = shade(mats, a.atlas, rec, h.u, h.v, L.ray, L.att, L.rng, out);
     if (cont && ++L.b >= a.depth) { // bounce loop exhausted: black (render.hpp:91)
       out = mk(0.0f, 0.0f, 0.0f);
       cont = false;
@@ -160,11 +172,14 @@ __device__ __forceinline__ void lane_prepare(Lane& L, const KArgs& a) {
 }
 
 // Scene blob resident for the whole kernel: staged once into LDS (LDS=true) or read through the scalar cache.
-template <bool IMG, bool LDS>
+// MLDS: the material table is staged too (small tables only: it rides behind the records in the same buffer), so
+// the whole bounce — traversal, hit record, material, texture constants — runs out of LDS without a global load.
+template <bool IMG, bool LDS, bool MLDS>
 __global__ __launch_bounds__(kBlock) void render_kernel(KArgs a) {
   extern __shared__ f4 smem[];
   if (LDS) {
-    for (int i = threadIdx.x; i < a.blob_f4; i += kBlock) smem[i] = a.blob[i];
+    const int n = a.blob_f4 + (MLDS ? a.mats_f4 : 0); // a.mats == a.blob + a.blob_f4 (one device buffer)
+    for (int i = threadIdx.x; i < n; i += kBlock) smem[i] = a.blob[i];
     __syncthreads();
   }
   Lane L;
@@ -179,9 +194,14 @@ __global__ __launch_bounds__(kBlock) void render_kernel(KArgs a) {
     RayCtx c = make_ctx(L.ray, a.fast_ok != 0);
     const bool fast = wave_all_regular(c, L.live);
     HitState h;
-    if constexpr (LDS) hit_world<IMG>((lds_f4p)smem, a.n_runs, c, fast, L.rng, h);
-    else hit_world<IMG>((cst_f4p)a.blob, a.n_runs, c, fast, L.rng, h);
-    lane_shade(L, a, h);
+    if constexpr (LDS) {
+      hit_world<IMG>((lds_f4p)smem, a.n_runs, c, fast, L.rng, h);
+      if constexpr (MLDS) lane_shade(L, a, h, (lds_f4p)smem, (lds_f4p)smem + a.blob_f4);
+      else lane_shade(L, a, h, (lds_f4p)smem, a.mats);
+    } else {
+      hit_world<IMG>((cst_f4p)a.blob, a.n_runs, c, fast, L.rng, h);
+      lane_shade(L, a, h, a.blob, a.mats);
+    }
   }
 }
 
@@ -227,8 +247,42 @@ __global__ __launch_bounds__(kBlock) void render_kernel_stream(KArgs a) {
         __syncthreads();
       }
     }
-    lane_shade(L, a, h);
+    lane_shade(L, a, h, a.blob, a.mats);
   }
+}
+
+// ---- longest-processing-time-first tile order -------------------------------------------------------------
+// A pixel cannot be split (one sequential RNG stream), so the frame's makespan is bounded below by its heaviest
+// tile, and a heavy tile picked up LAST adds its whole duration to the tail (measured on the 496-hittable scene:
+// mean 2.4 of 5 resident waves per SIMD over the launch).  A probe pass renders the first few samples of every
+// pixel and counts rays per tile (same seeds, results discarded: < 0.5 % extra work); this kernel buckets the tiles
+// into 32 classes of ratio 2^(1/4) below the maximum and emits them heaviest class first.  The order only decides
+// WHEN a pixel is rendered, never its value, so the (atomic, run-to-run varying) order inside a class is harmless.
+constexpr int kLptClasses = 32;
+__global__ __launch_bounds__(1024) void lpt_order_kernel(const unsigned int* __restrict__ cost, int n, int* __restrict__ order) {
+  __shared__ unsigned int s_max;
+  __shared__ unsigned int s_count[kLptClasses], s_cursor[kLptClasses];
+  if (threadIdx.x == 0) s_max = 1;
+  if (threadIdx.x < kLptClasses) s_count[threadIdx.x] = 0;
+  __syncthreads();
+  unsigned int m = 0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) m = max(m, cost[i]);
+  atomicMax(&s_max, m);
+  __syncthreads();
+  const float mx = (float)s_max;
+  auto cls = [&](unsigned int c) {
+    if (c == 0) return kLptClasses - 1;
+    int k = (int)(4.0f * __log2f(mx / (float)c)); // 0 = within 2^(1/4) of the heaviest tile
+    return min(max(k, 0), kLptClasses - 1);
+  };
+  for (int i = threadIdx.x; i < n; i += blockDim.x) atomicAdd(&s_count[cls(cost[i])], 1u);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned int acc = 0;
+    for (int k = 0; k < kLptClasses; k++) { s_cursor[k] = acc; acc += s_count[k]; }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += blockDim.x) order[atomicAdd(&s_cursor[cls(cost[i])], 1u)] = i;
 }
 
 // ---- probes ---------------------------------------------------------------------------------
@@ -364,11 +418,14 @@ struct PtScene {
   f4* blob = nullptr;
   f4* mats = nullptr;
   uint8_t* atlas = nullptr;
-  int n_runs = 0, blob_f4 = 0;
+  int n_runs = 0, blob_f4 = 0, mats_f4 = 0;
   bool has_image = false;
   bool fast_ok = false;
   size_t blob_bytes = 0;
   int num_cus = 256;
+  mutable unsigned int* ws_cost = nullptr; // LPT workspace: per-tile ray counts of the probe pass
+  mutable int* ws_order = nullptr;         //                cost-sorted tile order
+  mutable int ws_tiles = 0;
   unsigned int* queues = nullptr; // ring of per-launch pixel-queue counters
   mutable unsigned int next_queue = 0;
   int device = 0;
@@ -469,11 +526,13 @@ int pt_scene_create(const PtSceneDesc* desc, PtScene** out_scene) {
   s->has_image = flat.has_image;
   s->fast_ok = flat.fast_ok;
   s->blob_bytes = flat.blob.size() * 16;
-  size_t blob_bytes = std::max<size_t>(flat.blob.size(), 1) * 16, mats_bytes = std::max<size_t>(flat.mats.size(), 1) * 16;
-  PT_TRY(hipMalloc((void**)&s->blob, blob_bytes));
-  PT_TRY(hipMalloc((void**)&s->mats, mats_bytes));
-  if (!flat.blob.empty()) PT_TRY(hipMemcpy(s->blob, flat.blob.data(), flat.blob.size() * 16, hipMemcpyHostToDevice));
-  if (!flat.mats.empty()) PT_TRY(hipMemcpy(s->mats, flat.mats.data(), flat.mats.size() * 16, hipMemcpyHostToDevice));
+  s->mats_f4 = (int)flat.mats.size();
+  // one buffer: [blob records][material table] so a kernel can stage both with one contiguous copy
+  const size_t blob_bytes = flat.blob.size() * 16, mats_bytes = flat.mats.size() * 16;
+  PT_TRY(hipMalloc((void**)&s->blob, std::max<size_t>(blob_bytes + mats_bytes, 16)));
+  s->mats = s->blob + flat.blob.size();
+  if (blob_bytes) PT_TRY(hipMemcpy(s->blob, flat.blob.data(), blob_bytes, hipMemcpyHostToDevice));
+  if (mats_bytes) PT_TRY(hipMemcpy(s->mats, flat.mats.data(), mats_bytes, hipMemcpyHostToDevice));
   size_t atlas_bytes = flat.has_image ? (size_t)desc->atlas_bytes : 0;
   PT_TRY(hipMalloc((void**)&s->atlas, std::max<size_t>(atlas_bytes, 16)));
   if (atlas_bytes) PT_TRY(hipMemcpy(s->atlas, desc->atlas, atlas_bytes, hipMemcpyHostToDevice));
@@ -486,9 +545,10 @@ int pt_scene_create(const PtSceneDesc* desc, PtScene** out_scene) {
 void pt_scene_destroy(PtScene* s) {
   if (!s) return;
   if (s->blob) (void)hipFree(s->blob);
-  if (s->mats) (void)hipFree(s->mats);
   if (s->atlas) (void)hipFree(s->atlas);
   if (s->queues) (void)hipFree(s->queues);
+  if (s->ws_cost) (void)hipFree(s->ws_cost);
+  if (s->ws_order) (void)hipFree(s->ws_order);
   delete s;
 }
 
@@ -523,7 +583,7 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
   KArgs a;
   std::memcpy(&a.cam, cam, sizeof(Cam));
   a.blob = s->blob; a.mats = s->mats; a.atlas = s->atlas; a.fb = fb;
-  a.n_runs = s->n_runs; a.blob_f4 = s->blob_f4;
+  a.n_runs = s->n_runs; a.blob_f4 = s->blob_f4; a.mats_f4 = s->mats_f4;
   a.width = p->width; a.height = p->height; a.samples = p->samples; a.depth = p->depth;
   a.shard_index = p->shard_index; a.shard_count = p->shard_count;
   a.n_tiles = n_tiles_of(p, &a.tiles_x);
@@ -536,28 +596,55 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
   const bool resident = (blob_bytes <= kMaxLdsBlob || (p->flags & PT_FLAG_NO_LDS)) && !(p->flags & PT_FLAG_FORCE_STREAM);
   const bool lds = resident && !(p->flags & PT_FLAG_NO_LDS);
   a.n_local_pixels = local_tiles * PT_TILE_PIXELS;
-  a.tile_granular = (p->flags & PT_FLAG_TILE_GRANULAR) ? 1 : 0;
-  a.queue = s->queues + (s->next_queue++ % kQueueRing);
-  PT_HIP(hipMemsetAsync(a.queue, 0, sizeof(unsigned int), st));
-  const size_t shmem = lds ? blob_bytes : 0;
+  // default: whole tiles for the resident kernels (coherent primary rays), single pixels for the lock-step
+  // streaming kernel (a workgroup waits for its slowest lane); either can be forced
+  a.tile_granular = (p->flags & PT_FLAG_TILE_GRANULAR) ? 1 : (p->flags & PT_FLAG_PIXEL_GRANULAR) ? 0 : (resident ? 1 : 0);
+  a.cost = nullptr;
+  a.order = nullptr;
+  const bool mlds = lds && blob_bytes + (size_t)s->mats_f4 * 16 <= kMaxLdsWithMaterials;
+  const size_t shmem = lds ? blob_bytes + (mlds ? (size_t)s->mats_f4 * 16 : 0) : 0;
   // Persistent grid: no more workgroups than the chip holds at once; lanes pull pixels from the queue.
   auto launch = [&](auto kernel) -> int {
     int per_cu = 0;
     PT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, shmem));
     if (const char* e = std::getenv("PT_BLOCKS_PER_CU")) per_cu = std::min(per_cu, std::max(1, std::atoi(e))); // tuning knob
-    const int resident = std::max(1, per_cu) * std::max(1, s->num_cus);
-    dim3 grid(std::min((local_tiles + kWavesPerBlock - 1) / kWavesPerBlock, resident)), block(kBlock);
+    const int resident_blocks = std::max(1, per_cu) * std::max(1, s->num_cus);
+    a.queue = s->queues + (s->next_queue++ % kQueueRing);
+    PT_HIP(hipMemsetAsync(a.queue, 0, sizeof(unsigned int), st));
+    dim3 grid(std::min((local_tiles + kWavesPerBlock - 1) / kWavesPerBlock, resident_blocks)), block(kBlock);
     hipLaunchKernelGGL(kernel, grid, block, shmem, st, a);
+    PT_HIP(hipGetLastError());
     return PT_OK;
   };
-  int rc;
-  if (!resident) { // stream the list through LDS tiles
-    rc = s->has_image ? launch(render_kernel_stream<true>) : launch(render_kernel_stream<false>);
-  } else if (s->has_image) {
-    rc = lds ? launch(render_kernel<true, true>) : launch(render_kernel<true, false>);
-  } else {
-    rc = lds ? launch(render_kernel<false, true>) : launch(render_kernel<false, false>);
+  auto launch_variant = [&]() -> int {
+    if (!resident) return s->has_image ? launch(render_kernel_stream<true>) : launch(render_kernel_stream<false>);
+    if (s->has_image)
+      return mlds ? launch(render_kernel<true, true, true>) : lds ? launch(render_kernel<true, true, false>) : launch(render_kernel<true, false, false>);
+    return mlds ? launch(render_kernel<false, true, true>) : lds ? launch(render_kernel<false, true, false>) : launch(render_kernel<false, false, false>);
+  };
+  // Heaviest-first tile order from a probe pass (see lpt_order_kernel); pointless for short renders.
+  const int probe_spp = std::min(4, p->samples / 16);
+  if (probe_spp >= 1 && local_tiles >= 64 && !(p->flags & PT_FLAG_NO_LPT)) {
+    if (s->ws_tiles < local_tiles) { // grow-only workspace (first render at a new size only)
+      if (s->ws_cost) (void)hipFree(s->ws_cost);
+      if (s->ws_order) (void)hipFree(s->ws_order);
+      s->ws_cost = nullptr; s->ws_order = nullptr; s->ws_tiles = 0;
+      PT_HIP(hipMalloc((void**)&s->ws_cost, (size_t)local_tiles * sizeof(unsigned int)));
+      PT_HIP(hipMalloc((void**)&s->ws_order, (size_t)local_tiles * sizeof(int)));
+      s->ws_tiles = local_tiles;
+    }
+    PT_HIP(hipMemsetAsync(s->ws_cost, 0, (size_t)local_tiles * sizeof(unsigned int), st));
+    KArgs main_args = a;
+    a.cost = s->ws_cost;
+    a.samples = probe_spp;
+    int rc = launch_variant();
+    if (rc) return rc;
+    hipLaunchKernelGGL(lpt_order_kernel, dim3(1), dim3(1024), 0, st, s->ws_cost, local_tiles, s->ws_order);
+    PT_HIP(hipGetLastError());
+    a = main_args;
+    a.order = s->ws_order;
   }
+  int rc = launch_variant();
   if (rc) return rc;
   PT_HIP(hipGetLastError());
   return PT_OK;

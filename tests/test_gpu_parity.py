@@ -275,6 +275,34 @@ def test_streaming_kernel_many_tiles(orc):
     assert_bit_identical(fb, R.render_host(48, 27, 3, ps, c, flags=abi.PT_FLAG_NO_LDS), "stream vs scalar")
 
 
+@pytest.mark.parametrize("name", ["cornell", "mixed", "triangles"])
+def test_dequeue_granularity_does_not_matter(name):
+    """Which lane renders which pixel (tile-granular or pixel-granular dequeue, persistent grid) cannot change a
+    pixel: its RNG stream is seeded by its own global id."""
+    ps, cam = S.ALL[name]()
+    c = scenes.make_camera(cam, 100, 60)
+    a = R.render_host(100, 60, 12, ps, c, flags=abi.PT_FLAG_TILE_GRANULAR)
+    b = R.render_host(100, 60, 12, ps, c, flags=abi.PT_FLAG_PIXEL_GRANULAR)
+    assert_bit_identical(a, b, name)
+    s_ = R.render_host(100, 60, 12, ps, c, flags=abi.PT_FLAG_PIXEL_GRANULAR | abi.PT_FLAG_FORCE_STREAM)
+    assert_bit_identical(a, s_, name + " streamed")
+
+
+@pytest.mark.parametrize("name,flags", [("mixed", 0), ("cornell", 0), ("mixed", abi.PT_FLAG_PIXEL_GRANULAR),
+                                        ("triangles", abi.PT_FLAG_FORCE_STREAM)])
+def test_cost_sorted_tile_order_does_not_matter(orc, name, flags):
+    """spp >= 16 and >= 64 tiles turn on the cost-probe pass + heaviest-first tile order; it decides when a pixel
+    is rendered, never its value."""
+    ps, cam = S.ALL[name]()
+    w, h, spp = 120, 72, 32  # 15 x 9 = 135 tiles
+    c = scenes.make_camera(cam, w, h)
+    a = R.render_host(w, h, spp, ps, c, flags=flags)
+    b = R.render_host(w, h, spp, ps, c, flags=flags | abi.PT_FLAG_NO_LPT)
+    assert_bit_identical(a, b, name)
+    orc.set_math(True)
+    assert_bit_identical(a, orc.render(ps, c.c, w, h, spp), name + " vs oracle")
+
+
 @pytest.mark.parametrize("name", ["cornell", "mixed", "ties"])
 def test_plain_division_path_agrees(name):
     ps, cam = S.ALL[name]()

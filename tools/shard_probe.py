@@ -16,7 +16,7 @@ cam = scenes.make_camera(cam_args, W, H)
 ds = R.DeviceScene(packed)
 R.render(W, H, 8, ds, cam)  # warm up
 torch.cuda.synchronize()
-for flags, name in ((0, "pixel-queue"), (abi.PT_FLAG_TILE_GRANULAR, "tile-queue")):
+for flags, name in ((abi.PT_FLAG_PIXEL_GRANULAR, "pixel-queue"), (abi.PT_FLAG_TILE_GRANULAR, "tile-queue")):
     base = None
     for n in (1, 2, 4, 8):
         ms = min(R.render(W, H, spp, ds, cam, flags=flags, shard_index=0, shard_count=n, timed=True)[1] for _ in range(2))
