@@ -11,18 +11,19 @@ import sys
 
 def main():
     tag, w, h, spp = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
-    sums, launches = collections.defaultdict(float), collections.defaultdict(set)
+    # A render is two launches of the render kernel (a short cost-probe pass, then the frame): report the
+    # frame launch = the dispatch with the largest value, per counter.
+    disp = collections.defaultdict(lambda: collections.defaultdict(float))
     meta = {}
     for path in sys.argv[5:]:
         for r in csv.DictReader(open(path)):
             if "render_kernel" not in r["Kernel_Name"]:
                 continue
-            sums[r["Counter_Name"]] += float(r["Counter_Value"])
-            launches[r["Counter_Name"]].add(r["Dispatch_Id"])
+            disp[r["Counter_Name"]][(path, r["Dispatch_Id"])] += float(r["Counter_Value"])
             meta = {k: r[k] for k in ("Kernel_Name", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Grid_Size", "Workgroup_Size")}
-    per = {k: v / max(1, len(launches[k])) for k, v in sums.items()}
+    per = {k: max(v.values()) for k, v in disp.items()}
     samples = w * h * spp
-    out = {"tag": tag, "workload": f"{w}x{h}x{spp}", "kernel": meta, "per_launch": per, "derived": {}}
+    out = {"tag": tag, "scene": "cornell", "workload": f"{w}x{h}x{spp}", "kernel": meta, "per_launch": per, "derived": {}}
     d = out["derived"]
     if "GRBM_GUI_ACTIVE" in per:
         cyc = per["GRBM_GUI_ACTIVE"] / 8  # summed over the 8 XCDs
@@ -32,8 +33,10 @@ def main():
             d["valu_issue_occupancy"] = per["SQ_INSTS_VALU"] * 2 / (1024 * cyc)  # wave64 on SIMD-32: 2 cycles per instruction
         if "SQ_WAVE_CYCLES" in per:
             d["mean_waves_per_simd"] = per["SQ_WAVE_CYCLES"] * 4 / (1024 * cyc)  # SQ_WAVE_CYCLES counts quad-cycles
-    if "SQ_THREAD_CYCLES_VALU" in per and "SQ_ACTIVE_INST_VALU" in sums:
-        pass
+    if "SQ_THREAD_CYCLES_VALU" in per and "SQ_ACTIVE_INST_VALU" in per:
+        d["valu_lane_utilisation"] = per["SQ_THREAD_CYCLES_VALU"] / (64 * per["SQ_ACTIVE_INST_VALU"])
+    if "SQ_INSTS_SALU" in per and "SQ_INSTS_VALU" in per:
+        d["salu_per_valu"] = per["SQ_INSTS_SALU"] / per["SQ_INSTS_VALU"]
     if "FETCH_SIZE" in per or "WRITE_SIZE" in per:
         # KiB units. The guide's gfx950 x2 FETCH_SIZE correction is calibrated for 16 B/lane streaming reads only;
         # this kernel's reads are scalar/LDS-staged (uncalibrated), so both readings are reported.
