@@ -167,7 +167,10 @@ typedef struct PtRenderParams {
   int32_t reserved;
 } PtRenderParams;
 
-typedef struct PtScene PtScene; /* opaque: device-resident flattened scene */
+/* Opaque device-resident flattened scene.  Renders of one PtScene may be queued back to back on any streams
+ * (each launch gets its own work-queue slot), but must be ISSUED by one host thread at a time: the scene owns a
+ * small grow-only scheduling workspace.                                                                      */
+typedef struct PtScene PtScene;
 
 /* ---- error codes (the reference returns void and asserts; we return codes) -- */
 enum {

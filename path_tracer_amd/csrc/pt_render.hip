@@ -29,6 +29,9 @@ static_assert(sizeof(Cam) == sizeof(PtCamera));
 
 namespace {
 
+#ifndef PT_MIN_WAVES
+#define PT_MIN_WAVES 7 /* non-IMG resident kernel: 71 VGPRs, no scratch; +6.5 % on the headline scene (A/B, one process) */
+#endif
 constexpr int kBlock = 256;                 // 4 wavefronts = 4 tiles per workgroup
 constexpr int kWavesPerBlock = kBlock / 64;
 constexpr size_t kMaxLdsBlob = 64 * 1024;   // blob staged in LDS when it fits
@@ -175,7 +178,7 @@ __device__ __forceinline__ void lane_prepare(Lane& L, const KArgs& a) {
 // MLDS: the material table is staged too (small tables only: it rides behind the records in the same buffer), so
 // the whole bounce — traversal, hit record, material, texture constants — runs out of LDS without a global load.
 template <bool IMG, bool LDS, bool MLDS>
-__global__ __launch_bounds__(kBlock) void render_kernel(KArgs a) {
+__global__ __launch_bounds__(kBlock, IMG ? 1 : PT_MIN_WAVES) void render_kernel(KArgs a) {
   extern __shared__ f4 smem[];
   if (LDS) {
     const int n = a.blob_f4 + (MLDS ? a.mats_f4 : 0); // a.mats == a.blob + a.blob_f4 (one device buffer)
