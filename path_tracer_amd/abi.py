@@ -31,6 +31,7 @@ PT_FLAG_NO_FASTDIV = 4
 PT_FLAG_TILE_GRANULAR = 8
 PT_FLAG_PIXEL_GRANULAR = 16
 PT_FLAG_NO_LPT = 32
+PT_FLAG_NO_COOP = 64
 
 PT_OK, PT_ERR_INVALID_ARG, PT_ERR_BAD_SCENE, PT_ERR_HIP, PT_ERR_NO_DEVICE, PT_ERR_TOO_LARGE = range(6)
 PT_BOUNCE_MISS, PT_BOUNCE_SCATTERED, PT_BOUNCE_ABSORBED = 0, 1, 2

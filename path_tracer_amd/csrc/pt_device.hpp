@@ -490,6 +490,115 @@ __device__ __forceinline__ void hit_world(P blob, int n_runs, const RayCtx& c, b
   }
 }
 
+// ---- cooperative traversal: one ray's primitive list split over the idle lanes of its wave -----------------------
+// A pixel's samples are one sequential chain (one RNG stream), so when most lanes of a wave have finished their
+// pixels the stragglers set the wave's — and in the end the frame's — finishing time.  When a wave is down to
+// <= 32 live lanes, each live ray is handed to a group of G = 64 / 2^ceil(log2 live) lanes: lane j of the group scans
+// the j-th contiguous segment of the list (in hittable order), the group merges the G segment winners IN LIST ORDER
+// with the reference's own acceptance rule — a later candidate replaces an earlier one iff t is smaller, or equal and
+// its kind accepts t == max (rect/box/triangle do, rectangle.hpp:36 triangle.hpp:91; spheres need t < max,
+// sphere.hpp:77) — which is exactly what the sequential scan with its shrinking max computes:
+//   * every candidate's t is independent of max (sphere: first root > min; box: its own nearest side), max only
+//     decides acceptance; so the scan's result is "minimum t; among equal t the last candidate that accepts
+//     equality, else the first", and that selection is associative over contiguous segments.
+//   * constant_medium is the exception (it clamps against max and draws RNG, constant_medium.hpp:52-65): the list is
+//     split only up to the first medium (coop_prefix); the rest is scanned after the merge, by every lane of the
+//     group redundantly with the owner's RNG state, so it sees exactly the sequential max and draw order.
+//   * stale u,v (a triangle/medium hit keeps the u,v of the previously ACCEPTED candidate) depends on acceptance
+//     history, which segments do not reproduce: scenes where that value can reach an image texture disable this path
+//     (PtScene::coop_ok).  For sphere/rect/box winners u,v are computed from the winner itself.
+// Irregular rays (NaN/inf/axis-parallel) never take this path.
+struct CoopScene {
+  int n_runs;
+  int coop_prefix; // hittables before the first constant_medium (== n_hittables when there is none)
+};
+
+__device__ __forceinline__ int nth_set_bit(unsigned long long m, int n) { // lane index of the n-th (0-based) set bit
+  for (int k = 0; k < n; ++k) m &= m - 1;
+  return __builtin_ctzll(m);
+}
+
+__device__ __forceinline__ float shfl_f(float v, int src) { return __shfl(v, src, 64); }
+__device__ __forceinline__ int shfl_i(int v, int src) { return __shfl(v, src, 64); }
+
+// later candidate B replaces earlier A?  (list order: A before B)
+__device__ __forceinline__ bool later_wins(float tA, int hitA, float tB, int hitB) {
+  if (hitB < 0) return false;
+  if (hitA < 0) return true;
+  return (tB < tA) | ((tB == tA) & (hit_kind(hitB) != DK_SPHERE));
+}
+
+// Returns false (nothing done) when the wave should use the ordinary path this iteration.
+template <bool IMG, typename P>
+__device__ __forceinline__ bool hit_world_coop(P blob, const CoopScene& cs, const Ray& my_ray, uint32_t& my_rng, bool live,
+                                               bool scene_fast_ok, HitState& h) {
+  const unsigned long long live_mask = __builtin_amdgcn_ballot_w64(live);
+  const int nlive = __builtin_popcountll(live_mask);
+  if (nlive == 0 || nlive > 32) return false;
+  const int lane = threadIdx.x & 63;
+  const int logG = nlive == 1 ? 6 : 6 - (32 - __builtin_clz((unsigned)(nlive - 1))); // G = 64 >> ceil(log2 nlive)
+  const int G = 1 << logG;
+  const int group = lane >> logG, j = lane & (G - 1);
+  const bool active = group < nlive;
+  const int owner = nth_set_bit(live_mask, active ? group : 0);
+  // the group's ray and RNG state, from its owner lane
+  Ray r;
+  r.o = mk(shfl_f(my_ray.o.x, owner), shfl_f(my_ray.o.y, owner), shfl_f(my_ray.o.z, owner));
+  r.d = mk(shfl_f(my_ray.d.x, owner), shfl_f(my_ray.d.y, owner), shfl_f(my_ray.d.z, owner));
+  r.tm = shfl_f(my_ray.tm, owner);
+  uint32_t rng = (uint32_t)shfl_i((int)my_rng, owner);
+  RayCtx c = make_ctx(r, scene_fast_ok);
+  if (__builtin_amdgcn_ballot_w64(active && !c.reg) != 0) return false; // an irregular ray: ordinary path
+  // this lane's segment of the list, in hittable order
+  const int seg_lo = (int)(((long long)cs.coop_prefix * j) >> logG), seg_hi = (int)(((long long)cs.coop_prefix * (j + 1)) >> logG);
+  HitState s;
+  hit_begin(s);
+  int suffix_run = cs.n_runs; // first run that holds a constant_medium
+  for (int ri = 0; ri < cs.n_runs; ++ri) {
+    f4 runf = blob[ri];
+    const int kind = as_i(runf.x), off = as_i(runf.y), cnt = as_i(runf.z), first = as_i(runf.w);
+    if (kind == DK_MEDIUM) { suffix_run = ri; break; }
+    const int lo = max(seg_lo, first), hi = min(seg_hi, first + cnt);
+    if (active && hi > lo) {
+      const int sz = record_size(kind);
+      hit_records<IMG>(blob + off + (lo - first) * sz, kind, hi - lo, off + (lo - first) * sz, c, true, rng, s);
+    }
+  }
+  // merge the G segment winners in list order (tree: the lower lane of each pair is earlier in the list)
+  for (int step = 1; step < G; step <<= 1) {
+    const int src = lane + step;
+    const float tB = shfl_f(s.closest, src);
+    const int hB = shfl_i(s.hit, src);
+    float uB = 0.0f, vB = 0.0f;
+    if (IMG) { uB = shfl_f(s.u, src); vB = shfl_f(s.v, src); }
+    if (((j & (2 * step - 1)) == 0) && later_wins(s.closest, s.hit, tB, hB)) {
+      s.closest = tB; s.hit = hB;
+      if (IMG) { s.u = uB; s.v = vB; }
+    }
+  }
+  // the group leader holds the merged result of the prefix: give it to the whole group
+  const int leader = group << logG;
+  s.closest = shfl_f(s.closest, leader);
+  s.hit = shfl_i(s.hit, leader);
+  if (IMG) { s.u = shfl_f(s.u, leader); s.v = shfl_f(s.v, leader); }
+  // the rest of the list (from the first medium on), sequentially, identically in every lane of the group
+  for (int ri = suffix_run; ri < cs.n_runs; ++ri) {
+    f4 runf = blob[ri];
+    const int off = as_i(runf.y);
+    if (active) hit_records<IMG>(blob + off, as_i(runf.x), as_i(runf.z), off, c, true, rng, s);
+  }
+  // hand each owner its result: the r-th live lane reads from the leader of group r
+  const int my_rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(live_mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)live_mask, 0u));
+  const int my_leader = live ? (my_rank << logG) : lane;
+  h.closest = shfl_f(s.closest, my_leader);
+  h.hit = shfl_i(s.hit, my_leader);
+  h.u = IMG ? shfl_f(s.u, my_leader) : 0.0f;
+  h.v = IMG ? shfl_f(s.v, my_leader) : 0.0f;
+  const uint32_t orng = (uint32_t)shfl_i((int)rng, my_leader);
+  if (live) my_rng = orng;
+  return true;
+}
+
 // Wave-uniform switch: the straight-line rect/box path is used only when every live lane's ray is regular.
 __device__ __forceinline__ bool wave_all_regular(const RayCtx& c, bool live) {
   return __builtin_amdgcn_ballot_w64(live && !c.reg) == 0;

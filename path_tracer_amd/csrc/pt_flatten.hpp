@@ -30,6 +30,8 @@ struct Flat {
   int32_t n_runs = 0;
   bool has_image = false;
   bool has_medium = false;
+  bool coop_ok = true; // no triangle/medium carries an image texture (stale u,v cannot matter): pt_device.hpp coop
+  int32_t coop_prefix = 0; // hittables before the first constant_medium
   bool fast_ok = true; // all rect/box coordinates finite with |v| <= 2^60 (pt_device.hpp: RayCtx)
 };
 
@@ -132,6 +134,16 @@ inline int flatten(const PtSceneDesc* sc, Flat& out, std::string& err) {
     int nf = (h.kind == PT_HIT_BOX || h.kind == PT_HIT_CONSTANT_MEDIUM) ? 6 : 5;
     for (int k = 0; k < nf; k++)
       if (!(std::fabs(h.f[k]) <= 1.152921504606846976e18f)) out.fast_ok = false; // also false for NaN
+  }
+  out.coop_prefix = sc->n_hittables;
+  for (int i = 0; i < sc->n_hittables; i++) {
+    const PtHittable& h = sc->hittables[i];
+    if (h.kind == PT_HIT_CONSTANT_MEDIUM && i < out.coop_prefix) out.coop_prefix = i;
+    if (h.kind == PT_HIT_CONSTANT_MEDIUM || h.kind == PT_HIT_TRIANGLE) {
+      const PtMaterial& m = sc->materials[h.material];
+      bool tex = m.kind == PT_MAT_LAMBERTIAN || m.kind == PT_MAT_LIGHTSOURCE || m.kind == PT_MAT_ISOTROPIC;
+      if (tex && sc->textures[m.texture].kind == PT_TEX_IMAGE) out.coop_ok = false;
+    }
   }
   out.n_runs = (int32_t)runs.size();
   std::vector<F4>& b = out.blob;

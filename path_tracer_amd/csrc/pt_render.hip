@@ -53,6 +53,7 @@ struct KArgs {
   unsigned int* cost;  // non-NULL: cost-probe pass, per local tile ray counts (nothing is written to fb)
   const int* order;    // non-NULL: queue position -> local tile, heaviest first
   int tile_granular;   // PT_FLAG_TILE_GRANULAR
+  int coop_prefix;     // >= 0: cooperative traversal allowed, list splittable up to this hittable; -1: disabled
   int fast_ok; // every rect/box coordinate finite and <= 2^60: rays may use the shared-reciprocal division
 };
 
@@ -194,9 +195,19 @@ __global__ __launch_bounds__(kBlock, IMG ? 1 : PT_MIN_WAVES) void render_kernel(
       if (__builtin_amdgcn_ballot_w64(!L.retired) == 0) break; // queue drained for the whole wave
       continue;                                                 // only padding pixels this time: pull again
     }
+    HitState h;
+    if constexpr (LDS) {
+      if (a.coop_prefix >= 0 && a.fast_ok) { // few live lanes: split each live ray's list over the idle lanes
+        const CoopScene cs{a.n_runs, a.coop_prefix};
+        if (hit_world_coop<IMG>((lds_f4p)smem, cs, L.ray, L.rng, L.live, true, h)) {
+          if constexpr (MLDS) lane_shade(L, a, h, (lds_f4p)smem, (lds_f4p)smem + a.blob_f4);
+          else lane_shade(L, a, h, (lds_f4p)smem, a.mats);
+          continue;
+        }
+      }
+    }
     RayCtx c = make_ctx(L.ray, a.fast_ok != 0);
     const bool fast = wave_all_regular(c, L.live);
-    HitState h;
     if constexpr (LDS) {
       hit_world<IMG>((lds_f4p)smem, a.n_runs, c, fast, L.rng, h);
       if constexpr (MLDS) lane_shade(L, a, h, (lds_f4p)smem, (lds_f4p)smem + a.blob_f4);
@@ -424,6 +435,8 @@ struct PtScene {
   int n_runs = 0, blob_f4 = 0, mats_f4 = 0;
   bool has_image = false;
   bool fast_ok = false;
+  bool coop_ok = false;
+  int coop_prefix = 0;
   size_t blob_bytes = 0;
   int num_cus = 256;
   mutable unsigned int* ws_cost = nullptr; // LPT workspace: per-tile ray counts of the probe pass
@@ -528,6 +541,8 @@ int pt_scene_create(const PtSceneDesc* desc, PtScene** out_scene) {
   s->blob_f4 = (int)flat.blob.size();
   s->has_image = flat.has_image;
   s->fast_ok = flat.fast_ok;
+  s->coop_ok = flat.coop_ok;
+  s->coop_prefix = flat.coop_prefix;
   s->blob_bytes = flat.blob.size() * 16;
   s->mats_f4 = (int)flat.mats.size();
   // one buffer: [blob records][material table] so a kernel can stage both with one contiguous copy
@@ -595,6 +610,7 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
   PT_HIP(hipMemsetAsync(fb, 0, (size_t)pt_framebuffer_floats(p) * sizeof(float), st));
   if (local_tiles <= 0) return PT_OK;
   a.fast_ok = (s->fast_ok && !(p->flags & PT_FLAG_NO_FASTDIV)) ? 1 : 0;
+  a.coop_prefix = (s->coop_ok && a.fast_ok && !(p->flags & PT_FLAG_NO_COOP)) ? s->coop_prefix : -1;
   const size_t blob_bytes = (size_t)s->blob_f4 * 16;
   const bool resident = (blob_bytes <= kMaxLdsBlob || (p->flags & PT_FLAG_NO_LDS)) && !(p->flags & PT_FLAG_FORCE_STREAM);
   const bool lds = resident && !(p->flags & PT_FLAG_NO_LDS);

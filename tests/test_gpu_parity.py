@@ -303,6 +303,34 @@ def test_cost_sorted_tile_order_does_not_matter(orc, name, flags):
     assert_bit_identical(a, orc.render(ps, c.c, w, h, spp), name + " vs oracle")
 
 
+@pytest.mark.parametrize("name", ["cornell", "spheres", "triangles", "ties", "mixed"])
+@pytest.mark.parametrize("size", [(37, 21), (64, 40), (9, 5)])
+def test_cooperative_traversal_agrees(orc, name, size):
+    """Waves with <= 32 live lanes split each ray's list over idle lanes and merge the segment winners with the
+    list-order tie rule; odd frame sizes make partially filled tiles, so this path runs from the first iteration.
+    ('mixed' puts an image texture on a triangle, which disables the path: it must then be a no-op.)"""
+    w, h = size
+    ps, cam = S.ALL[name]()
+    c = scenes.make_camera(cam, w, h)
+    a = R.render_host(w, h, 24, ps, c)
+    b = R.render_host(w, h, 24, ps, c, flags=abi.PT_FLAG_NO_COOP)
+    assert_bit_identical(a, b, f"{name} {w}x{h}")
+    orc.set_math(True)
+    assert_bit_identical(a, orc.render(ps, c.c, w, h, 24), f"{name} {w}x{h} vs oracle")
+
+
+def test_cooperative_traversal_with_medium_suffix_and_image(orc):
+    """The SmokeSphere scene: image textures (u,v carried through the merge), a constant_medium at the end of the
+    list (scanned after the merge with the owner's RNG state), 496 hittables split over up to 64 lanes."""
+    ps, cam = scenes.build("smoke")
+    for w, h in ((19, 11), (40, 24)):
+        c = scenes.make_camera(cam, w, h)
+        a = R.render_host(w, h, 16, ps, c)
+        assert_bit_identical(a, R.render_host(w, h, 16, ps, c, flags=abi.PT_FLAG_NO_COOP), f"smoke {w}x{h}")
+        orc.set_math(True)
+        assert_bit_identical(a, orc.render(ps, c.c, w, h, 16), f"smoke {w}x{h} vs oracle")
+
+
 @pytest.mark.parametrize("name", ["cornell", "mixed", "ties"])
 def test_plain_division_path_agrees(name):
     ps, cam = S.ALL[name]()
