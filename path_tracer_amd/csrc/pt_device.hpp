@@ -490,6 +490,11 @@ __device__ __forceinline__ void hit_world(P blob, int n_runs, const RayCtx& c, b
   }
 }
 
+// Wave-uniform switch: the straight-line rect/box path is used only when every live lane's ray is regular.
+__device__ __forceinline__ bool wave_all_regular(const RayCtx& c, bool live) {
+  return __builtin_amdgcn_ballot_w64(live && !c.reg) == 0;
+}
+
 // ---- cooperative traversal: one ray's primitive list split over the idle lanes of its wave -----------------------
 // A pixel's samples are one sequential chain (one RNG stream), so when most lanes of a wave have finished their
 // pixels the stragglers set the wave's — and in the end the frame's — finishing time.  When a wave is down to
@@ -528,81 +533,88 @@ __device__ __forceinline__ bool later_wins(float tA, int hitA, float tB, int hit
   return (tB < tA) | ((tB == tA) & (hit_kind(hitB) != DK_SPHERE));
 }
 
-// Returns false (nothing done) when the wave should use the ordinary path this iteration.
+// hit_world for the LDS-resident kernel, ordinary and cooperative mode in ONE instantiation of the record loops
+// (two copies cost ~45 VGPRs = one to two waves of occupancy).  Ordinary mode is the degenerate case G = 1: every
+// lane is its own group, its segment is the whole list, nothing is shuffled or merged.
 template <bool IMG, typename P>
-__device__ __forceinline__ bool hit_world_coop(P blob, const CoopScene& cs, const Ray& my_ray, uint32_t& my_rng, bool live,
-                                               bool scene_fast_ok, HitState& h) {
+__device__ __forceinline__ void hit_world_lds(P blob, const CoopScene& cs, const Ray& my_ray, uint32_t& my_rng, bool live,
+                                              bool coop_allowed, bool scene_fast_ok, HitState& h) {
+  RayCtx c = make_ctx(my_ray, scene_fast_ok);
+  const bool fast = wave_all_regular(c, live);
   const unsigned long long live_mask = __builtin_amdgcn_ballot_w64(live);
   const int nlive = __builtin_popcountll(live_mask);
-  if (nlive == 0 || nlive > 32) return false;
   const int lane = threadIdx.x & 63;
-  const int logG = nlive == 1 ? 6 : 6 - (32 - __builtin_clz((unsigned)(nlive - 1))); // G = 64 >> ceil(log2 nlive)
+  int logG = 0;
+  if (coop_allowed && fast && nlive >= 1 && nlive <= 32)
+    logG = nlive == 1 ? 6 : 6 - (32 - __builtin_clz((unsigned)(nlive - 1))); // G = 64 >> ceil(log2 nlive)
   const int G = 1 << logG;
   const int group = lane >> logG, j = lane & (G - 1);
-  const bool active = group < nlive;
-  const int owner = nth_set_bit(live_mask, active ? group : 0);
-  // the group's ray and RNG state, from its owner lane
-  Ray r;
-  r.o = mk(shfl_f(my_ray.o.x, owner), shfl_f(my_ray.o.y, owner), shfl_f(my_ray.o.z, owner));
-  r.d = mk(shfl_f(my_ray.d.x, owner), shfl_f(my_ray.d.y, owner), shfl_f(my_ray.d.z, owner));
-  r.tm = shfl_f(my_ray.tm, owner);
-  uint32_t rng = (uint32_t)shfl_i((int)my_rng, owner);
-  RayCtx c = make_ctx(r, scene_fast_ok);
-  if (__builtin_amdgcn_ballot_w64(active && !c.reg) != 0) return false; // an irregular ray: ordinary path
-  // this lane's segment of the list, in hittable order
+  bool active = live;
+  uint32_t rng = my_rng;
+  if (logG) { // wave-uniform: hand every live ray (+ its context and RNG state) to a group of G lanes
+    active = group < nlive;
+    const int owner = nth_set_bit(live_mask, active ? group : 0);
+    c.r.o = mk(shfl_f(c.r.o.x, owner), shfl_f(c.r.o.y, owner), shfl_f(c.r.o.z, owner));
+    c.r.d = mk(shfl_f(c.r.d.x, owner), shfl_f(c.r.d.y, owner), shfl_f(c.r.d.z, owner));
+    c.r.tm = shfl_f(c.r.tm, owner);
+    c.a = shfl_f(c.a, owner);
+    c.yx = shfl_f(c.yx, owner); c.yy = shfl_f(c.yy, owner); c.yz = shfl_f(c.yz, owner);
+    c.reg = true; // fast == every live ray is regular
+    rng = (uint32_t)shfl_i((int)rng, owner);
+  }
+  // this lane's segment of the splittable prefix of the list, in hittable order (G = 1: all of it)
   const int seg_lo = (int)(((long long)cs.coop_prefix * j) >> logG), seg_hi = (int)(((long long)cs.coop_prefix * (j + 1)) >> logG);
   HitState s;
   hit_begin(s);
-  int suffix_run = cs.n_runs; // first run that holds a constant_medium
-  for (int ri = 0; ri < cs.n_runs; ++ri) {
-    f4 runf = blob[ri];
-    const int kind = as_i(runf.x), off = as_i(runf.y), cnt = as_i(runf.z), first = as_i(runf.w);
-    if (kind == DK_MEDIUM) { suffix_run = ri; break; }
-    const int lo = max(seg_lo, first), hi = min(seg_hi, first + cnt);
+  const int leader = group << logG;
+  bool merged = logG == 0;
+  // One pass over the runs.  Up to the first constant_medium each lane scans only its own segment; at that point
+  // (or after the last run) the G segment winners are merged and from then on every lane of the group scans the
+  // whole run with the merged state and the owner's RNG state.
+  for (int ri = 0; ri <= cs.n_runs; ++ri) {
+    int kind = DK_MEDIUM, off = 0, cnt = 0, first = 0;
+    if (ri < cs.n_runs) {
+      f4 runf = blob[ri];
+      kind = as_i(runf.x); off = as_i(runf.y); cnt = as_i(runf.z); first = as_i(runf.w);
+    }
+    if (!merged && kind == DK_MEDIUM) {
+      // merge in list order (tree: the lower lane of each pair is earlier in the list) ...
+      for (int step = 1; step < G; step <<= 1) {
+        const int src = lane + step;
+        const float tB = shfl_f(s.closest, src);
+        const int hB = shfl_i(s.hit, src);
+        float uB = 0.0f, vB = 0.0f;
+        if (IMG) { uB = shfl_f(s.u, src); vB = shfl_f(s.v, src); }
+        if (((j & (2 * step - 1)) == 0) && later_wins(s.closest, s.hit, tB, hB)) {
+          s.closest = tB; s.hit = hB;
+          if (IMG) { s.u = uB; s.v = vB; }
+        }
+      }
+      // ... and give the leader's result to the whole group
+      s.closest = shfl_f(s.closest, leader);
+      s.hit = shfl_i(s.hit, leader);
+      if (IMG) { s.u = shfl_f(s.u, leader); s.v = shfl_f(s.v, leader); }
+      merged = true;
+    }
+    if (ri == cs.n_runs) break;
+    const int lo = merged ? first : max(seg_lo, first), hi = merged ? first + cnt : min(seg_hi, first + cnt);
     if (active && hi > lo) {
       const int sz = record_size(kind);
-      hit_records<IMG>(blob + off + (lo - first) * sz, kind, hi - lo, off + (lo - first) * sz, c, true, rng, s);
+      hit_records<IMG>(blob + off + (lo - first) * sz, kind, hi - lo, off + (lo - first) * sz, c, fast, rng, s);
     }
   }
-  // merge the G segment winners in list order (tree: the lower lane of each pair is earlier in the list)
-  for (int step = 1; step < G; step <<= 1) {
-    const int src = lane + step;
-    const float tB = shfl_f(s.closest, src);
-    const int hB = shfl_i(s.hit, src);
-    float uB = 0.0f, vB = 0.0f;
-    if (IMG) { uB = shfl_f(s.u, src); vB = shfl_f(s.v, src); }
-    if (((j & (2 * step - 1)) == 0) && later_wins(s.closest, s.hit, tB, hB)) {
-      s.closest = tB; s.hit = hB;
-      if (IMG) { s.u = uB; s.v = vB; }
-    }
+  if (logG) { // hand each owner its result: the r-th live lane reads from the leader of group r
+    const int my_rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(live_mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)live_mask, 0u));
+    const int my_leader = live ? (my_rank << logG) : lane;
+    s.closest = shfl_f(s.closest, my_leader);
+    s.hit = shfl_i(s.hit, my_leader);
+    if (IMG) { s.u = shfl_f(s.u, my_leader); s.v = shfl_f(s.v, my_leader); }
+    rng = (uint32_t)shfl_i((int)rng, my_leader);
   }
-  // the group leader holds the merged result of the prefix: give it to the whole group
-  const int leader = group << logG;
-  s.closest = shfl_f(s.closest, leader);
-  s.hit = shfl_i(s.hit, leader);
-  if (IMG) { s.u = shfl_f(s.u, leader); s.v = shfl_f(s.v, leader); }
-  // the rest of the list (from the first medium on), sequentially, identically in every lane of the group
-  for (int ri = suffix_run; ri < cs.n_runs; ++ri) {
-    f4 runf = blob[ri];
-    const int off = as_i(runf.y);
-    if (active) hit_records<IMG>(blob + off, as_i(runf.x), as_i(runf.z), off, c, true, rng, s);
-  }
-  // hand each owner its result: the r-th live lane reads from the leader of group r
-  const int my_rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(live_mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)live_mask, 0u));
-  const int my_leader = live ? (my_rank << logG) : lane;
-  h.closest = shfl_f(s.closest, my_leader);
-  h.hit = shfl_i(s.hit, my_leader);
-  h.u = IMG ? shfl_f(s.u, my_leader) : 0.0f;
-  h.v = IMG ? shfl_f(s.v, my_leader) : 0.0f;
-  const uint32_t orng = (uint32_t)shfl_i((int)rng, my_leader);
-  if (live) my_rng = orng;
-  return true;
+  h = s;
+  if (live) my_rng = rng;
 }
 
-// Wave-uniform switch: the straight-line rect/box path is used only when every live lane's ray is regular.
-__device__ __forceinline__ bool wave_all_regular(const RayCtx& c, bool live) {
-  return __builtin_amdgcn_ballot_w64(live && !c.reg) == 0;
-}
 
 // ---- hit_record of the final nearest hit (hitable.hpp:8-24) ---------------------------------------------------
 struct Rec {

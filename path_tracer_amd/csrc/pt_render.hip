@@ -53,6 +53,7 @@ struct KArgs {
   unsigned int* cost;  // non-NULL: cost-probe pass, per local tile ray counts (nothing is written to fb)
   const int* order;    // non-NULL: queue position -> local tile, heaviest first
   int tile_granular;   // PT_FLAG_TILE_GRANULAR
+  int n_hittables;
   int coop_prefix;     // >= 0: cooperative traversal allowed, list splittable up to this hittable; -1: disabled
   int fast_ok; // every rect/box coordinate finite and <= 2^60: rays may use the shared-reciprocal division
 };
@@ -197,22 +198,14 @@ __global__ __launch_bounds__(kBlock, IMG ? 1 : PT_MIN_WAVES) void render_kernel(
     }
     HitState h;
     if constexpr (LDS) {
-      if (a.coop_prefix >= 0 && a.fast_ok) { // few live lanes: split each live ray's list over the idle lanes
-        const CoopScene cs{a.n_runs, a.coop_prefix};
-        if (hit_world_coop<IMG>((lds_f4p)smem, cs, L.ray, L.rng, L.live, true, h)) {
-          if constexpr (MLDS) lane_shade(L, a, h, (lds_f4p)smem, (lds_f4p)smem + a.blob_f4);
-          else lane_shade(L, a, h, (lds_f4p)smem, a.mats);
-          continue;
-        }
-      }
-    }
-    RayCtx c = make_ctx(L.ray, a.fast_ok != 0);
-    const bool fast = wave_all_regular(c, L.live);
-    if constexpr (LDS) {
-      hit_world<IMG>((lds_f4p)smem, a.n_runs, c, fast, L.rng, h);
+      // ordinary and cooperative traversal (few live lanes: each live ray's list split over the idle lanes)
+      const CoopScene cs{a.n_runs, a.coop_prefix >= 0 ? a.coop_prefix : a.n_hittables};
+      hit_world_lds<IMG>((lds_f4p)smem, cs, L.ray, L.rng, L.live, a.coop_prefix >= 0, a.fast_ok != 0, h);
       if constexpr (MLDS) lane_shade(L, a, h, (lds_f4p)smem, (lds_f4p)smem + a.blob_f4);
       else lane_shade(L, a, h, (lds_f4p)smem, a.mats);
     } else {
+      RayCtx c = make_ctx(L.ray, a.fast_ok != 0);
+      const bool fast = wave_all_regular(c, L.live);
       hit_world<IMG>((cst_f4p)a.blob, a.n_runs, c, fast, L.rng, h);
       lane_shade(L, a, h, a.blob, a.mats);
     }
@@ -437,6 +430,7 @@ struct PtScene {
   bool fast_ok = false;
   bool coop_ok = false;
   int coop_prefix = 0;
+  int n_hittables = 0;
   size_t blob_bytes = 0;
   int num_cus = 256;
   mutable unsigned int* ws_cost = nullptr; // LPT workspace: per-tile ray counts of the probe pass
@@ -543,6 +537,7 @@ int pt_scene_create(const PtSceneDesc* desc, PtScene** out_scene) {
   s->fast_ok = flat.fast_ok;
   s->coop_ok = flat.coop_ok;
   s->coop_prefix = flat.coop_prefix;
+  s->n_hittables = desc->n_hittables;
   s->blob_bytes = flat.blob.size() * 16;
   s->mats_f4 = (int)flat.mats.size();
   // one buffer: [blob records][material table] so a kernel can stage both with one contiguous copy
@@ -601,7 +596,7 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
   KArgs a;
   std::memcpy(&a.cam, cam, sizeof(Cam));
   a.blob = s->blob; a.mats = s->mats; a.atlas = s->atlas; a.fb = fb;
-  a.n_runs = s->n_runs; a.blob_f4 = s->blob_f4; a.mats_f4 = s->mats_f4;
+  a.n_runs = s->n_runs; a.blob_f4 = s->blob_f4; a.mats_f4 = s->mats_f4; a.n_hittables = s->n_hittables;
   a.width = p->width; a.height = p->height; a.samples = p->samples; a.depth = p->depth;
   a.shard_index = p->shard_index; a.shard_count = p->shard_count;
   a.n_tiles = n_tiles_of(p, &a.tiles_x);
