@@ -32,6 +32,8 @@ PT_FLAG_TILE_GRANULAR = 8
 PT_FLAG_PIXEL_GRANULAR = 16
 PT_FLAG_NO_LPT = 32
 PT_FLAG_NO_COOP = 64
+PT_FLAG_FORCE_COOP = 128
+PT_FLAG_NO_SPLIT = 256
 
 PT_OK, PT_ERR_INVALID_ARG, PT_ERR_BAD_SCENE, PT_ERR_HIP, PT_ERR_NO_DEVICE, PT_ERR_TOO_LARGE = range(6)
 PT_BOUNCE_MISS, PT_BOUNCE_SCATTERED, PT_BOUNCE_ABSORBED = 0, 1, 2

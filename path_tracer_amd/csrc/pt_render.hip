@@ -36,6 +36,7 @@ constexpr int kBlock = 256;                 // 4 wavefronts = 4 tiles per workgr
 constexpr int kWavesPerBlock = kBlock / 64;
 constexpr size_t kMaxLdsBlob = 64 * 1024;   // blob staged in LDS when it fits
 constexpr size_t kMaxLdsWithMaterials = 16 * 1024; // stage the material table too when records + materials are this small
+constexpr float kCoopMinTraversal = 2500.0f;        // estimated VALU instructions of one list scan (~110 spheres)
 constexpr unsigned kQueueRing = 256;        // launches in flight on one scene may not exceed this
 
 struct KArgs {
@@ -52,6 +53,7 @@ struct KArgs {
   unsigned int* queue; // per-launch dequeue counter, zeroed on the stream before the kernel
   unsigned int* cost;  // non-NULL: cost-probe pass, per local tile ray counts (nothing is written to fb)
   const int* order;    // non-NULL: queue position -> local tile, heaviest first
+  const int* n_split;  // non-NULL (COOP kernels): how many leading tiles of `order` are handed out row by row
   int tile_granular;   // PT_FLAG_TILE_GRANULAR
   int n_hittables;
   int coop_prefix;     // >= 0: cooperative traversal allowed, list splittable up to this hittable; -1: disabled
@@ -73,6 +75,7 @@ struct Lane {
   bool live;     // owns a pixel with samples left
   bool retired;  // the queue is empty for this lane
   bool need_new; // next iteration starts a new sample
+  bool split_done; // (wave-uniform) the split queue is exhausted
 };
 
 __device__ __forceinline__ void lane_reset(Lane& L) {
@@ -81,7 +84,7 @@ __device__ __forceinline__ void lane_reset(Lane& L) {
   L.att = mk(1.0f, 1.0f, 1.0f);
   L.ray.o = mk(0.0f, 0.0f, 0.0f); L.ray.d = mk(0.0f, 0.0f, 1.0f); L.ray.tm = 0.0f;
   L.s = 0; L.b = 0; L.iters = 0; L.pix = -1; L.x = 0; L.y = 0;
-  L.live = false; L.retired = false; L.need_new = true;
+  L.live = false; L.retired = false; L.need_new = true; L.split_done = false;
 }
 
 // Wave-aggregated dequeue: one atomicAdd per wave for all lanes that need a pixel (ballot + prefix count),
@@ -92,14 +95,34 @@ __device__ __forceinline__ void lane_acquire(Lane& L, const KArgs& a) {
   if (mask == 0) return;
   // tile-granular mode (A/B switch): a wave takes its next 64 pixels only when all of its lanes are idle
   if (a.tile_granular && __builtin_amdgcn_ballot_w64(L.live) != 0) return;
-  unsigned int base = 0;
   const int lane = threadIdx.x & 63;
   const int leader = __builtin_ctzll(mask);
-  if (lane == leader) base = atomicAdd(a.queue, (unsigned int)__builtin_popcountll(mask));
-  base = __builtin_amdgcn_readlane(base, leader);
-  if (!want) return;
   const unsigned int rank = __builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mask, 0u));
-  const unsigned int i = base + rank;
+  // Heavy tiles (the first *a.n_split positions of the cost-sorted order) are handed out 8 pixels = one tile row at a
+  // time from a queue of their own: a wave that holds only 8 live pixels runs them 8 lanes per ray (hit_world_lds),
+  // so a tile that would otherwise bound the makespan is spread over 8 waves and each of its rays over 8 lanes.
+  const unsigned int split_pixels = (a.n_split && !L.split_done) ? (unsigned int)(*a.n_split) * PT_TILE_PIXELS : 0u;
+  unsigned int i = 0;
+  bool got = false;
+  if (split_pixels) {
+    unsigned int b = 0;
+    if (lane == leader) b = atomicAdd(a.queue + 1, (unsigned int)PT_TILE);
+    b = __builtin_amdgcn_readlane(b, leader);
+    if (b < split_pixels) {
+      if (!want || rank >= (unsigned int)PT_TILE) return; // the other idle lanes serve these 8 rays
+      i = b + rank;
+      got = true;
+    } else {
+      L.split_done = true;
+    }
+  }
+  if (!got) {
+    unsigned int base = 0;
+    if (lane == leader) base = atomicAdd(a.queue, (unsigned int)__builtin_popcountll(mask));
+    base = __builtin_amdgcn_readlane(base, leader);
+    if (!want) return;
+    i = (a.n_split ? (unsigned int)(*a.n_split) * PT_TILE_PIXELS : 0u) + base + rank;
+  }
   if (i >= (unsigned int)a.n_local_pixels) { L.retired = true; return; }
   // queue position -> local tile: identity, or the cost-sorted order of the probe pass (heaviest tiles first)
   const int l = a.order ? a.order[i >> 6] : (int)(i >> 6), in_tile = (int)(i & 63);
@@ -179,7 +202,9 @@ __device__ __forceinline__ void lane_prepare(Lane& L, const KArgs& a) {
 // Scene blob resident for the whole kernel: staged once into LDS (LDS=true) or read through the scalar cache.
 // MLDS: the material table is staged too (small tables only: it rides behind the records in the same buffer), so
 // the whole bounce — traversal, hit record, material, texture constants — runs out of LDS without a global load.
-template <bool IMG, bool LDS, bool MLDS>
+// COOP: the traversal can split a ray's list over idle lanes (hit_world_lds); costs ~10 VGPRs and ~7 % of the
+// ordinary-mode throughput, so the launcher picks it only where the makespan floor matters (launch_render).
+template <bool IMG, bool LDS, bool MLDS, bool COOP>
 __global__ __launch_bounds__(kBlock, IMG ? 1 : PT_MIN_WAVES) void render_kernel(KArgs a) {
   extern __shared__ f4 smem[];
   if (LDS) {
@@ -198,9 +223,15 @@ __global__ __launch_bounds__(kBlock, IMG ? 1 : PT_MIN_WAVES) void render_kernel(
     }
     HitState h;
     if constexpr (LDS) {
-      // ordinary and cooperative traversal (few live lanes: each live ray's list split over the idle lanes)
-      const CoopScene cs{a.n_runs, a.coop_prefix >= 0 ? a.coop_prefix : a.n_hittables};
-      hit_world_lds<IMG>((lds_f4p)smem, cs, L.ray, L.rng, L.live, a.coop_prefix >= 0, a.fast_ok != 0, h);
+      if constexpr (COOP) {
+        // ordinary and cooperative traversal (few live lanes: each live ray's list split over the idle lanes)
+        const CoopScene cs{a.n_runs, a.coop_prefix};
+        hit_world_lds<IMG>((lds_f4p)smem, cs, L.ray, L.rng, L.live, true, a.fast_ok != 0, h);
+      } else {
+        RayCtx c = make_ctx(L.ray, a.fast_ok != 0);
+        const bool fast = wave_all_regular(c, L.live);
+        hit_world<IMG>((lds_f4p)smem, a.n_runs, c, fast, L.rng, h);
+      }
       if constexpr (MLDS) lane_shade(L, a, h, (lds_f4p)smem, (lds_f4p)smem + a.blob_f4);
       else lane_shade(L, a, h, (lds_f4p)smem, a.mats);
     } else {
@@ -266,15 +297,20 @@ __global__ __launch_bounds__(kBlock) void render_kernel_stream(KArgs a) {
 // into 32 classes of ratio 2^(1/4) below the maximum and emits them heaviest class first.  The order only decides
 // WHEN a pixel is rendered, never its value, so the (atomic, run-to-run varying) order inside a class is harmless.
 constexpr int kLptClasses = 32;
-__global__ __launch_bounds__(1024) void lpt_order_kernel(const unsigned int* __restrict__ cost, int n, int* __restrict__ order) {
+__global__ __launch_bounds__(1024) void lpt_order_kernel(const unsigned int* __restrict__ cost, int n, int* __restrict__ order,
+                                                        int n_waves, float split_eff, float split_speedup, int* __restrict__ n_split) {
+  __shared__ float s_cost_sum[kLptClasses];
   __shared__ unsigned int s_max;
+  __shared__ float s_sum;
   __shared__ unsigned int s_count[kLptClasses], s_cursor[kLptClasses];
-  if (threadIdx.x == 0) s_max = 1;
-  if (threadIdx.x < kLptClasses) s_count[threadIdx.x] = 0;
+  if (threadIdx.x == 0) { s_max = 1; s_sum = 0.0f; }
+  if (threadIdx.x < kLptClasses) { s_count[threadIdx.x] = 0; s_cost_sum[threadIdx.x] = 0.0f; }
   __syncthreads();
   unsigned int m = 0;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) m = max(m, cost[i]);
+  float sum = 0.0f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) { m = max(m, cost[i]); sum += (float)cost[i]; }
   atomicMax(&s_max, m);
+  atomicAdd(&s_sum, sum);
   __syncthreads();
   const float mx = (float)s_max;
   auto cls = [&](unsigned int c) {
@@ -282,11 +318,31 @@ __global__ __launch_bounds__(1024) void lpt_order_kernel(const unsigned int* __r
     int k = (int)(4.0f * __log2f(mx / (float)c)); // 0 = within 2^(1/4) of the heaviest tile
     return min(max(k, 0), kLptClasses - 1);
   };
-  for (int i = threadIdx.x; i < n; i += blockDim.x) atomicAdd(&s_count[cls(cost[i])], 1u);
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int k = cls(cost[i]);
+    atomicAdd(&s_count[k], 1u);
+    atomicAdd(&s_cost_sum[k], (float)cost[i]);
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
     unsigned int acc = 0;
-    for (int k = 0; k < kLptClasses; k++) { s_cursor[k] = acc; acc += s_count[k]; }
+    // How many of the heaviest tiles to hand out row by row (lane_acquire).  A tile rendered whole is one chain of
+    // length ~ its cost; split, its rows are chains `split_speedup` times shorter but cost 1/`split_eff` as much
+    // lane time (a ray's shading is not shared, shuffles and the merge are extra).  With the tiles handed out
+    // heaviest first the makespan is about
+    //     max( (cost kept whole + cost split / split_eff) / n_waves , heaviest tile kept whole , heaviest tile / split_speedup )
+    // evaluated for every prefix of classes; the best prefix wins (often the empty one).
+    float best = 3.4e38f, split_cost = 0.0f;
+    int split = 0;
+    const float nw = (float)max(n_waves, 1);
+    for (int k = 0; k <= kLptClasses; k++) { // k = number of leading classes that are split
+      const float next_whole = k < kLptClasses ? mx * exp2f(-0.25f * (float)k) : 0.0f; // upper bound of class k
+      const float balanced = ((s_sum - split_cost) + split_cost / split_eff) / nw;
+      const float span = fmaxf(balanced, fmaxf(next_whole, k > 0 ? mx / split_speedup : 0.0f));
+      if (span < best * 0.98f) { best = span; split = (int)acc; } // needs a clear win to split more
+      if (k < kLptClasses) { s_cursor[k] = acc; acc += s_count[k]; split_cost += s_cost_sum[k]; }
+    }
+    if (n_split) *n_split = split;
   }
   __syncthreads();
   for (int i = threadIdx.x; i < n; i += blockDim.x) order[atomicAdd(&s_cursor[cls(cost[i])], 1u)] = i;
@@ -431,11 +487,13 @@ struct PtScene {
   bool coop_ok = false;
   int coop_prefix = 0;
   int n_hittables = 0;
+  float traversal_cost = 0.0f; // estimated VALU instructions of one ray's scan of the list
   size_t blob_bytes = 0;
   int num_cus = 256;
   mutable unsigned int* ws_cost = nullptr; // LPT workspace: per-tile ray counts of the probe pass
   mutable int* ws_order = nullptr;         //                cost-sorted tile order
   mutable int ws_tiles = 0;
+  int* ws_nsplit = nullptr;                //                number of leading tiles to split (device scalar)
   unsigned int* queues = nullptr; // ring of per-launch pixel-queue counters
   mutable unsigned int next_queue = 0;
   int device = 0;
@@ -538,6 +596,15 @@ int pt_scene_create(const PtSceneDesc* desc, PtScene** out_scene) {
   s->coop_ok = flat.coop_ok;
   s->coop_prefix = flat.coop_prefix;
   s->n_hittables = desc->n_hittables;
+  for (int i = 0; i < desc->n_hittables; i++) {
+    switch (desc->hittables[i].kind) {
+      case PT_HIT_SPHERE: s->traversal_cost += 22.0f; break;
+      case PT_HIT_TRIANGLE: s->traversal_cost += 35.0f; break;
+      case PT_HIT_BOX: s->traversal_cost += 120.0f; break;
+      case PT_HIT_CONSTANT_MEDIUM: s->traversal_cost += 300.0f; break;
+      default: s->traversal_cost += 20.0f; break;
+    }
+  }
   s->blob_bytes = flat.blob.size() * 16;
   s->mats_f4 = (int)flat.mats.size();
   // one buffer: [blob records][material table] so a kernel can stage both with one contiguous copy
@@ -549,7 +616,8 @@ int pt_scene_create(const PtSceneDesc* desc, PtScene** out_scene) {
   size_t atlas_bytes = flat.has_image ? (size_t)desc->atlas_bytes : 0;
   PT_TRY(hipMalloc((void**)&s->atlas, std::max<size_t>(atlas_bytes, 16)));
   if (atlas_bytes) PT_TRY(hipMemcpy(s->atlas, desc->atlas, atlas_bytes, hipMemcpyHostToDevice));
-  PT_TRY(hipMalloc((void**)&s->queues, kQueueRing * sizeof(unsigned int)));
+  PT_TRY(hipMalloc((void**)&s->queues, 2 * kQueueRing * sizeof(unsigned int)));
+  PT_TRY(hipMalloc((void**)&s->ws_nsplit, sizeof(int)));
 #undef PT_TRY
   *out_scene = s;
   return PT_OK;
@@ -562,6 +630,7 @@ void pt_scene_destroy(PtScene* s) {
   if (s->queues) (void)hipFree(s->queues);
   if (s->ws_cost) (void)hipFree(s->ws_cost);
   if (s->ws_order) (void)hipFree(s->ws_order);
+  if (s->ws_nsplit) (void)hipFree(s->ws_nsplit);
   delete s;
 }
 
@@ -617,14 +686,22 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
   a.order = nullptr;
   const bool mlds = lds && blob_bytes + (size_t)s->mats_f4 * 16 <= kMaxLdsWithMaterials;
   const size_t shmem = lds ? blob_bytes + (mlds ? (size_t)s->mats_f4 * 16 : 0) : 0;
+  a.n_split = nullptr;
+  int n_waves_resident = 1;
+  // Cooperative kernels (a ray's list split over idle lanes + heavy tiles handed out row by row) cost ~7 % of the
+  // ordinary-mode throughput and ~35 cross-lane shuffles per cooperative iteration, so they pay only where the
+  // scan of the list dominates an iteration.  Measured on shard 0/8 of the 1080p frame: 496-hittable scene
+  // 512 -> 222 ms; Cornell-style scene (8 hittables) 90 -> 106 ms (188 ms with tiles split) — hence the threshold.
+  const bool coop = lds && a.coop_prefix >= 0 && (s->traversal_cost >= kCoopMinTraversal || (p->flags & PT_FLAG_FORCE_COOP));
   // Persistent grid: no more workgroups than the chip holds at once; lanes pull pixels from the queue.
   auto launch = [&](auto kernel) -> int {
     int per_cu = 0;
     PT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, shmem));
     if (const char* e = std::getenv("PT_BLOCKS_PER_CU")) per_cu = std::min(per_cu, std::max(1, std::atoi(e))); // tuning knob
     const int resident_blocks = std::max(1, per_cu) * std::max(1, s->num_cus);
-    a.queue = s->queues + (s->next_queue++ % kQueueRing);
-    PT_HIP(hipMemsetAsync(a.queue, 0, sizeof(unsigned int), st));
+    a.queue = s->queues + 2 * (s->next_queue++ % kQueueRing); // [0] ordinary queue, [1] split (row-granular) queue
+    PT_HIP(hipMemsetAsync(a.queue, 0, 2 * sizeof(unsigned int), st));
+    n_waves_resident = (int)std::min<long long>((local_tiles + kWavesPerBlock - 1) / kWavesPerBlock, resident_blocks) * kWavesPerBlock;
     dim3 grid(std::min((local_tiles + kWavesPerBlock - 1) / kWavesPerBlock, resident_blocks)), block(kBlock);
     hipLaunchKernelGGL(kernel, grid, block, shmem, st, a);
     PT_HIP(hipGetLastError());
@@ -632,9 +709,13 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
   };
   auto launch_variant = [&]() -> int {
     if (!resident) return s->has_image ? launch(render_kernel_stream<true>) : launch(render_kernel_stream<false>);
-    if (s->has_image)
-      return mlds ? launch(render_kernel<true, true, true>) : lds ? launch(render_kernel<true, true, false>) : launch(render_kernel<true, false, false>);
-    return mlds ? launch(render_kernel<false, true, true>) : lds ? launch(render_kernel<false, true, false>) : launch(render_kernel<false, false, false>);
+    if (!lds) return s->has_image ? launch(render_kernel<true, false, false, false>) : launch(render_kernel<false, false, false, false>);
+    if (s->has_image) {
+      if (coop) return mlds ? launch(render_kernel<true, true, true, true>) : launch(render_kernel<true, true, false, true>);
+      return mlds ? launch(render_kernel<true, true, true, false>) : launch(render_kernel<true, true, false, false>);
+    }
+    if (coop) return mlds ? launch(render_kernel<false, true, true, true>) : launch(render_kernel<false, true, false, true>);
+    return mlds ? launch(render_kernel<false, true, true, false>) : launch(render_kernel<false, true, false, false>);
   };
   // Heaviest-first tile order from a probe pass (see lpt_order_kernel); pointless for short renders.
   const int probe_spp = std::min(4, p->samples / 16);
@@ -653,10 +734,14 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
     a.samples = probe_spp;
     int rc = launch_variant();
     if (rc) return rc;
-    hipLaunchKernelGGL(lpt_order_kernel, dim3(1), dim3(1024), 0, st, s->ws_cost, local_tiles, s->ws_order);
+    // rough per-iteration instruction counts: traversal (splittable) vs shading + camera + cooperative overhead (not)
+    const float T = std::max(1.0f, s->traversal_cost), S = 1250.0f, G = (float)PT_TILE; // S: shading + camera + ~35 shuffles
+    hipLaunchKernelGGL(lpt_order_kernel, dim3(1), dim3(1024), 0, st, s->ws_cost, local_tiles, s->ws_order, n_waves_resident,
+                       (T + S) / (T + G * S), (T + S) / (T / G + S), coop ? s->ws_nsplit : nullptr);
     PT_HIP(hipGetLastError());
     a = main_args;
     a.order = s->ws_order;
+    a.n_split = (coop && !(p->flags & PT_FLAG_NO_SPLIT)) ? s->ws_nsplit : nullptr;
   }
   int rc = launch_variant();
   if (rc) return rc;

@@ -289,7 +289,9 @@ def test_dequeue_granularity_does_not_matter(name):
 
 
 @pytest.mark.parametrize("name,flags", [("mixed", 0), ("cornell", 0), ("mixed", abi.PT_FLAG_PIXEL_GRANULAR),
-                                        ("triangles", abi.PT_FLAG_FORCE_STREAM)])
+                                        ("triangles", abi.PT_FLAG_FORCE_STREAM), ("cornell", abi.PT_FLAG_FORCE_COOP),
+                                        ("spheres", abi.PT_FLAG_FORCE_COOP),
+                                        ("spheres", abi.PT_FLAG_FORCE_COOP | abi.PT_FLAG_PIXEL_GRANULAR)])
 def test_cost_sorted_tile_order_does_not_matter(orc, name, flags):
     """spp >= 16 and >= 64 tiles turn on the cost-probe pass + heaviest-first tile order; it decides when a pixel
     is rendered, never its value."""
@@ -312,9 +314,10 @@ def test_cooperative_traversal_agrees(orc, name, size):
     w, h = size
     ps, cam = S.ALL[name]()
     c = scenes.make_camera(cam, w, h)
-    a = R.render_host(w, h, 24, ps, c)
+    a = R.render_host(w, h, 24, ps, c, flags=abi.PT_FLAG_FORCE_COOP)
     b = R.render_host(w, h, 24, ps, c, flags=abi.PT_FLAG_NO_COOP)
     assert_bit_identical(a, b, f"{name} {w}x{h}")
+    assert_bit_identical(a, R.render_host(w, h, 24, ps, c, flags=abi.PT_FLAG_FORCE_COOP | abi.PT_FLAG_NO_SPLIT), "no split")
     orc.set_math(True)
     assert_bit_identical(a, orc.render(ps, c.c, w, h, 24), f"{name} {w}x{h} vs oracle")
 
@@ -325,7 +328,7 @@ def test_cooperative_traversal_with_medium_suffix_and_image(orc):
     ps, cam = scenes.build("smoke")
     for w, h in ((19, 11), (40, 24)):
         c = scenes.make_camera(cam, w, h)
-        a = R.render_host(w, h, 16, ps, c)
+        a = R.render_host(w, h, 16, ps, c)  # 496 hittables: the launcher picks the cooperative kernel by itself
         assert_bit_identical(a, R.render_host(w, h, 16, ps, c, flags=abi.PT_FLAG_NO_COOP), f"smoke {w}x{h}")
         orc.set_math(True)
         assert_bit_identical(a, orc.render(ps, c.c, w, h, 16), f"smoke {w}x{h} vs oracle")
