@@ -81,6 +81,8 @@ def main() -> None:
     ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--flags", type=int, default=0)
+    ap.add_argument("--dist-single", action="store_true",
+                    help="testing aid: run the N>1 code path (RCCL process group, sharded render, gather) with world size 1")
     args = ap.parse_args()
 
     import torch
@@ -95,7 +97,15 @@ def main() -> None:
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    dist_path = world > 1 or args.dist_single
+    if dist_path:
+        # the harness exports NCCL_DEBUG=VERSION and RCCL prints that banner on stdout; stdout carries ONE JSON line
+        os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     W, H, SPP, DEPTH = args.width, args.height, args.spp, args.depth
@@ -105,14 +115,14 @@ def main() -> None:
     ds = R.DeviceScene(packed)  # scene resident in HBM before the timed region
 
     def barrier():
-        if world > 1:
+        if dist_path:
             dist.barrier()
         torch.cuda.synchronize()
 
     kernel_ms = []
 
     def step():
-        if world == 1:
+        if not dist_path:
             fb, ms = R.render(W, H, SPP, ds, cam, DEPTH, flags=args.flags, timed=True)
             kernel_ms.append(ms)
             return fb
@@ -129,7 +139,7 @@ def main() -> None:
         fb = step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist_path:
         t = torch.tensor([elapsed, sum(kernel_ms) / max(1, len(kernel_ms))], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kern_ms = float(t[0]), float(t[1])
@@ -179,7 +189,7 @@ def main() -> None:
                                     "cores": orc.load().orc_max_threads(), "kind": "port",
                                     "sample": f"same scene, {bw}x{bh}, {bs} spp, depth {DEPTH} ({bw * bh * bs / 1e6:.1f} Msamples, {dt:.1f} s), OpenMP CPU oracle, portable math"}
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist_path:
         dist.destroy_process_group()
 
 

@@ -127,6 +127,8 @@ def gather_frame(local, width: int, height: int, group=None, unshard_fn=None):
     dist.gather(local, bufs, dst=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
     if rank != 0:
         return None
+    if world == 1:
+        return bufs[0]  # a one-shard render is already [H][W][3]
     return (unshard_fn or unshard)(torch.stack(bufs), width, height, world)
 
 
