@@ -99,7 +99,6 @@ def main() -> None:
     torch.cuda.set_device(local_rank)
     dist_path = world > 1 or args.dist_single
     if dist_path:
-        # the harness exports NCCL_DEBUG=VERSION and RCCL prints that banner on stdout; stdout carries ONE JSON line
         os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -107,6 +106,12 @@ def main() -> None:
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.barrier()  # creates the communicator now
+        # With NCCL_DEBUG=VERSION (exported by the harness) RCCL printf()s a version banner into C stdio's buffer,
+        # which would otherwise be flushed at exit, AFTER the result: push it out now so that the JSON line is the
+        # last line on stdout.
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
 
     W, H, SPP, DEPTH = args.width, args.height, args.spp, args.depth
     kw = {"n_triangles": 100_000} if args.scene == "triangles" else {}
