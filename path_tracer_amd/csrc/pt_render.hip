@@ -32,6 +32,9 @@ namespace {
 #ifndef PT_MIN_WAVES
 #define PT_MIN_WAVES 7 /* non-IMG resident kernel: 71 VGPRs, no scratch; +6.5 % on the headline scene (A/B, one process) */
 #endif
+#ifndef PT_MIN_WAVES_IMG
+#define PT_MIN_WAVES_IMG 5 /* image-texture kernels: 96 VGPRs; +10 % on the 496-hittable scene (A/B, one process) */
+#endif
 constexpr int kBlock = 256;                 // 4 wavefronts = 4 tiles per workgroup
 constexpr int kWavesPerBlock = kBlock / 64;
 constexpr size_t kMaxLdsBlob = 64 * 1024;   // blob staged in LDS when it fits
@@ -205,7 +208,7 @@ __device__ __forceinline__ void lane_prepare(Lane& L, const KArgs& a) {
 // COOP: the traversal can split a ray's list over idle lanes (hit_world_lds); costs ~10 VGPRs and ~7 % of the
 // ordinary-mode throughput, so the launcher picks it only where the makespan floor matters (launch_render).
 template <bool IMG, bool LDS, bool MLDS, bool COOP>
-__global__ __launch_bounds__(kBlock, IMG ? 1 : PT_MIN_WAVES) void render_kernel(KArgs a) {
+__global__ __launch_bounds__(kBlock, IMG ? PT_MIN_WAVES_IMG : PT_MIN_WAVES) void render_kernel(KArgs a) {
   extern __shared__ f4 smem[];
   if (LDS) {
     const int n = a.blob_f4 + (MLDS ? a.mats_f4 : 0); // a.mats == a.blob + a.blob_f4 (one device buffer)

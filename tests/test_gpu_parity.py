@@ -421,6 +421,27 @@ def test_full_size_1080p_full_frame_low_spp(orc):
     assert_bit_identical(R.render_host(1920, 1080, 2, ps, c), orc.render(ps, c.c, 1920, 1080, 2), "1080p x 2spp")
 
 
+def test_missing_image_falls_back_to_texel_zero(orc, capsys):
+    """texture.hpp:106-111: a texture file that cannot be loaded prints an error and becomes a 1x1 image at atlas
+    offset 0 = the {0,0,1} fallback texel."""
+    from path_tracer_amd.scene import TextureAtlas, image_texture, lambertian_material, lightsource_material, pack, sphere, xy_rect
+    atlas = TextureAtlas()
+    t = image_texture.image_texture_factory("/nonexistent/texture.png", 3.0, atlas)
+    assert (t.width, t.height, t.offset) == (1, 1, 0)
+    assert "Could not load texture image file" in capsys.readouterr().err
+    good = image_texture.from_array(np.full((4, 4, 3), 200, np.uint8), 1.0, atlas)  # forces the atlas to be shipped
+    hs = [sphere((0, 0, -1), 0.5, lightsource_material(t)), xy_rect(-2, 2, -2, 2, -3, lambertian_material(good)),
+          sphere((0, -100.5, -1), 100, lambertian_material(t))]
+    ps = pack(hs, atlas)
+    cam = dict(look_from=(0, 0, 1), look_at=(0, 0, -1), vup=(0, 1, 0), vfov=60.0, aperture=0.0, focus_dist=1.0, time0=0.0, time1=0.0)
+    c = scenes.make_camera(cam, 40, 24)
+    fb = R.render_host(40, 24, 8, ps, c)
+    orc.set_math(True)
+    assert_bit_identical(fb, orc.render(ps, c.c, 40, 24, 8), "fallback texel")
+    centre = fb[12, 20]
+    assert centre[0] == 0 and centre[1] == 0 and abs(centre[2] - 1 / 255) < 1e-6  # the light shows texel {0,0,1}/255
+
+
 def test_rerender_is_deterministic(torch_gpu):
     ps, cam = scenes.build("smoke")
     c = scenes.make_camera(cam, 200, 112)
