@@ -179,6 +179,20 @@ def main() -> None:
             t1 = time.perf_counter()
             orc.render(packed, bcam.c, bw, bh, bs, DEPTH)
             dt = time.perf_counter() - t1
+            # the "PSNR vs CPU ref" half of the metric: sampled pixels of the LAST timed GPU frame re-rendered by the
+            # oracle at full spp (a pixel depends only on its own RNG stream)
+            import numpy as np
+            rng_ = np.random.default_rng(1)
+            npx = 256 if args.scene != "triangles" else 4
+            xy = np.stack([rng_.integers(0, W, npx), rng_.integers(0, H, npx)], axis=1).astype(np.int32)
+            ref = orc.render_pixels(packed, cam.c, W, H, SPP, xy, DEPTH)
+            got = fb.cpu().numpy()[xy[:, 1], xy[:, 0]]
+            same = (got.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(got) & np.isnan(ref))
+            g8, r8 = orc.tonemap_rgb8(got[None]), orc.tonemap_rgb8(ref[None])
+            mse = float(np.mean((g8.astype(np.float64) - r8.astype(np.float64)) ** 2))
+            parity = {"pixels_checked": int(npx), "bit_identical_pixels": int(same.all(axis=1).sum()),
+                      "psnr_db_8bit": None if mse == 0 else round(10 * np.log10(255.0 ** 2 / mse), 2),
+                      "note": "GPU frame vs CPU oracle (portable math) at sampled pixels, full spp; null PSNR = identical"}
             cpu_line = {"value": round(bw * bh * bs / dt / 1e6, 3), "unit": "Msamples/s",
                         "cores": orc.load().orc_max_threads(), "kind": "port",
                         "sample": f"same scene, {bw}x{bh}, {bs} spp, depth {DEPTH} ({bw * bh * bs / 1e6:.1f} Msamples, {dt:.1f} s), OpenMP CPU oracle, portable math"}
@@ -203,6 +217,7 @@ def main() -> None:
         }
         if cpu_line:
             line["cpu_baseline"] = cpu_line
+            line["parity"] = parity
         print(json.dumps(line), flush=True)
     if dist_path:
         dist.destroy_process_group()
