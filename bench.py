@@ -63,7 +63,8 @@ def ops_per_sample(ctr: dict) -> float:
 
 def pmc_traffic(scene: str, w: int, h: int, spp: int):
     """HBM bytes per launch of the render kernel from the newest committed rocprofv3 PMC summary of the same
-    workload (FETCH_SIZE and WRITE_SIZE are collected in their own --pmc passes: tools/pmc_summary.py)."""
+    workload (FETCH_SIZE and WRITE_SIZE are collected in their own --pmc passes: tools/pmc_summary.py).
+    Returns (bytes, file name, derived dict)."""
     best = None
     for f in sorted((ROOT / "profiles").glob("r*_pmc_summary.json")):
         try:
@@ -71,7 +72,7 @@ def pmc_traffic(scene: str, w: int, h: int, spp: int):
         except Exception:  # noqa: BLE001
             continue
         if d.get("workload") == f"{w}x{h}x{spp}" and d.get("scene", "cornell") == scene and "hbm_bytes_per_launch" in d.get("derived", {}):
-            best = (d["derived"]["hbm_bytes_per_launch"], f.name)
+            best = (d["derived"]["hbm_bytes_per_launch"], f.name, d["derived"])
     return best
 
 
@@ -196,6 +197,7 @@ def main() -> None:
             cpu_line = {"value": round(bw * bh * bs / dt / 1e6, 3), "unit": "Msamples/s",
                         "cores": orc.load().orc_max_threads(), "kind": "port",
                         "sample": f"same scene, {bw}x{bh}, {bs} spp, depth {DEPTH} ({bw * bh * bs / 1e6:.1f} Msamples, {dt:.1f} s), OpenMP CPU oracle, portable math"}
+        pmc = pmc_traffic(args.scene, W, H, SPP) if world == 1 else None
         kernel_samples_per_s = (samples_per_step / world) / (kern_ms * 1e-3) * world if world > 1 else samples_per_step / (kern_ms * 1e-3)
         achieved = ops * kernel_samples_per_s / 1e12 / world  # per GPU
         line = {
@@ -208,8 +210,12 @@ def main() -> None:
                        "hittables": packed.n_hittables, "sharding": "whole frame" if world == 1 else f"8x8 tiles round-robin over {world} ranks + RCCL gather"},
             "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": round(PEAK_TLANEOPS, 1), "unit": "Tlaneop/s",
                          "frac": round(achieved / PEAK_TLANEOPS, 4),
-                         "traffic": (pmc_traffic(args.scene, W, H, SPP) or (None, None))[0] if world == 1 else None,
-                         "traffic_source": (pmc_traffic(args.scene, W, H, SPP) or (None, None))[1] if world == 1 else None,
+                         "traffic": pmc[0] if pmc else None, "traffic_source": pmc[1] if pmc else None,
+                         # north-star evidence: HBM is not the limiter, VALU issue is busy (PMC of the committed profile)
+                         "hbm": {"achieved_gbs": round(pmc[0] / (kern_ms * 1e-3) / 1e9, 3), "peak_gbs": 8000.0,
+                                 "frac": round(pmc[0] / (kern_ms * 1e-3) / 8e12, 6)} if pmc else None,
+                         "valu_issue_occupancy_pmc": round(pmc[2].get("valu_issue_occupancy", 0.0), 3) if pmc else None,
+                         "valu_lane_utilisation_pmc": round(pmc[2].get("valu_lane_utilisation", 0.0), 3) if pmc else None,
                          "kernel": "render_kernel", "kernel_ms": round(kern_ms, 3),
                          "algorithmic_ops_per_sample": round(ops, 1),
                          "kernel_msamples_per_s_per_gpu": round(kernel_samples_per_s / world / 1e6, 2),
