@@ -1,0 +1,144 @@
+// examples/main.cpp — the reference's src/main.cpp:61-197 rewritten against the C++20 facade: same scene literal
+// (the RNG calls inside one expression are evaluated left to right here; the reference leaves that order to the
+// compiler, main.cpp:83,87,92), same camera, same output stage (gamma 2, clamp, x256, rows flipped), PPM instead of
+// PNG (main.cpp:17-31; stb is not a dependency).  Image textures are procedural stand-ins unless raw RGB8 files are
+// given.
+//
+//   g++ -std=c++20 -O2 -ffp-contract=off -Ipath_tracer_amd/include examples/main.cpp -Lpath_tracer_amd -lpt_render \
+//       -Wl,-rpath,$PWD/path_tracer_amd -Wl,-rpath,/opt/rocm/lib -o sycl-rt-mi355x
+//   ./sycl-rt-mi355x [width height samples out.ppm [tables.bin]]
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <vector>
+
+#include "pt/path_tracer.hpp"
+
+using namespace pt;
+
+// LocalPseudoRNG (rtweekend.hpp:33-57) for host-side scene construction, main.cpp:76
+struct HostRNG {
+  uint32_t s = 2463534242u; // xorshift.hpp:18
+  float float_t() {
+    s ^= s >> 7; s ^= s << 1; s ^= s >> 9;
+    return (float)s * (1.0f / 4294967296.0f);
+  }
+  float float_t(float mn, float mx) { return mn + (mx - mn) * float_t(); }
+  vec vec_t() { float a = float_t(), b = float_t(), c = float_t(); return {a, b, c}; }
+  vec vec_t(float mn, float mx) { vec v = vec_t(); float sc = mx - mn; return {v.x() * sc + mn, v.y() * sc + mn, v.z() * sc + mn}; }
+};
+
+static std::vector<uint8_t> procedural_image(int w, int h, int seed) {
+  std::vector<uint8_t> px((size_t)w * h * 3);
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++) {
+      uint8_t* p = &px[((size_t)y * w + x) * 3];
+      p[0] = (uint8_t)(x * 255 / std::max(1, w - 1));
+      p[1] = (uint8_t)(y * 255 / std::max(1, h - 1));
+      p[2] = (uint8_t)((((x / 8) + (y / 8) + seed) % 2) * 200 + 30);
+    }
+  return px;
+}
+
+int main(int argc, char** argv) {
+  const int width = argc > 1 ? std::atoi(argv[1]) : 800, height = argc > 2 ? std::atoi(argv[2]) : 480; // CMakeLists.txt:44-54
+  const int samples = argc > 3 ? std::atoi(argv[3]) : 100;                                            // main.cpp:186
+  const char* out = argc > 4 ? argv[4] : "out.ppm";
+
+  std::vector<hittable_t> hittables;
+  texture_t t = checker_texture(color{0.2f, 0.3f, 0.1f}, color{0.9f, 0.9f, 0.9f});
+  hittables.emplace_back(sphere(point{0, -1000, 0}, 1000, lambertian_material(t)));
+  HostRNG rng;
+  for (int a = -11; a < 11; a++) {
+    for (int b = -11; b < 11; b++) {
+      float choose_mat = rng.float_t();
+      float cx = a + 0.9f * rng.float_t();
+      float cz = b + 0.9f * rng.float_t();
+      point center(cx, 0.2f, cz);
+      float dx = cx - 4.0f, dy = 0.2f - 0.2f, dz = cz - 0.0f;
+      if (std::sqrt(dx * dx + dy * dy + dz * dz) > 0.9f) {
+        if (choose_mat < 0.4f) {
+          vec p = rng.vec_t(), q = rng.vec_t();
+          hittables.emplace_back(sphere(center, 0.2f, lambertian_material(color{p.x() * q.x(), p.y() * q.y(), p.z() * q.z()})));
+        } else if (choose_mat < 0.8f) {
+          vec p = rng.vec_t(), q = rng.vec_t();
+          point center2(cx, 0.2f + rng.float_t(0, 0.25f), cz);
+          hittables.emplace_back(sphere(center, center2, 0.0f, 1.0f, 0.2f, lambertian_material(color{p.x() * q.x(), p.y() * q.y(), p.z() * q.z()})));
+        } else if (choose_mat < 0.95f) {
+          vec albedo = rng.vec_t(0.5f, 1);
+          float fuzz = rng.float_t(0, 0.5f);
+          hittables.emplace_back(sphere(center, 0.2f, metal_material(albedo, fuzz)));
+        } else {
+          hittables.emplace_back(sphere(center, 0.2f, dielectric_material(1.5f, color{1.0f, 1.0f, 1.0f})));
+        }
+      }
+    }
+  }
+  // pyramid main.cpp:113-126
+  hittables.emplace_back(triangle(point{6.5f, 0.0f, 1.30f}, point{6.25f, 0.50f, 1.05f}, point{6.5f, 0.0f, 0.80f}, lambertian_material(color(0.68f, 0.50f, 0.1f))));
+  hittables.emplace_back(triangle(point{6.0f, 0.0f, 1.30f}, point{6.25f, 0.50f, 1.05f}, point{6.5f, 0.0f, 1.30f}, lambertian_material(color(0.89f, 0.73f, 0.29f))));
+  hittables.emplace_back(triangle(point{6.5f, 0.0f, 0.80f}, point{6.25f, 0.50f, 1.05f}, point{6.0f, 0.0f, 0.80f}, lambertian_material(color(0.0f, 0.0f, 1))));
+  hittables.emplace_back(triangle(point{6.0f, 0.0f, 0.80f}, point{6.25f, 0.50f, 1.05f}, point{6.0f, 0.0f, 1.30f}, lambertian_material(color(0.0f, 0.0f, 1))));
+  hittables.emplace_back(sphere(point{4, 1, 0}, 0.2f, lightsource_material(color(10, 0, 10))));
+  auto xil = procedural_image(256, 128, 0);
+  t = image_texture::from_rgb8(xil.data(), 256, 128);
+  hittables.emplace_back(xy_rect(2, 4, 0, 1, -1, lambertian_material(t)));
+  hittables.emplace_back(sphere(point{4, 1, 2.25f}, 1, lambertian_material(t)));
+  hittables.emplace_back(sphere(point{0, 1, 0}, 1, dielectric_material(1.5f, color{1.0f, 0.5f, 0.5f})));
+  hittables.emplace_back(sphere(point{-4, 1, 0}, 1, lambertian_material(color(0.4f, 0.2f, 0.1f))));
+  hittables.emplace_back(sphere(point{0, 1, -2.25f}, 1, metal_material(color(0.7f, 0.6f, 0.5f), 0.0f)));
+  auto syc = procedural_image(320, 140, 1);
+  t = image_texture::from_rgb8(syc.data(), 320, 140, 5);
+  hittables.emplace_back(sphere{point{-60, 3, 5}, 4, lambertian_material{t}});
+  hittables.emplace_back(box{point{6.5f, 0, -1.5f}, point{7.0f, 3.0f, -1.0f}, metal_material{color{0.7f, 0.6f, 0.5f}, 0.25f}});
+  sphere smoke_sphere = sphere{point{5, 1, 3.5f}, 1, lambertian_material{color{0.75f, 0.75f, 0.75f}}};
+  hittables.emplace_back(constant_medium{smoke_sphere, 1, color{1, 1, 1}});
+
+  point look_from{13, 3, 3}, look_at{0, -1, 0};
+  vec vup{0, 1, 0};
+  float fx = look_at.x() - look_from.x(), fy = look_at.y() - look_from.y(), fz = look_at.z() - look_from.z();
+  real_t focus_dist = std::sqrt(fx * fx + fy * fy + fz * fz); // main.cpp:179
+  camera cam{look_from, look_at, vup, 40, static_cast<real_t>(width) / height, 0.04f, focus_dist, 0.0f, 1.0f};
+
+  if (argc > 5) { // testing aid: dump the flattened C-ABI tables instead of rendering (no GPU needed)
+    scene_tables tb = flatten(hittables);
+    std::ofstream d(argv[5], std::ios::binary);
+    int32_t n[3] = {(int32_t)tb.hittables.size(), (int32_t)tb.materials.size(), (int32_t)tb.textures.size()};
+    d.write((const char*)n, sizeof n);
+    d.write((const char*)tb.hittables.data(), tb.hittables.size() * sizeof(PtHittable));
+    d.write((const char*)tb.materials.data(), tb.materials.size() * sizeof(PtMaterial));
+    d.write((const char*)tb.textures.data(), tb.textures.size() * sizeof(PtTexture));
+    d.write((const char*)&cam.c, sizeof cam.c);
+    return 0;
+  }
+
+  frame_buffer fb;
+  auto t0 = std::chrono::steady_clock::now();
+  try {
+    render(width, height, samples, fb, hittables, cam);
+  } catch (const pt_error& e) {
+    std::fprintf(stderr, "%s\n", e.what());
+    return 1;
+  }
+  double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+
+  // dump_image_ppm main.cpp:17-31 (binary P6 instead of text P3)
+  std::ofstream f(out, std::ios::binary);
+  f << "P6\n" << width << " " << height << "\n255\n";
+  for (int y = height - 1; y >= 0; y--)
+    for (int x = 0; x < width; x++) {
+      const color& c = fb[(size_t)y * width + x];
+      for (int k = 0; k < 3; k++) {
+        float s = std::sqrt(c.v[k]);
+        float cl = std::clamp(s, 0.0f, 0.999f);
+        float v = 256 * cl;
+        f.put((char)(uint8_t)(v == v ? (int)v : 0));
+      }
+    }
+  std::printf("%zu hittables, %dx%dx%d spp in %.3f s (scene upload + render + copy back) -> %s\n", hittables.size(), width,
+              height, samples, sec, out);
+  return 0;
+}

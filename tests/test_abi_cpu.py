@@ -180,3 +180,24 @@ def test_no_gpu_is_reported_not_crashed(lib):
     h = C.c_void_p()
     rc = lib.pt_scene_create(C.byref(ps.desc), C.byref(h))
     assert rc in (abi.PT_ERR_NO_DEVICE, abi.PT_ERR_HIP) and not h.value
+
+
+def test_scene_fixture_roundtrip(tmp_path, orc):
+    """scene_io: the .npz fixture holds the C-ABI tables byte for byte; a reloaded scene renders identically."""
+    from path_tracer_amd import scene_io
+    for name in ("mixed", "cornell", "empty"):
+        ps, cam = S.ALL[name]()
+        f = tmp_path / f"{name}.npz"
+        scene_io.save_scene(str(f), ps, cam)
+        ps2, cam2 = scene_io.load_scene(str(f))
+        assert (ps2.n_hittables, ps2.n_materials, ps2.n_textures) == (ps.n_hittables, ps.n_materials, ps.n_textures)
+        assert bytes(ps2.hittables)[:ps.n_hittables * 64] == bytes(ps.hittables)[:ps.n_hittables * 64]
+        assert bytes(ps2.materials)[:ps.n_materials * 32] == bytes(ps.materials)[:ps.n_materials * 32]
+        assert bytes(ps2.textures)[:ps.n_textures * 48] == bytes(ps.textures)[:ps.n_textures * 48]
+        assert bytes(ps2.atlas)[:ps.atlas_bytes] == bytes(ps.atlas)[:ps.atlas_bytes]
+        assert {k: tuple(v) if isinstance(v, list) else v for k, v in cam2.items()} == \
+               {k: tuple(v) if isinstance(v, (list, tuple)) else v for k, v in cam.items()}
+        c = scenes.make_camera(cam, 16, 12)
+        orc.set_math(True)
+        a, b = orc.render(ps, c.c, 16, 12, 2), orc.render(ps2, c.c, 16, 12, 2)
+        assert a.tobytes() == b.tobytes()

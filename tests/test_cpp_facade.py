@@ -95,3 +95,42 @@ def test_cpp_render_matches_python_render(facade_bin, tmp_path, orc, name):
     assert_bit_identical(fb, R.render_host(w, h, spp, ps, c), f"C++ facade vs Python host: {name}")
     orc.set_math(True)
     assert_bit_identical(fb, orc.render(ps, c.c, w, h, spp), f"C++ facade vs oracle: {name}")
+
+
+@pytest.fixture(scope="module")
+def example_bin(tmp_path_factory, lib):
+    out = tmp_path_factory.mktemp("example") / "sycl-rt-mi355x"
+    libdir = ROOT / "path_tracer_amd"
+    subprocess.run(["g++", "-std=c++20", "-O1", "-ffp-contract=off", f"-I{ROOT / 'path_tracer_amd' / 'include'}",
+                    str(ROOT / "examples" / "main.cpp"), "-o", str(out), f"-L{libdir}", "-lpt_render",
+                    f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    return out
+
+
+def test_example_main_builds_the_same_scene_as_python(example_bin, tmp_path):
+    """examples/main.cpp (the reference's main.cpp against the C++ facade) and scenes.smoke_sphere_scene (Python)
+    construct the 496-hittable default scene with the same RNG draw order and binary32 arithmetic."""
+    out = tmp_path / "smoke.bin"
+    subprocess.run([str(example_bin), "400", "225", "1", str(tmp_path / "x.ppm"), str(out)], check=True)
+    n, (hb, mb, tb, cb) = read_dump(out)
+    ps, cam = scenes.build("smoke")
+    c = scenes.make_camera(cam, 400, 225)
+    assert n == [ps.n_hittables, ps.n_materials, ps.n_textures]
+    assert hb == bytes(ps.hittables)[:len(hb)]
+    assert mb == bytes(ps.materials)[:len(mb)]
+    assert tb == bytes(ps.textures)[:len(tb)]
+    assert cb == bytes(c.c)
+
+
+@pytest.mark.gpu
+def test_example_main_renders_the_python_frame(example_bin, tmp_path, orc):
+    from path_tracer_amd import render as R
+    ppm = tmp_path / "out.ppm"
+    subprocess.run([str(example_bin), "96", "54", "8", str(ppm)], check=True)
+    raw = ppm.read_bytes()
+    header, body = raw.split(b"\n255\n", 1)
+    assert header.startswith(b"P6\n96 54")
+    img = np.frombuffer(body, dtype=np.uint8).reshape(54, 96, 3)
+    ps, cam = scenes.build("smoke")
+    fb = R.render_host(96, 54, 8, ps, scenes.make_camera(cam, 96, 54))
+    np.testing.assert_array_equal(img, orc.tonemap_rgb8(fb))
