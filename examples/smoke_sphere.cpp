@@ -1,10 +1,10 @@
-// examples/main.cpp — the reference's src/main.cpp:61-197 rewritten against the C++20 facade: same scene literal
+// examples/smoke_sphere.cpp — the reference's src/main.cpp:61-197 rewritten against the C++20 facade: same scene literal
 // (the RNG calls inside one expression are evaluated left to right here; the reference leaves that order to the
 // compiler, main.cpp:83,87,92), same camera, same output stage (gamma 2, clamp, x256, rows flipped), PPM instead of
 // PNG (main.cpp:17-31; stb is not a dependency).  Image textures are procedural stand-ins unless raw RGB8 files are
 // given.
 //
-//   g++ -std=c++20 -O2 -ffp-contract=off -Ipath_tracer_amd/include examples/main.cpp -Lpath_tracer_amd -lpt_render \
+//   g++ -std=c++20 -O2 -ffp-contract=off -Ipath_tracer_amd/include examples/smoke_sphere.cpp -Lpath_tracer_amd -lpt_render \
 //       -Wl,-rpath,$PWD/path_tracer_amd -Wl,-rpath,/opt/rocm/lib -o sycl-rt-mi355x
 //   ./sycl-rt-mi355x [width height samples out.ppm [tables.bin]]
 #include <algorithm>

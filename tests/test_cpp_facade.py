@@ -102,13 +102,13 @@ def example_bin(tmp_path_factory, lib):
     out = tmp_path_factory.mktemp("example") / "sycl-rt-mi355x"
     libdir = ROOT / "path_tracer_amd"
     subprocess.run(["g++", "-std=c++20", "-O1", "-ffp-contract=off", f"-I{ROOT / 'path_tracer_amd' / 'include'}",
-                    str(ROOT / "examples" / "main.cpp"), "-o", str(out), f"-L{libdir}", "-lpt_render",
+                    str(ROOT / "examples" / "smoke_sphere.cpp"), "-o", str(out), f"-L{libdir}", "-lpt_render",
                     f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
     return out
 
 
 def test_example_main_builds_the_same_scene_as_python(example_bin, tmp_path):
-    """examples/main.cpp (the reference's main.cpp against the C++ facade) and scenes.smoke_sphere_scene (Python)
+    """examples/smoke_sphere.cpp (the reference's main.cpp against the C++ facade) and scenes.smoke_sphere_scene (Python)
     construct the 496-hittable default scene with the same RNG draw order and binary32 arithmetic."""
     out = tmp_path / "smoke.bin"
     subprocess.run([str(example_bin), "400", "225", "1", str(tmp_path / "x.ppm"), str(out)], check=True)
