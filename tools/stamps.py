@@ -1,0 +1,24 @@
+"""Reads the s_memtime shares of a diagnostic build (csrc built with -DPT_STAMPS -> libpt_stamps.so).
+    PT_RENDER_LIB=path_tracer_amd/libpt_stamps.so python tools/stamps.py cornell 256"""
+import ctypes as C, sys
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import torch
+from path_tracer_amd import abi, scenes
+from path_tracer_amd import render as R
+scene, spp = sys.argv[1], int(sys.argv[2])
+flags = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+lib = abi.load_library()
+lib.pt_debug_stamps.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+W, H = 1920, 1080
+packed, cam_args = scenes.build(scene)
+cam = scenes.make_camera(cam_args, W, H)
+ds = R.DeviceScene(packed)
+R.render(W, H, 8, ds, cam); torch.cuda.synchronize()
+lib.pt_debug_stamps(None, 1)
+fb, ms = R.render(W, H, spp, ds, cam, flags=flags | abi.PT_FLAG_NO_LPT, timed=True)
+out = (C.c_ulonglong * 8)()
+lib.pt_debug_stamps(out, 0)
+prep, trav, shade, iters = out[0], out[1], out[2], out[3]
+tot = prep + trav + shade
+print(f"{scene} {spp} spp: kernel {ms:.1f} ms; wave-iterations {iters:.3e}; cycles per wave-iteration: prepare {prep/iters:.0f}  traversal {trav/iters:.0f}  shade {shade/iters:.0f}  (total {tot/iters:.0f}); shares {prep/tot:.2f} {trav/tot:.2f} {shade/tot:.2f}")
