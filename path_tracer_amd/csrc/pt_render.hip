@@ -202,6 +202,13 @@ __device__ __forceinline__ void lane_prepare(Lane& L, const KArgs& a) {
   lane_regenerate(L, a); // and its first camera ray generated
 }
 
+#ifdef PT_STAMPS
+// Diagnostic build only (`make stamps` -> libpt_stamps.so; never shipped, never timed): s_memtime shares of one loop
+// iteration of the resident kernels, summed over waves; read with pt_debug_stamps / tools/stamps.py.
+__device__ unsigned long long g_stamps[8];
+#define PT_STAMP(var) unsigned long long var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0)
+#endif
+
 // Scene blob resident for the whole kernel: staged once into LDS (LDS=true) or read through the scalar cache.
 // MLDS: the material table is staged too (small tables only: it rides behind the records in the same buffer), so
 // the whole bounce — traversal, hit record, material, texture constants — runs out of LDS without a global load.
@@ -218,12 +225,21 @@ __global__ __launch_bounds__(kBlock, IMG ? PT_MIN_WAVES_IMG : PT_MIN_WAVES) void
   Lane L;
   lane_reset(L);
   if (a.depth <= 0) return; // depth 0: every sample returns black (render.hpp:58,91); the frame is pre-zeroed
+#ifdef PT_STAMPS
+  unsigned long long s_prep = 0, s_trav = 0, s_shade = 0, s_iters = 0;
+#endif
   for (;;) {
+#ifdef PT_STAMPS
+    PT_STAMP(t0);
+#endif
     lane_prepare(L, a);
     if (__builtin_amdgcn_ballot_w64(L.live) == 0) {
       if (__builtin_amdgcn_ballot_w64(!L.retired) == 0) break; // queue drained for the whole wave
       continue;                                                 // only padding pixels this time: pull again
     }
+#ifdef PT_STAMPS
+    PT_STAMP(t1);
+#endif
     HitState h;
     if constexpr (LDS) {
       if constexpr (COOP) {
@@ -235,8 +251,17 @@ __global__ __launch_bounds__(kBlock, IMG ? PT_MIN_WAVES_IMG : PT_MIN_WAVES) void
         const bool fast = wave_all_regular(c, L.live);
         hit_world<IMG>((lds_f4p)smem, a.n_runs, c, fast, L.rng, h);
       }
+#ifdef PT_STAMPS
+      asm volatile("" ::"v"(h.closest), "v"(h.hit));
+      PT_STAMP(t2);
+#endif
       if constexpr (MLDS) lane_shade(L, a, h, (lds_f4p)smem, (lds_f4p)smem + a.blob_f4);
       else lane_shade(L, a, h, (lds_f4p)smem, a.mats);
+#ifdef PT_STAMPS
+      asm volatile("" ::"v"(L.acc.x), "v"(L.ray.d.x));
+      PT_STAMP(t3);
+      s_prep += t1 - t0; s_trav += t2 - t1; s_shade += t3 - t2; s_iters++;
+#endif
     } else {
       RayCtx c = make_ctx(L.ray, a.fast_ok != 0);
       const bool fast = wave_all_regular(c, L.live);
@@ -244,6 +269,12 @@ __global__ __launch_bounds__(kBlock, IMG ? PT_MIN_WAVES_IMG : PT_MIN_WAVES) void
       lane_shade(L, a, h, a.blob, a.mats);
     }
   }
+#ifdef PT_STAMPS
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&g_stamps[0], s_prep); atomicAdd(&g_stamps[1], s_trav); atomicAdd(&g_stamps[2], s_shade);
+    atomicAdd(&g_stamps[3], s_iters);
+  }
+#endif
 }
 
 // Scene blob larger than LDS (100 k triangles = 4.8 MB): the workgroup walks the list in lock-step and streams
@@ -817,6 +848,14 @@ int pt_tonemap_rgb8(const float* fb_device, int32_t width, int32_t height, uint8
   PT_HIP(hipGetLastError());
   return PT_OK;
 }
+
+#ifdef PT_STAMPS
+int pt_debug_stamps(unsigned long long* out8, int reset) { // diagnostic build only; not part of include/pt_render.h
+  if (out8) PT_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_stamps), 8 * sizeof(unsigned long long)));
+  if (reset) { unsigned long long z[8] = {0}; PT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof z)); }
+  return PT_OK;
+}
+#endif
 
 // ---- probes: host arrays in/out ------------------------------------------------------------------------
 
