@@ -413,6 +413,22 @@ def test_full_size_cornell_1080p_sampled_pixels(torch_gpu, orc):
     print(f"\n[cornell 1080p 1024spp] kernel {ms:.1f} ms = {w * h * spp / ms / 1e3:.1f} Msamples/s")
 
 
+def test_full_size_smoke_1080p_sampled_pixels(torch_gpu, orc):
+    """BASELINE.json configs[2] shape (the 496-hittable scene at 1920x1080; 256 of its 1024 spp to keep the test
+    short): cooperative kernel, cost-sorted order and split queue all active; 400 sampled pixels re-rendered by the
+    oracle at the same spp, bit for bit."""
+    w, h, spp = 1920, 1080, 256
+    ps, cam = scenes.build("smoke")
+    c = scenes.make_camera(cam, w, h)
+    fb, ms = R.render(w, h, spp, ps, c, timed=True)
+    fbn = fb.cpu().numpy()
+    rng = np.random.default_rng(7)
+    xy = np.stack([rng.integers(0, w, 400), rng.integers(0, h, 400)], axis=1).astype(np.int32)
+    orc.set_math(True)
+    assert_bit_identical(fbn[xy[:, 1], xy[:, 0]], orc.render_pixels(ps, c.c, w, h, spp, xy), "smoke 1080p sampled pixels")
+    print(f"\n[smoke 1080p {spp}spp] kernel {ms:.1f} ms = {w * h * spp / ms / 1e3:.1f} Msamples/s")
+
+
 def test_full_size_1080p_full_frame_low_spp(orc):
     """Every pixel of a 1920x1080 frame (2 spp): seeds up to 2,073,599, edge tiles, all tile rows."""
     ps, cam = scenes.build("cornell")
