@@ -458,6 +458,26 @@ def test_missing_image_falls_back_to_texel_zero(orc, capsys):
     assert centre[0] == 0 and centre[1] == 0 and abs(centre[2] - 1 / 255) < 1e-6  # the light shows texel {0,0,1}/255
 
 
+@pytest.mark.parametrize("w,h,spp", [(1, 1, 9), (1, 70, 5), (70, 1, 5), (7, 7, 33), (9, 9, 17), (513, 3, 4)])
+def test_degenerate_frame_sizes(orc, w, h, spp):
+    """Frames smaller than a tile, one pixel wide/high, just over a tile: padding lanes, partial tiles, and the
+    pixel whose generator is stuck at 0 (render.hpp:131)."""
+    ps, cam = S.spheres_scene()
+    c = scenes.make_camera(cam, w, h)
+    orc.set_math(True)
+    ref = orc.render(ps, c.c, w, h, spp)
+    for flags in (0, abi.PT_FLAG_FORCE_COOP, abi.PT_FLAG_FORCE_STREAM, abi.PT_FLAG_NO_LDS):
+        assert_bit_identical(R.render_host(w, h, spp, ps, c, flags=flags), ref, f"{w}x{h} flags {flags}")
+
+
+def test_4k_frame_low_spp(orc):
+    """BASELINE.json configs[3] frame size (3840x2160): every pixel at 1 spp (seeds up to 8,294,399)."""
+    ps, cam = scenes.build("cornell")
+    c = scenes.make_camera(cam, 3840, 2160)
+    orc.set_math(True)
+    assert_bit_identical(R.render_host(3840, 2160, 1, ps, c), orc.render(ps, c.c, 3840, 2160, 1), "4K x 1spp")
+
+
 def test_rerender_is_deterministic(torch_gpu):
     ps, cam = scenes.build("smoke")
     c = scenes.make_camera(cam, 200, 112)
