@@ -2,13 +2,16 @@
 //
 // Replaces render<W,H,S>() / executor() / render_pixel()  (reference include/render.hpp:25-160).
 //
-// Mapping (DESIGN.md "Kernel"): one 64-lane wavefront owns one 8x8 pixel tile, one lane owns one
-// pixel for ALL of its samples — the reference's single xorshift32 stream per pixel, consumed
-// sequentially across samples (render.hpp:95-101,130-133), leaves no other bit-exact choice.  Each
-// lane runs a persistent "regenerate in place" loop: a lane whose path ended starts its next
-// sample in the same iteration, so the wave-uniform primitive loop always runs with all lanes
-// live (what ballot/prefix compaction would buy, without moving state between lanes).  The wave
-// leaves the loop when a ballot of the live lanes is empty.
+// Mapping: one lane owns one pixel for ALL of its samples — the reference's single xorshift32
+// stream per pixel, consumed sequentially across samples (render.hpp:95-101,130-133), leaves no other bit-exact
+// choice.  Lanes are persistent: they pull pixels (8x8 tiles by default) from a per-launch queue, heaviest tiles
+// first (cost-probe pass + lpt_order_kernel), and run a "regenerate in place" loop — a lane whose path ended starts
+// its next sample in the same iteration, so the wave-uniform primitive loop always runs with all live lanes (what
+// ballot/prefix compaction would buy, without moving state between lanes).  Three kernel families:
+//   render_kernel<IMG, LDS, MLDS, COOP>   scene resident in LDS (or the scalar cache); COOP adds the cooperative
+//                                         traversal (a ray's list split over idle lanes) and the split queue
+//   render_kernel_stream<IMG>             scene larger than LDS: workgroup-synchronous LDS-tile streaming
+//   bounce / camera_rays / math kernels   function-level probes for the parity tests
 #include <hip/hip_runtime.h>
 
 #include <cmath>
