@@ -135,6 +135,21 @@ def render_pixels(packed, cam: abi.PtCamera, width, height, samples, xy: np.ndar
     return out
 
 
+def render_pixels_rays(packed, cam: abi.PtCamera, width, height, samples, xy: np.ndarray, depth=50):
+    """(colours [n][3], rays traced per pixel [n]) — the per-pixel chain lengths behind DESIGN.md §6."""
+    lib = load()
+    p = params(width, height, samples, depth)
+    xy = np.ascontiguousarray(xy, dtype=np.int32)
+    out = np.zeros((len(xy), 3), dtype=np.float32)
+    rays = np.zeros(len(xy), dtype=np.uint64)
+    lib.orc_render_pixels_rays.restype = C.c_int
+    rc = lib.orc_render_pixels_rays(C.byref(packed.desc), C.byref(cam), C.byref(p), xy.ctypes.data_as(C.POINTER(C.c_int32)),
+                                    len(xy), _fp(out), rays.ctypes.data_as(C.POINTER(C.c_uint64)))
+    if rc:
+        raise RuntimeError(f"orc_render_pixels_rays: error {rc}")
+    return out, rays
+
+
 def bounce(packed, recs_in):
     lib = load()
     n = len(recs_in)

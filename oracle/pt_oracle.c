@@ -625,6 +625,24 @@ int orc_render_pixels(const PtSceneDesc* sc, const PtCamera* cam, const PtRender
   return PT_OK;
 }
 
+/* As orc_render_pixels, plus the number of rays (hit_world calls, render.hpp:60) each pixel traced: the length of
+ * that pixel's sequential chain, which bounds any schedule of the frame.                 */
+int orc_render_pixels_rays(const PtSceneDesc* sc, const PtCamera* cam, const PtRenderParams* p, const int32_t* xy,
+                           int32_t n, float* out, uint64_t* rays) {
+  int rc = validate(sc);
+  if (rc) return rc;
+  if (!cam || !p || !xy || !out || !rays || p->width <= 0 || p->height <= 0 || p->samples <= 0 || p->depth < 0)
+    return PT_ERR_INVALID_ARG;
+#pragma omp parallel for schedule(dynamic, 4)
+  for (int32_t k = 0; k < n; k++) {
+    OrcCounters c;
+    memset(&c, 0, sizeof c);
+    render_pixel(sc, cam, p, xy[2 * k], xy[2 * k + 1], out + 3 * (int64_t)k, &c);
+    rays[k] = c.rays;
+  }
+  return PT_OK;
+}
+
 /* ---- function-level probes ---------------------------------------------------------------------------- */
 
 int orc_bounce(const PtSceneDesc* sc, const PtBounceIn* in, PtBounceOut* out, int32_t n, int32_t depth_unused) {

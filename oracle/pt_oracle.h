@@ -68,6 +68,10 @@ int orc_render_rows(const PtSceneDesc* scene, const PtCamera* cam, const PtRende
 int orc_render_pixels(const PtSceneDesc* scene, const PtCamera* cam, const PtRenderParams* p,
                       const int32_t* xy, int32_t n, float* out);
 
+/* Same, plus rays[n] = rays traced per pixel (its sequential chain length).     */
+int orc_render_pixels_rays(const PtSceneDesc* scene, const PtCamera* cam, const PtRenderParams* p,
+                           const int32_t* xy, int32_t n, float* out, uint64_t* rays);
+
 int orc_bounce(const PtSceneDesc* scene, const PtBounceIn* in, PtBounceOut* out, int32_t n,
                int32_t depth_unused);
 
