@@ -154,7 +154,7 @@ enum {
   PT_FLAG_NO_FASTDIV = 1u << 2,   /* plain IEEE division for every rect/box side (no shared reciprocal) */
   PT_FLAG_TILE_GRANULAR = 1u << 3,  /* waves dequeue whole 8x8 tiles (default when the scene is LDS/scalar-cache resident) */
   PT_FLAG_FORCE_COOP = 1u << 7,     /* use the cooperative kernels even where the launcher's heuristic would not */
-  PT_FLAG_NO_SPLIT = 1u << 8,       /* cooperative kernels, but heavy tiles are not handed out row by row */
+  PT_FLAG_NO_SPLIT = 1u << 8,       /* cooperative kernels, but no tile is rendered several lanes per pixel */
   PT_FLAG_NO_COOP = 1u << 6,        /* never split a ray's primitive list over idle lanes (tail acceleration off) */
   PT_FLAG_NO_LPT = 1u << 5,         /* skip the cost-probe pass: tiles are dequeued in raster order */
   PT_FLAG_PIXEL_GRANULAR = 1u << 4, /* lanes dequeue single pixels (default for the LDS-tile streaming kernel) */

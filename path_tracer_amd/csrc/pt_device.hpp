@@ -475,6 +475,71 @@ __device__ __forceinline__ void hit_records(P recs, int kind, int n, int goff, c
   }
 }
 
+// One run, split over a group of G = 2^logG lanes (cooperative traversal, regular rays only, never a medium run): lane j
+// tests the records whose hittable index is == j (mod G).  The loop itself stays wave-uniform — ceil(cnt / G) trips for
+// everybody, a lane without a record in a trip re-tests record 0 of the run and discards the outcome — so the only
+// per-lane things are the record address and one predicate (divergent trip counts cost ~10 SALU + 2 branches per trip).
+template <bool IMG, typename P>
+__device__ __forceinline__ void hit_records_strided(P recs, int kind, int cnt, int first, int goff, int j, int logG,
+                                                    const RayCtx& c, HitState& h) {
+  const Ray& r = c.r;
+  const int G = 1 << logG, trips = (cnt + G - 1) >> logG;
+  int k = (j - first) & (G - 1);
+  if (kind == DK_SPHERE) {
+    for (int i = 0; i < trips; ++i, k += G) {
+      const bool valid = k < cnt;
+      const int off = (valid ? k : 0) * SZ_SPHERE;
+      float t;
+      if (sphere_t(recs, off, c, PT_TMIN, h.closest, t) && valid) {
+        h.closest = t;
+        h.hit = hit_pack(DK_SPHERE, 0, goff + off);
+        if (IMG) {
+          f4 R0 = recs[off], R1 = recs[off + 1], R2 = recs[off + 2];
+          V3 p = r.o + t * r.d;
+          V3 n_ = (p - sphere_center(R0, R1, R2, r.tm)) / R1.x;
+          bool ff = dot(r.d, n_) < 0;
+          V3 nn = ff ? n_ : mk(0.0f, 0.0f, 0.0f) - n_;
+          mercator(nn, h.u, h.v);
+        }
+      }
+    }
+  } else if (kind == DK_RECT) {
+    for (int i = 0; i < trips; ++i, k += G) {
+      const bool valid = k < cnt;
+      const int off = (valid ? k : 0) * SZ_RECT;
+      f4 R0 = recs[off], R1 = recs[off + 1];
+      float t, ca, cb;
+      const bool acc = rect_any(true, as_i(R1.z), R0.x, R0.y, R0.z, R0.w, R1.x, c, h.closest, t, ca, cb) && valid;
+      if (acc) {
+        h.closest = t;
+        h.hit = hit_pack(DK_RECT, 0, goff + off);
+        if (IMG) { h.u = (ca - R0.x) / (R0.y - R0.x); h.v = (cb - R0.z) / (R0.w - R0.z); }
+      }
+    }
+  } else if (kind == DK_TRI) {
+    for (int i = 0; i < trips; ++i, k += G) {
+      const bool valid = k < cnt;
+      const int off = (valid ? k : 0) * SZ_TRI;
+      float t;
+      if (tri_t(recs[off], recs[off + 1], recs[off + 2], r, PT_TMIN, h.closest, t) && valid) {
+        h.closest = t;
+        h.hit = hit_pack(DK_TRI, 0, goff + off);
+      }
+    }
+  } else { // DK_BOX
+    for (int i = 0; i < trips; ++i, k += G) {
+      const bool valid = k < cnt;
+      const int off = (valid ? k : 0) * SZ_BOX;
+      float t, bu = 0.0f, bv = 0.0f;
+      int side = 0;
+      const bool acc = box_fast<IMG>(recs[off], recs[off + 1], c, h.closest, t, side, bu, bv) & valid;
+      h.closest = acc ? t : h.closest;
+      h.hit = acc ? hit_pack(DK_BOX, side, goff + off) : h.hit;
+      if (IMG) { if (acc) { h.u = bu; h.v = bv; } }
+    }
+  }
+}
+
 __device__ __forceinline__ int record_size(int kind) {
   return kind == DK_SPHERE ? SZ_SPHERE : kind == DK_RECT ? SZ_RECT : kind == DK_TRI ? SZ_TRI : kind == DK_BOX ? SZ_BOX : SZ_MEDIUM;
 }
@@ -499,13 +564,14 @@ __device__ __forceinline__ bool wave_all_regular(const RayCtx& c, bool live) {
 // A pixel's samples are one sequential chain (one RNG stream), so when most lanes of a wave have finished their
 // pixels the stragglers set the wave's — and in the end the frame's — finishing time.  When a wave is down to
 // <= 32 live lanes, each live ray is handed to a group of G = 64 / 2^ceil(log2 live) lanes: lane j of the group scans
-// the j-th contiguous segment of the list (in hittable order), the group merges the G segment winners IN LIST ORDER
-// with the reference's own acceptance rule — a later candidate replaces an earlier one iff t is smaller, or equal and
-// its kind accepts t == max (rect/box/triangle do, rectangle.hpp:36 triangle.hpp:91; spheres need t < max,
-// sphere.hpp:77) — which is exactly what the sequential scan with its shrinking max computes:
+// every G-th hittable of the list (in hittable order), the group merges the G partial winners with the reference's own
+// acceptance rule — a later candidate replaces an earlier one iff t is smaller, or equal and its kind accepts
+// t == max (rect/box/triangle do, rectangle.hpp:36 triangle.hpp:91; spheres need t < max, sphere.hpp:77) — which is
+// exactly what the sequential scan with its shrinking max computes:
 //   * every candidate's t is independent of max (sphere: first root > min; box: its own nearest side), max only
 //     decides acceptance; so the scan's result is "minimum t; among equal t the last candidate that accepts
-//     equality, else the first", and that selection is associative over contiguous segments.
+//     equality, else the first", a selection that is associative and commutative over any split of the list
+//     (other_wins).
 //   * constant_medium is the exception (it clamps against max and draws RNG, constant_medium.hpp:52-65): the list is
 //     split only up to the first medium (coop_prefix); the rest is scanned after the merge, by every lane of the
 //     group redundantly with the owner's RNG state, so it sees exactly the sequential max and draw order.
@@ -526,11 +592,41 @@ __device__ __forceinline__ int nth_set_bit(unsigned long long m, int n) { // lan
 __device__ __forceinline__ float shfl_f(float v, int src) { return __shfl(v, src, 64); }
 __device__ __forceinline__ int shfl_i(int v, int src) { return __shfl(v, src, 64); }
 
-// later candidate B replaces earlier A?  (list order: A before B)
-__device__ __forceinline__ bool later_wins(float tA, int hitA, float tB, int hitB) {
-  if (hitB < 0) return false;
-  if (hitA < 0) return true;
-  return (tB < tA) | ((tB == tA) & (hit_kind(hitB) != DK_SPHERE));
+// The scan's selection for two candidates in ANY list positions (strided splits): smaller t wins; at equal t the scan
+// keeps the LAST candidate whose kind accepts t == max if there is one, else the FIRST candidate — so: both accept
+// equality -> the later one, exactly one does -> that one, none -> the earlier one.  Record offsets grow in list order.
+// Commutative and associative, hence valid for a butterfly over arbitrary disjoint subsets of the list.
+__device__ __forceinline__ bool other_wins(float tA, int hitA, float tB, int hitB) { // does B replace A?  (branch-free)
+  const bool validA = hitA >= 0, validB = hitB >= 0;
+  const bool eqA = hit_kind(hitA) != DK_SPHERE, eqB = hit_kind(hitB) != DK_SPHERE;
+  const bool b_later = hit_off(hitB) > hit_off(hitA);
+  const bool tie = (eqB & (!eqA | b_later)) | (!eqA & !eqB & !b_later);
+  return validB & (!validA | (tB < tA) | ((tB == tA) & tie));
+}
+
+// value of lane (lane ^ STEP): DPP inside a row of 16, LDS crossbar beyond.  Steps 4 and 8 use the mirror patterns
+// (lane ^ 7, lane ^ 15): equivalent for a butterfly whose earlier steps have already made every aligned group of STEP
+// lanes agree.
+template <int STEP>
+__device__ __forceinline__ int xor_exchange(int v) {
+  if constexpr (STEP == 1) return __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false);       // quad_perm [1,0,3,2]
+  else if constexpr (STEP == 2) return __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false);  // quad_perm [2,3,0,1]
+  else if constexpr (STEP == 4) return __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false); // row_half_mirror
+  else if constexpr (STEP == 8) return __builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false); // row_mirror
+  else return __shfl_xor(v, STEP, 64);
+}
+
+// one butterfly stage of the group merge: afterwards both partners hold the better of their two candidates
+template <bool IMG, int STEP>
+__device__ __forceinline__ void merge_stage(HitState& s) {
+  const float tB = as_f(xor_exchange<STEP>(as_i(s.closest)));
+  const int hB = xor_exchange<STEP>(s.hit);
+  float uB = 0.0f, vB = 0.0f;
+  if (IMG) { uB = as_f(xor_exchange<STEP>(as_i(s.u))); vB = as_f(xor_exchange<STEP>(as_i(s.v))); }
+  if (other_wins(s.closest, s.hit, tB, hB)) {
+    s.closest = tB; s.hit = hB;
+    if (IMG) { s.u = uB; s.v = vB; }
+  }
 }
 
 // hit_world for the LDS-resident kernel, ordinary and cooperative mode in ONE instantiation of the record loops
@@ -538,22 +634,29 @@ __device__ __forceinline__ bool later_wins(float tA, int hitA, float tB, int hit
 // lane is its own group, its segment is the whole list, nothing is shuffled or merged.
 template <bool IMG, typename P>
 __device__ __forceinline__ void hit_world_lds(P blob, const CoopScene& cs, const Ray& my_ray, uint32_t& my_rng, bool live,
-                                              bool coop_allowed, bool scene_fast_ok, HitState& h) {
+                                              bool coop_allowed, bool scene_fast_ok, int wide_logG, HitState& h) {
   RayCtx c = make_ctx(my_ray, scene_fast_ok);
   const bool fast = wave_all_regular(c, live);
   const unsigned long long live_mask = __builtin_amdgcn_ballot_w64(live);
   const int nlive = __builtin_popcountll(live_mask);
   const int lane = threadIdx.x & 63;
+  // Two ways to be cooperative (both wave-uniform):
+  //  * wide (static groups, render_kernel's split-queue phase): every aligned group of G lanes already holds the SAME
+  //    pixel — ray, RNG state, everything — computed redundantly, so nothing is handed over and everybody keeps the result;
+  //  * dynamic: the wave is down to <= 32 live lanes; each live ray is handed to a group of idle lanes and handed back.
   int logG = 0;
-  if (coop_allowed && fast && nlive >= 1 && nlive <= 32)
+  bool handoff = false;
+  if (wide_logG) {
+    if (fast) logG = wide_logG; // irregular ray somewhere: every lane scans the whole list (still identical per group)
+  } else if (coop_allowed && fast && nlive >= 1 && nlive <= 32) {
     logG = nlive == 1 ? 6 : 6 - (32 - __builtin_clz((unsigned)(nlive - 1))); // G = 64 >> ceil(log2 nlive)
+    handoff = true;
+  }
   const int G = 1 << logG;
   const int group = lane >> logG, j = lane & (G - 1);
-  bool active = live;
   uint32_t rng = my_rng;
-  if (logG) { // wave-uniform: hand every live ray (+ its context and RNG state) to a group of G lanes
-    active = group < nlive;
-    const int owner = nth_set_bit(live_mask, active ? group : 0);
+  if (handoff) { // hand every live ray (+ its context and RNG state) to a group of G lanes
+    const int owner = nth_set_bit(live_mask, group < nlive ? group : 0); // surplus groups shadow ray 0 (outcome unused)
     c.r.o = mk(shfl_f(c.r.o.x, owner), shfl_f(c.r.o.y, owner), shfl_f(c.r.o.z, owner));
     c.r.d = mk(shfl_f(c.r.d.x, owner), shfl_f(c.r.d.y, owner), shfl_f(c.r.d.z, owner));
     c.r.tm = shfl_f(c.r.tm, owner);
@@ -562,48 +665,36 @@ __device__ __forceinline__ void hit_world_lds(P blob, const CoopScene& cs, const
     c.reg = true; // fast == every live ray is regular
     rng = (uint32_t)shfl_i((int)rng, owner);
   }
-  // this lane's segment of the splittable prefix of the list, in hittable order (G = 1: all of it)
-  const int seg_lo = (int)(((long long)cs.coop_prefix * j) >> logG), seg_hi = (int)(((long long)cs.coop_prefix * (j + 1)) >> logG);
   HitState s;
   hit_begin(s);
-  const int leader = group << logG;
   bool merged = logG == 0;
-  // One pass over the runs.  Up to the first constant_medium each lane scans only its own segment; at that point
-  // (or after the last run) the G segment winners are merged and from then on every lane of the group scans the
-  // whole run with the merged state and the owner's RNG state.
+  // One pass over the runs.  Up to the first constant_medium lane j of a group tests the hittables whose list index is
+  // == j (mod G) (strided: every run, however short, is spread over the group); at that point (or after the last run)
+  // the G partial winners are merged and from then on every lane of the group scans whole runs with the merged state and
+  // the ray's RNG state.
   for (int ri = 0; ri <= cs.n_runs; ++ri) {
     int kind = DK_MEDIUM, off = 0, cnt = 0, first = 0;
     if (ri < cs.n_runs) {
       f4 runf = blob[ri];
       kind = as_i(runf.x); off = as_i(runf.y); cnt = as_i(runf.z); first = as_i(runf.w);
     }
-    if (!merged && kind == DK_MEDIUM) {
-      // merge in list order (tree: the lower lane of each pair is earlier in the list) ...
-      for (int step = 1; step < G; step <<= 1) {
-        const int src = lane + step;
-        const float tB = shfl_f(s.closest, src);
-        const int hB = shfl_i(s.hit, src);
-        float uB = 0.0f, vB = 0.0f;
-        if (IMG) { uB = shfl_f(s.u, src); vB = shfl_f(s.v, src); }
-        if (((j & (2 * step - 1)) == 0) && later_wins(s.closest, s.hit, tB, hB)) {
-          s.closest = tB; s.hit = hB;
-          if (IMG) { s.u = uB; s.v = vB; }
-        }
-      }
-      // ... and give the leader's result to the whole group
-      s.closest = shfl_f(s.closest, leader);
-      s.hit = shfl_i(s.hit, leader);
-      if (IMG) { s.u = shfl_f(s.u, leader); s.v = shfl_f(s.v, leader); }
+    if (!merged && kind == DK_MEDIUM) { // butterfly: afterwards all G lanes hold the group's winner
+      merge_stage<IMG, 1>(s);
+      if (logG > 1) merge_stage<IMG, 2>(s);
+      if (logG > 2) merge_stage<IMG, 4>(s);
+      if (logG > 3) merge_stage<IMG, 8>(s);
+      if (logG > 4) merge_stage<IMG, 16>(s);
+      if (logG > 5) merge_stage<IMG, 32>(s);
       merged = true;
     }
     if (ri == cs.n_runs) break;
-    const int lo = merged ? first : max(seg_lo, first), hi = merged ? first + cnt : min(seg_hi, first + cnt);
-    if (active && hi > lo) {
-      const int sz = record_size(kind);
-      hit_records<IMG>(blob + off + (lo - first) * sz, kind, hi - lo, off + (lo - first) * sz, c, fast, rng, s);
-    }
+    if (cnt <= 0) continue;
+    // (idle lanes scan too and their outcome is dropped: a per-lane skip would put the whole scan under exec-mask
+    // branches — the ordinary kernels do the same)
+    if (merged) hit_records<IMG>(blob + off, kind, cnt, off, c, fast, rng, s);
+    else hit_records_strided<IMG>(blob + off, kind, cnt, first, off, j, logG, c, s);
   }
-  if (logG) { // hand each owner its result: the r-th live lane reads from the leader of group r
+  if (handoff) { // hand each owner its result: the r-th live lane reads from (a lane of) group r
     const int my_rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(live_mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)live_mask, 0u));
     const int my_leader = live ? (my_rank << logG) : lane;
     s.closest = shfl_f(s.closest, my_leader);

@@ -38,6 +38,12 @@ namespace {
 #ifndef PT_MIN_WAVES_IMG
 #define PT_MIN_WAVES_IMG 5 /* image-texture kernels: 96 VGPRs; +10 % on the 496-hittable scene (A/B, one process) */
 #endif
+#ifndef PT_MIN_WAVES_COOP
+#define PT_MIN_WAVES_COOP 5 /* cooperative kernels: 93 VGPRs, no scratch (7 waves: 72 VGPRs + 76 B/lane of spills in the loop) */
+#endif
+#ifndef PT_MIN_WAVES_COOP_IMG
+#define PT_MIN_WAVES_COOP_IMG 5 /* 96 VGPRs + 60 B/lane of spills; spill-free needs 116 VGPRs = 4 waves: 496-hittable scene -9 % (A/B) */
+#endif
 constexpr int kBlock = 256;                 // 4 wavefronts = 4 tiles per workgroup
 constexpr int kWavesPerBlock = kBlock / 64;
 constexpr size_t kMaxLdsBlob = 64 * 1024;   // blob staged in LDS when it fits
@@ -59,10 +65,11 @@ struct KArgs {
   unsigned int* queue; // per-launch dequeue counter, zeroed on the stream before the kernel
   unsigned int* cost;  // non-NULL: cost-probe pass, per local tile ray counts (nothing is written to fb)
   const int* order;    // non-NULL: queue position -> local tile, heaviest first
-  const int* n_split;  // non-NULL (COOP kernels): how many leading tiles of `order` are handed out row by row
+  const int* n_split;  // non-NULL (COOP kernels): how many leading tiles of `order` go through the wide phase
   int tile_granular;   // PT_FLAG_TILE_GRANULAR
   int n_hittables;
   int coop_prefix;     // >= 0: cooperative traversal allowed, list splittable up to this hittable; -1: disabled
+  int wide_logG;       // log2 of the lanes that share one pixel while a wave serves the split queue (COOP kernels)
   int fast_ok; // every rect/box coordinate finite and <= 2^60: rays may use the shared-reciprocal division
 };
 
@@ -82,6 +89,8 @@ struct Lane {
   bool retired;  // the queue is empty for this lane
   bool need_new; // next iteration starts a new sample
   bool split_done; // (wave-uniform) the split queue is exhausted
+  int wide;        // (wave-uniform) log2 lanes per pixel while this wave serves the split queue; 0 = one lane per pixel
+  unsigned int split_pixels; // (wave-uniform) 64 x the tiles handed out through the split queue
 };
 
 __device__ __forceinline__ void lane_reset(Lane& L) {
@@ -90,44 +99,51 @@ __device__ __forceinline__ void lane_reset(Lane& L) {
   L.att = mk(1.0f, 1.0f, 1.0f);
   L.ray.o = mk(0.0f, 0.0f, 0.0f); L.ray.d = mk(0.0f, 0.0f, 1.0f); L.ray.tm = 0.0f;
   L.s = 0; L.b = 0; L.iters = 0; L.pix = -1; L.x = 0; L.y = 0;
-  L.live = false; L.retired = false; L.need_new = true; L.split_done = false;
+  L.live = false; L.retired = false; L.need_new = true; L.split_done = false; L.wide = 0; L.split_pixels = 0;
 }
 
 // Wave-aggregated dequeue: one atomicAdd per wave for all lanes that need a pixel (ballot + prefix count),
 // pixels handed out in tile order so a fresh wave starts on one coherent 8x8 tile.
+//
+// Wide phase (COOP kernels, L.wide = log2 G > 0): the heaviest tiles (the first *a.n_split positions of the cost-sorted
+// order) come from a queue of their own, one PIXEL per aligned group of G lanes.  All G lanes of a group hold the same
+// pixel and compute everything redundantly — same seed, same RNG draws, same shading — except the traversal, where each
+// tests 1/G of the list (hit_world_lds) — so a pixel's sequential chain gets shorter without any state ever moving
+// between lanes.  A wave leaves the phase when that queue is empty and its last wide pixel is done.
 __device__ __forceinline__ void lane_acquire(Lane& L, const KArgs& a) {
   const bool want = !L.live && !L.retired;
   const unsigned long long mask = __builtin_amdgcn_ballot_w64(want);
   if (mask == 0) return;
-  // tile-granular mode (A/B switch): a wave takes its next 64 pixels only when all of its lanes are idle
-  if (a.tile_granular && __builtin_amdgcn_ballot_w64(L.live) != 0) return;
   const int lane = threadIdx.x & 63;
   const int leader = __builtin_ctzll(mask);
   const unsigned int rank = __builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mask, 0u));
-  // Heavy tiles (the first *a.n_split positions of the cost-sorted order) are handed out 8 pixels = one tile row at a
-  // time from a queue of their own: a wave that holds only 8 live pixels runs them 8 lanes per ray (hit_world_lds),
-  // so a tile that would otherwise bound the makespan is spread over 8 waves and each of its rays over 8 lanes.
-  const unsigned int split_pixels = (a.n_split && !L.split_done) ? (unsigned int)(*a.n_split) * PT_TILE_PIXELS : 0u;
+  const unsigned int split_pixels = L.split_pixels; // read once per wave (render_kernel): constant during the launch
   unsigned int i = 0;
-  bool got = false;
-  if (split_pixels) {
-    unsigned int b = 0;
-    if (lane == leader) b = atomicAdd(a.queue + 1, (unsigned int)PT_TILE);
-    b = __builtin_amdgcn_readlane(b, leader);
-    if (b < split_pixels) {
-      if (!want || rank >= (unsigned int)PT_TILE) return; // the other idle lanes serve these 8 rays
-      i = b + rank;
-      got = true;
-    } else {
-      L.split_done = true;
-    }
+  if (L.wide && L.split_done) {                           // nothing left to hand out in this phase:
+    if (__builtin_amdgcn_ballot_w64(L.live) != 0) return; //   idle groups wait for the wave's last wide pixels (no memory op)
+    L.wide = 0;                                           //   all done: carry on with the ordinary queue below
   }
-  if (!got) {
+  if (L.wide) {
+    const unsigned int groups = (unsigned int)__builtin_popcountll(mask) >> L.wide; // idle groups (all-or-none per group)
+    unsigned int b = 0;
+    if (lane == leader) b = atomicAdd(a.queue + 1, groups);
+    b = __builtin_amdgcn_readlane(b, leader);
+    if (b + groups >= split_pixels) L.split_done = true;
+    i = b + (rank >> L.wide);
+    const bool got = want && i < split_pixels;
+    // wave-uniform decisions first (no ballot under a divergent branch)
+    const bool any_got = __builtin_amdgcn_ballot_w64(got) != 0, any_live = __builtin_amdgcn_ballot_w64(L.live) != 0;
+    if (!any_got && !any_live) L.wide = 0; // queue was already empty and nothing in flight: ordinary queue below
+    else if (!got) return;                 // (groups that got a pixel go on to set it up)
+  }
+  if (!L.wide) {
+    // tile-granular mode: a wave takes its next 64 pixels only when all of its lanes are idle
+    if (a.tile_granular && __builtin_amdgcn_ballot_w64(L.live) != 0) return;
     unsigned int base = 0;
     if (lane == leader) base = atomicAdd(a.queue, (unsigned int)__builtin_popcountll(mask));
     base = __builtin_amdgcn_readlane(base, leader);
     if (!want) return;
-    i = (a.n_split ? (unsigned int)(*a.n_split) * PT_TILE_PIXELS : 0u) + base + rank;
+    i = split_pixels + base + rank;
   }
   if (i >= (unsigned int)a.n_local_pixels) { L.retired = true; return; }
   // queue position -> local tile: identity, or the cost-sorted order of the probe pass (heaviest tiles first)
@@ -148,6 +164,7 @@ __device__ __forceinline__ void lane_acquire(Lane& L, const KArgs& a) {
 
 __device__ __forceinline__ void lane_store(Lane& L, const KArgs& a) {
   L.live = false;
+  if (L.wide && ((threadIdx.x & 63) & ((1 << L.wide) - 1))) return; // wide phase: one lane of the group writes
   if (a.cost) { // cost-probe pass: only the tile's ray count is kept
     atomicAdd(&a.cost[L.pix >> 6], L.iters);
     return;
@@ -218,7 +235,8 @@ __device__ unsigned long long g_stamps[8];
 // COOP: the traversal can split a ray's list over idle lanes (hit_world_lds); costs ~10 VGPRs and ~7 % of the
 // ordinary-mode throughput, so the launcher picks it only where the makespan floor matters (launch_render).
 template <bool IMG, bool LDS, bool MLDS, bool COOP>
-__global__ __launch_bounds__(kBlock, IMG ? PT_MIN_WAVES_IMG : PT_MIN_WAVES) void render_kernel(KArgs a) {
+__global__ __launch_bounds__(kBlock, COOP ? (IMG ? PT_MIN_WAVES_COOP_IMG : PT_MIN_WAVES_COOP) : (IMG ? PT_MIN_WAVES_IMG : PT_MIN_WAVES))
+void render_kernel(KArgs a) {
   extern __shared__ f4 smem[];
   if (LDS) {
     const int n = a.blob_f4 + (MLDS ? a.mats_f4 : 0); // a.mats == a.blob + a.blob_f4 (one device buffer)
@@ -227,6 +245,10 @@ __global__ __launch_bounds__(kBlock, IMG ? PT_MIN_WAVES_IMG : PT_MIN_WAVES) void
   }
   Lane L;
   lane_reset(L);
+  if (COOP && a.n_split) {
+    L.split_pixels = (unsigned int)(*a.n_split) * PT_TILE_PIXELS;
+    L.wide = a.wide_logG;
+  }
   if (a.depth <= 0) return; // depth 0: every sample returns black (render.hpp:58,91); the frame is pre-zeroed
 #ifdef PT_STAMPS
   unsigned long long s_prep = 0, s_trav = 0, s_shade = 0, s_iters = 0;
@@ -248,7 +270,7 @@ __global__ __launch_bounds__(kBlock, IMG ? PT_MIN_WAVES_IMG : PT_MIN_WAVES) void
       if constexpr (COOP) {
         // ordinary and cooperative traversal (few live lanes: each live ray's list split over the idle lanes)
         const CoopScene cs{a.n_runs, a.coop_prefix};
-        hit_world_lds<IMG>((lds_f4p)smem, cs, L.ray, L.rng, L.live, true, a.fast_ok != 0, h);
+        hit_world_lds<IMG>((lds_f4p)smem, cs, L.ray, L.rng, L.live, true, a.fast_ok != 0, L.wide, h);
       } else {
         RayCtx c = make_ctx(L.ray, a.fast_ok != 0);
         const bool fast = wave_all_regular(c, L.live);
@@ -363,9 +385,9 @@ __global__ __launch_bounds__(1024) void lpt_order_kernel(const unsigned int* __r
   __syncthreads();
   if (threadIdx.x == 0) {
     unsigned int acc = 0;
-    // How many of the heaviest tiles to hand out row by row (lane_acquire).  A tile rendered whole is one chain of
-    // length ~ its cost; split, its rows are chains `split_speedup` times shorter but cost 1/`split_eff` as much
-    // lane time (a ray's shading is not shared, shuffles and the merge are extra).  With the tiles handed out
+    // How many of the heaviest tiles to render G lanes per pixel (lane_acquire).  A tile rendered whole is one chain of
+    // length ~ its cost; wide, its pixels are chains `split_speedup` times shorter but cost 1/`split_eff` as much
+    // lane time (camera and shading are computed redundantly by the G lanes, the merge is extra).  With the tiles handed out
     // heaviest first the makespan is about
     //     max( (cost kept whole + cost split / split_eff) / n_waves , heaviest tile kept whole , heaviest tile / split_speedup )
     // evaluated for every prefix of classes; the best prefix wins (often the empty one).
@@ -524,6 +546,7 @@ struct PtScene {
   bool coop_ok = false;
   int coop_prefix = 0;
   int n_hittables = 0;
+  mutable int nsplit_override = 0; // PT_SPLIT_TILES tuning knob (host copy must outlive the async upload)
   float traversal_cost = 0.0f; // estimated VALU instructions of one ray's scan of the list
   size_t blob_bytes = 0;
   int num_cus = 256;
@@ -724,11 +747,13 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
   const bool mlds = lds && blob_bytes + (size_t)s->mats_f4 * 16 <= kMaxLdsWithMaterials;
   const size_t shmem = lds ? blob_bytes + (mlds ? (size_t)s->mats_f4 * 16 : 0) : 0;
   a.n_split = nullptr;
+  a.wide_logG = 0;
   int n_waves_resident = 1;
-  // Cooperative kernels (a ray's list split over idle lanes + heavy tiles handed out row by row) cost ~7 % of the
-  // ordinary-mode throughput and ~35 cross-lane shuffles per cooperative iteration, so they pay only where the
-  // scan of the list dominates an iteration.  Measured on shard 0/8 of the 1080p frame: 496-hittable scene
-  // 512 -> 222 ms; Cornell-style scene (8 hittables) 90 -> 106 ms (188 ms with tiles split) — hence the threshold.
+  // Cooperative kernels (a ray's list split over idle lanes; the heaviest tiles rendered G lanes per pixel) cost ~15 % of
+  // the ordinary-mode throughput, and the part of an iteration that cannot be split (camera, shading, ray context:
+  // ~4 500 cycles of a lone wave's 13 200 on the Cornell-style scene) bounds what they can win: there G = 8 shortens a
+  // pixel's chain by 1.4x for 4.6x the lane time, so they pay only where the scan of the list dominates an iteration
+  // (496-hittable scene, shard 0/8: 522 -> 229 ms).
   const bool coop = lds && a.coop_prefix >= 0 && (s->traversal_cost >= kCoopMinTraversal || (p->flags & PT_FLAG_FORCE_COOP));
   // Persistent grid: no more workgroups than the chip holds at once; lanes pull pixels from the queue.
   auto launch = [&](auto kernel) -> int {
@@ -736,10 +761,13 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
     PT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, shmem));
     if (const char* e = std::getenv("PT_BLOCKS_PER_CU")) per_cu = std::min(per_cu, std::max(1, std::atoi(e))); // tuning knob
     const int resident_blocks = std::max(1, per_cu) * std::max(1, s->num_cus);
-    a.queue = s->queues + 2 * (s->next_queue++ % kQueueRing); // [0] ordinary queue, [1] split (row-granular) queue
+    a.queue = s->queues + 2 * (s->next_queue++ % kQueueRing); // [0] ordinary queue, [1] wide-phase queue
     PT_HIP(hipMemsetAsync(a.queue, 0, 2 * sizeof(unsigned int), st));
-    n_waves_resident = (int)std::min<long long>((local_tiles + kWavesPerBlock - 1) / kWavesPerBlock, resident_blocks) * kWavesPerBlock;
-    dim3 grid(std::min((local_tiles + kWavesPerBlock - 1) / kWavesPerBlock, resident_blocks)), block(kBlock);
+    // one wave per tile is enough, except in the wide phase, where a split tile keeps G waves busy (how many tiles are
+    // split is decided on the device, so such a launch simply fills the chip; surplus waves find the queues empty and exit)
+    const long long wanted = a.n_split ? (long long)resident_blocks : (long long)((local_tiles + kWavesPerBlock - 1) / kWavesPerBlock);
+    n_waves_resident = (int)std::min<long long>(wanted, resident_blocks) * kWavesPerBlock;
+    dim3 grid((unsigned int)std::min<long long>(wanted, resident_blocks)), block(kBlock);
     hipLaunchKernelGGL(kernel, grid, block, shmem, st, a);
     PT_HIP(hipGetLastError());
     return PT_OK;
@@ -772,10 +800,20 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
     int rc = launch_variant();
     if (rc) return rc;
     // rough per-iteration instruction counts: traversal (splittable) vs shading + camera + cooperative overhead (not)
-    const float T = std::max(1.0f, s->traversal_cost), S = 1250.0f, G = (float)PT_TILE; // S: shading + camera + ~35 shuffles
+    int wide_logG = 3;
+    if (const char* e = std::getenv("PT_WIDE_LOGG")) wide_logG = std::min(6, std::max(1, std::atoi(e))); // tuning knob
+    main_args.wide_logG = wide_logG;
+    const float T = std::max(1.0f, s->traversal_cost), S = 500.0f, G = (float)(1 << wide_logG); // S: shading + camera + merge
     hipLaunchKernelGGL(lpt_order_kernel, dim3(1), dim3(1024), 0, st, s->ws_cost, local_tiles, s->ws_order, n_waves_resident,
                        (T + S) / (T + G * S), (T + S) / (T / G + S), coop ? s->ws_nsplit : nullptr);
     PT_HIP(hipGetLastError());
+    if (const char* e = std::getenv("PT_SPLIT_TILES")) { // tuning knob: fixed number of split tiles (< 0: all)
+      if (coop) {
+        const int k = std::atoi(e);
+        s->nsplit_override = k < 0 ? local_tiles : std::min(k, local_tiles);
+        PT_HIP(hipMemcpyAsync(s->ws_nsplit, &s->nsplit_override, sizeof(int), hipMemcpyHostToDevice, st));
+      }
+    }
     a = main_args;
     a.order = s->ws_order;
     a.n_split = (coop && !(p->flags & PT_FLAG_NO_SPLIT)) ? s->ws_nsplit : nullptr;

@@ -322,6 +322,40 @@ def test_cooperative_traversal_agrees(orc, name, size):
     assert_bit_identical(a, orc.render(ps, c.c, w, h, 24), f"{name} {w}x{h} vs oracle")
 
 
+@pytest.mark.parametrize("name", ["cornell", "spheres", "triangles", "ties", "mixed"])
+def test_wide_phase_every_group_size(orc, name, monkeypatch):
+    """Heavy tiles are rendered G lanes per pixel: all G lanes hold the same pixel (same seed, same draws), each tests the
+    hittables == its lane (mod G), a butterfly merges the partial winners with the scan's own tie rule.  Tuning knobs force
+    EVERY tile through that phase for every group size; the frame must not change by a bit.  ('ties' has coincident faces
+    of different kinds: the tie rule is what is being tested there.)"""
+    w, h = 136, 72  # 17 x 9 = 153 tiles (>= 64 and spp >= 16: the probe pass that feeds the split runs)
+    ps, cam = S.ALL[name]()
+    c = scenes.make_camera(cam, w, h)
+    ref = R.render_host(w, h, 16, ps, c, flags=abi.PT_FLAG_NO_COOP)
+    orc.set_math(True)
+    assert_bit_identical(ref, orc.render(ps, c.c, w, h, 16), f"{name} ordinary vs oracle")
+    monkeypatch.setenv("PT_SPLIT_TILES", "-1")
+    for log_g in range(1, 7):
+        monkeypatch.setenv("PT_WIDE_LOGG", str(log_g))
+        assert_bit_identical(R.render_host(w, h, 16, ps, c, flags=abi.PT_FLAG_FORCE_COOP), ref, f"{name} G={1 << log_g}")
+    monkeypatch.setenv("PT_SPLIT_TILES", "40")  # mixed launch: 40 tiles wide, the rest ordinary, waves change phase
+    monkeypatch.setenv("PT_WIDE_LOGG", "2")
+    assert_bit_identical(R.render_host(w, h, 16, ps, c, flags=abi.PT_FLAG_FORCE_COOP), ref, f"{name} 40 tiles wide")
+
+
+def test_wide_phase_smoke_scene(orc, monkeypatch):
+    """496 hittables with a constant_medium suffix and image textures: the medium is scanned after the merge by every lane
+    of a group (identical RNG state in all of them); u,v travel through the butterfly."""
+    ps, cam = scenes.build("smoke")
+    w, h = 96, 56
+    c = scenes.make_camera(cam, w, h)
+    ref = R.render_host(w, h, 16, ps, c, flags=abi.PT_FLAG_NO_COOP)
+    monkeypatch.setenv("PT_SPLIT_TILES", "-1")
+    for log_g in (1, 3, 5, 6):
+        monkeypatch.setenv("PT_WIDE_LOGG", str(log_g))
+        assert_bit_identical(R.render_host(w, h, 16, ps, c), ref, f"smoke G={1 << log_g}")
+
+
 def test_cooperative_traversal_with_medium_suffix_and_image(orc):
     """The SmokeSphere scene: image textures (u,v carried through the merge), a constant_medium at the end of the
     list (scanned after the merge with the owner's RNG state), 496 hittables split over up to 64 lanes."""
