@@ -172,13 +172,25 @@ __device__ __forceinline__ float div_exact(float n, float d, float y, float q0) 
 }
 
 // ---- sphere.hpp -----------------------------------------------------------------------------
-// record: R0 = (c0.xyz, +-radius^2: sign bit set = moving)  R1 = (radius, mat, time0, time1)  R2 = (c1.xyz, hittable index)
+// record: R0 = (c0.xyz, +-radius^2: sign bit set = moving)  R1 = (radius, mat, time0, time1)  R2 = (c1-c0, hittable index)
+
+// The time fraction (time - time0) / (time1 - time0) of sphere.hpp:54 depends on the ray and on (time0, time1) only, and
+// consecutive moving spheres of a list nearly always share their shutter interval: the quotient is kept while the
+// interval stays the same (one IEEE division per ray instead of one per moving sphere; same operation, same bits).
+struct TimeFrac {
+  float t0, t1, frac;
+};
+__device__ __forceinline__ TimeFrac time_frac_none() { return TimeFrac{__builtin_nanf(""), __builtin_nanf(""), 0.0f}; }
+__device__ __forceinline__ float time_frac(TimeFrac& m, float time, float t0, float t1) {
+  if (!(t0 == m.t0 && t1 == m.t1)) { m.t0 = t0; m.t1 = t1; m.frac = (time - t0) / (t1 - t0); }
+  return m.frac;
+}
 
 // sphere.hpp:51-56
 __device__ __forceinline__ V3 sphere_center(f4 R0, f4 R1, f4 R2, float time) {
   V3 c0 = xyz(R0);
   if (R1.z == R1.w) return c0; // wave-uniform
-  return c0 + ((time - R1.z) / (R1.w - R1.z)) * (xyz(R2) - c0);
+  return c0 + ((time - R1.z) / (R1.w - R1.z)) * xyz(R2);
 }
 
 // sphere.hpp:13-24
@@ -191,13 +203,13 @@ __device__ __forceinline__ void mercator(V3 p, float& u, float& v) {
 
 // Roots of sphere.hpp:68-93; returns true and t if one lies in (mn, mx).
 template <typename P>
-__device__ __forceinline__ bool sphere_t(P recs, int off, const RayCtx& c, float mn, float mx, float& t) {
+__device__ __forceinline__ bool sphere_t(P recs, int off, const RayCtx& c, float mn, float mx, float& t, TimeFrac& tf) {
   const Ray& r = c.r;
   f4 R0 = recs[off]; // the only read on the miss path of a static sphere
   V3 center = xyz(R0);
   if (as_i(R0.w) < 0) { // moving (flatten stores -(radius^2) when time0 != time1): wave-uniform
     f4 R1 = recs[off + 1];
-    center = sphere_center(R0, R1, recs[off + 2], r.tm);
+    center = center + time_frac(tf, r.tm, R1.z, R1.w) * xyz(recs[off + 2]);
   }
   V3 oc = r.o - center;
   float b = dot(oc, r.d);
@@ -366,7 +378,7 @@ __device__ __forceinline__ bool tri_t(f4 R0, f4 R1, f4 R2, const Ray& r, float m
 // record: R0 = (boundary kind, neg_inv_density, mat, hittable index)  R1.. = boundary (sphere 3 f4 | box 2 f4)
 template <typename P>
 __device__ __forceinline__ bool boundary_t(P recs, int off, int bkind, const RayCtx& c, float mn, float mx, float& t) {
-  if (bkind == DK_SPHERE) return sphere_t(recs, off, c, mn, mx, t);
+  if (bkind == DK_SPHERE) { TimeFrac tf = time_frac_none(); return sphere_t(recs, off, c, mn, mx, t, tf); }
   int side; float u, v;
   return box_plain<false>(recs[off], recs[off + 1], c, mn, mx, t, side, u, v);
 }
@@ -409,9 +421,10 @@ __device__ __forceinline__ void hit_records(P recs, int kind, int n, int goff, c
   const Ray& r = c.r;
   int off = 0;
   if (kind == DK_SPHERE) {
+    TimeFrac tf = time_frac_none();
     for (int i = 0; i < n; ++i, off += SZ_SPHERE) {
       float t;
-      if (sphere_t(recs, off, c, PT_TMIN, h.closest, t)) {
+      if (sphere_t(recs, off, c, PT_TMIN, h.closest, t, tf)) {
         h.closest = t;
         h.hit = hit_pack(DK_SPHERE, 0, goff + off);
         if (IMG) {
@@ -486,11 +499,12 @@ __device__ __forceinline__ void hit_records_strided(P recs, int kind, int cnt, i
   const int G = 1 << logG, trips = (cnt + G - 1) >> logG;
   int k = (j - first) & (G - 1);
   if (kind == DK_SPHERE) {
+    TimeFrac tf = time_frac_none();
     for (int i = 0; i < trips; ++i, k += G) {
       const bool valid = k < cnt;
       const int off = (valid ? k : 0) * SZ_SPHERE;
       float t;
-      if (sphere_t(recs, off, c, PT_TMIN, h.closest, t) && valid) {
+      if (sphere_t(recs, off, c, PT_TMIN, h.closest, t, tf) && valid) {
         h.closest = t;
         h.hit = hit_pack(DK_SPHERE, 0, goff + off);
         if (IMG) {

@@ -89,7 +89,7 @@ inline void put_sphere(std::vector<F4>& b, const float* f, int32_t mat, int32_t 
   const float r2 = f[6] * f[6];                          // radius^2 (sphere.hpp:71)
   b.push_back({f[0], f[1], f[2], f[7] != f[8] ? -r2 : r2}); // c0; sign bit of r^2 = "moving" (sphere.hpp:52)
   b.push_back({f[6], as_f(mat), f[7], f[8]});            // radius, material, time0, time1
-  b.push_back({f[3], f[4], f[5], as_f(hidx)});           // c1
+  b.push_back({f[3] - f[0], f[4] - f[1], f[5] - f[2], as_f(hidx)}); // center1 - center0 (sphere.hpp:55), ray-independent
 }
 inline void put_box(std::vector<F4>& b, const float* f, int32_t mat, int32_t hidx) {
   b.push_back({f[0], f[1], f[2], as_f(mat)});

@@ -98,7 +98,7 @@ def test_flatten_preserves_list_order(lib):
         assert first == off
         off += sizes[int(kind)] * int(count)
     assert off == len(blob)
-    # sphere record: (c0, r^2) (r, mat, t0, t1) (c1, hittable index)
+    # sphere record: (c0, r^2) (r, mat, t0, t1) (c1 - c0, hittable index)
     s1 = blob[runs[0, 1] + 3: runs[0, 1] + 6]
     assert s1[0].tolist() == [1, 0, 0, 4] and s1[1, 0] == 2 and s1[2].view(np.int32)[3] == 1
     # rect record carries its axis (xy=0, xz=1)
