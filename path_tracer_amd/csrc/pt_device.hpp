@@ -767,6 +767,35 @@ __device__ __forceinline__ Rec resolve_hit(P blob, int hit, const Ray& r, float 
   return rec;
 }
 
+// u,v of the final hit, from the hit itself (sphere.hpp:88-89 mercator of the face normal; rectangle.hpp:41-42 and its
+// xz/yz twins; box = its hit side).  The reference fills them on EVERY accepted candidate; for sphere, rect and box hits
+// they are a pure function of (ray, primitive, t), so the value of the final hit is the same computed once here.
+// Triangles and constant_media never write u,v (theirs are whatever an earlier accepted candidate left behind): scenes
+// where such a stale value could reach an image texture use the kernels that track u,v through the scan (IMG = true).
+template <typename P>
+__device__ __forceinline__ void winner_uv(P blob, int hit, const Ray& r, float t, const Rec& rec, float& u, float& v) {
+  const int off = hit_off(hit), kind = hit_kind(hit);
+  u = 0.0f; v = 0.0f;
+  if (kind == DK_SPHERE) {
+    mercator(rec.normal, u, v);
+  } else if (kind == DK_RECT || kind == DK_BOX) {
+    const f4 R0 = blob[off], R1 = blob[off + 1];
+    int axis;
+    float a0, a1, b0, b1;
+    if (kind == DK_RECT) { axis = as_i(R1.z); a0 = R0.x; a1 = R0.y; b0 = R0.z; b1 = R0.w; }
+    else {
+      axis = hit_side(hit) >> 1; // sides 0,1: xy  2,3: xz  4,5: yz (PT_BOX_SIDES)
+      a0 = axis == 2 ? R0.y : R0.x; a1 = axis == 2 ? R1.y : R1.x;
+      b0 = axis == 0 ? R0.y : R0.z; b1 = axis == 0 ? R1.y : R1.z;
+    }
+    const float oa = axis == 2 ? r.o.y : r.o.x, da = axis == 2 ? r.d.y : r.d.x;
+    const float ob = axis == 0 ? r.o.y : r.o.z, db = axis == 0 ? r.d.y : r.d.z;
+    const float a = oa + t * da, b = ob + t * db;
+    u = (a - a0) / (a1 - a0);
+    v = (b - b0) / (b1 - b0);
+  }
+}
+
 // ---- textures: texture.hpp:25, 42-49, 135-151 -------------------------------------------------------------------
 // material record (global memory, 4 f4): M0 = (mat kind, tex kind, param, freq)  M1 = (color0.xyz, width)
 //                                        M2 = (color1.xyz, height)  M3 = (atlas offset, 0, 0, 0)
@@ -776,8 +805,8 @@ __device__ __forceinline__ uint32_t texel_index(float f, uint32_t maxv) {
   return (uint32_t)f;
 }
 
-__device__ __forceinline__ V3 texture_value(f4 M0, f4 M1, f4 M2, f4 M3, V3 p, float u, float v,
-                                            const uint8_t* __restrict__ atlas) {
+template <typename UV>
+__device__ __forceinline__ V3 texture_value(f4 M0, f4 M1, f4 M2, f4 M3, V3 p, UV uv, const uint8_t* __restrict__ atlas) {
   const int tk = as_i(M0.y);
   if (tk == 1) return xyz(M1); // solid
   if (tk == 0) {               // checker
@@ -785,6 +814,8 @@ __device__ __forceinline__ V3 texture_value(f4 M0, f4 M1, f4 M2, f4 M3, V3 p, fl
     return (sines < 0) ? xyz(M1) : xyz(M2);
   }
   const uint32_t w = (uint32_t)as_i(M1.w), h = (uint32_t)as_i(M2.w), offset = (uint32_t)as_i(M3.x);
+  float u, v;
+  uv(u, v); // only image textures look at u,v
   uint32_t i = texel_index(ptm::fmod1f_(u * M0.w) * (float)(w - 1), w - 1);
   uint32_t j = texel_index((1.0f - ptm::fmod1f_(v * M0.w)) * (float)(h - 1), h - 1);
   uint64_t pix = (uint64_t)j * w + i + offset;
@@ -818,15 +849,16 @@ __device__ __forceinline__ V3 sky_color(const Ray& r, V3 att) {
 
 // One iteration of the bounce loop render.hpp:58-89 after hit_world: emitted + scatter.
 // Returns true if the path continues (ray/att updated); false if it ended with `out`.
-template <typename PM>
+// `uv(u, v)` yields the hit's texture coordinates; it is called before the ray is overwritten.
+template <typename PM, typename UV>
 __device__ __forceinline__ bool shade(PM mats, const uint8_t* __restrict__ atlas, const Rec& rec,
-                                      float hu, float hv, Ray& ray, V3& att, uint32_t& rng, V3& out) {
+                                      UV uv, Ray& ray, V3& att, uint32_t& rng, V3& out) {
   PM M = mats + rec.mat * SZ_MATERIAL;
   f4 M0 = M[0], M1 = M[1];
   const int mk_ = as_i(M0.x);
   if (mk_ == 0) { // lambertian material.hpp:18-28
     V3 dir = rec.normal + rng_unit_vec(rng);
-    V3 tv = texture_value(M0, M1, M[2], M[3], rec.p, hu, hv, atlas);
+    V3 tv = texture_value(M0, M1, M[2], M[3], rec.p, uv, atlas);
     ray.o = rec.p; ray.d = dir;
     att = att * tv;
     return true;
@@ -857,12 +889,12 @@ __device__ __forceinline__ bool shade(PM mats, const uint8_t* __restrict__ atlas
     return true;
   }
   if (mk_ == 3) { // lightsource material.hpp:104-108; returned un-attenuated (render.hpp:73)
-    out = texture_value(M0, M1, M[2], M[3], rec.p, hu, hv, atlas);
+    out = texture_value(M0, M1, M[2], M[3], rec.p, uv, atlas);
     return false;
   }
   // isotropic material.hpp:119-126
   V3 ball = rng_in_unit_ball(rng);
-  V3 tv = texture_value(M0, M1, M[2], M[3], rec.p, hu, hv, atlas);
+  V3 tv = texture_value(M0, M1, M[2], M[3], rec.p, uv, atlas);
   ray.o = rec.p; ray.d = ball;
   att = att * tv;
   return true;

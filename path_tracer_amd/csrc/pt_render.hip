@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <string>
 #include <vector>
 
@@ -44,6 +45,8 @@ namespace {
 #ifndef PT_MIN_WAVES_COOP_IMG
 #define PT_MIN_WAVES_COOP_IMG 5 /* 96 VGPRs + 60 B/lane of spills; spill-free needs 116 VGPRs = 4 waves: 496-hittable scene -9 % (A/B) */
 #endif
+// How a kernel obtains the u,v an image texture looks up (DESIGN.md §3 "u,v of the final hit")
+enum { UV_NONE = 0, UV_WINNER = 1, UV_TRACKED = 2 };
 constexpr int kBlock = 256;                 // 4 wavefronts = 4 tiles per workgroup
 constexpr int kWavesPerBlock = kBlock / 64;
 constexpr size_t kMaxLdsBlob = 64 * 1024;   // blob staged in LDS when it fits
@@ -190,7 +193,7 @@ __device__ __forceinline__ void lane_regenerate(Lane& L, const KArgs& a) {
 }
 
 // emitted / scatter / sky for the nearest hit (render.hpp:60-88) and the sample bookkeeping (:100).
-template <typename PB, typename PM>
+template <int UV, typename PB, typename PM>
 __device__ __forceinline__ void lane_shade(Lane& L, const KArgs& a, const HitState& h, PB recs, PM mats) {
   if (!L.live) return;
   L.iters++;
@@ -201,7 +204,14 @@ __device__ __forceinline__ void lane_shade(Lane& L, const KArgs& a, const HitSta
     cont = false;
   } else {
     Rec rec = resolve_hit(recs, h.hit, L.ray, h.closest); // per-lane gather of the one record that was hit
-    cont = shade(mats, a.atlas, rec, h.u, h.v, L.ray, L.att, L.rng, out);
+    // UV_TRACKED kernels carried u,v through the scan (stale values included); UV_WINNER derives them from the final hit
+    // when an image texture asks; UV_NONE: the scene has no image texture, nothing reads them
+    auto uv = [&](float& u, float& v) {
+      if (UV == UV_TRACKED) { u = h.u; v = h.v; }
+      else if (UV == UV_WINNER) winner_uv(recs, h.hit, L.ray, h.closest, rec, u, v);
+      else { u = 0.0f; v = 0.0f; }
+    };
+    cont = shade(mats, a.atlas, rec, uv, L.ray, L.att, L.rng, out);
     if (cont && ++L.b >= a.depth) { // bounce loop exhausted: black (render.hpp:91)
       out = mk(0.0f, 0.0f, 0.0f);
       cont = false;
@@ -234,9 +244,10 @@ __device__ unsigned long long g_stamps[8];
 // the whole bounce — traversal, hit record, material, texture constants — runs out of LDS without a global load.
 // COOP: the traversal can split a ray's list over idle lanes (hit_world_lds); costs ~10 VGPRs and ~7 % of the
 // ordinary-mode throughput, so the launcher picks it only where the makespan floor matters (launch_render).
-template <bool IMG, bool LDS, bool MLDS, bool COOP>
-__global__ __launch_bounds__(kBlock, COOP ? (IMG ? PT_MIN_WAVES_COOP_IMG : PT_MIN_WAVES_COOP) : (IMG ? PT_MIN_WAVES_IMG : PT_MIN_WAVES))
+template <int UV, bool LDS, bool MLDS, bool COOP>
+__global__ __launch_bounds__(kBlock, COOP ? (UV ? PT_MIN_WAVES_COOP_IMG : PT_MIN_WAVES_COOP) : (UV ? PT_MIN_WAVES_IMG : PT_MIN_WAVES))
 void render_kernel(KArgs a) {
+  constexpr bool IMG = UV == UV_TRACKED;
   extern __shared__ f4 smem[];
   if (LDS) {
     const int n = a.blob_f4 + (MLDS ? a.mats_f4 : 0); // a.mats == a.blob + a.blob_f4 (one device buffer)
@@ -280,8 +291,8 @@ void render_kernel(KArgs a) {
       asm volatile("" ::"v"(h.closest), "v"(h.hit));
       PT_STAMP(t2);
 #endif
-      if constexpr (MLDS) lane_shade(L, a, h, (lds_f4p)smem, (lds_f4p)smem + a.blob_f4);
-      else lane_shade(L, a, h, (lds_f4p)smem, a.mats);
+      if constexpr (MLDS) lane_shade<UV>(L, a, h, (lds_f4p)smem, (lds_f4p)smem + a.blob_f4);
+      else lane_shade<UV>(L, a, h, (lds_f4p)smem, a.mats);
 #ifdef PT_STAMPS
       asm volatile("" ::"v"(L.acc.x), "v"(L.ray.d.x));
       PT_STAMP(t3);
@@ -291,7 +302,7 @@ void render_kernel(KArgs a) {
       RayCtx c = make_ctx(L.ray, a.fast_ok != 0);
       const bool fast = wave_all_regular(c, L.live);
       hit_world<IMG>((cst_f4p)a.blob, a.n_runs, c, fast, L.rng, h);
-      lane_shade(L, a, h, a.blob, a.mats);
+      lane_shade<UV>(L, a, h, a.blob, a.mats);
     }
   }
 #ifdef PT_STAMPS
@@ -309,8 +320,9 @@ void render_kernel(KArgs a) {
 constexpr int kTileF4 = 2040;      // 32,640 B; a multiple of every record size (2, 3, 4 f4)
 constexpr int kSmallRunF4 = 48;    // runs this short are read through the scalar cache instead (no barriers)
 
-template <bool IMG>
+template <int UV>
 __global__ __launch_bounds__(kBlock) void render_kernel_stream(KArgs a) {
+  constexpr bool IMG = UV == UV_TRACKED;
   __shared__ f4 tile[kTileF4];
   Lane L;
   lane_reset(L);
@@ -344,7 +356,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel_stream(KArgs a) {
         __syncthreads();
       }
     }
-    lane_shade(L, a, h, a.blob, a.mats);
+    lane_shade<UV>(L, a, h, a.blob, a.mats);
   }
 }
 
@@ -438,9 +450,12 @@ __global__ void bounce_kernel(const f4* __restrict__ blob, int n_runs, const f4*
     O.t = closest;
     O.p[0] = rec.p.x; O.p[1] = rec.p.y; O.p[2] = rec.p.z;
     O.normal[0] = rec.normal.x; O.normal[1] = rec.normal.y; O.normal[2] = rec.normal.z;
-    O.u = hu; O.v = hv;
+    float pu = hu, pv = hv;
+    if (!IMG) winner_uv(blob, hit, ray, closest, rec, pu, pv);
+    O.u = pu; O.v = pv;
     V3 out = mk(0.0f, 0.0f, 0.0f);
-    if (shade(mats, atlas, rec, hu, hv, ray, att, rng, out)) {
+    auto uv = [&](float& u, float& v) { u = pu; v = pv; };
+    if (shade(mats, atlas, rec, uv, ray, att, rng, out)) {
       O.status = PT_BOUNCE_SCATTERED;
       O.color[0] = att.x; O.color[1] = att.y; O.color[2] = att.z;
       O.sc_origin[0] = ray.o.x; O.sc_origin[1] = ray.o.y; O.sc_origin[2] = ray.o.z;
@@ -542,6 +557,7 @@ struct PtScene {
   uint8_t* atlas = nullptr;
   int n_runs = 0, blob_f4 = 0, mats_f4 = 0;
   bool has_image = false;
+  bool track_uv = false; // an image texture sits on a triangle or a medium: the stale u,v such hits inherit must be tracked
   bool fast_ok = false;
   bool coop_ok = false;
   int coop_prefix = 0;
@@ -654,6 +670,7 @@ int pt_scene_create(const PtSceneDesc* desc, PtScene** out_scene) {
   s->has_image = flat.has_image;
   s->fast_ok = flat.fast_ok;
   s->coop_ok = flat.coop_ok;
+  s->track_uv = flat.has_image && !flat.coop_ok;
   s->coop_prefix = flat.coop_prefix;
   s->n_hittables = desc->n_hittables;
   for (int i = 0; i < desc->n_hittables; i++) {
@@ -772,15 +789,17 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
     PT_HIP(hipGetLastError());
     return PT_OK;
   };
+  auto launch_uv = [&](auto uv) -> int {
+    constexpr int UV = decltype(uv)::value;
+    if (!resident) return launch(render_kernel_stream<UV>);
+    if (!lds) return launch(render_kernel<UV, false, false, false>);
+    if (coop) return mlds ? launch(render_kernel<UV, true, true, true>) : launch(render_kernel<UV, true, false, true>);
+    return mlds ? launch(render_kernel<UV, true, true, false>) : launch(render_kernel<UV, true, false, false>);
+  };
   auto launch_variant = [&]() -> int {
-    if (!resident) return s->has_image ? launch(render_kernel_stream<true>) : launch(render_kernel_stream<false>);
-    if (!lds) return s->has_image ? launch(render_kernel<true, false, false, false>) : launch(render_kernel<false, false, false, false>);
-    if (s->has_image) {
-      if (coop) return mlds ? launch(render_kernel<true, true, true, true>) : launch(render_kernel<true, true, false, true>);
-      return mlds ? launch(render_kernel<true, true, true, false>) : launch(render_kernel<true, true, false, false>);
-    }
-    if (coop) return mlds ? launch(render_kernel<false, true, true, true>) : launch(render_kernel<false, true, false, true>);
-    return mlds ? launch(render_kernel<false, true, true, false>) : launch(render_kernel<false, true, false, false>);
+    if (s->track_uv) return launch_uv(std::integral_constant<int, UV_TRACKED>{});
+    if (s->has_image) return launch_uv(std::integral_constant<int, UV_WINNER>{});
+    return launch_uv(std::integral_constant<int, UV_NONE>{});
   };
   // Heaviest-first tile order from a probe pass (see lpt_order_kernel); pointless for short renders.
   const int probe_spp = std::min(4, p->samples / 16);
@@ -909,7 +928,7 @@ int pt_debug_bounce(const PtScene* scene, const PtBounceIn* in, PtBounceOut* out
   PT_HIP(dout.alloc(n));
   PT_HIP(hipMemcpy(din.p, in, (size_t)n * sizeof(PtBounceIn), hipMemcpyHostToDevice));
   dim3 block(64), grid((n + 63) / 64);
-  if (scene->has_image)
+  if (scene->track_uv)
     hipLaunchKernelGGL(bounce_kernel<true>, grid, block, 0, nullptr, scene->blob, scene->n_runs, scene->mats, scene->atlas, din.p, dout.p, n, scene->fast_ok ? 1 : 0);
   else
     hipLaunchKernelGGL(bounce_kernel<false>, grid, block, 0, nullptr, scene->blob, scene->n_runs, scene->mats, scene->atlas, din.p, dout.p, n, scene->fast_ok ? 1 : 0);
