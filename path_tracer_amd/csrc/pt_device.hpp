@@ -208,8 +208,8 @@ __device__ __forceinline__ bool sphere_t(P recs, int off, const RayCtx& c, float
   f4 R0 = recs[off]; // the only read on the miss path of a static sphere
   V3 center = xyz(R0);
   if (as_i(R0.w) < 0) { // moving (flatten stores -(radius^2) when time0 != time1): wave-uniform
-    f4 R1 = recs[off + 1];
-    center = center + time_frac(tf, r.tm, R1.z, R1.w) * xyz(recs[off + 2]);
+    const f4 R1 = recs[off + 1], R2 = recs[off + 2]; // one LDS round trip for both
+    center = center + time_frac(tf, r.tm, R1.z, R1.w) * xyz(R2);
   }
   V3 oc = r.o - center;
   float b = dot(oc, r.d);
