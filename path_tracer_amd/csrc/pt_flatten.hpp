@@ -134,6 +134,10 @@ inline int flatten(const PtSceneDesc* sc, Flat& out, std::string& err) {
     int nf = (h.kind == PT_HIT_BOX || h.kind == PT_HIT_CONSTANT_MEDIUM) ? 6 : 5;
     for (int k = 0; k < nf; k++)
       if (!(std::fabs(h.f[k]) <= 1.152921504606846976e18f)) out.fast_ok = false; // also false for NaN
+    // the straight-line test clamps with v_med3 (rect_fast): every interval must be lo <= hi (an inverted rect or box can
+    // never be hit in the reference either, but "median == value" would say otherwise)
+    if (nf == 5) { if (!(h.f[0] <= h.f[1] && h.f[2] <= h.f[3])) out.fast_ok = false; }
+    else if (!(h.f[0] <= h.f[3] && h.f[1] <= h.f[4] && h.f[2] <= h.f[5])) out.fast_ok = false;
   }
   out.coop_prefix = sc->n_hittables;
   for (int i = 0; i < sc->n_hittables; i++) {
