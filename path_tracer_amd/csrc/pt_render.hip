@@ -179,16 +179,14 @@ __device__ __forceinline__ void lane_store(Lane& L, const KArgs& a) {
   a.fb[idx] = acc.x; a.fb[idx + 1] = acc.y; a.fb[idx + 2] = acc.z;
 }
 
-// Start the next sample of a lane whose path ended (render.hpp:95-99), or finish the pixel.
+// Start the next sample of a lane whose path ended (render.hpp:95-99); the pixel itself is finished where its last
+// sample ends (lane_shade), so this — and the camera code — appears once in the loop.
 __device__ __forceinline__ void lane_regenerate(Lane& L, const KArgs& a) {
   if (L.live && L.need_new) {
-    if (L.s == a.samples) lane_store(L, a);
-    else {
-      L.ray = camera_ray(a.cam, L.x, L.y, a.width, a.height, L.rng);
-      L.att = mk(1.0f, 1.0f, 1.0f);
-      L.b = 0;
-      L.need_new = false;
-    }
+    L.ray = camera_ray(a.cam, L.x, L.y, a.width, a.height, L.rng);
+    L.att = mk(1.0f, 1.0f, 1.0f);
+    L.b = 0;
+    L.need_new = false;
   }
 }
 
@@ -219,17 +217,16 @@ __device__ __forceinline__ void lane_shade(Lane& L, const KArgs& a, const HitSta
   }
   if (!cont) {
     L.acc = L.acc + out; // final_color += get_color(r)  render.hpp:100
-    L.s++;
     L.need_new = true;
+    if (++L.s == a.samples) lane_store(L, a); // pixel done: the lane is idle from here on
   }
 }
 
 // One turn of the crank before tracing: finish/advance pixels, pull new ones, start new samples.
 // Returns false when this lane has nothing to trace this iteration.
 __device__ __forceinline__ void lane_prepare(Lane& L, const KArgs& a) {
-  lane_regenerate(L, a); // may finish the pixel (store) ...
-  lane_acquire(L, a);    // ... in which case a new one is pulled in the same iteration
-  lane_regenerate(L, a); // and its first camera ray generated
+  lane_acquire(L, a);    // idle lanes pull their next pixel ...
+  lane_regenerate(L, a); // ... and every lane whose path ended (or that is new) starts a sample
 }
 
 #ifdef PT_STAMPS
