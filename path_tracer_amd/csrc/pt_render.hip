@@ -39,6 +39,9 @@ namespace {
 #ifndef PT_MIN_WAVES_IMG
 #define PT_MIN_WAVES_IMG 5 /* image-texture kernels: 96 VGPRs; +10 % on the 496-hittable scene (A/B, one process) */
 #endif
+#ifndef PT_MIN_WAVES_CL
+#define PT_MIN_WAVES_CL 7 /* cold lane state in LDS: 68 VGPRs; measured 8 waves (64 VGPRs, no spill) -5 %, 7 waves +2 %, 6 waves -3 % */
+#endif
 #ifndef PT_MIN_WAVES_COOP
 #define PT_MIN_WAVES_COOP 5 /* cooperative kernels: 93 VGPRs, no scratch (7 waves: 72 VGPRs + 76 B/lane of spills in the loop) */
 #endif
@@ -51,6 +54,7 @@ constexpr int kBlock = 256;                 // 4 wavefronts = 4 tiles per workgr
 constexpr int kWavesPerBlock = kBlock / 64;
 constexpr size_t kMaxLdsBlob = 64 * 1024;   // blob staged in LDS when it fits
 constexpr size_t kMaxLdsWithMaterials = 16 * 1024; // stage the material table too when records + materials are this small
+constexpr size_t kMaxLdsColdScene = 10 * 1024;    // records + materials this small: the 8-wave kernel with LDS-resident cold lane state
 constexpr float kCoopMinTraversal = 2500.0f;        // estimated VALU instructions of one list scan (~110 spheres)
 constexpr unsigned kQueueRing = 256;        // launches in flight on one scene may not exceed this
 
@@ -80,14 +84,56 @@ struct KArgs {
 // reference's single RNG stream per pixel, render.hpp:130-133, forbids splitting a pixel), but lanes are not
 // tied to a tile: a lane that has finished its pixel pulls the next one from a per-launch queue, so every lane
 // of the chip stays busy until the frame's pixels run out.
-struct Lane {
+// The part of a lane's state that is touched only when a sample or a pixel ends — the radiance sum, the sample count,
+// which pixel it is — lives either in registers or, for small scenes, in per-thread LDS slots (~10 LDS instructions per
+// finished sample): 8 registers less pressure inside the traversal.  It would even fit 8 waves per SIMD (64 VGPRs, no
+// spill), but that is slower than 7 (-5 % vs +2 % on the headline scene; PT_MIN_WAVES_CL).
+typedef __attribute__((address_space(3))) float* lds_fp;
+constexpr int kColdSlots = 8; // dwords per thread
+template <bool IN_LDS> struct Cold;
+template <> struct Cold<false> {
+  V3 acc;
+  int s, pix, x, y;
+  unsigned int iters;
+  __device__ __forceinline__ void init(lds_fp) { acc = mk(0.0f, 0.0f, 0.0f); s = 0; pix = -1; x = 0; y = 0; iters = 0; }
+  __device__ __forceinline__ void begin(int pix_, int x_, int y_) { acc = mk(0.0f, 0.0f, 0.0f); s = 0; iters = 0; pix = pix_; x = x_; y = y_; }
+  __device__ __forceinline__ int add_sample(V3 o) { acc = acc + o; return ++s; }
+  __device__ __forceinline__ void count_ray() { iters++; }
+  __device__ __forceinline__ V3 get_acc() const { return acc; }
+  __device__ __forceinline__ int get_pix() const { return pix; }
+  __device__ __forceinline__ int get_x() const { return x; }
+  __device__ __forceinline__ int get_y() const { return y; }
+  __device__ __forceinline__ unsigned int get_iters() const { return iters; }
+};
+template <> struct Cold<true> {
+  lds_fp p; // this thread's slots: field k at p[k * kBlock]
+  __device__ __forceinline__ void init(lds_fp base) { p = base + threadIdx.x; }
+  __device__ __forceinline__ void begin(int pix_, int x_, int y_) {
+    p[0] = 0.0f; p[kBlock] = 0.0f; p[2 * kBlock] = 0.0f;
+    p[3 * kBlock] = __int_as_float(0); p[4 * kBlock] = __int_as_float(pix_); p[5 * kBlock] = __int_as_float(x_);
+    p[6 * kBlock] = __int_as_float(y_); p[7 * kBlock] = __int_as_float(0);
+  }
+  __device__ __forceinline__ int add_sample(V3 o) {
+    p[0] = p[0] + o.x; p[kBlock] = p[kBlock] + o.y; p[2 * kBlock] = p[2 * kBlock] + o.z;
+    const int s = __float_as_int(p[3 * kBlock]) + 1;
+    p[3 * kBlock] = __int_as_float(s);
+    return s;
+  }
+  __device__ __forceinline__ void count_ray() { p[7 * kBlock] = __int_as_float(__float_as_int(p[7 * kBlock]) + 1); }
+  __device__ __forceinline__ V3 get_acc() const { return mk(p[0], p[kBlock], p[2 * kBlock]); }
+  __device__ __forceinline__ int get_pix() const { return __float_as_int(p[4 * kBlock]); }
+  __device__ __forceinline__ int get_x() const { return __float_as_int(p[5 * kBlock]); }
+  __device__ __forceinline__ int get_y() const { return __float_as_int(p[6 * kBlock]); }
+  __device__ __forceinline__ unsigned int get_iters() const { return (unsigned int)__float_as_int(p[7 * kBlock]); }
+};
+
+template <bool CL>
+struct LaneT {
   uint32_t rng;
-  V3 acc, att;
+  V3 att;
   Ray ray;
-  int s, b;
-  unsigned int iters; // rays traced for the current pixel (cost probe)
-  int pix;       // local pixel index = local_tile * 64 + lane-in-tile; -1 = none
-  int x, y;
+  int b;
+  Cold<CL> cold; // radiance sum, sample count, pixel identity, ray count (cost probe)
   bool live;     // owns a pixel with samples left
   bool retired;  // the queue is empty for this lane
   bool need_new; // next iteration starts a new sample
@@ -96,12 +142,13 @@ struct Lane {
   unsigned int split_pixels; // (wave-uniform) 64 x the tiles handed out through the split queue
 };
 
-__device__ __forceinline__ void lane_reset(Lane& L) {
+template <typename Lane>
+__device__ __forceinline__ void lane_reset(Lane& L, lds_fp cold_base) {
   L.rng = 0;
-  L.acc = mk(0.0f, 0.0f, 0.0f);
   L.att = mk(1.0f, 1.0f, 1.0f);
   L.ray.o = mk(0.0f, 0.0f, 0.0f); L.ray.d = mk(0.0f, 0.0f, 1.0f); L.ray.tm = 0.0f;
-  L.s = 0; L.b = 0; L.iters = 0; L.pix = -1; L.x = 0; L.y = 0;
+  L.b = 0;
+  L.cold.init(cold_base);
   L.live = false; L.retired = false; L.need_new = true; L.split_done = false; L.wide = 0; L.split_pixels = 0;
 }
 
@@ -113,6 +160,7 @@ __device__ __forceinline__ void lane_reset(Lane& L) {
 // pixel and compute everything redundantly — same seed, same RNG draws, same shading — except the traversal, where each
 // tests 1/G of the list (hit_world_lds) — so a pixel's sequential chain gets shorter without any state ever moving
 // between lanes.  A wave leaves the phase when that queue is empty and its last wide pixel is done.
+template <typename Lane>
 __device__ __forceinline__ void lane_acquire(Lane& L, const KArgs& a) {
   const bool want = !L.live && !L.retired;
   const unsigned long long mask = __builtin_amdgcn_ballot_w64(want);
@@ -155,35 +203,34 @@ __device__ __forceinline__ void lane_acquire(Lane& L, const KArgs& a) {
   const int tx = (int)(g % a.tiles_x), ty = (int)(g / a.tiles_x);
   const int x = tx * PT_TILE + (in_tile & 7), y = ty * PT_TILE + (in_tile >> 3);
   if (g >= a.n_tiles || x >= a.width || y >= a.height) return; // padding pixel: stays 0, ask again next iteration
-  L.pix = l * PT_TILE_PIXELS + in_tile; L.x = x; L.y = y;
+  L.cold.begin(l * PT_TILE_PIXELS + in_tile, x, y);
   // render.hpp:130-132: seed = linear id of the pixel in the WHOLE frame, truncated to 32 bits
   L.rng = (uint32_t)((unsigned long long)y * (unsigned long long)a.width + (unsigned long long)x);
-  L.acc = mk(0.0f, 0.0f, 0.0f);
-  L.s = 0;
-  L.iters = 0;
   L.live = true;
   L.need_new = true;
 }
 
+template <typename Lane>
 __device__ __forceinline__ void lane_store(Lane& L, const KArgs& a) {
   L.live = false;
   if (L.wide && ((threadIdx.x & 63) & ((1 << L.wide) - 1))) return; // wide phase: one lane of the group writes
   if (a.cost) { // cost-probe pass: only the tile's ray count is kept
-    atomicAdd(&a.cost[L.pix >> 6], L.iters);
+    atomicAdd(&a.cost[L.cold.get_pix() >> 6], L.cold.get_iters());
     return;
   }
-  V3 acc = L.acc / (float)a.samples; // render.hpp:102
+  V3 acc = L.cold.get_acc() / (float)a.samples; // render.hpp:102
   long long idx;
-  if (a.shard_count == 1) idx = ((long long)L.y * a.width + L.x) * 3;
-  else idx = (long long)L.pix * 3;
+  if (a.shard_count == 1) idx = ((long long)L.cold.get_y() * a.width + L.cold.get_x()) * 3;
+  else idx = (long long)L.cold.get_pix() * 3;
   a.fb[idx] = acc.x; a.fb[idx + 1] = acc.y; a.fb[idx + 2] = acc.z;
 }
 
 // Start the next sample of a lane whose path ended (render.hpp:95-99); the pixel itself is finished where its last
 // sample ends (lane_shade), so this — and the camera code — appears once in the loop.
+template <typename Lane>
 __device__ __forceinline__ void lane_regenerate(Lane& L, const KArgs& a) {
   if (L.live && L.need_new) {
-    L.ray = camera_ray(a.cam, L.x, L.y, a.width, a.height, L.rng);
+    L.ray = camera_ray(a.cam, L.cold.get_x(), L.cold.get_y(), a.width, a.height, L.rng);
     L.att = mk(1.0f, 1.0f, 1.0f);
     L.b = 0;
     L.need_new = false;
@@ -191,10 +238,10 @@ __device__ __forceinline__ void lane_regenerate(Lane& L, const KArgs& a) {
 }
 
 // emitted / scatter / sky for the nearest hit (render.hpp:60-88) and the sample bookkeeping (:100).
-template <int UV, typename PB, typename PM>
+template <int UV, typename Lane, typename PB, typename PM>
 __device__ __forceinline__ void lane_shade(Lane& L, const KArgs& a, const HitState& h, PB recs, PM mats) {
   if (!L.live) return;
-  L.iters++;
+  if (a.cost) L.cold.count_ray(); // cost-probe pass (wave-uniform)
   V3 out = mk(0.0f, 0.0f, 0.0f);
   bool cont;
   if (h.hit < 0) {
@@ -216,14 +263,15 @@ __device__ __forceinline__ void lane_shade(Lane& L, const KArgs& a, const HitSta
     }
   }
   if (!cont) {
-    L.acc = L.acc + out; // final_color += get_color(r)  render.hpp:100
     L.need_new = true;
-    if (++L.s == a.samples) lane_store(L, a); // pixel done: the lane is idle from here on
+    // final_color += get_color(r)  render.hpp:100; pixel done: the lane is idle from here on
+    if (L.cold.add_sample(out) == a.samples) lane_store(L, a);
   }
 }
 
 // One turn of the crank before tracing: finish/advance pixels, pull new ones, start new samples.
 // Returns false when this lane has nothing to trace this iteration.
+template <typename Lane>
 __device__ __forceinline__ void lane_prepare(Lane& L, const KArgs& a) {
   lane_acquire(L, a);    // idle lanes pull their next pixel ...
   lane_regenerate(L, a); // ... and every lane whose path ended (or that is new) starts a sample
@@ -241,10 +289,13 @@ __device__ unsigned long long g_stamps[8];
 // the whole bounce — traversal, hit record, material, texture constants — runs out of LDS without a global load.
 // COOP: the traversal can split a ray's list over idle lanes (hit_world_lds); costs ~10 VGPRs and ~7 % of the
 // ordinary-mode throughput, so the launcher picks it only where the makespan floor matters (launch_render).
-template <int UV, bool LDS, bool MLDS, bool COOP>
-__global__ __launch_bounds__(kBlock, COOP ? (UV ? PT_MIN_WAVES_COOP_IMG : PT_MIN_WAVES_COOP) : (UV ? PT_MIN_WAVES_IMG : PT_MIN_WAVES))
+// CL: the cold part of the lane state lives in LDS (Cold<true>); small scenes only (8 KB per workgroup).
+template <int UV, bool LDS, bool MLDS, bool COOP, bool CL = false>
+__global__ __launch_bounds__(kBlock, CL ? PT_MIN_WAVES_CL : COOP ? (UV ? PT_MIN_WAVES_COOP_IMG : PT_MIN_WAVES_COOP) : (UV ? PT_MIN_WAVES_IMG : PT_MIN_WAVES))
 void render_kernel(KArgs a) {
   constexpr bool IMG = UV == UV_TRACKED;
+  typedef LaneT<CL> Lane;
+  __shared__ float cold_slots[CL ? kColdSlots * kBlock : 1];
   extern __shared__ f4 smem[];
   if (LDS) {
     const int n = a.blob_f4 + (MLDS ? a.mats_f4 : 0); // a.mats == a.blob + a.blob_f4 (one device buffer)
@@ -252,7 +303,7 @@ void render_kernel(KArgs a) {
     __syncthreads();
   }
   Lane L;
-  lane_reset(L);
+  lane_reset(L, (lds_fp)cold_slots);
   if (COOP && a.n_split) {
     L.split_pixels = (unsigned int)(*a.n_split) * PT_TILE_PIXELS;
     L.wide = a.wide_logG;
@@ -291,7 +342,7 @@ void render_kernel(KArgs a) {
       if constexpr (MLDS) lane_shade<UV>(L, a, h, (lds_f4p)smem, (lds_f4p)smem + a.blob_f4);
       else lane_shade<UV>(L, a, h, (lds_f4p)smem, a.mats);
 #ifdef PT_STAMPS
-      asm volatile("" ::"v"(L.acc.x), "v"(L.ray.d.x));
+      asm volatile("" ::"v"(L.att.x), "v"(L.ray.d.x));
       PT_STAMP(t3);
       s_prep += t1 - t0; s_trav += t2 - t1; s_shade += t3 - t2; s_iters++;
 #endif
@@ -314,15 +365,16 @@ void render_kernel(KArgs a) {
 // each run through one LDS tile — cooperative 16 B/lane copy, barrier, every wave tests its 64 rays against the
 // tile's records by LDS broadcast, barrier.  Arithmetic intensity is ~200 lane-ops per streamed byte
 // (256 rays x ~40 ops per 48-byte triangle), so the stream needs < 0.4 TB/s chip-wide: compute-bound by design.
-constexpr int kTileF4 = 2040;      // 32,640 B; a multiple of every record size (2, 3, 4 f4)
+constexpr int kTileF4 = 2016;      // 32,256 B; a multiple of every record size (2, 3, 4 f4); five workgroups per CU
 constexpr int kSmallRunF4 = 48;    // runs this short are read through the scalar cache instead (no barriers)
 
 template <int UV>
 __global__ __launch_bounds__(kBlock) void render_kernel_stream(KArgs a) {
   constexpr bool IMG = UV == UV_TRACKED;
   __shared__ f4 tile[kTileF4];
+  typedef LaneT<false> Lane;
   Lane L;
-  lane_reset(L);
+  lane_reset(L, (lds_fp) nullptr);
   if (a.depth <= 0) return;
   const cst_f4p cblob = (cst_f4p)a.blob;
   for (;;) {
@@ -791,6 +843,9 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
     if (!resident) return launch(render_kernel_stream<UV>);
     if (!lds) return launch(render_kernel<UV, false, false, false>);
     if (coop) return mlds ? launch(render_kernel<UV, true, true, true>) : launch(render_kernel<UV, true, false, true>);
+    if constexpr (UV == UV_NONE) { // small scene: cold lane state in LDS (7 workgroups x (scene + 8 KB) per CU)
+      if (mlds && shmem <= kMaxLdsColdScene && !std::getenv("PT_NO_COLD_LDS")) return launch(render_kernel<UV, true, true, false, true>);
+    }
     return mlds ? launch(render_kernel<UV, true, true, false>) : launch(render_kernel<UV, true, false, false>);
   };
   auto launch_variant = [&]() -> int {
