@@ -368,6 +368,48 @@ def test_cooperative_traversal_with_medium_suffix_and_image(orc):
         assert_bit_identical(a, orc.render(ps, c.c, w, h, 16), f"smoke {w}x{h} vs oracle")
 
 
+@pytest.mark.parametrize("name", ["cornell", "ties", "spheres"])
+def test_lds_resident_cold_lane_state_agrees(orc, name, monkeypatch):
+    """Small scenes without image textures keep each lane's radiance sum / sample count / pixel id in LDS slots; the
+    register-resident variant of the same kernel must give the same bits (and both the oracle's)."""
+    ps, cam = S.ALL[name]()
+    for (w, h, spp) in ((96, 54, 20), (13, 9, 3)):
+        c = scenes.make_camera(cam, w, h)
+        a = R.render_host(w, h, spp, ps, c)
+        monkeypatch.setenv("PT_NO_COLD_LDS", "1")
+        b = R.render_host(w, h, spp, ps, c)
+        monkeypatch.delenv("PT_NO_COLD_LDS")
+        assert_bit_identical(a, b, f"{name} {w}x{h}")
+        orc.set_math(True)
+        assert_bit_identical(a, orc.render(ps, c.c, w, h, spp), f"{name} {w}x{h} vs oracle")
+
+
+def test_image_texture_uv_modes(orc):
+    """u,v reach image textures three ways: derived from the final hit (scene whose image textures sit on spheres, rects or
+    boxes only), tracked through the scan ('mixed': an image texture on a triangle inherits stale values), or not at all."""
+    from path_tracer_amd.scene import (TextureAtlas, sphere, xy_rect, xz_rect, yz_rect, box, lambertian_material,
+                                       lightsource_material, image_texture, pack)
+    rng = np.random.default_rng(5)
+    atlas = TextureAtlas()
+    tex = image_texture.from_array(rng.integers(0, 256, size=(16, 32, 3), dtype=np.uint8), 3.0, atlas)
+    m_img = lambertian_material(tex)
+    grey = lambertian_material((0.6, 0.6, 0.6))
+    hs = [sphere((0, -100.5, -1), 100, grey), sphere((0, 0, -1), 0.5, m_img), xy_rect(-2, -0.8, -0.5, 1, -1.5, m_img),
+          box((0.8, -0.5, -1.6), (1.6, 0.4, -0.9), m_img), yz_rect(-0.5, 1, -2, 0, -2.2, lightsource_material(tex)),
+          xz_rect(-3, 3, -3, 1, 2.5, lightsource_material((2, 2, 2)))]
+    ps = pack(hs, atlas)
+    cam = dict(look_from=(0.3, 0.6, 1.5), look_at=(0, 0, -1), vup=(0, 1, 0), vfov=60.0, aperture=0.0, focus_dist=2.0,
+               time0=0.0, time1=1.0)
+    for (w, h, spp) in ((80, 48, 12), (136, 72, 16)):
+        c = scenes.make_camera(cam, w, h)
+        a = R.render_host(w, h, spp, ps, c)
+        orc.set_math(True)
+        assert_bit_identical(a, orc.render(ps, c.c, w, h, spp), f"image textures on sphere/rect/box {w}x{h}")
+        assert_bit_identical(a, R.render_host(w, h, spp, ps, c, flags=abi.PT_FLAG_FORCE_COOP), "cooperative kernel")
+        assert_bit_identical(a, R.render_host(w, h, spp, ps, c, flags=abi.PT_FLAG_FORCE_STREAM), "streaming kernel")
+        assert_bit_identical(a, R.render_host(w, h, spp, ps, c, flags=abi.PT_FLAG_NO_LDS), "scalar-cache kernel")
+
+
 @pytest.mark.parametrize("name", ["cornell", "mixed", "ties"])
 def test_plain_division_path_agrees(name):
     ps, cam = S.ALL[name]()
