@@ -123,13 +123,15 @@ def gather_frame(local, width: int, height: int, group=None, unshard_fn=None):
     import torch.distributed as dist
 
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    bufs = [torch.empty_like(local) for _ in range(world)] if rank == 0 else None
+    # one contiguous [world][tiles][64][3] receive buffer, the gather list = its slices (no re-pack before the un-interleave)
+    gathered = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device) if rank == 0 else None
+    bufs = list(gathered.unbind(0)) if rank == 0 else None
     dist.gather(local, bufs, dst=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
     if rank != 0:
         return None
     if world == 1:
-        return bufs[0]  # a one-shard render is already [H][W][3]
-    return (unshard_fn or unshard)(torch.stack(bufs), width, height, world)
+        return gathered[0]  # a one-shard render is already [H][W][3]
+    return (unshard_fn or unshard)(gathered, width, height, world)
 
 
 def render_distributed(width: int, height: int, samples: int, scene, cam: camera, depth: int = 50, *,
