@@ -25,3 +25,22 @@ for seed in range(first, last):
             bad += 1
             print(f"MISMATCH seed {seed} flags {f}: {int((~same).sum())} values", flush=True)
 print(f"seeds {first}..{last - 1}: {bad} mismatching renders of {(last - first) * len(FLAVOURS)}")
+# the wide phase (G lanes per pixel) needs >= 64 tiles and >= 16 spp for the probe pass that feeds it: larger frames,
+# every tile forced through it (tuning knobs), three group sizes
+import os
+bad = n = 0
+os.environ["PT_SPLIT_TILES"] = "-1"
+for seed in range(first, last):
+    ps, cam = random_scene(seed, allow_image_on_triangle=(seed % 4 == 0))
+    w, h, spp = 72 + seed % 9, 64 + seed % 5, 16 + seed % 3
+    c = scenes.make_camera(cam, w, h)
+    ref = orc.render(ps, c.c, w, h, spp)
+    for lg in (1, 3, 6):
+        os.environ["PT_WIDE_LOGG"] = str(lg)
+        got = R.render_host(w, h, spp, ps, c, flags=abi.PT_FLAG_FORCE_COOP)
+        same = (got.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(got) & np.isnan(ref))
+        n += 1
+        if not same.all():
+            bad += 1
+            print(f"MISMATCH (wide) seed {seed} G={1 << lg}: {int((~same).sum())} values", flush=True)
+print(f"wide phase, seeds {first}..{last - 1}: {bad} mismatching renders of {n}")
