@@ -201,9 +201,12 @@ __device__ __forceinline__ void mercator(V3 p, float& u, float& v) {
   v = (theta + PT_PI / 2.0f) / PT_PI;
 }
 
-// Roots of sphere.hpp:68-93; returns true and t if one lies in (mn, mx).
-template <typename P>
-__device__ __forceinline__ bool sphere_t(P recs, int off, const RayCtx& c, float mn, float mx, float& t, TimeFrac& tf) {
+// Roots of sphere.hpp:68-93: calls accept(t) if one lies in (mn, mx) and `valid`.  The acceptance runs INSIDE the
+// discriminant branch, which a wave enters only when some lane's line meets the sphere: returning a flag instead made the
+// compiler update the caller's state with three v_cndmask on every sphere of the list.
+template <typename P, typename Accept>
+__device__ __forceinline__ void sphere_roots(P recs, int off, const RayCtx& c, float mn, float mx, bool valid, TimeFrac& tf,
+                                             Accept accept) {
   const Ray& r = c.r;
   f4 R0 = recs[off]; // the only read on the miss path of a static sphere
   V3 center = xyz(R0);
@@ -218,11 +221,20 @@ __device__ __forceinline__ bool sphere_t(P recs, int off, const RayCtx& c, float
   if (discriminant > 0) {
     float sq = sqrt_rn(discriminant);
     float temp = (-b - sq) / c.a;
-    if (temp < mx && temp > mn) { t = temp; return true; }
-    temp = (-b + sq) / c.a;
-    if (temp < mx && temp > mn) { t = temp; return true; }
+    bool ok = temp < mx && temp > mn;
+    if (!ok) {
+      temp = (-b + sq) / c.a;
+      ok = temp < mx && temp > mn;
+    }
+    if (ok && valid) accept(temp);
   }
-  return false;
+}
+
+template <typename P>
+__device__ __forceinline__ bool sphere_t(P recs, int off, const RayCtx& c, float mn, float mx, float& t, TimeFrac& tf) {
+  bool hit = false;
+  sphere_roots(recs, off, c, mn, mx, true, tf, [&](float temp) { t = temp; hit = true; });
+  return hit;
 }
 
 // ---- rectangle.hpp:31-49,69-87,107-125 --------------------------------------------------------
@@ -427,8 +439,7 @@ __device__ __forceinline__ void hit_records(P recs, int kind, int n, int goff, c
   if (kind == DK_SPHERE) {
     TimeFrac tf = time_frac_none();
     for (int i = 0; i < n; ++i, off += SZ_SPHERE) {
-      float t;
-      if (sphere_t(recs, off, c, PT_TMIN, h.closest, t, tf)) {
+      sphere_roots(recs, off, c, PT_TMIN, h.closest, true, tf, [&](float t) {
         h.closest = t;
         h.hit = hit_pack(DK_SPHERE, 0, goff + off);
         if (IMG) {
@@ -439,7 +450,7 @@ __device__ __forceinline__ void hit_records(P recs, int kind, int n, int goff, c
           V3 nn = ff ? n_ : mk(0.0f, 0.0f, 0.0f) - n_;
           mercator(nn, h.u, h.v);
         }
-      }
+      });
     }
   } else if (kind == DK_RECT) {
     for (int i = 0; i < n; ++i, off += SZ_RECT) {
@@ -507,8 +518,7 @@ __device__ __forceinline__ void hit_records_strided(P recs, int kind, int cnt, i
     for (int i = 0; i < trips; ++i, k += G) {
       const bool valid = k < cnt;
       const int off = (valid ? k : 0) * SZ_SPHERE;
-      float t;
-      if (sphere_t(recs, off, c, PT_TMIN, h.closest, t, tf) && valid) {
+      sphere_roots(recs, off, c, PT_TMIN, h.closest, valid, tf, [&](float t) {
         h.closest = t;
         h.hit = hit_pack(DK_SPHERE, 0, goff + off);
         if (IMG) {
@@ -519,7 +529,7 @@ __device__ __forceinline__ void hit_records_strided(P recs, int kind, int cnt, i
           V3 nn = ff ? n_ : mk(0.0f, 0.0f, 0.0f) - n_;
           mercator(nn, h.u, h.v);
         }
-      }
+      });
     }
   } else if (kind == DK_RECT) {
     for (int i = 0; i < trips; ++i, k += G) {
