@@ -204,9 +204,10 @@ __device__ __forceinline__ void mercator(V3 p, float& u, float& v) {
 // Roots of sphere.hpp:68-93: calls accept(t) if one lies in (mn, mx) and `valid`.  The acceptance runs INSIDE the
 // discriminant branch, which a wave enters only when some lane's line meets the sphere: returning a flag instead made the
 // compiler update the caller's state with three v_cndmask on every sphere of the list.
-template <typename P, typename Accept>
-__device__ __forceinline__ void sphere_roots(P recs, int off, const RayCtx& c, float mn, float mx, bool valid, TimeFrac& tf,
-                                             Accept accept) {
+// first half: centre, b, discriminant — branch-free except the wave-uniform "moving" read
+struct SphereEval { float b, disc; };
+template <typename P>
+__device__ __forceinline__ SphereEval sphere_eval(P recs, int off, const RayCtx& c, TimeFrac& tf) {
   const Ray& r = c.r;
   f4 R0 = recs[off]; // the only read on the miss path of a static sphere
   V3 center = xyz(R0);
@@ -217,18 +218,27 @@ __device__ __forceinline__ void sphere_roots(P recs, int off, const RayCtx& c, f
   V3 oc = r.o - center;
   float b = dot(oc, r.d);
   float cc = dot(oc, oc) - __builtin_fabsf(R0.w);
-  float discriminant = b * b - c.a * cc;
-  // (a straight-line root block was tried: 2.5x slower — most spheres of a long list are missed by all 64 lines of a wave)
-  if (discriminant > 0) {
-    float sq = sqrt_rn(discriminant);
-    float temp = (-b - sq) / c.a;
+  return SphereEval{b, b * b - c.a * cc};
+}
+// second half: the roots.  (A straight-line version was tried: 2.5x slower — most spheres of a long list are missed by
+// all 64 lines of a wave, so the branch skips the block for the whole wave.)
+template <typename Accept>
+__device__ __forceinline__ void sphere_finish(SphereEval e, const RayCtx& c, float mn, float mx, bool valid, Accept accept) {
+  if (e.disc > 0) {
+    float sq = sqrt_rn(e.disc);
+    float temp = (-e.b - sq) / c.a;
     bool ok = temp < mx && temp > mn;
     if (!ok) {
-      temp = (-b + sq) / c.a;
+      temp = (-e.b + sq) / c.a;
       ok = temp < mx && temp > mn;
     }
     if (ok && valid) accept(temp);
   }
+}
+template <typename P, typename Accept>
+__device__ __forceinline__ void sphere_roots(P recs, int off, const RayCtx& c, float mn, float mx, bool valid, TimeFrac& tf,
+                                             Accept accept) {
+  sphere_finish(sphere_eval(recs, off, c, tf), c, mn, mx, valid, accept);
 }
 
 template <typename P>
@@ -439,20 +449,29 @@ __device__ __forceinline__ void hit_records(P recs, int kind, int n, int goff, c
   int off = 0;
   if (kind == DK_SPHERE) {
     TimeFrac tf = time_frac_none();
-    for (int i = 0; i < n; ++i, off += SZ_SPHERE) {
-      sphere_roots(recs, off, c, PT_TMIN, h.closest, true, tf, [&](float t) {
+    auto accept_at = [&](int o) {
+      return [&h, &r, recs, goff, o](float t) {
         h.closest = t;
-        h.hit = hit_pack(DK_SPHERE, 0, goff + off);
+        h.hit = hit_pack(DK_SPHERE, 0, goff + o);
         if (IMG) {
-          f4 R0 = recs[off], R1 = recs[off + 1], R2 = recs[off + 2];
+          f4 R0 = recs[o], R1 = recs[o + 1], R2 = recs[o + 2];
           V3 p = r.o + t * r.d;
           V3 n_ = (p - sphere_center(R0, R1, R2, r.tm)) / R1.x;
           bool ff = dot(r.d, n_) < 0;
           V3 nn = ff ? n_ : mk(0.0f, 0.0f, 0.0f) - n_;
           mercator(nn, h.u, h.v);
         }
-      });
+      };
+    };
+    int i = 0;
+    // two spheres per trip: both first records in flight together, two independent arithmetic chains, half the loop
+    // control; the roots are still taken in list order (the second sees the first's closest)
+    for (; i + 1 < n; i += 2, off += 2 * SZ_SPHERE) {
+      const SphereEval A = sphere_eval(recs, off, c, tf), B = sphere_eval(recs, off + SZ_SPHERE, c, tf);
+      sphere_finish(A, c, PT_TMIN, h.closest, true, accept_at(off));
+      sphere_finish(B, c, PT_TMIN, h.closest, true, accept_at(off + SZ_SPHERE));
     }
+    if (i < n) sphere_roots(recs, off, c, PT_TMIN, h.closest, true, tf, accept_at(off));
   } else if (kind == DK_RECT) {
     for (int i = 0; i < n; ++i, off += SZ_RECT) {
       f4 R0 = recs[off], R1 = recs[off + 1];
