@@ -379,7 +379,9 @@ __device__ __forceinline__ bool box_fast(f4 R0, f4 R1, const RayCtx& c, float mx
 
 // ---- triangle.hpp:58-100 (Moller-Trumbore) ---------------------------------------------------------
 // record: R0 = (v0.xyz, mat)  R1 = (edge1.xyz, hittable index)  R2 = (edge2.xyz, 0); edges = v1-v0, v2-v0
-__device__ __forceinline__ bool tri_t(f4 R0, f4 R1, f4 R2, const Ray& r, float mn, float mx, float& t_out) {
+// first half: a = e1.(d x e2), u = s.(d x e2) and the first two rejections of triangle.hpp:71-81 evaluated together
+struct TriEval { float a, u; bool pass; };
+__device__ __forceinline__ TriEval tri_eval(f4 R0, f4 R1, f4 R2, const Ray& r) {
   const float epsilon = 0.0000001f;
   V3 edge1 = xyz(R1), edge2 = xyz(R2);
   V3 h = cross(r.d, edge2);
@@ -389,16 +391,31 @@ __device__ __forceinline__ bool tri_t(f4 R0, f4 R1, f4 R2, const Ray& r, float m
   V3 s = r.o - xyz(R0);
   float u = dot(s, h);
   bool u_pos = u > 0.0f;
-  // the first two rejections of triangle.hpp:71-81 evaluated together (both are pure): one exec-mask branch
-  if ((a_abs < epsilon) | (u_pos != a_pos) | (__builtin_fabsf(u) > a_abs)) return false;
-  V3 q = cross(s, edge1);
-  float v = dot(r.d, q);
-  bool v_pos = v > 0.0f;
-  if ((v_pos != a_pos) | (__builtin_fabsf(u + v) > a_abs)) return false;
-  float length = dot(edge2, q) / a;
-  if (length < mn || length > mx) return false;
-  t_out = length;
-  return true;
+  return TriEval{a, u, !((a_abs < epsilon) | (u_pos != a_pos) | (__builtin_fabsf(u) > a_abs))};
+}
+// second half, under ONE exec-mask branch that a wave rarely enters; the acceptance runs inside it (returning a flag made
+// the compiler update the caller's state with selects on every triangle of the list)
+template <typename Accept>
+__device__ __forceinline__ void tri_finish(f4 R0, f4 R1, f4 R2, const Ray& r, TriEval e, float mn, float mx, bool valid,
+                                           Accept accept) {
+  if (e.pass) {
+    const float a_abs = __builtin_fabsf(e.a);
+    const bool a_pos = e.a > 0.0f;
+    V3 edge1 = xyz(R1), edge2 = xyz(R2);
+    V3 s = r.o - xyz(R0);
+    V3 q = cross(s, edge1);
+    float v = dot(r.d, q);
+    bool v_pos = v > 0.0f;
+    if (!((v_pos != a_pos) | (__builtin_fabsf(e.u + v) > a_abs))) {
+      float length = dot(edge2, q) / e.a;
+      if (!(length < mn || length > mx) && valid) accept(length);
+    }
+  }
+}
+__device__ __forceinline__ bool tri_t(f4 R0, f4 R1, f4 R2, const Ray& r, float mn, float mx, float& t_out) {
+  bool hit = false;
+  tri_finish(R0, R1, R2, r, tri_eval(R0, R1, R2, r), mn, mx, true, [&](float t) { t_out = t; hit = true; });
+  return hit;
 }
 
 // ---- constant_medium.hpp:28-78 -------------------------------------------------------------------------
@@ -484,12 +501,20 @@ __device__ __forceinline__ void hit_records(P recs, int kind, int n, int goff, c
       }
     }
   } else if (kind == DK_TRI) {
-    for (int i = 0; i < n; ++i, off += SZ_TRI) {
-      float t;
-      if (tri_t(recs[off], recs[off + 1], recs[off + 2], r, PT_TMIN, h.closest, t)) {
-        h.closest = t;
-        h.hit = hit_pack(DK_TRI, 0, goff + off);
-      }
+    auto accept_at = [&](int o) { return [&h, goff, o](float t) { h.closest = t; h.hit = hit_pack(DK_TRI, 0, goff + o); }; };
+    int i = 0;
+    // two triangles per trip: six record reads in flight together, two independent arithmetic chains, half the loop
+    // control; the second halves still run in list order (the second sees the first's closest)
+    for (; i + 1 < n; i += 2, off += 2 * SZ_TRI) {
+      const f4 A0 = recs[off], A1 = recs[off + 1], A2 = recs[off + 2];
+      const f4 B0 = recs[off + 3], B1 = recs[off + 4], B2 = recs[off + 5];
+      const TriEval ea = tri_eval(A0, A1, A2, r), eb = tri_eval(B0, B1, B2, r);
+      tri_finish(A0, A1, A2, r, ea, PT_TMIN, h.closest, true, accept_at(off));
+      tri_finish(B0, B1, B2, r, eb, PT_TMIN, h.closest, true, accept_at(off + SZ_TRI));
+    }
+    if (i < n) {
+      const f4 A0 = recs[off], A1 = recs[off + 1], A2 = recs[off + 2];
+      tri_finish(A0, A1, A2, r, tri_eval(A0, A1, A2, r), PT_TMIN, h.closest, true, accept_at(off));
     }
   } else if (kind == DK_BOX) {
     if (fast) {
@@ -568,11 +593,9 @@ __device__ __forceinline__ void hit_records_strided(P recs, int kind, int cnt, i
     for (int i = 0; i < trips; ++i, k += G) {
       const bool valid = k < cnt;
       const int off = (valid ? k : 0) * SZ_TRI;
-      float t;
-      if (tri_t(recs[off], recs[off + 1], recs[off + 2], r, PT_TMIN, h.closest, t) && valid) {
-        h.closest = t;
-        h.hit = hit_pack(DK_TRI, 0, goff + off);
-      }
+      const f4 A0 = recs[off], A1 = recs[off + 1], A2 = recs[off + 2];
+      tri_finish(A0, A1, A2, r, tri_eval(A0, A1, A2, r), PT_TMIN, h.closest, valid,
+                 [&](float t) { h.closest = t; h.hit = hit_pack(DK_TRI, 0, goff + off); });
     }
   } else { // DK_BOX
     for (int i = 0; i < trips; ++i, k += G) {
