@@ -505,12 +505,17 @@ __device__ __forceinline__ void hit_records(P recs, int kind, int n, int goff, c
     int i = 0;
     // two triangles per trip: six record reads in flight together, two independent arithmetic chains, half the loop
     // control; the second halves still run in list order (the second sees the first's closest)
+    auto eval_at = [&](int o) { return tri_eval(recs[o], recs[o + 1], recs[o + 2], r); };
+    auto finish_at = [&](int o, TriEval e) { // re-reads the records: only inside the rare branch
+      if (e.pass) tri_finish(recs[o], recs[o + 1], recs[o + 2], r, e, PT_TMIN, h.closest, true, accept_at(o));
+    };
+    for (; i + 3 < n; i += 4, off += 4 * SZ_TRI) {
+      const TriEval ea = eval_at(off), eb = eval_at(off + SZ_TRI), ec = eval_at(off + 2 * SZ_TRI), ed = eval_at(off + 3 * SZ_TRI);
+      finish_at(off, ea); finish_at(off + SZ_TRI, eb); finish_at(off + 2 * SZ_TRI, ec); finish_at(off + 3 * SZ_TRI, ed);
+    }
     for (; i + 1 < n; i += 2, off += 2 * SZ_TRI) {
-      const f4 A0 = recs[off], A1 = recs[off + 1], A2 = recs[off + 2];
-      const f4 B0 = recs[off + 3], B1 = recs[off + 4], B2 = recs[off + 5];
-      const TriEval ea = tri_eval(A0, A1, A2, r), eb = tri_eval(B0, B1, B2, r);
-      tri_finish(A0, A1, A2, r, ea, PT_TMIN, h.closest, true, accept_at(off));
-      tri_finish(B0, B1, B2, r, eb, PT_TMIN, h.closest, true, accept_at(off + SZ_TRI));
+      const TriEval ea = eval_at(off), eb = eval_at(off + SZ_TRI);
+      finish_at(off, ea); finish_at(off + SZ_TRI, eb);
     }
     if (i < n) {
       const f4 A0 = recs[off], A1 = recs[off + 1], A2 = recs[off + 2];
