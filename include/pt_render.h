@@ -170,9 +170,10 @@ typedef struct PtRenderParams {
   int32_t reserved;
 } PtRenderParams;
 
-/* Opaque device-resident flattened scene.  Renders of one PtScene may be queued back to back on any streams
- * (each launch gets its own work-queue slot), but must be ISSUED by one host thread at a time: the scene owns a
- * small grow-only scheduling workspace.                                                                      */
+/* Opaque device-resident flattened scene.  Renders of one PtScene may be queued back to back (each launch gets its
+ * own work-queue slot) but must be ORDERED with respect to each other — same stream, or synchronised by the caller —
+ * and issued by one host thread at a time: the scene owns a small grow-only scheduling workspace (per-tile costs,
+ * tile order) that consecutive renders reuse.  For concurrent renders create one PtScene per stream.            */
 typedef struct PtScene PtScene;
 
 /* ---- error codes (the reference returns void and asserts; we return codes) -- */
