@@ -81,6 +81,12 @@ def pmc_traffic(scene: str, w: int, h: int, spp: int):
     return best
 
 
+def weak_frame(width: int, height: int, n_gpus: int):
+    """Frame of an N-GPU weak-scaling step: N x the pixels of the 1-GPU frame, aspect kept (every rank gets one 1-GPU
+    frame's worth of 8x8 tiles).  1920x1080 -> 2715x1527, 3840x2160, 5431x3055 for N = 2, 4, 8."""
+    return int(round(width * n_gpus ** 0.5)), int(round(height * n_gpus ** 0.5))
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -128,8 +134,8 @@ def main() -> None:
         ctypes.CDLL(None).fflush(None)
 
     W, H, SPP, DEPTH = args.width, args.height, args.spp, args.depth
-    if world > 1 and args.scaling == "weak":  # N x the pixels, aspect kept (every rank gets a 1-GPU frame's worth of tiles)
-        W, H = int(round(W * world ** 0.5)), int(round(H * world ** 0.5))
+    if world > 1 and args.scaling == "weak":
+        W, H = weak_frame(W, H, world)
     kw = {"n_triangles": 100_000} if args.scene == "triangles" else {}
     packed, cam_args = scenes.build(args.scene, **kw)
     cam = scenes.make_camera(cam_args, W, H)

@@ -39,3 +39,16 @@ def test_peak_and_defaults():
         d = json.loads(f.read_text())
         assert d["unit"] == "Msamples/s" and "roofline" in d and "cpu_baseline" in d
         assert d["roofline"]["bound"] == "valu" and 0 < d["roofline"]["frac"] < 1
+
+
+def test_weak_scaling_frames_keep_pixels_per_gpu_and_aspect():
+    """bench.py --gpus N (weak scaling): N x the pixels of the 1080p frame, same aspect; N = 4 is exactly 4K."""
+    import bench
+    assert bench.weak_frame(1920, 1080, 1) == (1920, 1080)
+    assert bench.weak_frame(1920, 1080, 4) == (3840, 2160)
+    for n in (2, 3, 8):
+        w, h = bench.weak_frame(1920, 1080, n)
+        assert abs(w * h / (1920 * 1080 * n) - 1.0) < 2e-3
+        assert abs(w / h - 1920 / 1080) < 2e-3
+        tiles = ((w + 7) // 8) * ((h + 7) // 8)
+        assert abs(tiles / n / 32400 - 1.0) < 0.01  # one 1-GPU frame's worth of tiles per rank
