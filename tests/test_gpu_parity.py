@@ -505,6 +505,22 @@ def test_full_size_smoke_1080p_sampled_pixels(torch_gpu, orc):
     print(f"\n[smoke 1080p {spp}spp] kernel {ms:.1f} ms = {w * h * spp / ms / 1e3:.1f} Msamples/s")
 
 
+def test_full_size_triangle_mesh_1080p_sampled_pixels(torch_gpu, orc):
+    """BASELINE config 5 at full geometry: 100 000 triangles (4.8 MB of records, 149 LDS tiles per ray, four triangles per
+    trip of the scan) at 1920x1080; 17 spp so that the cost-probe pass and the heaviest-first order run too.  96 sampled
+    pixels are re-rendered by the oracle at full spp."""
+    ps, cam = scenes.build("triangles", n_triangles=100_000)
+    w, h, spp = 1920, 1080, 17
+    c = scenes.make_camera(cam, w, h)
+    fb, ms = R.render(w, h, spp, R.DeviceScene(ps), c, timed=True)
+    fbn = fb.cpu().numpy()
+    rng = np.random.default_rng(99)
+    xy = np.stack([rng.integers(0, w, 96), rng.integers(0, h, 96)], axis=1).astype(np.int32)
+    orc.set_math(True)
+    assert_bit_identical(fbn[xy[:, 1], xy[:, 0]], orc.render_pixels(ps, c.c, w, h, spp, xy), "100k triangles 1080p sampled pixels")
+    print(f"\n[triangles 1080p {spp}spp] kernel {ms:.1f} ms = {w * h * spp / ms / 1e3:.2f} Msamples/s")
+
+
 def test_full_size_1080p_full_frame_low_spp(orc):
     """Every pixel of a 1920x1080 frame (2 spp): seeds up to 2,073,599, edge tiles, all tile rows."""
     ps, cam = scenes.build("cornell")
