@@ -124,6 +124,25 @@ def test_depth_zero_and_one(orc):
     assert np.isfinite(one).all()
 
 
+def test_per_pixel_ray_counts(orc):
+    """orc_render_pixels_rays: the colours are those of the frame, the per-pixel ray counts (the sequential chain lengths
+    behind DESIGN.md section 6) add up to the frame's ray counter, and a background-only pixel traces one ray per sample."""
+    ps, cam = S.cornell_scene()
+    w, h, spp = 24, 16, 5
+    c = scenes.make_camera(cam, w, h)
+    orc.set_math(True)
+    fb, ctr = orc.render(ps, c.c, w, h, spp, counters=True)
+    xy = np.array([[x, y] for y in range(h) for x in range(w)], dtype=np.int32)
+    col, rays = orc.render_pixels_rays(ps, c.c, w, h, spp, xy)
+    assert_bit_identical(col.reshape(h, w, 3), fb)
+    assert int(rays.sum()) == ctr.as_dict()["rays"]
+    assert rays.min() >= spp
+    pe, came = S.empty_scene()
+    ce = scenes.make_camera(came, 8, 8)
+    _, r0 = orc.render_pixels_rays(pe, ce.c, 8, 8, 7, np.array([[3, 4]], dtype=np.int32))
+    assert int(r0[0]) == 7
+
+
 def test_pixel_zero_rng_stuck(orc):
     """Pixel (0,0) has state 0 forever: u=v=0 jitter, lens sample x=-1,y=0 (render.hpp:131)."""
     ps, cam = S.empty_scene()
