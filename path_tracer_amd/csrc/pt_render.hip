@@ -72,11 +72,10 @@ struct KArgs {
   unsigned int* queue; // per-launch dequeue counter, zeroed on the stream before the kernel
   unsigned int* cost;  // non-NULL: cost-probe pass, per local tile ray counts (nothing is written to fb)
   const int* order;    // non-NULL: queue position -> local tile, heaviest first
-  const int* n_split;  // non-NULL (COOP kernels): how many leading tiles of `order` go through the wide phase
+  const int* n_split;  // non-NULL (COOP kernels): [0] how many leading tiles of `order` go through the wide phase, [1] log2 G
   int tile_granular;   // PT_FLAG_TILE_GRANULAR
   int n_hittables;
   int coop_prefix;     // >= 0: cooperative traversal allowed, list splittable up to this hittable; -1: disabled
-  int wide_logG;       // log2 of the lanes that share one pixel while a wave serves the split queue (COOP kernels)
   int fast_ok; // every rect/box coordinate finite and <= 2^60: rays may use the shared-reciprocal division
 };
 
@@ -305,8 +304,8 @@ void render_kernel(KArgs a) {
   Lane L;
   lane_reset(L, (lds_fp)cold_slots);
   if (COOP && a.n_split) {
-    L.split_pixels = (unsigned int)(*a.n_split) * PT_TILE_PIXELS;
-    L.wide = a.wide_logG;
+    L.split_pixels = (unsigned int)a.n_split[0] * PT_TILE_PIXELS;
+    L.wide = a.n_split[1];
   }
   if (a.depth <= 0) return; // depth 0: every sample returns black (render.hpp:58,91); the frame is pre-zeroed
 #ifdef PT_STAMPS
@@ -418,7 +417,8 @@ __global__ __launch_bounds__(kBlock) void render_kernel_stream(KArgs a) {
 // WHEN a pixel is rendered, never its value, so the (atomic, run-to-run varying) order inside a class is harmless.
 constexpr int kLptClasses = 32;
 __global__ __launch_bounds__(1024) void lpt_order_kernel(const unsigned int* __restrict__ cost, int n, int* __restrict__ order,
-                                                        int n_waves, float split_eff, float split_speedup, int* __restrict__ n_split) {
+                                                        int n_waves, float trav_cost, float fixed_cost, int forced_logG,
+                                                        int* __restrict__ n_split) {
   __shared__ float s_cost_sum[kLptClasses];
   __shared__ unsigned int s_max;
   __shared__ float s_sum;
@@ -445,23 +445,37 @@ __global__ __launch_bounds__(1024) void lpt_order_kernel(const unsigned int* __r
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    unsigned int acc = 0;
-    // How many of the heaviest tiles to render G lanes per pixel (lane_acquire).  A tile rendered whole is one chain of
-    // length ~ its cost; wide, its pixels are chains `split_speedup` times shorter but cost 1/`split_eff` as much
-    // lane time (camera and shading are computed redundantly by the G lanes, the merge is extra).  With the tiles handed out
-    // heaviest first the makespan is about
-    //     max( (cost kept whole + cost split / split_eff) / n_waves , heaviest tile kept whole , heaviest tile / split_speedup )
-    // evaluated for every prefix of classes; the best prefix wins (often the empty one).
-    float best = 3.4e38f, split_cost = 0.0f;
-    int split = 0;
+    // How many of the heaviest tiles to render G lanes per pixel (lane_acquire), and G itself.  A tile rendered whole is one
+    // chain of length ~ its cost; wide, its pixels are chains `speedup` times shorter but cost 1/`eff` as much lane time
+    // (camera and shading are computed redundantly by the G lanes, the merge is extra).  Per iteration: traversal T
+    // (splittable) + S(G) (not; grows with the merge stages):  speedup = (T + S1) / (T/G + S),  eff = (T + S1) / (T + G*S).
+    // With the tiles handed out heaviest first the makespan is about
+    //     max( (cost kept whole + cost wide / eff) / n_waves , heaviest tile kept whole , heaviest tile / speedup )
+    // evaluated for every group size and every prefix of classes; the best pair wins (often the empty prefix).  Small
+    // frames and the shards of a multi-GPU job are chain-bound and get large groups; big frames get small ones or none.
+    float best = 3.4e38f;
+    int split = 0, best_logG = forced_logG > 0 ? forced_logG : 3;
     const float nw = (float)max(n_waves, 1);
-    for (int k = 0; k <= kLptClasses; k++) { // k = number of leading classes that are split
-      const float next_whole = k < kLptClasses ? mx * exp2f(-0.25f * (float)k) : 0.0f; // upper bound of class k
-      const float balanced = ((s_sum - split_cost) + split_cost / split_eff) / nw;
-      const float span = fmaxf(balanced, fmaxf(next_whole, k > 0 ? mx / split_speedup : 0.0f));
-      if (span < best * 0.98f) { best = span; split = (int)acc; } // needs a clear win to split more
-      if (k < kLptClasses) { s_cursor[k] = acc; acc += s_count[k]; split_cost += s_cost_sum[k]; }
+    unsigned int acc = 0;
+    for (int k = 0; k < kLptClasses; k++) { s_cursor[k] = acc; acc += s_count[k]; }
+    for (int logG = (forced_logG > 0 ? forced_logG : 1); logG <= (forced_logG > 0 ? forced_logG : 6); logG++) {
+      // Fitted on the 496-hittable scene with every tile wide (tools/wide_chain.py): lane time grows as 1 + 0.037 (G - 1)
+      // (unsplit ~420 of ~11 200 instructions per iteration), while a pixel's chain shortens only as if ~2 400 were unsplit
+      // (latency of run headers, merge stages and shading counts there, not their instruction count).
+      const float G = (float)(1 << logG), s_chain = 2400.0f;
+      const float eff = (trav_cost + fixed_cost) / (trav_cost + G * fixed_cost);
+      const float speedup = (trav_cost + s_chain) / (trav_cost / G + s_chain);
+      float split_cost = 0.0f;
+      unsigned int tiles = 0;
+      for (int k = 0; k <= kLptClasses; k++) { // k = number of leading classes that are wide
+        const float next_whole = k < kLptClasses ? mx * exp2f(-0.25f * (float)k) : 0.0f; // upper bound of class k
+        const float balanced = ((s_sum - split_cost) + split_cost / eff) / nw;
+        const float span = fmaxf(balanced, fmaxf(next_whole, k > 0 ? mx / speedup : 0.0f));
+        if (span < best * 0.98f) { best = span; split = (int)tiles; best_logG = logG; } // needs a clear win to change
+        if (k < kLptClasses) { tiles += s_count[k]; split_cost += s_cost_sum[k]; }
+      }
     }
+    if (n_split) n_split[1] = best_logG;
     if (n_split) *n_split = split;
   }
   __syncthreads();
@@ -743,7 +757,7 @@ int pt_scene_create(const PtSceneDesc* desc, PtScene** out_scene) {
   PT_TRY(hipMalloc((void**)&s->atlas, std::max<size_t>(atlas_bytes, 16)));
   if (atlas_bytes) PT_TRY(hipMemcpy(s->atlas, desc->atlas, atlas_bytes, hipMemcpyHostToDevice));
   PT_TRY(hipMalloc((void**)&s->queues, 2 * kQueueRing * sizeof(unsigned int)));
-  PT_TRY(hipMalloc((void**)&s->ws_nsplit, sizeof(int)));
+  PT_TRY(hipMalloc((void**)&s->ws_nsplit, 2 * sizeof(int))); // [0] tiles through the wide phase, [1] log2 of its group size
 #undef PT_TRY
   *out_scene = s;
   return PT_OK;
@@ -813,7 +827,6 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
   const bool mlds = lds && blob_bytes + (size_t)s->mats_f4 * 16 <= kMaxLdsWithMaterials;
   const size_t shmem = lds ? blob_bytes + (mlds ? (size_t)s->mats_f4 * 16 : 0) : 0;
   a.n_split = nullptr;
-  a.wide_logG = 0;
   int n_waves_resident = 1;
   // Cooperative kernels (a ray's list split over idle lanes; the heaviest tiles rendered G lanes per pixel) cost ~15 % of
   // the ordinary-mode throughput, and the part of an iteration that cannot be split (camera, shading, ray context:
@@ -871,12 +884,11 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
     int rc = launch_variant();
     if (rc) return rc;
     // rough per-iteration instruction counts: traversal (splittable) vs shading + camera + cooperative overhead (not)
-    int wide_logG = 3;
-    if (const char* e = std::getenv("PT_WIDE_LOGG")) wide_logG = std::min(6, std::max(1, std::atoi(e))); // tuning knob
-    main_args.wide_logG = wide_logG;
-    const float T = std::max(1.0f, s->traversal_cost), S = 500.0f, G = (float)(1 << wide_logG); // S: shading + camera + merge
+    int forced_logG = 0; // 0: the model picks the group size of the wide phase
+    if (const char* e = std::getenv("PT_WIDE_LOGG")) forced_logG = std::min(6, std::max(1, std::atoi(e))); // tuning knob
+    // rough per-iteration instruction counts: traversal (splittable) vs shading + camera (not)
     hipLaunchKernelGGL(lpt_order_kernel, dim3(1), dim3(1024), 0, st, s->ws_cost, local_tiles, s->ws_order, n_waves_resident,
-                       (T + S) / (T + G * S), (T + S) / (T / G + S), coop ? s->ws_nsplit : nullptr);
+                       std::max(1.0f, s->traversal_cost), 420.0f, forced_logG, coop ? s->ws_nsplit : nullptr);
     PT_HIP(hipGetLastError());
     if (const char* e = std::getenv("PT_SPLIT_TILES")) { // tuning knob: fixed number of split tiles (< 0: all)
       if (coop) {
