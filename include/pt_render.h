@@ -285,6 +285,11 @@ int pt_debug_camera_rays(const PtCamera* cam, int32_t width, int32_t height,
 int pt_debug_flatten(const PtSceneDesc* desc, float* blob_out, int64_t blob_cap_f4, int32_t* n_blob_f4,
                      int32_t* n_runs, float* mats_out, int64_t mats_cap_f4, int32_t* flags_out);
 
+/* What the scheduler decided for the LAST render of this scene (blocks until that render is done): out[0] = tiles sent
+ * through the wide phase, out[1] = lanes per pixel there (0 when the render had no cost-probe pass or used a kernel
+ * without that phase).  For tuning the makespan model (csrc/pt_render.hip: lpt_order_kernel) and for tests.            */
+int pt_debug_schedule(const PtScene* scene, int32_t out[2]);
+
 /* Device math used by the kernel, elementwise over host arrays.
  * op: 0 sin 1 cos 2 log 3 pow5 4 atan2(a,b) 5 asin 6 fmod(a,1) 7 sqrt 8 div(a,b)
  *     9 the shared-reciprocal exact quotient a/b used for rect/box sides (pt_device.hpp: div_exact) */

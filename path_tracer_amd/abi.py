@@ -118,6 +118,7 @@ SIGNATURES = {
     "pt_debug_bounce": (C.c_int, [_SCENE_P, C.POINTER(PtBounceIn), C.POINTER(PtBounceOut), C.c_int32]),
     "pt_debug_camera_rays": (C.c_int, [C.POINTER(PtCamera), C.c_int32, C.c_int32, C.POINTER(C.c_int32),
                                        C.POINTER(C.c_uint32), C.POINTER(PtCameraRay), C.c_int32]),
+    "pt_debug_schedule": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "pt_debug_flatten": (C.c_int, [C.POINTER(PtSceneDesc), _FP, C.c_int64, C.POINTER(C.c_int32),
                                    C.POINTER(C.c_int32), _FP, C.c_int64, C.POINTER(C.c_int32)]),
     "pt_debug_math": (C.c_int, [C.c_int32, _FP, _FP, _FP, C.c_int64]),

@@ -625,6 +625,7 @@ struct PtScene {
   bool coop_ok = false;
   int coop_prefix = 0;
   int n_hittables = 0;
+  mutable bool last_had_wide_phase = false;
   mutable int nsplit_override = 0; // PT_SPLIT_TILES tuning knob (host copy must outlive the async upload)
   float traversal_cost = 0.0f; // estimated VALU instructions of one ray's scan of the list
   size_t blob_bytes = 0;
@@ -901,6 +902,7 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
     a.order = s->ws_order;
     a.n_split = (coop && !(p->flags & PT_FLAG_NO_SPLIT)) ? s->ws_nsplit : nullptr;
   }
+  s->last_had_wide_phase = a.n_split != nullptr;
   int rc = launch_variant();
   if (rc) return rc;
   PT_HIP(hipGetLastError());
@@ -998,6 +1000,17 @@ int pt_debug_bounce(const PtScene* scene, const PtBounceIn* in, PtBounceOut* out
     hipLaunchKernelGGL(bounce_kernel<false>, grid, block, 0, nullptr, scene->blob, scene->n_runs, scene->mats, scene->atlas, din.p, dout.p, n, scene->fast_ok ? 1 : 0);
   PT_HIP(hipGetLastError());
   PT_HIP(hipMemcpy(out, dout.p, (size_t)n * sizeof(PtBounceOut), hipMemcpyDeviceToHost));
+  return PT_OK;
+}
+
+int pt_debug_schedule(const PtScene* scene, int32_t out[2]) {
+  if (!scene || !out) return fail(PT_ERR_INVALID_ARG, "pt_debug_schedule: NULL argument");
+  out[0] = out[1] = 0;
+  PT_HIP(hipDeviceSynchronize());
+  if (!scene->last_had_wide_phase) return PT_OK;
+  int v[2] = {0, 0};
+  PT_HIP(hipMemcpy(v, scene->ws_nsplit, sizeof v, hipMemcpyDeviceToHost));
+  out[0] = v[0]; out[1] = v[0] > 0 ? (1 << v[1]) : 0;
   return PT_OK;
 }
 

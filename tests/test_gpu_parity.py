@@ -343,6 +343,23 @@ def test_wide_phase_every_group_size(orc, name, monkeypatch):
     assert_bit_identical(R.render_host(w, h, 16, ps, c, flags=abi.PT_FLAG_FORCE_COOP), ref, f"{name} 40 tiles wide")
 
 
+def test_schedule_probe_reports_the_wide_phase(lib, monkeypatch):
+    """pt_debug_schedule: what the makespan model decided for the last render (tiles through the wide phase, lanes per pixel)."""
+    ps, cam = scenes.build("smoke")
+    ds = R.DeviceScene(ps)
+    c = scenes.make_camera(cam, 136, 72)
+    out = (C.c_int32 * 2)()
+    R.render(136, 72, 16, ds, c, flags=abi.PT_FLAG_NO_COOP)
+    assert lib.pt_debug_schedule(ds.handle, out) == 0 and (out[0], out[1]) == (0, 0)  # ordinary kernel: no such phase
+    monkeypatch.setenv("PT_SPLIT_TILES", "40")
+    monkeypatch.setenv("PT_WIDE_LOGG", "4")
+    R.render(136, 72, 16, ds, c)
+    assert lib.pt_debug_schedule(ds.handle, out) == 0 and (out[0], out[1]) == (40, 16)
+    monkeypatch.delenv("PT_SPLIT_TILES"); monkeypatch.delenv("PT_WIDE_LOGG")
+    R.render(136, 72, 16, ds, c)
+    assert lib.pt_debug_schedule(ds.handle, out) == 0 and 0 <= out[0] <= 153 and out[1] in (0, 2, 4, 8, 16, 32, 64)
+
+
 def test_wide_phase_smoke_scene(orc, monkeypatch):
     """496 hittables with a constant_medium suffix and image textures: the medium is scanned after the merge by every lane
     of a group (identical RNG state in all of them); u,v travel through the butterfly."""
