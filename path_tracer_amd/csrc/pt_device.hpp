@@ -149,6 +149,16 @@ struct RayCtx {
   bool reg;
 };
 
+// RN(1/d) for 2^-40 <= |d| <= 2^40: the hardware estimate (v_rcp_f32, <= 1 ulp) and ONE Newton step in fma arithmetic.
+// Correctly rounded for EVERY significand: checked exhaustively (all 2^23, both signs, eight exponents across the range;
+// the computation is scale-invariant while nothing over- or underflows) by tests/test_gpu_parity.py::
+// test_guarded_reciprocal_is_correctly_rounded against the IEEE quotient.  3 instructions instead of the ~10 of the full
+// division expansion (v_div_scale x2, v_rcp, 4 fma, v_div_fmas, v_div_fixup), three times per ray.
+__device__ __forceinline__ float rcp_rn_guarded(float d) {
+  const float y0 = __builtin_amdgcn_rcpf(d);
+  return __builtin_fmaf(__builtin_fmaf(-d, y0, 1.0f), y0, y0);
+}
+
 __device__ __forceinline__ RayCtx make_ctx(const Ray& r, bool scene_fast_ok) {
   RayCtx c;
   c.r = r;
@@ -157,9 +167,10 @@ __device__ __forceinline__ RayCtx make_ctx(const Ray& r, bool scene_fast_ok) {
   float ax = __builtin_fabsf(r.d.x), ay = __builtin_fabsf(r.d.y), az = __builtin_fabsf(r.d.z);
   c.reg = scene_fast_ok && ax >= lo && ax <= hi && ay >= lo && ay <= hi && az >= lo && az <= hi &&
           __builtin_fabsf(r.o.x) <= ohi && __builtin_fabsf(r.o.y) <= ohi && __builtin_fabsf(r.o.z) <= ohi;
-  c.yx = 1.0f / r.d.x;
-  c.yy = 1.0f / r.d.y;
-  c.yz = 1.0f / r.d.z;
+  c.yx = rcp_rn_guarded(r.d.x); // only used when the ray is regular
+  c.yy = rcp_rn_guarded(r.d.y);
+  c.yz = rcp_rn_guarded(r.d.z);
+  __builtin_amdgcn_sched_barrier(0); // keep the context ahead of the scan: interleaving it with the record loops spills
   return c;
 }
 
@@ -459,7 +470,11 @@ __device__ __forceinline__ void hit_begin(HitState& h) { h.closest = PT_INF; h.h
 
 // n records of one kind at recs[0..): record i is blob offset goff + i*size.  `recs` is either the resident
 // blob (LDS or scalar-cached) advanced to the run, or an LDS tile of a streamed run.
-template <bool IMG, typename P>
+// TRIP: how many spheres / triangles a trip of those loops evaluates together (see "several records per trip" below).
+// Every resident kernel contains all the loops, and the ones that run at a 72-register budget (7 waves) pay for a wide
+// triangle loop with spills around EVERY scan, triangles or not: they take TRIP = 1; the cooperative and the streaming
+// kernels, which have registers to spare, take 2 spheres / 4 triangles.
+template <bool IMG, int TRIP = 1, typename P>
 __device__ __forceinline__ void hit_records(P recs, int kind, int n, int goff, const RayCtx& c, bool fast,
                                             uint32_t& rng, HitState& h) {
   const Ray& r = c.r;
@@ -483,12 +498,14 @@ __device__ __forceinline__ void hit_records(P recs, int kind, int n, int goff, c
     int i = 0;
     // two spheres per trip: both first records in flight together, two independent arithmetic chains, half the loop
     // control; the roots are still taken in list order (the second sees the first's closest)
-    for (; i + 1 < n; i += 2, off += 2 * SZ_SPHERE) {
-      const SphereEval A = sphere_eval(recs, off, c, tf), B = sphere_eval(recs, off + SZ_SPHERE, c, tf);
-      sphere_finish(A, c, PT_TMIN, h.closest, true, accept_at(off));
-      sphere_finish(B, c, PT_TMIN, h.closest, true, accept_at(off + SZ_SPHERE));
+    if constexpr (TRIP >= 2) {
+      for (; i + 1 < n; i += 2, off += 2 * SZ_SPHERE) {
+        const SphereEval A = sphere_eval(recs, off, c, tf), B = sphere_eval(recs, off + SZ_SPHERE, c, tf);
+        sphere_finish(A, c, PT_TMIN, h.closest, true, accept_at(off));
+        sphere_finish(B, c, PT_TMIN, h.closest, true, accept_at(off + SZ_SPHERE));
+      }
     }
-    if (i < n) sphere_roots(recs, off, c, PT_TMIN, h.closest, true, tf, accept_at(off));
+    for (; i < n; ++i, off += SZ_SPHERE) sphere_roots(recs, off, c, PT_TMIN, h.closest, true, tf, accept_at(off));
   } else if (kind == DK_RECT) {
     for (int i = 0; i < n; ++i, off += SZ_RECT) {
       f4 R0 = recs[off], R1 = recs[off + 1];
@@ -509,18 +526,19 @@ __device__ __forceinline__ void hit_records(P recs, int kind, int n, int goff, c
     auto finish_at = [&](int o, TriEval e) { // re-reads the records: only inside the rare branch
       if (e.pass) tri_finish(recs[o], recs[o + 1], recs[o + 2], r, e, PT_TMIN, h.closest, true, accept_at(o));
     };
-    for (; i + 3 < n; i += 4, off += 4 * SZ_TRI) {
-      const TriEval ea = eval_at(off), eb = eval_at(off + SZ_TRI), ec = eval_at(off + 2 * SZ_TRI), ed = eval_at(off + 3 * SZ_TRI);
-      finish_at(off, ea); finish_at(off + SZ_TRI, eb); finish_at(off + 2 * SZ_TRI, ec); finish_at(off + 3 * SZ_TRI, ed);
+    if constexpr (TRIP >= 4) {
+      for (; i + 3 < n; i += 4, off += 4 * SZ_TRI) {
+        const TriEval ea = eval_at(off), eb = eval_at(off + SZ_TRI), ec = eval_at(off + 2 * SZ_TRI), ed = eval_at(off + 3 * SZ_TRI);
+        finish_at(off, ea); finish_at(off + SZ_TRI, eb); finish_at(off + 2 * SZ_TRI, ec); finish_at(off + 3 * SZ_TRI, ed);
+      }
     }
-    for (; i + 1 < n; i += 2, off += 2 * SZ_TRI) {
-      const TriEval ea = eval_at(off), eb = eval_at(off + SZ_TRI);
-      finish_at(off, ea); finish_at(off + SZ_TRI, eb);
+    if constexpr (TRIP >= 2) {
+      for (; i + 1 < n; i += 2, off += 2 * SZ_TRI) {
+        const TriEval ea = eval_at(off), eb = eval_at(off + SZ_TRI);
+        finish_at(off, ea); finish_at(off + SZ_TRI, eb);
+      }
     }
-    if (i < n) {
-      const f4 A0 = recs[off], A1 = recs[off + 1], A2 = recs[off + 2];
-      tri_finish(A0, A1, A2, r, tri_eval(A0, A1, A2, r), PT_TMIN, h.closest, true, accept_at(off));
-    }
+    for (; i < n; ++i, off += SZ_TRI) finish_at(off, eval_at(off));
   } else if (kind == DK_BOX) {
     if (fast) {
       for (int i = 0; i < n; ++i, off += SZ_BOX) {
@@ -767,7 +785,7 @@ __device__ __forceinline__ void hit_world_lds(P blob, const CoopScene& cs, const
     if (cnt <= 0) continue;
     // (idle lanes scan too and their outcome is dropped: a per-lane skip would put the whole scan under exec-mask
     // branches — the ordinary kernels do the same)
-    if (merged) hit_records<IMG>(blob + off, kind, cnt, off, c, fast, rng, s);
+    if (merged) hit_records<IMG, 2>(blob + off, kind, cnt, off, c, fast, rng, s);
     else hit_records_strided<IMG>(blob + off, kind, cnt, first, off, j, logG, c, s);
   }
   if (handoff) { // hand each owner its result: the r-th live lane reads from (a lane of) group r

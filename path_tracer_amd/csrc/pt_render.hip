@@ -391,7 +391,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel_stream(KArgs a) {
       const int kind = as_i(runf.x), off = as_i(runf.y), cnt = as_i(runf.z);
       const int sz = record_size(kind);
       if (cnt * sz <= kSmallRunF4) {
-        hit_records<IMG>(cblob + off, kind, cnt, off, c, fast, L.rng, h);
+        hit_records<IMG, 4>(cblob + off, kind, cnt, off, c, fast, L.rng, h);
         continue;
       }
       const int per_tile = kTileF4 / sz;
@@ -400,7 +400,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel_stream(KArgs a) {
         const int nf4 = n * sz, base = off + first * sz;
         for (int i = threadIdx.x; i < nf4; i += kBlock) tile[i] = a.blob[base + i];
         __syncthreads();
-        hit_records<IMG>((lds_f4p)tile, kind, n, base, c, fast, L.rng, h);
+        hit_records<IMG, 4>((lds_f4p)tile, kind, n, base, c, fast, L.rng, h);
         __syncthreads();
       }
     }
@@ -561,6 +561,7 @@ __global__ void math_kernel(int op, const float* __restrict__ a, const float* __
     case 6: r = ptm::fmod1f_(x); break;
     case 7: r = sqrt_rn(x); break;
     case 9: { float yy = 1.0f / y; r = div_exact(x, y, yy, x * yy); break; } // the shared-reciprocal quotient (|q| >= 2^-60)
+    case 10: r = rcp_rn_guarded(x); break; // RN(1/a) for 2^-40 <= |a| <= 2^40 (pt_device.hpp: make_ctx)
     default: r = x / y; break;
   }
   out[i] = r;
@@ -1036,7 +1037,7 @@ int pt_debug_camera_rays(const PtCamera* cam, int32_t width, int32_t height, con
 }
 
 int pt_debug_math(int32_t op, const float* a, const float* b, float* out, int64_t n) {
-  if (!a || !out || n < 0 || op < 0 || op > 9) return fail(PT_ERR_INVALID_ARG, "pt_debug_math: bad argument");
+  if (!a || !out || n < 0 || op < 0 || op > 10) return fail(PT_ERR_INVALID_ARG, "pt_debug_math: bad argument");
   if ((op == 4 || op == 8 || op == 9) && !b) return fail(PT_ERR_INVALID_ARG, "pt_debug_math: op needs two operands");
   if (n == 0) return PT_OK;
   DevBuf<float> da, db, dout;

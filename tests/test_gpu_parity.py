@@ -112,6 +112,18 @@ def test_fast_division_is_exact(lib):
     assert (gpu_math(lib, 9, z, d[:2000]) == 0).all()
 
 
+def test_guarded_reciprocal_is_correctly_rounded(lib):
+    """The ray context's RN(1/d) = hardware estimate + one Newton step in fma arithmetic (pt_device.hpp: rcp_rn_guarded):
+    equal to the IEEE quotient for EVERY significand, both signs, exponents across the guarded range [2^-40, 2^40]
+    (the computation is scale-invariant there)."""
+    m = np.arange(2 ** 23, dtype=np.uint32)
+    for e in (-40, -7, -1, 0, 1, 2, 23, 40):
+        for sgn in (0, 1):
+            d = ((np.uint32(e + 127) << 23) | m | (np.uint32(sgn) << 31)).astype(np.uint32).view(np.float32)
+            with np.errstate(all="ignore"):
+                assert_bit_identical(gpu_math(lib, 10, d, None), (np.float32(1.0) / d).astype(np.float32), f"1/d, exponent {e}")
+
+
 def test_camera_rays_bit_exact(lib, orc):
     rng = np.random.default_rng(11)
     for cam_args, (w, h) in [(S.cornell_scene()[1], (1920, 1080)), (S.mixed_scene()[1], (400, 225))]:
