@@ -1,0 +1,53 @@
+"""Register budget of the hot kernels, checked at build time (hipcc cross-compiles gfx950 without a GPU): the resident
+kernels for scenes without image textures must fit 7 waves per SIMD (<= 72 VGPRs) WITHOUT scratch — a spill there sits
+around every list scan and cost 4 % of the headline number when a wider triangle loop once pushed them over."""
+import re
+import subprocess
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+CSRC = ROOT / "path_tracer_amd" / "csrc"
+
+
+def _flags():
+    mk = (CSRC / "Makefile").read_text()
+    m = re.search(r"^FLAGS\s*=\s*(.*?)(?<!\\)\n", mk, re.S | re.M)
+    flags = m.group(1).replace("\\\n", " ").replace("$(ARCH)", "gfx950").split()
+    return [f for f in flags if f not in ("-fPIC",) and not f.startswith("-W")]
+
+
+@pytest.fixture(scope="module")
+def usage():
+    cmd = ["/opt/rocm/bin/hipcc", *_flags(), "--cuda-device-only", "-c", "-Rpass-analysis=kernel-resource-usage", "-o", "/dev/null",
+           str(CSRC / "pt_render.hip")]
+    p = subprocess.run(cmd, capture_output=True, text=True, cwd=CSRC, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = {}
+    name = None
+    for line in p.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            out[name] = {}
+        for key in ("VGPRs", "ScratchSize [bytes/lane]", "Occupancy [waves/SIMD]"):
+            m = re.search(re.escape(key) + r": (\d+)", line)
+            if m and name:
+                out[name][key] = int(m.group(1))
+    return out
+
+
+def test_headline_kernels_fit_seven_waves_without_scratch(usage):
+    # render_kernel<UV_NONE, LDS, MLDS, COOP=false, CL>: mangled ...render_kernelILi0ELb?ELb?ELb0ELb?E...
+    hot = {k: v for k, v in usage.items() if re.search(r"render_kernelILi0ELb[01]ELb[01]ELb0ELb[01]E", k)}
+    assert len(hot) == 4, sorted(usage)
+    for k, v in hot.items():
+        assert v["ScratchSize [bytes/lane]"] == 0, (k, v)
+        assert v["VGPRs"] <= 72 and v["Occupancy [waves/SIMD]"] >= 7, (k, v)
+
+
+def test_streaming_and_cooperative_kernels_without_image_textures_do_not_spill(usage):
+    for k, v in usage.items():
+        if re.search(r"render_kernel_streamILi0E", k) or re.search(r"render_kernelILi0ELb1ELb[01]ELb1ELb0E", k):
+            assert v["ScratchSize [bytes/lane]"] == 0, (k, v)
