@@ -639,14 +639,20 @@ __device__ __forceinline__ int record_size(int kind) {
 }
 
 // Whole list, blob resident (LDS or scalar cache): blob = [n_runs x (kind, first record offset, count, -)] [records]
-template <bool IMG, typename P>
-__device__ __forceinline__ void hit_world(P blob, int n_runs, const RayCtx& c, bool fast, uint32_t& rng, HitState& h) {
+// `headers` may be another view of the same blob: the LDS kernels read the run headers through the scalar cache (they are
+// kernel constants: an s_load lands in SGPRs directly, no LDS round trip + v_readfirstlane per run) and the records from LDS.
+template <bool IMG, typename P, typename H>
+__device__ __forceinline__ void hit_world(P blob, H headers, int n_runs, const RayCtx& c, bool fast, uint32_t& rng, HitState& h) {
   hit_begin(h);
   for (int ri = 0; ri < n_runs; ++ri) {
-    f4 runf = blob[ri];
+    f4 runf = headers[ri];
     const int off = as_i(runf.y);
     hit_records<IMG>(blob + off, as_i(runf.x), as_i(runf.z), off, c, fast, rng, h);
   }
+}
+template <bool IMG, typename P>
+__device__ __forceinline__ void hit_world(P blob, int n_runs, const RayCtx& c, bool fast, uint32_t& rng, HitState& h) {
+  hit_world<IMG>(blob, blob, n_runs, c, fast, rng, h);
 }
 
 // Wave-uniform switch: the straight-line rect/box path is used only when every live lane's ray is regular.

@@ -332,7 +332,7 @@ void render_kernel(KArgs a) {
       } else {
         RayCtx c = make_ctx(L.ray, a.fast_ok != 0);
         const bool fast = wave_all_regular(c, L.live);
-        hit_world<IMG>((lds_f4p)smem, a.n_runs, c, fast, L.rng, h);
+        hit_world<IMG>((lds_f4p)smem, (cst_f4p)a.blob, a.n_runs, c, fast, L.rng, h);
       }
 #ifdef PT_STAMPS
       asm volatile("" ::"v"(h.closest), "v"(h.hit));
