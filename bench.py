@@ -1,24 +1,28 @@
 """bench.py — Msamples/s of the render() hot path on BASELINE.json's headline config.
 
-  python bench.py --gpus N --steps K --warmup W
-  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  python bench.py --gpus N --steps K --warmup W          (N > 1 from a bare shell: bench.py starts the N ranks itself)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (the driver's form)
 
-Workload (config.workload): configs[1] — Cornell-style scene (7 box + 1 xy_rect, diffuse light),
-1920x1080, 1024 spp, depth 50.  One step = one full render of a frame: N=1 that frame on one GPU;
-N>1 a frame's 8x8 tiles dealt round-robin to the ranks (no collective inside the render), then one
-RCCL gather of the float tiles to rank 0 over xGMI and a device-side un-interleave (inside the timed
-step).  The path partitions by pixels, so the default is WEAK scaling: the N-GPU frame has N x the
-pixels of the 1080p frame at the same spp, same scene, same camera and aspect (width and height x
-sqrt(N): N = 4 is exactly 3840x2160) — per-GPU work is fixed, `value` = all samples of that frame /
-time.  `--scaling strong` renders the fixed 1920x1080 frame on N GPUs instead; at this kernel speed
-that is bounded by the frame's heaviest pixel, one sequential chain.  The scene is
-resident in HBM before the timed region (it is ~1 KB; the boundary hands over host tables, and
+Workload (config.workload): configs[1] — Cornell-style scene (7 box + 1 xy_rect, diffuse light), 1920x1080,
+1024 spp, depth 50.  One step = one full render of that frame.  N = 1: the frame on one GPU.  N > 1: the SAME
+frame (north_star: "a 1920x1080 Cornell-box-style scene at 1024 spp reported at 1/2/4/8 GPUs"), its 8x8 tiles dealt
+round-robin to the ranks (no collective inside the render), then one RCCL gather of the float tiles to rank 0 over
+xGMI and a device-side un-interleave, both inside the timed step: STRONG scaling, `value` = the frame's samples /
+the slowest rank's time.  At this kernel speed the fixed frame is bounded by its heaviest pixel — one sequential RNG
+chain — so the line also carries `weak_scaling`: the same measurement on a frame with N x the pixels
+(same scene, camera, aspect, spp; width and height x sqrt(N)), i.e. fixed work per GPU.  `--scaling weak` makes that
+the headline instead (and says so in `metric`, `scaling` and `config`).
+Other BASELINE configs: `--config cfg3` (SmokeSphere 1920x1080x1024), `--config cfg4` (SmokeSphere 3840x2160x4096,
+the 8-GPU config), `--config cfg5` (100 k triangles 1920x1080x256); `--scene/--width/--height/--spp` override.
+`--mode fast` = the opt-in decorrelated-RNG mode (NOT parity: judged by PSNR; never the default).
+The scene is resident in HBM before the timed region (it is ~1 KB; the boundary hands over host tables, and
 uploading them costs microseconds — see DESIGN.md).
 
 Extra objects on the JSON line:
-  roofline      bound = VALU issue (not HBM, not MFMA).  achieved = algorithmic
-                lane-ops/sample (oracle event counters x the per-event op costs of SURVEY.md §8d)
-                x samples/s of the render kernel, measured with HIP events on the launch stream.
+  roofline      bound = VALU issue (not HBM, not MFMA).  achieved = algorithmic lane-ops/sample
+                (oracle exit-point counters x the per-exit op costs of SURVEY.md §8d) x samples/s of the render
+                kernel, measured with HIP events on the launch stream; `executed_over_algorithmic` = the PMC's
+                VALU lane-instructions per sample / that figure.
   cpu_baseline  the CPU oracle (kind "port": the reference itself needs triSYCL and cannot be built)
                 timed on this host's cores on a bounded sample of the same workload (rank 0, N=1 only).
 """
@@ -35,34 +39,45 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12  # 78.6 T lane-ops/s: 256 CU x 4 SIMD-32 x 2.4 GHz (MI355X_MICROARCH.md)
 
-# per-event algorithmic op costs as written in the reference (1 op = one fp32
-# add/sub/mul/div/cmp/sqrt/cvt or int32 shift/xor; a transcendental call counts 4)
-OPS = dict(rng_draw=8, sphere_miss=25, sphere_accept=58 + 2 * 4, rect_test=12, rect_accept=33, tri_test=40,
-           tri_accept=84, medium_extra=25 + 4, camera=91 - 5 * 8, sky=24, lambertian=46 - 3 * 8, metal=71 + 16 - 3 * 8,
-           dielectric=60 + 4, isotropic=41 + 16 - 3 * 8, light=4)
+# Per-exit algorithmic op costs as written in the reference — SURVEY.md §8(d)'s table (1 op = one fp32
+# add/sub/mul/div/cmp/sqrt/cvt or int32 shift/xor; a transcendental call T counts 4).  RNG draws are priced once, by
+# the draw counter, and taken out of the per-event figures that §8(d) quotes with their draws included.
+T = 4
+OPS = dict(
+    rng_draw=8,                                   # xorshift.hpp:72-74 + rtweekend.hpp:40-41
+    sphere_nodisc=25, sphere_roots_rejected=25 + 12,  # discriminant <= 0 | sqrt + two roots + their comparisons, none inside
+    sphere_accept=58 + 2 * T, sphere_moving=12,   # + center(time) per test of a moving sphere (sphere.hpp:51-56)
+    rect=(4, 12, 33),                             # t-reject | bounds-reject | accept   (a box = 6 of these)
+    tri=(22, 34, 52, 60, 84),                     # |a|<eps | u | v | t-range | accept  (triangle.hpp:71-91)
+    medium_extra=25 + T,                          # constant_medium beyond its two boundary tests (its draw: rng_draw)
+    camera=91 - 5 * 8, sky=24,
+    lambertian=46 - 3 * 8, metal=71 + 4 * T - 3 * 8, dielectric=60 + T, isotropic=41 + 4 * T - 3 * 8, light=4,
+    tex=(8 + 3 * T, 0, 20),                       # checker | solid | image (texture.hpp:154 order)
+)
 
 
-# Algorithmic lane-ops per sample of the standard scenes at depth 50: oracle event counters (a 480x270x4 render;
+# Algorithmic lane-ops per sample of the standard scenes at depth 50: oracle exit-point counters (a 480x270x4 render;
 # 96x54x1 for the mesh) priced with OPS above.  Recorded so that ranks of an N>1 job, where the cpu_baseline leg does
 # not run, need nothing from oracle/; the N=1 cpu_baseline leg re-derives the figure live and reports that.
-ALGORITHMIC_OPS_PER_SAMPLE = {"cornell": 3064.1, "smoke": 33791.0, "triangles": 9609266.0}
+ALGORITHMIC_OPS_PER_SAMPLE = {"cornell": 2062.7, "smoke": 39395.4, "triangles": 8220663.0}
 
 
 def ops_per_sample(ctr: dict) -> float:
-    """Algorithmic lane-ops per sample from the oracle's event counters."""
+    """Algorithmic lane-ops per sample from the oracle's exit-point counters, priced per exit."""
     n = ctr["samples"]
-    acc = ctr["accepts"]
-    sphere_acc = acc[0]
-    rect_acc = acc[1] + acc[5] + acc[6] + acc[3]  # top-level rects + one accepted side per accepted box (lower bound)
+    dot = lambda counts, prices: sum(c * p for c, p in zip(counts, prices))  # noqa: E731
+    se = ctr["sphere_exit"]
     total = (ctr["rng_draws"] * OPS["rng_draw"]
-             + (ctr["sphere_tests"] - sphere_acc) * OPS["sphere_miss"] + sphere_acc * OPS["sphere_accept"]
-             + (ctr["rect_tests"] - rect_acc) * OPS["rect_test"] + rect_acc * OPS["rect_accept"]
-             + (ctr["tests"][2] - acc[2]) * OPS["tri_test"] + acc[2] * OPS["tri_accept"]
+             + se[0] * OPS["sphere_nodisc"] + se[1] * OPS["sphere_roots_rejected"] + se[2] * OPS["sphere_accept"]
+             + ctr["sphere_moving"] * OPS["sphere_moving"]
+             + dot(ctr["rect_exit"], OPS["rect"])
+             + dot(ctr["tri_exit"], OPS["tri"])
              + ctr["tests"][4] * OPS["medium_extra"]
              + n * OPS["camera"] + ctr["end_sky"] * OPS["sky"]
              + ctr["scatters"][0] * OPS["lambertian"] + ctr["scatters"][1] * OPS["metal"]
              + ctr["scatters"][2] * OPS["dielectric"] + ctr["scatters"][3] * OPS["light"]
-             + ctr["scatters"][4] * OPS["isotropic"])
+             + ctr["scatters"][4] * OPS["isotropic"]
+             + dot(ctr["tex_evals"], OPS["tex"]))
     return total / n
 
 
@@ -87,23 +102,72 @@ def weak_frame(width: int, height: int, n_gpus: int):
     return int(round(width * n_gpus ** 0.5)), int(round(height * n_gpus ** 0.5))
 
 
+CONFIGS = {  # BASELINE.json `configs`
+    "cfg2": dict(scene="cornell", width=1920, height=1080, spp=1024),    # the headline: what `metric` is quoted on
+    "cfg3": dict(scene="smoke", width=1920, height=1080, spp=1024),
+    "cfg4": dict(scene="smoke", width=3840, height=2160, spp=4096),      # the 8-GPU tile-sharded config
+    "cfg5": dict(scene="triangles", width=1920, height=1080, spp=256),
+}
+SCENE_TEXT = {"cornell": "Cornell-style 7 box + 1 xy_rect + diffuse light",
+              "smoke": "SmokeSphere scene of main.cpp:67-161 (496 hittables, the reference's two image textures)",
+              "triangles": "100 k triangles + ground sphere + emissive xy_rect"}
+PT_FLAG_FAST_RNG = 1 << 9  # include/pt_render.h
+
+
+def self_launch(n_gpus: int) -> int:
+    """`python bench.py --gpus N` from a bare shell: start the N ranks as children (torch.distributed.run) and relay
+    rank 0's JSON line.  Runs BEFORE anything in this process touches the GPU, and nothing is exec()ed."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    if os.environ.get("PT_BENCH_DRY_LAUNCH"):  # testing aid (no GPU here): show what would be started
+        print(json.dumps({"launch": cmd}))
+        return 0
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
+    result = [ln for ln in lines if ln.lstrip().startswith('{"metric"')]
+    for ln in lines:
+        if ln not in result:
+            print(ln, file=sys.stderr)
+    if result:
+        print(result[-1], flush=True)  # the JSON line is the last line on stdout
+    return proc.returncode if proc.returncode else (0 if result else 1)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--scene", default="cornell", choices=["cornell", "smoke", "triangles"])
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--spp", type=int, default=1024)
+    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS), help="BASELINE.json config (default: the headline)")
+    ap.add_argument("--scene", default=None, choices=["cornell", "smoke", "triangles"])
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--spp", type=int, default=None)
     ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--flags", type=int, default=0)
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="N>1: weak = N x the pixels of the --width x --height frame (same aspect), strong = that frame itself")
+    ap.add_argument("--mode", choices=["parity", "fast"], default="parity",
+                    help="fast = opt-in decorrelated per-(pixel, sample) RNG streams: NOT the reference's image bit for bit")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="N>1 headline: strong = the fixed frame on N GPUs (default; the other one is reported beside it), "
+                         "weak = a frame with N x the pixels (same aspect)")
     ap.add_argument("--dist-single", action="store_true",
                     help="testing aid: run the N>1 code path (RCCL process group, sharded render, gather) with world size 1")
     args = ap.parse_args()
+    cfg = dict(CONFIGS[args.config])
+    for k in ("scene", "width", "height", "spp"):
+        if getattr(args, k) is not None:
+            cfg[k] = getattr(args, k)
+    if args.mode == "fast":
+        args.flags |= PT_FLAG_FAST_RNG
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -115,7 +179,7 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dist_path = world > 1 or args.dist_single
     if dist_path:
@@ -133,12 +197,9 @@ def main() -> None:
         import ctypes
         ctypes.CDLL(None).fflush(None)
 
-    W, H, SPP, DEPTH = args.width, args.height, args.spp, args.depth
-    if world > 1 and args.scaling == "weak":
-        W, H = weak_frame(W, H, world)
-    kw = {"n_triangles": 100_000} if args.scene == "triangles" else {}
-    packed, cam_args = scenes.build(args.scene, **kw)
-    cam = scenes.make_camera(cam_args, W, H)
+    scene_name, W1, H1, SPP, DEPTH = cfg["scene"], cfg["width"], cfg["height"], cfg["spp"], args.depth
+    kw = {"n_triangles": 100_000} if scene_name == "triangles" else {}
+    packed, cam_args = scenes.build(scene_name, **kw)
     ds = R.DeviceScene(packed)  # scene resident in HBM before the timed region
 
     def barrier():
@@ -146,47 +207,62 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    kernel_ms = []
+    def measure(W, H, steps, warmup):
+        """`warmup` untimed + exactly `steps` timed steps of the W x H frame; returns (seconds, kernel ms, last frame)."""
+        cam = scenes.make_camera(cam_args, W, H)
+        kernel_ms = []
+        fb = None
 
-    def step():
-        if not dist_path:
-            fb, ms = R.render(W, H, SPP, ds, cam, DEPTH, flags=args.flags, timed=True)
+        def step():
+            if not dist_path:
+                fb, ms = R.render(W, H, SPP, ds, cam, DEPTH, flags=args.flags, timed=True)
+                kernel_ms.append(ms)
+                return fb
+            local, ms = R.render(W, H, SPP, ds, cam, DEPTH, flags=args.flags, shard_index=rank, shard_count=world, timed=True)
             kernel_ms.append(ms)
-            return fb
-        local, ms = R.render(W, H, SPP, ds, cam, DEPTH, flags=args.flags, shard_index=rank, shard_count=world, timed=True)
-        kernel_ms.append(ms)
-        return R.gather_frame(local, W, H)  # one RCCL gather of the float tiles to rank 0 + un-interleave
+            return R.gather_frame(local, W, H)  # one RCCL gather of the float tiles to rank 0 + un-interleave
 
-    for _ in range(args.warmup):
-        step()
-    kernel_ms.clear()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        fb = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist_path:
-        t = torch.tensor([elapsed, sum(kernel_ms) / max(1, len(kernel_ms))], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, kern_ms = float(t[0]), float(t[1])
-    else:
-        kern_ms = sum(kernel_ms) / max(1, len(kernel_ms))
+        for _ in range(warmup):
+            step()
+        kernel_ms.clear()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fb = step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        kern = sum(kernel_ms) / max(1, len(kernel_ms))
+        if dist_path:
+            t = torch.tensor([elapsed, kern], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)  # the slowest rank's clock
+            elapsed, kern = float(t[0]), float(t[1])
+        return elapsed, kern, fb, cam
+
+    Ww, Hw = weak_frame(W1, H1, world)
+    W, H = (Ww, Hw) if (world > 1 and args.scaling == "weak") else (W1, H1)
+    elapsed, kern_ms, fb, cam = measure(W, H, args.steps, args.warmup)
+    other = None
+    if world > 1:  # the other scaling mode, reported beside the headline (same steps / warmup)
+        Wo, Ho = (W1, H1) if args.scaling == "weak" else (Ww, Hw)
+        eo, ko, _, _ = measure(Wo, Ho, args.steps, args.warmup)
+        other = {"scaling": "strong" if args.scaling == "weak" else "weak", "frame": f"{Wo}x{Ho}",
+                 "value": round(Wo * Ho * SPP * args.steps / eo / 1e6, 2), "unit": "Msamples/s",
+                 "ms_per_step": round(eo / args.steps * 1e3, 3), "kernel_ms": round(ko, 3)}
 
     if rank == 0:
         samples_per_step = W * H * SPP
         value = samples_per_step * args.steps / elapsed / 1e6
-        ops = ALGORITHMIC_OPS_PER_SAMPLE[args.scene]
+        ops = ALGORITHMIC_OPS_PER_SAMPLE[scene_name]
         cpu_line = None
         if world == 1 and not args.no_cpu_baseline:
             # --- cpu_baseline leg: the only place bench.py touches oracle/ (test infrastructure) ---------------
             from oracle import binding as orc
             orc.set_math(True)
-            cw, ch, cs = (480, 270, 4) if args.scene != "triangles" else (96, 54, 1)
+            cw, ch, cs = (480, 270, 4) if scene_name != "triangles" else (96, 54, 1)
             _, ctr = orc.render(packed, scenes.make_camera(cam_args, cw, ch).c, cw, ch, cs, DEPTH, counters=True)
-            ops = ops_per_sample(ctr.as_dict())  # event counters -> algorithmic ops per sample, live
+            ops = ops_per_sample(ctr.as_dict())  # exit-point counters -> algorithmic ops per sample, live
             # bounded sample of the same workload, sized for ~15 s of CPU work from a 1-spp probe
-            bw, bh = (W, H) if args.scene != "triangles" else (240, 135)
+            bw, bh = (W, H) if scene_name != "triangles" else (240, 135)
             bcam = scenes.make_camera(cam_args, bw, bh)
             t1 = time.perf_counter()
             orc.render(packed, bcam.c, bw, bh, 1, DEPTH)
@@ -195,11 +271,14 @@ def main() -> None:
             t1 = time.perf_counter()
             orc.render(packed, bcam.c, bw, bh, bs, DEPTH)
             dt = time.perf_counter() - t1
+            cpu_line = {"value": round(bw * bh * bs / dt / 1e6, 3), "unit": "Msamples/s",
+                        "cores": orc.load().orc_max_threads(), "kind": "port",
+                        "sample": f"same scene, {bw}x{bh}, {bs} spp, depth {DEPTH} ({bw * bh * bs / 1e6:.1f} Msamples, {dt:.1f} s), OpenMP CPU oracle, portable math"}
             # the "PSNR vs CPU ref" half of the metric: sampled pixels of the LAST timed GPU frame re-rendered by the
             # oracle at full spp (a pixel depends only on its own RNG stream)
             import numpy as np
             rng_ = np.random.default_rng(1)
-            npx = 256 if args.scene != "triangles" else 4
+            npx = 256 if scene_name == "cornell" else 24 if scene_name == "smoke" else 4
             xy = np.stack([rng_.integers(0, W, npx), rng_.integers(0, H, npx)], axis=1).astype(np.int32)
             ref = orc.render_pixels(packed, cam.c, W, H, SPP, xy, DEPTH)
             got = fb.cpu().numpy()[xy[:, 1], xy[:, 0]]
@@ -208,22 +287,25 @@ def main() -> None:
             mse = float(np.mean((g8.astype(np.float64) - r8.astype(np.float64)) ** 2))
             parity = {"pixels_checked": int(npx), "bit_identical_pixels": int(same.all(axis=1).sum()),
                       "psnr_db_8bit": None if mse == 0 else round(10 * np.log10(255.0 ** 2 / mse), 2),
-                      "note": "GPU frame vs CPU oracle (portable math) at sampled pixels, full spp; null PSNR = identical"}
-            cpu_line = {"value": round(bw * bh * bs / dt / 1e6, 3), "unit": "Msamples/s",
-                        "cores": orc.load().orc_max_threads(), "kind": "port",
-                        "sample": f"same scene, {bw}x{bh}, {bs} spp, depth {DEPTH} ({bw * bh * bs / 1e6:.1f} Msamples, {dt:.1f} s), OpenMP CPU oracle, portable math"}
-        pmc = pmc_traffic(args.scene, W, H, SPP) if world == 1 else None
-        kernel_samples_per_s = (samples_per_step / world) / (kern_ms * 1e-3) * world if world > 1 else samples_per_step / (kern_ms * 1e-3)
+                      "note": "GPU frame vs CPU oracle (portable math) at sampled pixels, full spp; null PSNR = identical"
+                              + ("; fast mode is NOT expected to be bit-identical" if args.mode == "fast" else "")}
+        pmc = pmc_traffic(scene_name, W, H, SPP) if world == 1 else None
+        kernel_samples_per_s = samples_per_step / (kern_ms * 1e-3)  # whole job; each rank renders 1/world of it
         achieved = ops * kernel_samples_per_s / 1e12 / world  # per GPU
+        headline = (scene_name, W1, H1, SPP) == ("cornell", 1920, 1080, 1024)
+        at = "1080p 1024spp" if (W, H, SPP) == (1920, 1080, 1024) else f"{W}x{H} {SPP}spp"
+        scaling = args.scaling if world > 1 else "weak"  # N = 1: both modes coincide
         line = {
-            "metric": "Msamples/s (W x H x spp / s) at 1080p 1024spp", "value": round(value, 2), "unit": "Msamples/s",
+            "metric": f"Msamples/s (W x H x spp / s) at {at}" + ("" if headline else f" [{args.config}: {scene_name}]")
+                      + (" [fast mode: decorrelated RNG, not parity]" if args.mode == "fast" else ""),
+            "value": round(value, 2), "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.scene}: " + ("Cornell-style 7 box + 1 xy_rect + diffuse light" if args.scene == "cornell" else args.scene)
-                       + f", {W}x{H}, {SPP} spp, depth {DEPTH}, seed = pixel linear id",
-                       "hittables": packed.n_hittables,
-                       "frame_at_1_gpu": f"{args.width}x{args.height}",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": scaling,
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic", "frame": f"{W}x{H}",
+            "config": {"workload": f"{scene_name}: {SCENE_TEXT[scene_name]}, {W}x{H}, {SPP} spp, depth {DEPTH}, "
+                                   + ("seed = pixel linear id" if args.mode == "parity" else "FAST MODE: one RNG stream per (pixel, sample)"),
+                       "baseline_config": args.config, "hittables": packed.n_hittables, "mode": args.mode,
+                       "frame_at_1_gpu": f"{W1}x{H1}",
                        "sharding": "whole frame" if world == 1 else f"8x8 tiles round-robin over {world} ranks + RCCL gather"},
             "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": round(PEAK_TLANEOPS, 1), "unit": "Tlaneop/s",
                          "frac": round(achieved / PEAK_TLANEOPS, 4),
@@ -233,11 +315,17 @@ def main() -> None:
                                  "frac": round(pmc[0] / (kern_ms * 1e-3) / 8e12, 6)} if pmc else None,
                          "valu_issue_occupancy_pmc": round(pmc[2].get("valu_issue_occupancy", 0.0), 3) if pmc else None,
                          "valu_lane_utilisation_pmc": round(pmc[2].get("valu_lane_utilisation", 0.0), 3) if pmc else None,
+                         "valu_lane_instr_per_sample_pmc": round(pmc[2].get("valu_lane_instr_per_sample", 0.0), 1) if pmc else None,
+                         # how much more the kernel executes than the reference's arithmetic as written
+                         "executed_over_algorithmic": round(pmc[2]["valu_lane_instr_per_sample"] / ops, 3)
+                         if pmc and pmc[2].get("valu_lane_instr_per_sample") else None,
                          "kernel": "render_kernel", "kernel_ms": round(kern_ms, 3),
                          "algorithmic_ops_per_sample": round(ops, 1),
                          "kernel_msamples_per_s_per_gpu": round(kernel_samples_per_s / world / 1e6, 2),
                          "hbm_algorithmic_bytes": W * H * 12 // world},
         }
+        if other:
+            line[other["scaling"] + "_scaling"] = other
         if cpu_line:
             line["cpu_baseline"] = cpu_line
             line["parity"] = parity

@@ -1,18 +1,22 @@
 // examples/smoke_sphere.cpp — the reference's src/main.cpp:61-197 rewritten against the C++20 facade: same scene literal
 // (the RNG calls inside one expression are evaluated left to right here; the reference leaves that order to the
 // compiler, main.cpp:83,87,92), same camera, same output stage (gamma 2, clamp, x256, rows flipped), PPM instead of
-// PNG (main.cpp:17-31; stb is not a dependency).  Image textures are procedural stand-ins unless raw RGB8 files are
-// given.
+// PNG (main.cpp:17-31; stb is not a dependency).  The two image textures are loaded like main.cpp:133,145 does, through
+// image_texture::image_texture_factory, from <images_dir>/Xilinx.ppm and <images_dir>/SYCL.ppm (default "../images" as in
+// the reference; `python -m path_tracer_amd --export-textures DIR` writes the decoded reference images there); a file
+// that cannot be loaded gets the reference's treatment — a message on stderr and the fallback texel.  images_dir
+// "procedural" selects small generated stand-ins instead.
 //
 //   g++ -std=c++20 -O2 -ffp-contract=off -Ipath_tracer_amd/include examples/smoke_sphere.cpp -Lpath_tracer_amd -lpt_render \
 //       -Wl,-rpath,$PWD/path_tracer_amd -Wl,-rpath,/opt/rocm/lib -o sycl-rt-mi355x
-//   ./sycl-rt-mi355x [width height samples out.ppm [tables.bin]]
+//   ./sycl-rt-mi355x [width height samples out.ppm [tables.bin|- [images_dir]]]
 #include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
+#include <string>
 #include <vector>
 
 #include "pt/path_tracer.hpp"
@@ -47,6 +51,8 @@ int main(int argc, char** argv) {
   const int width = argc > 1 ? std::atoi(argv[1]) : 800, height = argc > 2 ? std::atoi(argv[2]) : 480; // CMakeLists.txt:44-54
   const int samples = argc > 3 ? std::atoi(argv[3]) : 100;                                            // main.cpp:186
   const char* out = argc > 4 ? argv[4] : "out.ppm";
+  const std::string images_dir = argc > 6 ? argv[6] : "../images";
+  const bool procedural = images_dir == "procedural";
 
   std::vector<hittable_t> hittables;
   texture_t t = checker_texture(color{0.2f, 0.3f, 0.1f}, color{0.9f, 0.9f, 0.9f});
@@ -83,15 +89,15 @@ int main(int argc, char** argv) {
   hittables.emplace_back(triangle(point{6.5f, 0.0f, 0.80f}, point{6.25f, 0.50f, 1.05f}, point{6.0f, 0.0f, 0.80f}, lambertian_material(color(0.0f, 0.0f, 1))));
   hittables.emplace_back(triangle(point{6.0f, 0.0f, 0.80f}, point{6.25f, 0.50f, 1.05f}, point{6.0f, 0.0f, 1.30f}, lambertian_material(color(0.0f, 0.0f, 1))));
   hittables.emplace_back(sphere(point{4, 1, 0}, 0.2f, lightsource_material(color(10, 0, 10))));
-  auto xil = procedural_image(256, 128, 0);
-  t = image_texture::from_rgb8(xil.data(), 256, 128);
+  if (procedural) { auto xil = procedural_image(256, 128, 0); t = image_texture::from_rgb8(xil.data(), 256, 128); }
+  else t = image_texture::image_texture_factory((images_dir + "/Xilinx.ppm").c_str()); // main.cpp:133
   hittables.emplace_back(xy_rect(2, 4, 0, 1, -1, lambertian_material(t)));
   hittables.emplace_back(sphere(point{4, 1, 2.25f}, 1, lambertian_material(t)));
   hittables.emplace_back(sphere(point{0, 1, 0}, 1, dielectric_material(1.5f, color{1.0f, 0.5f, 0.5f})));
   hittables.emplace_back(sphere(point{-4, 1, 0}, 1, lambertian_material(color(0.4f, 0.2f, 0.1f))));
   hittables.emplace_back(sphere(point{0, 1, -2.25f}, 1, metal_material(color(0.7f, 0.6f, 0.5f), 0.0f)));
-  auto syc = procedural_image(320, 140, 1);
-  t = image_texture::from_rgb8(syc.data(), 320, 140, 5);
+  if (procedural) { auto syc = procedural_image(320, 140, 1); t = image_texture::from_rgb8(syc.data(), 320, 140, 5); }
+  else t = image_texture::image_texture_factory((images_dir + "/SYCL.ppm").c_str(), 5); // main.cpp:145
   hittables.emplace_back(sphere{point{-60, 3, 5}, 4, lambertian_material{t}});
   hittables.emplace_back(box{point{6.5f, 0, -1.5f}, point{7.0f, 3.0f, -1.0f}, metal_material{color{0.7f, 0.6f, 0.5f}, 0.25f}});
   sphere smoke_sphere = sphere{point{5, 1, 3.5f}, 1, lambertian_material{color{0.75f, 0.75f, 0.75f}}};
@@ -103,7 +109,7 @@ int main(int argc, char** argv) {
   real_t focus_dist = std::sqrt(fx * fx + fy * fy + fz * fz); // main.cpp:179
   camera cam{look_from, look_at, vup, 40, static_cast<real_t>(width) / height, 0.04f, focus_dist, 0.0f, 1.0f};
 
-  if (argc > 5) { // testing aid: dump the flattened C-ABI tables instead of rendering (no GPU needed)
+  if (argc > 5 && std::string(argv[5]) != "-") { // testing aid: dump the flattened C-ABI tables instead of rendering (no GPU needed)
     scene_tables tb = flatten(hittables);
     std::ofstream d(argv[5], std::ios::binary);
     int32_t n[3] = {(int32_t)tb.hittables.size(), (int32_t)tb.materials.size(), (int32_t)tb.textures.size()};

@@ -21,7 +21,9 @@ class OrcCounters(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("rays", C.c_uint64), ("rng_draws", C.c_uint64),
                 ("tests", C.c_uint64 * abi.PT_HIT_KIND_COUNT), ("accepts", C.c_uint64 * abi.PT_HIT_KIND_COUNT),
                 ("rect_tests", C.c_uint64), ("sphere_tests", C.c_uint64), ("scatters", C.c_uint64 * 5),
-                ("end_sky", C.c_uint64), ("end_emit", C.c_uint64), ("end_depth", C.c_uint64)]
+                ("end_sky", C.c_uint64), ("end_emit", C.c_uint64), ("end_depth", C.c_uint64),
+                ("rect_exit", C.c_uint64 * 3), ("tri_exit", C.c_uint64 * 5), ("sphere_exit", C.c_uint64 * 3),
+                ("sphere_moving", C.c_uint64), ("tex_evals", C.c_uint64 * 3)]
 
     def as_dict(self) -> dict:
         d = {}

@@ -170,7 +170,7 @@ static inline v3 sphere_center(const float* f, float time) {
 /* sphere.hpp:59-106.  want_uv=0 only where the record's u,v are never read
  * (constant_medium boundaries): mercator_coordinates is pure.                 */
 static int sphere_hit(ctx_t* c, const float* f, const ray_t* r, float mn, float mx, hit_record* rec, int want_uv) {
-  if (c->c) c->c->sphere_tests++;
+  if (c->c) { c->c->sphere_tests++; if (f[7] != f[8]) c->c->sphere_moving++; }
   float radius = f[6];
   v3 oc = vsub(r->orig, sphere_center(f, r->tm));
   float a = vdot(r->dir, r->dir);
@@ -185,6 +185,7 @@ static int sphere_hit(ctx_t* c, const float* f, const ray_t* r, float mn, float 
       v3 outward_normal = vdivs(vsub(rec->p, sphere_center(f, r->tm)), radius);
       set_face_normal(rec, r, outward_normal);
       if (want_uv) mercator_coordinates(rec->normal, &rec->u, &rec->v);
+      if (c->c) c->c->sphere_exit[2]++;
       return 1;
     }
     temp = (-b + sqrtf(discriminant)) / a;
@@ -194,9 +195,13 @@ static int sphere_hit(ctx_t* c, const float* f, const ray_t* r, float mn, float 
       v3 outward_normal = vdivs(vsub(rec->p, sphere_center(f, r->tm)), radius);
       set_face_normal(rec, r, outward_normal);
       if (want_uv) mercator_coordinates(rec->normal, &rec->u, &rec->v);
+      if (c->c) c->c->sphere_exit[2]++;
       return 1;
     }
+    if (c->c) c->c->sphere_exit[1]++;
+    return 0;
   }
+  if (c->c) c->c->sphere_exit[0]++;
   return 0;
 }
 
@@ -212,10 +217,11 @@ static int rect_hit(ctx_t* c, int axis, float a0, float a1, float b0, float b1, 
   else if (axis == 1) { ok = r->orig.y; dk = r->dir.y; oa = r->orig.x; da = r->dir.x; ob = r->orig.z; db = r->dir.z; n = V(0, 1, 0); }
   else                { ok = r->orig.x; dk = r->dir.x; oa = r->orig.y; da = r->dir.y; ob = r->orig.z; db = r->dir.z; n = V(1, 0, 0); }
   float t = (k - ok) / dk;
-  if (t < mn || t > mx) return 0;
+  if (t < mn || t > mx) { if (c->c) c->c->rect_exit[0]++; return 0; }
   float a = oa + t * da;
   float b = ob + t * db;
-  if (a < a0 || a > a1 || b < b0 || b > b1) return 0;
+  if (a < a0 || a > a1 || b < b0 || b > b1) { if (c->c) c->c->rect_exit[1]++; return 0; }
+  if (c->c) c->c->rect_exit[2]++;
   rec->u = (a - a0) / (a1 - a0);
   rec->v = (b - b0) / (b1 - b0);
   rec->t = t;
@@ -225,7 +231,7 @@ static int rect_hit(ctx_t* c, int axis, float a0, float a1, float b0, float b1, 
 }
 
 /* ---- triangle, Moller-Trumbore strategy (triangle.hpp:58-100) ----------------------------- */
-static int triangle_hit(const float* f, const ray_t* r, float mn, float mx, hit_record* rec) {
+static int triangle_hit(ctx_t* c, const float* f, const ray_t* r, float mn, float mx, hit_record* rec) {
   const float epsilon = 0.0000001f;
   v3 v0 = vld(f), v1 = vld(f + 3), v2 = vld(f + 6);
   v3 edge1 = vsub(v1, v0);
@@ -233,18 +239,19 @@ static int triangle_hit(const float* f, const ray_t* r, float mn, float mx, hit_
   v3 h = vcross(r->dir, edge2);
   float a = vdot(edge1, h);
   float a_abs = fabsf(a);
-  if (a_abs < epsilon) return 0;
+  if (a_abs < epsilon) { if (c->c) c->c->tri_exit[0]++; return 0; }
   int a_pos = a > 0.0f;
   v3 s = vsub(r->orig, v0);
   float u = vdot(s, h);
   int u_pos = u > 0.0f;
-  if ((u_pos ^ a_pos) || fabsf(u) > a_abs) return 0;
+  if ((u_pos ^ a_pos) || fabsf(u) > a_abs) { if (c->c) c->c->tri_exit[1]++; return 0; }
   v3 q = vcross(s, edge1);
   float v = vdot(r->dir, q);
   int v_pos = v > 0.0f;
-  if ((v_pos ^ a_pos) || (fabsf(u + v) > a_abs)) return 0;
+  if ((v_pos ^ a_pos) || (fabsf(u + v) > a_abs)) { if (c->c) c->c->tri_exit[2]++; return 0; }
   float length = vdot(edge2, q) / a;
-  if (length < mn || length > mx) return 0;
+  if (length < mn || length > mx) { if (c->c) c->c->tri_exit[3]++; return 0; }
+  if (c->c) c->c->tri_exit[4]++;
   v3 hit_pt = ray_at(r, length);
   set_face_normal(rec, r, vcross(edge1, edge2)); /* NOT normalised (triangle.hpp:96) */
   rec->t = length;
@@ -320,7 +327,7 @@ static int hit_world(ctx_t* c, const ray_t* r, hit_record* rec, int* material, i
       case PT_HIT_XY_RECT: hit = rect_hit(c, 0, h->f[0], h->f[1], h->f[2], h->f[3], h->f[4], r, 0.001f, closest_so_far, &temp_rec); break;
       case PT_HIT_XZ_RECT: hit = rect_hit(c, 1, h->f[0], h->f[1], h->f[2], h->f[3], h->f[4], r, 0.001f, closest_so_far, &temp_rec); break;
       case PT_HIT_YZ_RECT: hit = rect_hit(c, 2, h->f[0], h->f[1], h->f[2], h->f[3], h->f[4], r, 0.001f, closest_so_far, &temp_rec); break;
-      case PT_HIT_TRIANGLE: hit = triangle_hit(h->f, r, 0.001f, closest_so_far, &temp_rec); break;
+      case PT_HIT_TRIANGLE: hit = triangle_hit(c, h->f, r, 0.001f, closest_so_far, &temp_rec); break;
       case PT_HIT_BOX: hit = box_hit(c, h->f, r, 0.001f, closest_so_far, &temp_rec); break;
       default: hit = medium_hit(c, h, r, 0.001f, closest_so_far, &temp_rec); break;
     }
@@ -346,6 +353,7 @@ static inline uint32_t texel_index(float f, uint32_t maxv) {
 
 static v3 texture_value(ctx_t* c, int tex, const hit_record* rec) {
   const PtTexture* t = &c->sc->textures[tex];
+  if (c->c) c->c->tex_evals[t->kind]++;
   if (t->kind == PT_TEX_SOLID) return vld(t->color0);
   if (t->kind == PT_TEX_CHECKER) {
     float sines = m_sin(10.0f * rec->p.x) * m_sin(10.0f * rec->p.y) * m_sin(10.0f * rec->p.z);

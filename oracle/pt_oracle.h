@@ -52,6 +52,13 @@ typedef struct OrcCounters {
   uint64_t sphere_tests;      /* incl. medium boundary tests */
   uint64_t scatters[5];       /* scatter() calls by material kind */
   uint64_t end_sky, end_emit, end_depth;
+  /* Exit points, so that the algorithmic work can be priced per exit as SURVEY.md §8(d) does (appended: the
+   * fields above keep their offsets).                                                                          */
+  uint64_t rect_exit[3];      /* rectangle.hpp:36 t-reject | :40 bounds-reject | accept  (box sides included)   */
+  uint64_t tri_exit[5];       /* triangle.hpp:71 |a|<eps | :81 u | :86 v | :91 t-range | accept                 */
+  uint64_t sphere_exit[3];    /* sphere.hpp:74 discriminant <= 0 | both roots outside (min,max) | accept        */
+  uint64_t sphere_moving;     /* sphere tests that evaluated center(time) with time0 != time1 (sphere.hpp:52)   */
+  uint64_t tex_evals[3];      /* texture value() calls by kind: checker, solid, image (texture.hpp:154 order)   */
 } OrcCounters;
 
 /* render<W,H,S>() render.hpp:25-160 on host cores (OpenMP over rows).

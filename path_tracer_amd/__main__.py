@@ -20,10 +20,17 @@ def main() -> None:
     ap.add_argument("--depth", type=int, default=50)     # render.hpp:144
     ap.add_argument("--triangles", type=int, default=100_000)
     ap.add_argument("--out", default="out.png")          # main.cpp:57
+    ap.add_argument("--textures", default="reference", choices=["reference", "procedural"],
+                    help="smoke scene: the decoded reference images (tests/golden/cfg1_textures.npz) or generated stand-ins")
+    ap.add_argument("--export-textures", metavar="DIR", help="write Xilinx.ppm / SYCL.ppm for the C++ host and exit (no GPU)")
     a = ap.parse_args()
+    if a.export_textures:
+        print(*scenes.export_reference_textures(a.export_textures), sep="\n")
+        return
     import torch
 
-    packed, cam_args = scenes.build(a.scene, **({"n_triangles": a.triangles} if a.scene == "triangles" else {}))
+    kw = {"n_triangles": a.triangles} if a.scene == "triangles" else {"textures": a.textures} if a.scene == "smoke" else {}
+    packed, cam_args = scenes.build(a.scene, **kw)
     cam = scenes.make_camera(cam_args, a.width, a.height)
     t0 = time.perf_counter()
     fb, ms = R.render(a.width, a.height, a.spp, packed, cam, a.depth, timed=True)

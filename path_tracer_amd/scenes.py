@@ -8,6 +8,8 @@ arithmetic), so the same call gives the same tables here and on the GPU box.
 """
 from __future__ import annotations
 
+from pathlib import Path
+
 import numpy as np
 
 from . import abi
@@ -69,10 +71,33 @@ def cornell_box():
     return hittables, cam
 
 
+CFG1_TEXTURES = Path(__file__).resolve().parent.parent / "tests" / "golden" / "cfg1_textures.npz"
+
+
+def reference_textures():
+    """Decoded RGB8 of the two images main.cpp:133,145 load (images/Xilinx.jpg 1024x512, images/SYCL.png 1280x559):
+    a committed DATA fixture (tests/golden/make_textures.py decoded them once in the build container; the reference
+    tree does not travel).  Returns (xilinx, sycl) uint8 [h][w][3]."""
+    with np.load(CFG1_TEXTURES) as z:
+        return z["xilinx"], z["sycl"]
+
+
+def export_reference_textures(directory) -> list:
+    """Writes the decoded reference images as binary PPM (Xilinx.ppm, SYCL.ppm) — the format the C++ host's
+    image_texture::image_texture_factory reads (path_tracer_amd/include/pt/path_tracer.hpp)."""
+    directory = Path(directory)
+    directory.mkdir(parents=True, exist_ok=True)
+    out = []
+    for name, rgb in zip(("Xilinx.ppm", "SYCL.ppm"), reference_textures()):
+        path = directory / name
+        path.write_bytes(b"P6\n%d %d\n255\n" % (rgb.shape[1], rgb.shape[0]) + np.ascontiguousarray(rgb).tobytes())
+        out.append(path)
+    return out
+
+
 def _procedural_image(w: int, h: int, seed: int) -> np.ndarray:
-    """Stand-in for images/Xilinx.jpg / images/SYCL.png (the reference tree does not travel to the GPU
-    box): a deterministic gradient + block pattern, so image_texture::value is exercised with real
-    row/column structure."""
+    """Explicit stand-in for the two reference images (textures="procedural"): a deterministic gradient +
+    block pattern, so image_texture::value is exercised with real row/column structure without any file."""
     y, x = np.mgrid[0:h, 0:w]
     r = (x * 255 // max(1, w - 1)).astype(np.uint8)
     g = (y * 255 // max(1, h - 1)).astype(np.uint8)
@@ -81,14 +106,23 @@ def _procedural_image(w: int, h: int, seed: int) -> np.ndarray:
 
 
 def smoke_sphere_scene(atlas: TextureAtlas | None = None, xilinx_rgb: np.ndarray | None = None,
-                       sycl_rgb: np.ndarray | None = None):
+                       sycl_rgb: np.ndarray | None = None, textures: str = "reference"):
     """The default scene of /root/reference/src/main.cpp:67-161 ("SmokeSphere").
 
     main.cpp:83,87,92 leave the order of the rng calls inside one expression unspecified, so the
     reference's exact scene depends on its compiler; here the order is DEFINED left-to-right.  The
     result has the same population (≈490 small spheres: 40 % lambertian, 40 % moving lambertian,
     15 % metal, 5 % glass; pyramid; light; image-textured rect + sphere; glass, lambertian and metal
-    big spheres; logo sphere; metal monolith; smoke ball).  Returns (hittables, camera_args, atlas)."""
+    big spheres; logo sphere; metal monolith; smoke ball).  The atlas follows texture.hpp:113-114,157: the {0,0,1}
+    fallback texel, then Xilinx.jpg's texels at offset 1, then SYCL.png's at 1 + 1024*512.
+    textures: "reference" = the decoded reference images (reference_textures()), "procedural" = small generated
+    stand-ins; explicit xilinx_rgb / sycl_rgb arrays override either.  Returns (hittables, camera_args, atlas)."""
+    if textures not in ("reference", "procedural"):
+        raise ValueError("textures must be 'reference' or 'procedural'")
+    if textures == "reference" and (xilinx_rgb is None or sycl_rgb is None):
+        rx, rs = reference_textures()
+        xilinx_rgb = rx if xilinx_rgb is None else xilinx_rgb
+        sycl_rgb = rs if sycl_rgb is None else sycl_rgb
     atlas = atlas or TextureAtlas()
     hittables = []
     t = checker_texture((0.2, 0.3, 0.1), (0.9, 0.9, 0.9))

@@ -41,6 +41,48 @@ def test_peak_and_defaults():
         assert d["roofline"]["bound"] == "valu" and 0 < d["roofline"]["frac"] < 1
 
 
+def test_exit_point_pricing_follows_survey_8d():
+    """rect 4 / 12 / 33 (t-reject / bounds-reject / accept), triangle 22 / 34 / 52 / 60 / 84, RNG draw 8,
+    sphere miss 25 / accept 58 + 2T — and the counters that feed them partition the tests."""
+    bench = load_bench()
+    assert bench.OPS["rect"] == (4, 12, 33) and bench.OPS["tri"] == (22, 34, 52, 60, 84)
+    assert bench.OPS["rng_draw"] == 8 and bench.OPS["sphere_nodisc"] == 25 and bench.OPS["sphere_accept"] == 58 + 8
+    ctr = dict(samples=2, rays=0, rng_draws=10, tests=[0] * 7, accepts=[0] * 7, rect_tests=6, sphere_tests=0,
+               scatters=[0] * 5, end_sky=0, end_emit=0, end_depth=0, rect_exit=[3, 2, 1], tri_exit=[0] * 5,
+               sphere_exit=[0] * 3, sphere_moving=0, tex_evals=[0] * 3)
+    assert bench.ops_per_sample(ctr) == (10 * 8 + 3 * 4 + 2 * 12 + 33 + 2 * bench.OPS["camera"]) / 2
+
+
+def test_oracle_exit_counters_partition_the_tests(orc):
+    packed, cam_args = scenes.build("smoke", textures="procedural")
+    orc.set_math(True)
+    _, ctr = orc.render(packed, scenes.make_camera(cam_args, 96, 54).c, 96, 54, 2, 50, counters=True)
+    d = ctr.as_dict()
+    assert sum(d["rect_exit"]) == d["rect_tests"] and sum(d["sphere_exit"]) == d["sphere_tests"]
+    assert sum(d["tri_exit"]) == d["tests"][2]
+    assert d["rect_exit"][0] > 0 and d["tri_exit"][1] > 0 and d["sphere_exit"][2] > 0 and d["sphere_moving"] > 0
+    assert sum(d["tex_evals"]) >= d["scatters"][0] + d["scatters"][4]  # every lambertian / isotropic scatter evaluates a texture
+
+
+def test_multi_gpu_self_launch_and_configs(monkeypatch, capsys):
+    """`python bench.py --gpus N` from a bare shell starts the N ranks itself (torch.distributed.run, 127.0.0.1) before
+    touching a GPU; --config names BASELINE.json's configs."""
+    import subprocess
+    import sys
+    import os
+    env = dict(os.environ, PT_BENCH_DRY_LAUNCH="1")
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1"],
+                         env=env, capture_output=True, text=True, check=True).stdout
+    cmd = json.loads(out)["launch"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "2", "--warmup", "1"]
+    bench = load_bench()
+    assert bench.CONFIGS["cfg2"] == dict(scene="cornell", width=1920, height=1080, spp=1024)
+    assert bench.CONFIGS["cfg4"] == dict(scene="smoke", width=3840, height=2160, spp=4096)
+    assert bench.CONFIGS["cfg5"]["spp"] == 256 and bench.CONFIGS["cfg3"]["scene"] == "smoke"
+
+
 def test_weak_scaling_frames_keep_pixels_per_gpu_and_aspect():
     """bench.py --gpus N (weak scaling): N x the pixels of the 1080p frame, same aspect; N = 4 is exactly 4K."""
     import bench

@@ -107,26 +107,62 @@ def example_bin(tmp_path_factory, lib):
     return out
 
 
-def test_example_main_builds_the_same_scene_as_python(example_bin, tmp_path):
+@pytest.fixture(scope="module")
+def images_dir(tmp_path_factory):
+    d = tmp_path_factory.mktemp("images")
+    scenes.export_reference_textures(d)  # Xilinx.ppm / SYCL.ppm from the committed decoded-pixel fixture
+    return d
+
+
+@pytest.mark.parametrize("textures", ["reference", "procedural"])
+def test_example_main_builds_the_same_scene_as_python(example_bin, tmp_path, images_dir, textures):
     """examples/smoke_sphere.cpp (the reference's main.cpp against the C++ facade) and scenes.smoke_sphere_scene (Python)
-    construct the 496-hittable default scene with the same RNG draw order and binary32 arithmetic."""
+    construct the 496-hittable default scene with the same RNG draw order and binary32 arithmetic — with the reference's
+    two images loaded by the C++ host's own image_texture_factory (PPM) or with the generated stand-ins."""
     out = tmp_path / "smoke.bin"
-    subprocess.run([str(example_bin), "400", "225", "1", str(tmp_path / "x.ppm"), str(out)], check=True)
+    subprocess.run([str(example_bin), "400", "225", "1", str(tmp_path / "x.ppm"), str(out),
+                    str(images_dir) if textures == "reference" else "procedural"], check=True)
     n, (hb, mb, tb, cb) = read_dump(out)
-    ps, cam = scenes.build("smoke")
+    ps, cam = scenes.build("smoke", textures=textures)
     c = scenes.make_camera(cam, 400, 225)
     assert n == [ps.n_hittables, ps.n_materials, ps.n_textures]
     assert hb == bytes(ps.hittables)[:len(hb)]
     assert mb == bytes(ps.materials)[:len(mb)]
     assert tb == bytes(ps.textures)[:len(tb)]
     assert cb == bytes(c.c)
+    if textures == "reference":  # texture.hpp:113-114: fallback texel, Xilinx.jpg at texel 1, SYCL.png right behind it
+        assert len(ps.atlas) == 3 + 1024 * 512 * 3 + 1280 * 559 * 3
+        tex = np.frombuffer(tb, dtype=np.uint8).reshape(n[2], 48)
+        img = tex[tex[:, :4].copy().view(np.int32)[:, 0] == abi.PT_TEX_IMAGE]
+        assert img[:, 28:40].copy().view(np.uint32).tolist() == [[1024, 512, 1], [1280, 559, 1 + 1024 * 512]]
+
+
+def test_example_main_missing_image_gets_the_fallback_texel(example_bin, tmp_path):
+    """texture.hpp:106-111: a load failure is a message on stderr and the 1x1 texture at offset 0 — never an error exit."""
+    (tmp_path / "imgs").mkdir()
+    (tmp_path / "imgs" / "SYCL.ppm").write_bytes(b"P3\n1 1\n255\n0 0 0\n")  # a format this host does not decode
+    out = tmp_path / "smoke.bin"
+    r = subprocess.run([str(example_bin), "40", "22", "1", str(tmp_path / "x.ppm"), str(out), str(tmp_path / "imgs")],
+                       check=True, capture_output=True, text=True)
+    assert r.stderr.count("ERROR: Could not load texture image file") == 2
+    assert "can't fopen" in r.stderr and "unknown image type" in r.stderr
+    n, (hb, mb, tb, cb) = read_dump(out)
+    ps, _ = scenes.build("smoke", textures="procedural")
+    assert n[0] == ps.n_hittables
+    tex = np.frombuffer(tb, dtype=np.uint8).reshape(n[2], 48)
+    kinds = tex[:, :4].copy().view(np.int32)[:, 0]
+    img = tex[kinds == abi.PT_TEX_IMAGE]
+    assert len(img) == 2
+    whoff = img[:, 28:40].copy().view(np.uint32)  # PtTexture: kind, color0[3], color1[3], width, height, offset, freq
+    assert whoff.tolist() == [[1, 1, 0], [1, 1, 0]]
+    assert img[:, 40:44].copy().view(np.float32)[:, 0].tolist() == [1.0, 5.0]
 
 
 @pytest.mark.gpu
-def test_example_main_renders_the_python_frame(example_bin, tmp_path, orc):
+def test_example_main_renders_the_python_frame(example_bin, tmp_path, images_dir, orc):
     from path_tracer_amd import render as R
     ppm = tmp_path / "out.ppm"
-    subprocess.run([str(example_bin), "96", "54", "8", str(ppm)], check=True)
+    subprocess.run([str(example_bin), "96", "54", "8", str(ppm), "-", str(images_dir)], check=True)
     raw = ppm.read_bytes()
     header, body = raw.split(b"\n255\n", 1)
     assert header.startswith(b"P6\n96 54")

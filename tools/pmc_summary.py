@@ -1,7 +1,7 @@
 """Aggregate rocprofv3 --pmc counter_collection CSVs (one pass per CSV) into one JSON summary for the
 render kernel: per-launch counter sums plus the derived figures DESIGN.md quotes.
 
-  python tools/pmc_summary.py profiles/r01 1920 1080 1024 profiles/r01_pmc_*.csv > profiles/r01_pmc_summary.json
+  python tools/pmc_summary.py r02_smoke smoke 1920 1080 1024 profiles/r02_smoke_pmc_*.csv > profiles/r02_smoke_pmc_summary.json
 """
 import collections
 import csv
@@ -10,12 +10,12 @@ import sys
 
 
 def main():
-    tag, w, h, spp = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+    tag, scene, w, h, spp = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
     # A render is two launches of the render kernel (a short cost-probe pass, then the frame): report the
     # frame launch = the dispatch with the largest value, per counter.
     disp = collections.defaultdict(lambda: collections.defaultdict(float))
     meta = {}
-    for path in sys.argv[5:]:
+    for path in sys.argv[6:]:
         for r in csv.DictReader(open(path)):
             if "render_kernel" not in r["Kernel_Name"]:
                 continue
@@ -23,7 +23,7 @@ def main():
             meta = {k: r[k] for k in ("Kernel_Name", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Grid_Size", "Workgroup_Size")}
     per = {k: max(v.values()) for k, v in disp.items()}
     samples = w * h * spp
-    out = {"tag": tag, "scene": "cornell", "workload": f"{w}x{h}x{spp}", "kernel": meta, "per_launch": per, "derived": {}}
+    out = {"tag": tag, "scene": scene, "workload": f"{w}x{h}x{spp}", "kernel": meta, "per_launch": per, "derived": {}}
     d = out["derived"]
     if "GRBM_GUI_ACTIVE" in per:
         cyc = per["GRBM_GUI_ACTIVE"] / 8  # summed over the 8 XCDs
