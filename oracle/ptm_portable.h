@@ -4,7 +4,7 @@
  * TEST INFRASTRUCTURE ONLY (see oracle/README.md).  Nothing under
  * path_tracer_amd/ includes this file; the HIP kernels carry their own
  * restatement of the same published algorithms in csrc/pt_math.hpp, and
- * tests/test_math_parity.py checks the two bit-for-bit on the GPU.
+ * tests/test_gpu_parity.py::test_math_bit_exact checks the two bit-for-bit on the GPU.
  *
  * Why it exists: the reference calls sycl::sin/cos/log/pow/atan2/asin/fmod
  * (rtweekend.hpp:75-79, texture.hpp:43-44,140-143, material.hpp:65,

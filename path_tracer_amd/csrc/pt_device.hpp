@@ -729,6 +729,40 @@ __device__ __forceinline__ void merge_stage(HitState& s) {
   }
 }
 
+// The three steps of the dynamic cooperative mode as separate pieces (used by the LDS-tile streaming kernel, whose scan is
+// spread over many workgroup-synchronous tiles; hit_world_lds below has them inline).
+// group size for a wave with 1 <= nlive <= 32 live rays: G = 64 >> ceil(log2 nlive)
+__device__ __forceinline__ int coop_group_log(int nlive) {
+  return nlive == 1 ? 6 : 6 - (32 - __builtin_clz((unsigned)(nlive - 1)));
+}
+// hand every live ray (+ its context) to a group of G lanes: group g serves the g-th live lane; surplus groups shadow ray 0
+__device__ __forceinline__ void coop_handoff(RayCtx& c, unsigned long long live_mask, int nlive, int logG) {
+  const int group = (threadIdx.x & 63) >> logG;
+  const int owner = nth_set_bit(live_mask, group < nlive ? group : 0);
+  c.r.o = mk(shfl_f(c.r.o.x, owner), shfl_f(c.r.o.y, owner), shfl_f(c.r.o.z, owner));
+  c.r.d = mk(shfl_f(c.r.d.x, owner), shfl_f(c.r.d.y, owner), shfl_f(c.r.d.z, owner));
+  c.r.tm = shfl_f(c.r.tm, owner);
+  c.a = shfl_f(c.a, owner);
+  c.yx = shfl_f(c.yx, owner); c.yy = shfl_f(c.yy, owner); c.yz = shfl_f(c.yz, owner);
+  c.reg = true; // cooperative mode is entered only when every live ray is regular
+}
+// butterfly over the G partial winners of every group, then each owner reads its group's result
+template <bool IMG>
+__device__ __forceinline__ void coop_merge_handback(HitState& s, unsigned long long live_mask, bool live, int logG) {
+  merge_stage<IMG, 1>(s);
+  if (logG > 1) merge_stage<IMG, 2>(s);
+  if (logG > 2) merge_stage<IMG, 4>(s);
+  if (logG > 3) merge_stage<IMG, 8>(s);
+  if (logG > 4) merge_stage<IMG, 16>(s);
+  if (logG > 5) merge_stage<IMG, 32>(s);
+  const int lane = threadIdx.x & 63;
+  const int my_rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(live_mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)live_mask, 0u));
+  const int my_leader = live ? (my_rank << logG) : lane;
+  s.closest = shfl_f(s.closest, my_leader);
+  s.hit = shfl_i(s.hit, my_leader);
+  if (IMG) { s.u = shfl_f(s.u, my_leader); s.v = shfl_f(s.v, my_leader); }
+}
+
 // hit_world for the LDS-resident kernel, ordinary and cooperative mode in ONE instantiation of the record loops
 // (two copies cost ~45 VGPRs = one to two waves of occupancy).  Ordinary mode is the degenerate case G = 1: every
 // lane is its own group, its segment is the whole list, nothing is shuffled or merged.

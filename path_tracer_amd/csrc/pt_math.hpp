@@ -11,7 +11,7 @@
 // binary32.  Same published algorithms (Sun fdlibm lineage: k_sin, k_cos,
 // medium-range rem_pio2, s_atan, e_atan2, atanh-series log) and therefore the
 // same bits on any IEEE machine; they land within 1 ulp of glibc's float
-// functions (tests/test_math_parity.py states the measured bound).
+// functions (tests/test_math_cpu.py states the measured bound; tests/test_gpu_parity.py::test_math_bit_exact checks GPU == oracle copy).
 //
 // Rare in the instruction mix (shading only, never in the primitive loop), so
 // fp64 throughput is not a concern.

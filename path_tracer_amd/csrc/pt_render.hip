@@ -18,6 +18,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <type_traits>
 #include <string>
 #include <vector>
@@ -367,6 +369,13 @@ void render_kernel(KArgs a) {
 constexpr int kTileF4 = 2016;      // 32,256 B; a multiple of every record size (2, 3, 4 f4); five workgroups per CU
 constexpr int kSmallRunF4 = 48;    // runs this short are read through the scalar cache instead (no barriers)
 
+// Tail of such a frame: a pixel is one sequential chain and a full scan of the list is long (100 k triangles: ~15 ms per
+// workgroup iteration), so the heaviest pixels (8-15 rays per sample against a mean of 2) keep a few lanes busy long after
+// the queue is empty, while the lock-step scan costs the same whether 1 or 64 lanes of a wave are live.  So a wave that is
+// down to <= 32 live rays spreads each of them over G = 64 >> ceil(log2 live) lanes for the whole scan (lane j of a group
+// tests every G-th record of each tile; one butterfly merge with the reference's acceptance rule at the end: see
+// hit_world_lds), and a wave with no live ray only keeps the barriers.  Scenes with a constant_medium (in-traversal RNG
+// draw) or stale-u,v hazards scan the ordinary way.
 template <int UV>
 __global__ __launch_bounds__(kBlock) void render_kernel_stream(KArgs a) {
   constexpr bool IMG = UV == UV_TRACKED;
@@ -376,6 +385,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel_stream(KArgs a) {
   lane_reset(L, (lds_fp) nullptr);
   if (a.depth <= 0) return;
   const cst_f4p cblob = (cst_f4p)a.blob;
+  const bool coop_scene = !IMG && a.coop_prefix >= a.n_hittables; // list splittable end to end (no medium)
   for (;;) {
     lane_prepare(L, a);
     if (!__syncthreads_or(L.live)) {
@@ -384,6 +394,15 @@ __global__ __launch_bounds__(kBlock) void render_kernel_stream(KArgs a) {
     }
     RayCtx c = make_ctx(L.ray, a.fast_ok != 0);
     const bool fast = wave_all_regular(c, L.live);
+    const unsigned long long live_mask = __builtin_amdgcn_ballot_w64(L.live);
+    const int nlive = __builtin_popcountll(live_mask);
+    const bool wave_idle = nlive == 0; // nothing to trace: this wave only copies tiles and keeps the barriers
+    int logG = 0;
+    if (coop_scene && fast && nlive >= 1 && nlive <= 32) {
+      logG = coop_group_log(nlive);
+      coop_handoff(c, live_mask, nlive, logG);
+    }
+    const int j = (threadIdx.x & 63) & ((1 << logG) - 1);
     HitState h;
     hit_begin(h);
     for (int ri = 0; ri < a.n_runs; ++ri) {
@@ -391,7 +410,10 @@ __global__ __launch_bounds__(kBlock) void render_kernel_stream(KArgs a) {
       const int kind = as_i(runf.x), off = as_i(runf.y), cnt = as_i(runf.z);
       const int sz = record_size(kind);
       if (cnt * sz <= kSmallRunF4) {
-        hit_records<IMG, 4>(cblob + off, kind, cnt, off, c, fast, L.rng, h);
+        if (!wave_idle) {
+          if (logG) hit_records_strided<IMG>(a.blob + off, kind, cnt, 0, off, j, logG, c, h);
+          else hit_records<IMG, 4>(cblob + off, kind, cnt, off, c, fast, L.rng, h);
+        }
         continue;
       }
       const int per_tile = kTileF4 / sz;
@@ -400,10 +422,14 @@ __global__ __launch_bounds__(kBlock) void render_kernel_stream(KArgs a) {
         const int nf4 = n * sz, base = off + first * sz;
         for (int i = threadIdx.x; i < nf4; i += kBlock) tile[i] = a.blob[base + i];
         __syncthreads();
-        hit_records<IMG, 4>((lds_f4p)tile, kind, n, base, c, fast, L.rng, h);
+        if (!wave_idle) {
+          if (logG) hit_records_strided<IMG>((lds_f4p)tile, kind, n, 0, base, j, logG, c, h);
+          else hit_records<IMG, 4>((lds_f4p)tile, kind, n, base, c, fast, L.rng, h);
+        }
         __syncthreads();
       }
     }
+    if (logG) coop_merge_handback<IMG>(h, live_mask, L.live, logG);
     lane_shade<UV>(L, a, h, a.blob, a.mats);
   }
 }
@@ -606,6 +632,26 @@ int fail(int code, const std::string& msg) {
     if (e_ != hipSuccess) return fail(PT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
   } while (0)
 
+// Tuning knobs (environment), read once per scene in pt_scene_create — never on the launch path.
+struct EnvKnobs {
+  int blocks_per_cu = 0;   // PT_BLOCKS_PER_CU: cap on resident workgroups per CU (0 = none)
+  bool no_cold_lds = false; // PT_NO_COLD_LDS
+  int wide_logG = 0;       // PT_WIDE_LOGG: forced log2 group size of the wide phase (0 = the model picks)
+  bool has_split_tiles = false;
+  int split_tiles = 0;     // PT_SPLIT_TILES: fixed number of tiles through the wide phase (< 0: all)
+  EnvKnobs() {
+    if (const char* e = std::getenv("PT_BLOCKS_PER_CU")) blocks_per_cu = std::max(1, std::atoi(e));
+    no_cold_lds = std::getenv("PT_NO_COLD_LDS") != nullptr;
+    if (const char* e = std::getenv("PT_WIDE_LOGG")) wide_logG = std::min(6, std::max(1, std::atoi(e)));
+    if (const char* e = std::getenv("PT_SPLIT_TILES")) { has_split_tiles = true; split_tiles = std::atoi(e); }
+  }
+};
+
+struct EventPair { // RAII: no leak on an early return
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  ~EventPair() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }
+};
+
 template <typename T>
 struct DevBuf {
   T* p = nullptr;
@@ -638,6 +684,12 @@ struct PtScene {
   unsigned int* queues = nullptr; // ring of per-launch pixel-queue counters
   mutable unsigned int next_queue = 0;
   int device = 0;
+  // Scheduling state above marked `mutable` (queue ring cursor, LPT workspace, last-launch info) changes per launch although
+  // the scene DATA is immutable: launches on one scene from several host threads serialise their enqueue on this mutex
+  // (the kernels themselves still overlap on their streams).
+  mutable std::mutex sched;
+  mutable std::map<const void*, int> occupancy; // resident workgroups per CU, per kernel variant (queried once)
+  EnvKnobs knobs;                               // environment tuning knobs as they were when the scene was created
 };
 
 extern "C" {
@@ -804,6 +856,12 @@ int64_t pt_framebuffer_floats(const PtRenderParams* p) {
 }
 
 static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderParams* p, float* fb, hipStream_t st) {
+  int cur = -1;
+  PT_HIP(hipGetDevice(&cur));
+  if (cur != s->device)
+    return fail(PT_ERR_INVALID_ARG, "pt_render: the scene lives on device " + std::to_string(s->device) + " but the current device is " +
+                                        std::to_string(cur) + " (hipSetDevice to the scene's device first)");
+  std::lock_guard<std::mutex> lock(s->sched);
   KArgs a;
   std::memcpy(&a.cam, cam, sizeof(Cam));
   a.blob = s->blob; a.mats = s->mats; a.atlas = s->atlas; a.fb = fb;
@@ -839,8 +897,13 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
   // Persistent grid: no more workgroups than the chip holds at once; lanes pull pixels from the queue.
   auto launch = [&](auto kernel) -> int {
     int per_cu = 0;
-    PT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, shmem));
-    if (const char* e = std::getenv("PT_BLOCKS_PER_CU")) per_cu = std::min(per_cu, std::max(1, std::atoi(e))); // tuning knob
+    auto cached = s->occupancy.find((const void*)kernel);
+    if (cached != s->occupancy.end()) per_cu = cached->second;
+    else {
+      PT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, shmem));
+      s->occupancy[(const void*)kernel] = per_cu;
+    }
+    if (s->knobs.blocks_per_cu) per_cu = std::min(per_cu, s->knobs.blocks_per_cu); // tuning knob
     const int resident_blocks = std::max(1, per_cu) * std::max(1, s->num_cus);
     a.queue = s->queues + 2 * (s->next_queue++ % kQueueRing); // [0] ordinary queue, [1] wide-phase queue
     PT_HIP(hipMemsetAsync(a.queue, 0, 2 * sizeof(unsigned int), st));
@@ -859,7 +922,7 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
     if (!lds) return launch(render_kernel<UV, false, false, false>);
     if (coop) return mlds ? launch(render_kernel<UV, true, true, true>) : launch(render_kernel<UV, true, false, true>);
     if constexpr (UV == UV_NONE) { // small scene: cold lane state in LDS (7 workgroups x (scene + 8 KB) per CU)
-      if (mlds && shmem <= kMaxLdsColdScene && !std::getenv("PT_NO_COLD_LDS")) return launch(render_kernel<UV, true, true, false, true>);
+      if (mlds && shmem <= kMaxLdsColdScene && !s->knobs.no_cold_lds) return launch(render_kernel<UV, true, true, false, true>);
     }
     return mlds ? launch(render_kernel<UV, true, true, false>) : launch(render_kernel<UV, true, false, false>);
   };
@@ -886,15 +949,14 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
     int rc = launch_variant();
     if (rc) return rc;
     // rough per-iteration instruction counts: traversal (splittable) vs shading + camera + cooperative overhead (not)
-    int forced_logG = 0; // 0: the model picks the group size of the wide phase
-    if (const char* e = std::getenv("PT_WIDE_LOGG")) forced_logG = std::min(6, std::max(1, std::atoi(e))); // tuning knob
+    const int forced_logG = s->knobs.wide_logG; // 0: the model picks the group size of the wide phase
     // rough per-iteration instruction counts: traversal (splittable) vs shading + camera (not)
     hipLaunchKernelGGL(lpt_order_kernel, dim3(1), dim3(1024), 0, st, s->ws_cost, local_tiles, s->ws_order, n_waves_resident,
                        std::max(1.0f, s->traversal_cost), 420.0f, forced_logG, coop ? s->ws_nsplit : nullptr);
     PT_HIP(hipGetLastError());
-    if (const char* e = std::getenv("PT_SPLIT_TILES")) { // tuning knob: fixed number of split tiles (< 0: all)
+    if (s->knobs.has_split_tiles) { // tuning knob: fixed number of split tiles (< 0: all)
       if (coop) {
-        const int k = std::atoi(e);
+        const int k = s->knobs.split_tiles;
         s->nsplit_override = k < 0 ? local_tiles : std::min(k, local_tiles);
         PT_HIP(hipMemcpyAsync(s->ws_nsplit, &s->nsplit_override, sizeof(int), hipMemcpyHostToDevice, st));
       }
@@ -923,19 +985,16 @@ int pt_render_timed(const PtScene* scene, const PtCamera* cam, const PtRenderPar
   int rc = check_params(p);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
-  hipEvent_t e0, e1;
-  PT_HIP(hipEventCreate(&e0));
-  PT_HIP(hipEventCreate(&e1));
-  PT_HIP(hipEventRecord(e0, st));
+  EventPair ev;
+  PT_HIP(hipEventCreate(&ev.e0));
+  PT_HIP(hipEventCreate(&ev.e1));
+  PT_HIP(hipEventRecord(ev.e0, st));
   rc = launch_render(scene, cam, p, fb_device, st);
-  if (rc == PT_OK) {
-    PT_HIP(hipEventRecord(e1, st));
-    PT_HIP(hipEventSynchronize(e1));
-    PT_HIP(hipEventElapsedTime(kernel_ms, e0, e1));
-  }
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
-  return rc;
+  if (rc != PT_OK) return rc;
+  PT_HIP(hipEventRecord(ev.e1, st));
+  PT_HIP(hipEventSynchronize(ev.e1));
+  PT_HIP(hipEventElapsedTime(kernel_ms, ev.e0, ev.e1));
+  return PT_OK;
 }
 
 int pt_render_host(const PtScene* scene, const PtCamera* cam, const PtRenderParams* p, float* fb_host) {

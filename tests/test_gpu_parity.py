@@ -4,7 +4,7 @@ against the CPU oracle on the same seeded inputs.
 Bar: BIT-EXACT float32 (any NaN == any NaN) against the oracle in portable-math mode — the project's
 pinned definition of the seven transcendentals — for every function-level probe and every framebuffer;
 against the oracle in glibc mode (the reference's own libm semantics on this host) the comparison is
-statistical because one differing ulp re-rolls a pixel's RNG stream: 8-bit PSNR >= 35 dB
+statistical because one differing ulp re-rolls a pixel's RNG stream: 8-bit PSNR >= 38 dB
 at 96x54x16 spp and mean radiance within 2 %.  Scenes without transcendentals (Cornell) are bit-exact in
 both modes."""
 import ctypes as C
@@ -234,7 +234,7 @@ def test_config1_smoke_scene_400x225x64(orc):
     orc.set_math(False)
     ref_libm = orc.render(ps, c.c, 400, 225, 64)
     p = psnr_8bit(orc.tonemap_rgb8(fb), orc.tonemap_rgb8(ref_libm))
-    assert p >= 35.0, f"PSNR vs glibc oracle {p:.1f} dB"
+    assert p >= 38.0, f"PSNR vs glibc oracle {p:.1f} dB"  # BASELINE.md §4's bar; measured 83.5 dB (99.8 % of the pixels bit-identical)
     assert abs(fb.mean() / ref_libm.mean() - 1) < 0.02
 
 
@@ -246,7 +246,7 @@ def test_vs_glibc_oracle_statistical(orc, name):
     orc.set_math(False)
     ref = orc.render(ps, c.c, 96, 54, 16)
     p = psnr_8bit(orc.tonemap_rgb8(fb), orc.tonemap_rgb8(ref))
-    assert p >= 35.0, f"{name}: PSNR {p:.1f} dB"
+    assert p >= 38.0, f"{name}: PSNR {p:.1f} dB"  # BASELINE.md §4's bar; measured: identical 8-bit images
     assert abs(np.nanmean(fb) / np.nanmean(ref) - 1) < 0.02
 
 
@@ -275,6 +275,31 @@ def test_streaming_kernel_agrees(name):
     a = R.render_host(64, 40, 8, ps, c)
     b = R.render_host(64, 40, 8, ps, c, flags=abi.PT_FLAG_FORCE_STREAM)
     assert_bit_identical(a, b, name)
+
+
+@pytest.mark.parametrize("name", ["cornell", "spheres", "triangles", "ties", "mixed"])
+@pytest.mark.parametrize("size", [(1, 1), (2, 1), (3, 1), (5, 1), (3, 3), (17, 1), (8, 4), (33, 1), (40, 2)])
+def test_streaming_kernel_cooperative_tail(orc, name, size):
+    """The streaming kernel spreads the rays of a wave that is down to <= 32 live lanes over groups of G = 64 >>
+    ceil(log2 live) lanes (G = 64, 32, 16, 8, 4, 2 for these frame sizes; 33 and 80 pixels: ordinary scan, then the tail)
+    — bit-identical to the oracle, ties included ("mixed" has media: it must take the ordinary scan)."""
+    w, h = size
+    ps, cam = S.ALL[name]()
+    c = scenes.make_camera(cam, w, h)
+    orc.set_math(True)
+    ref = orc.render(ps, c.c, w, h, 6)
+    assert_bit_identical(R.render_host(w, h, 6, ps, c, flags=abi.PT_FLAG_FORCE_STREAM | abi.PT_FLAG_PIXEL_GRANULAR), ref, f"{name} {w}x{h}")
+    assert_bit_identical(R.render_host(w, h, 6, ps, c, flags=abi.PT_FLAG_FORCE_STREAM | abi.PT_FLAG_NO_COOP), ref, f"{name} {w}x{h} no coop")
+
+
+def test_streaming_kernel_cooperative_tail_many_tiles(orc):
+    """3 000 triangles (several LDS tiles) with few live rays: the strided scan across tile boundaries + small runs either
+    side, against the oracle."""
+    ps, cam = S.triangles_scene(3000)
+    orc.set_math(True)
+    for w, h in ((3, 2), (16, 2), (48, 27)):
+        c = scenes.make_camera(cam, w, h)
+        assert_bit_identical(R.render_host(w, h, 5, ps, c, flags=abi.PT_FLAG_FORCE_STREAM), orc.render(ps, c.c, w, h, 5), f"{w}x{h}")
 
 
 def test_streaming_kernel_many_tiles(orc):
@@ -519,10 +544,10 @@ def test_full_size_cornell_1080p_sampled_pixels(torch_gpu, orc):
 
 
 def test_full_size_smoke_1080p_sampled_pixels(torch_gpu, orc):
-    """BASELINE.json configs[2] shape (the 496-hittable scene at 1920x1080; 256 of its 1024 spp to keep the test
-    short): cooperative kernel, cost-sorted order and split queue all active; 400 sampled pixels re-rendered by the
-    oracle at the same spp, bit for bit."""
-    w, h, spp = 1920, 1080, 256
+    """BASELINE.json configs[2] at FULL size (the 496-hittable scene with the reference's two image textures,
+    1920x1080, 1024 spp, depth 50): cooperative kernel, cost-sorted order and split queue all active; 400 sampled pixels
+    re-rendered by the oracle at full spp, bit for bit."""
+    w, h, spp = 1920, 1080, 1024
     ps, cam = scenes.build("smoke")
     c = scenes.make_camera(cam, w, h)
     fb, ms = R.render(w, h, spp, ps, c, timed=True)
@@ -531,23 +556,82 @@ def test_full_size_smoke_1080p_sampled_pixels(torch_gpu, orc):
     xy = np.stack([rng.integers(0, w, 400), rng.integers(0, h, 400)], axis=1).astype(np.int32)
     orc.set_math(True)
     assert_bit_identical(fbn[xy[:, 1], xy[:, 0]], orc.render_pixels(ps, c.c, w, h, spp, xy), "smoke 1080p sampled pixels")
-    print(f"\n[smoke 1080p {spp}spp] kernel {ms:.1f} ms = {w * h * spp / ms / 1e3:.1f} Msamples/s")
+    print(f"\n[cfg3 smoke 1080p {spp}spp] kernel {ms:.1f} ms = {w * h * spp / ms / 1e3:.1f} Msamples/s")
+
+
+@pytest.mark.parametrize("shard", [0, 5])
+def test_cfg4_shard_of_8_at_4k_4096spp(torch_gpu, orc, shard):
+    """BASELINE.json configs[3] (SmokeSphere, 3840x2160, 4096 spp, 8-way tile-sharded): what ONE of its eight GPUs
+    renders — shard `shard` of 8, full resolution, full spp — with sampled pixels of that shard re-rendered by the
+    oracle at full spp, bit for bit; the shard's tile layout is checked through the same sampled pixels."""
+    w, h, spp, n = 3840, 2160, 4096, 8
+    ps, cam = scenes.build("smoke")
+    c = scenes.make_camera(cam, w, h)
+    local, ms = R.render(w, h, spp, ps, c, shard_index=shard, shard_count=n, timed=True)
+    tiles = local.cpu().numpy()  # [tiles_per_shard][64][3]
+    tiles_x = (w + 7) // 8
+    rng = np.random.default_rng(40 + shard)
+    lt = rng.integers(0, tiles.shape[0] - 1, 160)  # local tile l is global tile l * n + shard (pt_render.h)
+    inner = rng.integers(0, 64, 160)
+    g = lt * n + shard
+    xy = np.stack([(g % tiles_x) * 8 + (inner & 7), (g // tiles_x) * 8 + (inner >> 3)], axis=1).astype(np.int32)
+    assert (xy[:, 0] < w).all() and (xy[:, 1] < h).all()
+    orc.set_math(True)
+    assert_bit_identical(tiles[lt, inner], orc.render_pixels(ps, c.c, w, h, spp, xy), f"cfg4 shard {shard}/8 sampled pixels")
+    samples = tiles.shape[0] * 64 * spp
+    print(f"\n[cfg4 shard {shard}/8 of 4K x {spp}spp] kernel {ms:.1f} ms = {samples / ms / 1e3:.1f} Msamples/s on this GPU")
 
 
 def test_full_size_triangle_mesh_1080p_sampled_pixels(torch_gpu, orc):
-    """BASELINE config 5 at full geometry: 100 000 triangles (4.8 MB of records, 149 LDS tiles per ray, four triangles per
-    trip of the scan) at 1920x1080; 17 spp so that the cost-probe pass and the heaviest-first order run too.  96 sampled
-    pixels are re-rendered by the oracle at full spp."""
+    """BASELINE.json configs[4] at FULL size: 100 000 triangles (4.8 MB of records streamed through LDS tiles) + ground
+    sphere + emissive rect, 1920x1080, 256 spp.  64 sampled pixels are re-rendered by the oracle at full spp."""
     ps, cam = scenes.build("triangles", n_triangles=100_000)
-    w, h, spp = 1920, 1080, 17
+    w, h, spp = 1920, 1080, 256
     c = scenes.make_camera(cam, w, h)
     fb, ms = R.render(w, h, spp, R.DeviceScene(ps), c, timed=True)
     fbn = fb.cpu().numpy()
     rng = np.random.default_rng(99)
-    xy = np.stack([rng.integers(0, w, 96), rng.integers(0, h, 96)], axis=1).astype(np.int32)
+    xy = np.stack([rng.integers(0, w, 64), rng.integers(0, h, 64)], axis=1).astype(np.int32)
     orc.set_math(True)
     assert_bit_identical(fbn[xy[:, 1], xy[:, 0]], orc.render_pixels(ps, c.c, w, h, spp, xy), "100k triangles 1080p sampled pixels")
-    print(f"\n[triangles 1080p {spp}spp] kernel {ms:.1f} ms = {w * h * spp / ms / 1e3:.2f} Msamples/s")
+    print(f"\n[cfg5 triangles 1080p {spp}spp] kernel {ms:.1f} ms = {w * h * spp / ms / 1e3:.2f} Msamples/s")
+
+
+def test_cfg1_reference_textures_full_frame_and_png(torch_gpu, orc, tmp_path):
+    """BASELINE.json configs[0]: the default SmokeSphere scene with the REAL image textures (decoded Xilinx.jpg /
+    SYCL.png from tests/golden/cfg1_textures.npz at the atlas offsets of texture.hpp:113-114), 400x225, 64 spp: every
+    pixel bit-exact against the oracle, and out.png written through the device output stage (pt_tonemap_rgb8) + png.py
+    decodes to the oracle's 8-bit image (main.cpp:33-59)."""
+    import zlib
+    from path_tracer_amd.png import write_png
+    torch = torch_gpu
+    w, h, spp = 400, 225, 64
+    ps, cam = scenes.build("smoke")
+    assert len(ps.atlas) == 3 + 1024 * 512 * 3 + 1280 * 559 * 3
+    c = scenes.make_camera(cam, w, h)
+    fb = R.render(w, h, spp, ps, c)
+    rgb8 = R.tonemap_rgb8(fb)
+    torch.cuda.synchronize()
+    orc.set_math(True)
+    ref = orc.render(ps, c.c, w, h, spp)
+    assert_bit_identical(fb.cpu().numpy(), ref, "cfg1 with the reference textures")
+    np.testing.assert_array_equal(rgb8.cpu().numpy(), orc.tonemap_rgb8(ref))
+    out = tmp_path / "out.png"
+    write_png(out, rgb8.cpu().numpy())
+    raw = out.read_bytes()
+    assert raw[:8] == b"\x89PNG\r\n\x1a\n"
+    idat, pos = b"", 8
+    while pos < len(raw):  # minimal PNG reader: concatenate IDAT, undo filter type 0 rows
+        ln = int.from_bytes(raw[pos:pos + 4], "big"); kind = raw[pos + 4:pos + 8]
+        if kind == b"IDAT":
+            idat += raw[pos + 8:pos + 8 + ln]
+        pos += 12 + ln
+    rows = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, 1 + w * 3)
+    assert (rows[:, 0] == 0).all()
+    np.testing.assert_array_equal(rows[:, 1:].reshape(h, w, 3), orc.tonemap_rgb8(ref))
+    # the image textures really are on screen: the logo sphere (top left) shows the SYCL logo's yellow and red
+    top = orc.tonemap_rgb8(ref)[:60, 60:140].reshape(-1, 3).astype(int)
+    assert ((top[:, 0] > 150) & (top[:, 1] > 150) & (top[:, 2] < 110)).sum() > 200
 
 
 def test_full_size_1080p_full_frame_low_spp(orc):
