@@ -24,6 +24,10 @@
 
 #include "pt_math.hpp"
 
+#ifdef PT_STAMPS
+extern __device__ unsigned long long g_stamps[8]; // diagnostic build only (pt_render.hip)
+#endif
+
 namespace ptd {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -46,6 +50,9 @@ __device__ __forceinline__ int hit_off(int h) { return h & 0xffffff; }
 __device__ __forceinline__ float as_f(int i) { return __int_as_float(i); }
 __device__ __forceinline__ int as_i(float f) { return __float_as_int(f); }
 
+#ifndef PT_COOP_TRIP
+#define PT_COOP_TRIP 4 /* spheres / triangles per trip in the cooperative kernels' ordinary scan */
+#endif
 #define PT_INF (__builtin_inff())
 #define PT_PI 3.1415926535897932385f /* rtweekend.hpp:22 */
 #define PT_TMIN 0.001f               /* render.hpp:40 */
@@ -468,19 +475,87 @@ struct HitState {
 };
 __device__ __forceinline__ void hit_begin(HitState& h) { h.closest = PT_INF; h.hit = -1; h.u = 0.0f; h.v = 0.0f; }
 
+// ---- a run of spheres, in list order ----------------------------------------------------------------------------------
+// In front of a sphere run's records the flattener puts (pt_flatten.hpp: put_sphere_run_aux)
+//     [ceil(n/128) f4: bit i = sphere i of the run is moving]  [aux f4 = (time0, time1, number of mask f4, flags)]
+// flags bit 0: every moving sphere of the run has the shutter interval (time0, time1) — then the time fraction of
+// sphere.hpp:54 is ONE division per ray and run; bit 1: the run has a moving sphere at all.
+// Why: with the "moving" flag only inside the record (sign of R0.w) every sphere cost a full LDS round trip before the
+// wave knew whether to fetch R2 = center1 - center0, and a second one if so; the scan of the 496-hittable scene spent 48 %
+// of its wave-cycles in s_waitcnt with 60 % VALU issue.  The mask is read through the scalar cache (one dword per 32
+// spheres), so a trip knows up front which records it needs: it issues the first records of K spheres and the R2 of the
+// moving ones together (one exposed LDS latency per trip instead of one or two per sphere), evaluates the K discriminants
+// back to back and takes the roots in list order.  Same operations on the same operands as sphere.hpp:51-56,68-72.
+typedef const __attribute__((address_space(4))) int* cst_ip;
+
+template <int K, typename P, typename AcceptAt>
+__device__ __forceinline__ void sphere_trip(P recs, int o, unsigned int bits, float frac, const RayCtx& c, HitState& h,
+                                            AcceptAt accept_at) {
+  const Ray& r = c.r;
+  f4 R0[K], R2[K];
+#pragma unroll
+  for (int k = 0; k < K; k++) R0[k] = recs[o + k * SZ_SPHERE];
+#pragma unroll
+  for (int k = 0; k < K; k++)
+    if ((bits >> k) & 1u) R2[k] = recs[o + k * SZ_SPHERE + 2]; // scalar condition: fetched only for the moving ones (and only read for them)
+  SphereEval e[K];
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    V3 center = xyz(R0[k]);
+    if ((bits >> k) & 1u) { // a real (scalar) branch: if-converted it costs every static sphere 6 VALU + 3 selects
+      asm volatile("" ::: "memory");
+      center = center + frac * xyz(R2[k]); // sphere.hpp:54-55
+    }
+    V3 oc = r.o - center;
+    float b = dot(oc, r.d);
+    float cc = dot(oc, oc) - __builtin_fabsf(R0[k].w);
+    e[k] = SphereEval{b, b * b - c.a * cc};
+  }
+#pragma unroll
+  for (int k = 0; k < K; k++) sphere_finish(e[k], c, PT_TMIN, h.closest, true, accept_at(o + k * SZ_SPHERE));
+}
+
+// n records at recs[0..); record i of this call is sphere (first + i) of the run whose records start at blob offset run_off.
+template <int TRIP, typename P, typename AcceptAt>
+__device__ __forceinline__ void sphere_scan(P recs, cst_f4p cblob, int n, int run_off, int first, const RayCtx& c, HitState& h,
+                                            AcceptAt accept_at) {
+  const f4 aux = cblob[run_off - 1];
+  const int flags = as_i(aux.w);
+  if (!(flags & 1)) { // moving spheres with different shutter intervals: one sphere at a time, fraction memoised
+    TimeFrac tf = time_frac_none();
+    for (int i = 0, off = 0; i < n; ++i, off += SZ_SPHERE) sphere_roots(recs, off, c, PT_TMIN, h.closest, true, tf, accept_at(off));
+    return;
+  }
+  float frac = 0.0f;
+  if (flags & 2) frac = (c.r.tm - aux.x) / (aux.y - aux.x); // (time - time0) / (time1 - time0)  sphere.hpp:54
+  const cst_ip maskw = (cst_ip)(cblob + (run_off - 1 - as_i(aux.z)));
+  for (int base = 0; base < n; base += 32) { // first is a multiple of 32 (whole run, or an LDS tile of 672 spheres)
+    const unsigned int m = (unsigned int)maskw[(first + base) >> 5];
+    asm volatile("" ::"s"(m)); // have the mask word in its SGPR here: scalar loads and LDS reads share lgkmcnt, and a wait for
+                               // it inside a trip would drain that trip's first-record reads before the R2 reads are issued
+    const int lim = min(32, n - base);
+    int q = 0;
+    if constexpr (TRIP >= 4)
+      for (; q + 3 < lim; q += 4) sphere_trip<4>(recs, (base + q) * SZ_SPHERE, m >> q, frac, c, h, accept_at);
+    if constexpr (TRIP >= 2)
+      for (; q + 1 < lim; q += 2) sphere_trip<2>(recs, (base + q) * SZ_SPHERE, m >> q, frac, c, h, accept_at);
+    for (; q < lim; ++q) sphere_trip<1>(recs, (base + q) * SZ_SPHERE, m >> q, frac, c, h, accept_at);
+  }
+}
+
+
 // n records of one kind at recs[0..): record i is blob offset goff + i*size.  `recs` is either the resident
 // blob (LDS or scalar-cached) advanced to the run, or an LDS tile of a streamed run.
-// TRIP: how many spheres / triangles a trip of those loops evaluates together (see "several records per trip" below).
+// TRIP / TTRIP: how many spheres / triangles a trip of those loops evaluates together (see "several records per trip" below).
 // Every resident kernel contains all the loops, and the ones that run at a 72-register budget (7 waves) pay for a wide
 // triangle loop with spills around EVERY scan, triangles or not: they take TRIP = 1; the cooperative and the streaming
 // kernels, which have registers to spare, take 2 spheres / 4 triangles.
-template <bool IMG, int TRIP = 1, typename P>
-__device__ __forceinline__ void hit_records(P recs, int kind, int n, int goff, const RayCtx& c, bool fast,
-                                            uint32_t& rng, HitState& h) {
+template <bool IMG, int TRIP = 1, int TTRIP = TRIP, typename P>
+__device__ __forceinline__ void hit_records(P recs, cst_f4p cblob, int kind, int n, int goff, int run_off, int first,
+                                            const RayCtx& c, bool fast, uint32_t& rng, HitState& h) {
   const Ray& r = c.r;
   int off = 0;
   if (kind == DK_SPHERE) {
-    TimeFrac tf = time_frac_none();
     auto accept_at = [&](int o) {
       return [&h, &r, recs, goff, o](float t) {
         h.closest = t;
@@ -495,17 +570,7 @@ __device__ __forceinline__ void hit_records(P recs, int kind, int n, int goff, c
         }
       };
     };
-    int i = 0;
-    // two spheres per trip: both first records in flight together, two independent arithmetic chains, half the loop
-    // control; the roots are still taken in list order (the second sees the first's closest)
-    if constexpr (TRIP >= 2) {
-      for (; i + 1 < n; i += 2, off += 2 * SZ_SPHERE) {
-        const SphereEval A = sphere_eval(recs, off, c, tf), B = sphere_eval(recs, off + SZ_SPHERE, c, tf);
-        sphere_finish(A, c, PT_TMIN, h.closest, true, accept_at(off));
-        sphere_finish(B, c, PT_TMIN, h.closest, true, accept_at(off + SZ_SPHERE));
-      }
-    }
-    for (; i < n; ++i, off += SZ_SPHERE) sphere_roots(recs, off, c, PT_TMIN, h.closest, true, tf, accept_at(off));
+    sphere_scan<TRIP>(recs, cblob, n, run_off, first, c, h, accept_at);
   } else if (kind == DK_RECT) {
     for (int i = 0; i < n; ++i, off += SZ_RECT) {
       f4 R0 = recs[off], R1 = recs[off + 1];
@@ -526,13 +591,13 @@ __device__ __forceinline__ void hit_records(P recs, int kind, int n, int goff, c
     auto finish_at = [&](int o, TriEval e) { // re-reads the records: only inside the rare branch
       if (e.pass) tri_finish(recs[o], recs[o + 1], recs[o + 2], r, e, PT_TMIN, h.closest, true, accept_at(o));
     };
-    if constexpr (TRIP >= 4) {
+    if constexpr (TTRIP >= 4) {
       for (; i + 3 < n; i += 4, off += 4 * SZ_TRI) {
         const TriEval ea = eval_at(off), eb = eval_at(off + SZ_TRI), ec = eval_at(off + 2 * SZ_TRI), ed = eval_at(off + 3 * SZ_TRI);
         finish_at(off, ea); finish_at(off + SZ_TRI, eb); finish_at(off + 2 * SZ_TRI, ec); finish_at(off + 3 * SZ_TRI, ed);
       }
     }
-    if constexpr (TRIP >= 2) {
+    if constexpr (TTRIP >= 2) {
       for (; i + 1 < n; i += 2, off += 2 * SZ_TRI) {
         const TriEval ea = eval_at(off), eb = eval_at(off + SZ_TRI);
         finish_at(off, ea); finish_at(off + SZ_TRI, eb);
@@ -641,18 +706,16 @@ __device__ __forceinline__ int record_size(int kind) {
 // Whole list, blob resident (LDS or scalar cache): blob = [n_runs x (kind, first record offset, count, -)] [records]
 // `headers` may be another view of the same blob: the LDS kernels read the run headers through the scalar cache (they are
 // kernel constants: an s_load lands in SGPRs directly, no LDS round trip + v_readfirstlane per run) and the records from LDS.
-template <bool IMG, typename P, typename H>
-__device__ __forceinline__ void hit_world(P blob, H headers, int n_runs, const RayCtx& c, bool fast, uint32_t& rng, HitState& h) {
+// `cblob`: the blob in global memory through the scalar cache (run headers, sphere-run masks); `blob`: where the records are
+// read from (LDS copy, or the same global blob).
+template <bool IMG, typename P>
+__device__ __forceinline__ void hit_world(P blob, cst_f4p cblob, int n_runs, const RayCtx& c, bool fast, uint32_t& rng, HitState& h) {
   hit_begin(h);
   for (int ri = 0; ri < n_runs; ++ri) {
-    f4 runf = headers[ri];
+    f4 runf = cblob[ri];
     const int off = as_i(runf.y);
-    hit_records<IMG>(blob + off, as_i(runf.x), as_i(runf.z), off, c, fast, rng, h);
+    hit_records<IMG>(blob + off, cblob, as_i(runf.x), as_i(runf.z), off, off, 0, c, fast, rng, h);
   }
-}
-template <bool IMG, typename P>
-__device__ __forceinline__ void hit_world(P blob, int n_runs, const RayCtx& c, bool fast, uint32_t& rng, HitState& h) {
-  hit_world<IMG>(blob, blob, n_runs, c, fast, rng, h);
 }
 
 // Wave-uniform switch: the straight-line rect/box path is used only when every live lane's ray is regular.
@@ -767,7 +830,7 @@ __device__ __forceinline__ void coop_merge_handback(HitState& s, unsigned long l
 // (two copies cost ~45 VGPRs = one to two waves of occupancy).  Ordinary mode is the degenerate case G = 1: every
 // lane is its own group, its segment is the whole list, nothing is shuffled or merged.
 template <bool IMG, typename P>
-__device__ __forceinline__ void hit_world_lds(P blob, const CoopScene& cs, const Ray& my_ray, uint32_t& my_rng, bool live,
+__device__ __forceinline__ void hit_world_lds(P blob, cst_f4p cblob, const CoopScene& cs, const Ray& my_ray, uint32_t& my_rng, bool live,
                                               bool coop_allowed, bool scene_fast_ok, int wide_logG, HitState& h) {
   RayCtx c = make_ctx(my_ray, scene_fast_ok);
   const bool fast = wave_all_regular(c, live);
@@ -788,6 +851,10 @@ __device__ __forceinline__ void hit_world_lds(P blob, const CoopScene& cs, const
   }
   const int G = 1 << logG;
   const int group = lane >> logG, j = lane & (G - 1);
+#ifdef PT_STAMPS
+  if (lane == 0) { atomicAdd(&g_stamps[4], (unsigned long long)(logG > 0)); atomicAdd(&g_stamps[5], (unsigned long long)(handoff ? 1 : 0)); atomicAdd(&g_stamps[6], (unsigned long long)nlive); }
+  const unsigned long long st0 = __builtin_amdgcn_s_memtime();
+#endif
   uint32_t rng = my_rng;
   if (handoff) { // hand every live ray (+ its context and RNG state) to a group of G lanes
     const int owner = nth_set_bit(live_mask, group < nlive ? group : 0); // surplus groups shadow ray 0 (outcome unused)
@@ -825,7 +892,7 @@ __device__ __forceinline__ void hit_world_lds(P blob, const CoopScene& cs, const
     if (cnt <= 0) continue;
     // (idle lanes scan too and their outcome is dropped: a per-lane skip would put the whole scan under exec-mask
     // branches — the ordinary kernels do the same)
-    if (merged) hit_records<IMG, 2>(blob + off, kind, cnt, off, c, fast, rng, s);
+    if (merged) hit_records<IMG, PT_COOP_TRIP, 2>(blob + off, cblob, kind, cnt, off, off, 0, c, fast, rng, s);
     else hit_records_strided<IMG>(blob + off, kind, cnt, first, off, j, logG, c, s);
   }
   if (handoff) { // hand each owner its result: the r-th live lane reads from (a lane of) group r
@@ -838,6 +905,10 @@ __device__ __forceinline__ void hit_world_lds(P blob, const CoopScene& cs, const
   }
   h = s;
   if (live) my_rng = rng;
+#ifdef PT_STAMPS
+  asm volatile("" ::"v"(h.closest), "v"(h.hit));
+  if (lane == 0 && logG > 0) atomicAdd(&g_stamps[7], __builtin_amdgcn_s_memtime() - st0);
+#endif
 }
 
 

@@ -28,6 +28,10 @@
 #include "pt_device.hpp"
 #include "pt_flatten.hpp"
 
+#ifdef PT_STAMPS
+__device__ unsigned long long g_stamps[8];
+#endif
+
 using namespace ptd;
 
 static_assert(sizeof(PtHittable) == 64 && sizeof(PtMaterial) == 32 && sizeof(PtTexture) == 48 && sizeof(PtCamera) == 96);
@@ -281,7 +285,6 @@ __device__ __forceinline__ void lane_prepare(Lane& L, const KArgs& a) {
 #ifdef PT_STAMPS
 // Diagnostic build only (`make stamps` -> libpt_stamps.so; never shipped, never timed): s_memtime shares of one loop
 // iteration of the resident kernels, summed over waves; read with pt_debug_stamps / tools/stamps.py.
-__device__ unsigned long long g_stamps[8];
 #define PT_STAMP(var) unsigned long long var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0)
 #endif
 
@@ -330,7 +333,7 @@ void render_kernel(KArgs a) {
       if constexpr (COOP) {
         // ordinary and cooperative traversal (few live lanes: each live ray's list split over the idle lanes)
         const CoopScene cs{a.n_runs, a.coop_prefix};
-        hit_world_lds<IMG>((lds_f4p)smem, cs, L.ray, L.rng, L.live, true, a.fast_ok != 0, L.wide, h);
+        hit_world_lds<IMG>((lds_f4p)smem, (cst_f4p)a.blob, cs, L.ray, L.rng, L.live, true, a.fast_ok != 0, L.wide, h);
       } else {
         RayCtx c = make_ctx(L.ray, a.fast_ok != 0);
         const bool fast = wave_all_regular(c, L.live);
@@ -350,7 +353,7 @@ void render_kernel(KArgs a) {
     } else {
       RayCtx c = make_ctx(L.ray, a.fast_ok != 0);
       const bool fast = wave_all_regular(c, L.live);
-      hit_world<IMG>((cst_f4p)a.blob, a.n_runs, c, fast, L.rng, h);
+      hit_world<IMG>((cst_f4p)a.blob, (cst_f4p)a.blob, a.n_runs, c, fast, L.rng, h);
       lane_shade<UV>(L, a, h, a.blob, a.mats);
     }
   }
@@ -412,7 +415,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel_stream(KArgs a) {
       if (cnt * sz <= kSmallRunF4) {
         if (!wave_idle) {
           if (logG) hit_records_strided<IMG>(a.blob + off, kind, cnt, 0, off, j, logG, c, h);
-          else hit_records<IMG, 4>(cblob + off, kind, cnt, off, c, fast, L.rng, h);
+          else hit_records<IMG, 4>(cblob + off, cblob, kind, cnt, off, off, 0, c, fast, L.rng, h);
         }
         continue;
       }
@@ -424,7 +427,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel_stream(KArgs a) {
         __syncthreads();
         if (!wave_idle) {
           if (logG) hit_records_strided<IMG>((lds_f4p)tile, kind, n, 0, base, j, logG, c, h);
-          else hit_records<IMG, 4>((lds_f4p)tile, kind, n, base, c, fast, L.rng, h);
+          else hit_records<IMG, 4>((lds_f4p)tile, cblob, kind, n, base, off, first, c, fast, L.rng, h);
         }
         __syncthreads();
       }
@@ -526,7 +529,7 @@ __global__ void bounce_kernel(const f4* __restrict__ blob, int n_runs, const f4*
   memset(&O, 0, sizeof O);
   RayCtx c = make_ctx(ray, fast_ok != 0);
   HitState h;
-  hit_world<IMG>(blob, n_runs, c, wave_all_regular(c, true), rng, h);
+  hit_world<IMG>(blob, (cst_f4p)blob, n_runs, c, wave_all_regular(c, true), rng, h);
   const float closest = h.closest, hu = h.u, hv = h.v;
   const int hit = h.hit;
   if (hit < 0) {

@@ -95,6 +95,11 @@ def test_flatten_preserves_list_order(lib):
     sizes = {0: 3, 1: 2, 2: 3, 3: 2, 4: 4}
     off = n_runs
     for kind, first, count, _ in runs:
+        if kind == 0:  # a sphere run is preceded by its "moving" bit mask (1 F4 per 128 spheres) and an aux F4
+            off += (int(count) + 127) // 128 + 1
+            aux = blob[first - 1]
+            assert aux.view(np.int32)[2] == (int(count) + 127) // 128 and aux.view(np.int32)[3] == 1  # uniform interval, nothing moves
+            assert not blob[first - 2].view(np.uint32).any()
         assert first == off
         off += sizes[int(kind)] * int(count)
     assert off == len(blob)
@@ -110,6 +115,36 @@ def test_flatten_preserves_list_order(lib):
     # medium record: boundary kind, neg_inv_density = -1/2
     md = blob[runs[5, 1]]
     assert md.view(np.int32)[0] == 0 and md[1] == np.float32(-0.5)
+
+
+def test_flatten_sphere_run_masks(lib):
+    """pt_flatten.hpp put_sphere_run_aux: bit i of the mask = sphere i of the run moves (time0 != time1, sphere.hpp:52);
+    aux = (time0, time1, mask F4s, flags: 1 = one shutter interval for all moving spheres, 2 = something moves)."""
+    m = lambertian_material((0.5, 0.5, 0.5))
+    def scene(intervals):
+        hs = []
+        for i in range(150):
+            if i in intervals:
+                t0, t1 = intervals[i]
+                hs.append(sphere((i, 0, 0), (i, 1, 0), t0, t1, 0.5, m))
+            else:
+                hs.append(sphere((i, 0, 0), 0.5, m))
+        return pack(hs)
+    moving = {3: (0.0, 1.0), 31: (0.0, 1.0), 32: (0.0, 1.0), 129: (0.0, 1.0), 149: (0.0, 1.0)}
+    rc, blob, mats, n_runs, flags = flatten(lib, scene(moving))
+    assert rc == 0 and n_runs == 1
+    first = int(blob[0].view(np.int32)[1])
+    assert first == 1 + 2 + 1  # header, two mask F4s (150 spheres), aux
+    aux = blob[first - 1]
+    assert aux[0] == 0.0 and aux[1] == 1.0 and aux.view(np.int32)[2:].tolist() == [2, 3]
+    bits = blob[first - 3:first - 1].view(np.uint32).reshape(-1)
+    got = {i for i in range(150) if (int(bits[i >> 5]) >> (i & 31)) & 1}
+    assert got == set(moving)
+    for i in range(150):  # the per-record flag (sign of r^2) agrees with the mask
+        assert (blob[first + 3 * i, 3] < 0) == (i in moving)
+    moving[77] = (0.25, 1.0)  # a second shutter interval: the run falls back to the one-sphere-at-a-time scan
+    rc, blob, *_ = flatten(lib, scene(moving))
+    assert blob[int(blob[0].view(np.int32)[1]) - 1].view(np.int32)[3] == 2
 
 
 def test_flatten_flags_and_materials(lib):

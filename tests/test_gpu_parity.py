@@ -302,6 +302,52 @@ def test_streaming_kernel_cooperative_tail_many_tiles(orc):
         assert_bit_identical(R.render_host(w, h, 5, ps, c, flags=abi.PT_FLAG_FORCE_STREAM), orc.render(ps, c.c, w, h, 5), f"{w}x{h}")
 
 
+def test_sphere_runs_masks_chunks_and_mixed_shutter_intervals(orc):
+    """Sphere runs longer than a 32-sphere mask word, with moving spheres at every position class (first, last, chunk
+    borders), in every kernel family — and the same scene with a second shutter interval, which takes the
+    one-sphere-at-a-time fallback of sphere_scan."""
+    from path_tracer_amd.scene import lambertian_material, metal_material, pack, sphere
+    rng = scenes.HostRNG(99)
+    def build(second_interval):
+        hs = [sphere((0, -1000, 0), 1000, lambertian_material((0.5, 0.5, 0.5)))]
+        for i in range(70):
+            c = (-3.5 + 0.1 * i + 0.05 * float(rng.float_t()), 0.2 + 0.3 * float(rng.float_t()), -2.0 + 4.0 * float(rng.float_t()))
+            mat = lambertian_material(tuple(rng.vec_t())) if i % 3 else metal_material(tuple(rng.vec_t(0.5, 1)), 0.2)
+            if i in (0, 5, 30, 31, 32, 33, 63, 64, 69) or i % 7 == 3:
+                t0, t1 = ((0.25, 0.75) if (second_interval and i == 33) else (0.0, 1.0))
+                hs.append(sphere(c, (c[0], c[1] + 0.4, c[2]), t0, t1, 0.15, mat))
+            else:
+                hs.append(sphere(c, 0.15, mat))
+        return pack(hs)
+    cam = dict(look_from=(0, 1.5, 6), look_at=(0, 0.3, 0), vup=(0, 1, 0), vfov=45.0, aperture=0.05, focus_dist=6.0, time0=0.0, time1=1.0)
+    orc.set_math(True)
+    for second in (False, True):
+        ps = build(second)
+        c = scenes.make_camera(cam, 72, 40)
+        ref = orc.render(ps, c.c, 72, 40, 6)
+        for flags in (0, abi.PT_FLAG_FORCE_COOP, abi.PT_FLAG_FORCE_STREAM, abi.PT_FLAG_NO_LDS, abi.PT_FLAG_FORCE_COOP | abi.PT_FLAG_NO_SPLIT):
+            assert_bit_identical(R.render_host(72, 40, 6, ps, c, flags=flags), ref, f"second interval {second}, flags {flags}")
+
+
+def test_streaming_kernel_sphere_tiles(orc):
+    """A sphere run longer than one LDS tile (672 spheres) through the streaming kernel: the mask word index follows the
+    tile's position in the run."""
+    from path_tracer_amd.scene import lambertian_material, pack, sphere
+    rng = scenes.HostRNG(5)
+    hs = []
+    for i in range(1500):
+        c = (-4 + 8 * float(rng.float_t()), 0.1 + 2 * float(rng.float_t()), -4 + 8 * float(rng.float_t()))
+        m = lambertian_material(tuple(rng.vec_t()))
+        hs.append(sphere(c, (c[0], c[1] + 0.2, c[2]), 0.0, 1.0, 0.05, m) if i % 5 == 2 else sphere(c, 0.05, m))
+    ps = pack(hs)
+    cam = dict(look_from=(0, 2, 9), look_at=(0, 1, 0), vup=(0, 1, 0), vfov=50.0, aperture=0.0, focus_dist=9.0, time0=0.0, time1=1.0)
+    c = scenes.make_camera(cam, 40, 24)
+    orc.set_math(True)
+    ref = orc.render(ps, c.c, 40, 24, 4)
+    assert_bit_identical(R.render_host(40, 24, 4, ps, c, flags=abi.PT_FLAG_FORCE_STREAM), ref, "streamed sphere tiles")
+    assert_bit_identical(R.render_host(40, 24, 4, ps, c), ref, "resident")
+
+
 def test_streaming_kernel_many_tiles(orc):
     """3 000 triangles = 9 000 records: several LDS tiles per run, partial last tile, small runs either side."""
     ps, cam = S.triangles_scene(3000)
@@ -390,11 +436,12 @@ def test_schedule_probe_reports_the_wide_phase(lib, monkeypatch):
     assert lib.pt_debug_schedule(ds.handle, out) == 0 and (out[0], out[1]) == (0, 0)  # ordinary kernel: no such phase
     monkeypatch.setenv("PT_SPLIT_TILES", "40")
     monkeypatch.setenv("PT_WIDE_LOGG", "4")
-    R.render(136, 72, 16, ds, c)
-    assert lib.pt_debug_schedule(ds.handle, out) == 0 and (out[0], out[1]) == (40, 16)
-    monkeypatch.delenv("PT_SPLIT_TILES"); monkeypatch.delenv("PT_WIDE_LOGG")
-    R.render(136, 72, 16, ds, c)
+    ds2 = R.DeviceScene(ps)  # the tuning knobs are read when a scene is created, never on the launch path
+    R.render(136, 72, 16, ds2, c)
+    assert lib.pt_debug_schedule(ds2.handle, out) == 0 and (out[0], out[1]) == (40, 16)
+    R.render(136, 72, 16, ds, c)  # the scene created before the knobs were set still follows the model
     assert lib.pt_debug_schedule(ds.handle, out) == 0 and 0 <= out[0] <= 153 and out[1] in (0, 2, 4, 8, 16, 32, 64)
+    monkeypatch.delenv("PT_SPLIT_TILES"); monkeypatch.delenv("PT_WIDE_LOGG")
 
 
 def test_wide_phase_smoke_scene(orc, monkeypatch):

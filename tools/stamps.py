@@ -16,9 +16,11 @@ cam = scenes.make_camera(cam_args, W, H)
 ds = R.DeviceScene(packed)
 R.render(W, H, 8, ds, cam); torch.cuda.synchronize()
 lib.pt_debug_stamps(None, 1)
-fb, ms = R.render(W, H, spp, ds, cam, flags=flags | abi.PT_FLAG_NO_LPT, timed=True)
+no_lpt = 0 if (len(sys.argv) > 4 and sys.argv[4] == 'lpt') else abi.PT_FLAG_NO_LPT
+fb, ms = R.render(W, H, spp, ds, cam, flags=flags | no_lpt, timed=True)
 out = (C.c_ulonglong * 8)()
 lib.pt_debug_stamps(out, 0)
 prep, trav, shade, iters = out[0], out[1], out[2], out[3]
 tot = prep + trav + shade
+print(f"  cooperative iterations {out[4]/iters:.3f} of all (dynamic hand-off {out[5]/iters:.3f}); mean live lanes {out[6]/iters:.1f}; their traversal {out[7]/max(out[4],1):.0f} cycles each = {out[7]/max(trav,1):.2f} of all traversal cycles")
 print(f"{scene} {spp} spp: kernel {ms:.1f} ms; wave-iterations {iters:.3e}; cycles per wave-iteration: prepare {prep/iters:.0f}  traversal {trav/iters:.0f}  shade {shade/iters:.0f}  (total {tot/iters:.0f}); shares {prep/tot:.2f} {trav/tot:.2f} {shade/tot:.2f}")
