@@ -50,8 +50,8 @@ __device__ __forceinline__ int hit_off(int h) { return h & 0xffffff; }
 __device__ __forceinline__ float as_f(int i) { return __int_as_float(i); }
 __device__ __forceinline__ int as_i(float f) { return __float_as_int(f); }
 
-#ifndef PT_COOP_TRIP
-#define PT_COOP_TRIP 4 /* spheres / triangles per trip in the cooperative kernels' ordinary scan */
+#ifndef PT_STRIDED_K
+#define PT_STRIDED_K 4 /* spheres per trip of the cooperative (strided) scan: 4 or 2 */
 #endif
 #define PT_INF (__builtin_inff())
 #define PT_PI 3.1415926535897932385f /* rtweekend.hpp:22 */
@@ -475,74 +475,120 @@ struct HitState {
 };
 __device__ __forceinline__ void hit_begin(HitState& h) { h.closest = PT_INF; h.hit = -1; h.u = 0.0f; h.v = 0.0f; }
 
-// ---- a run of spheres, in list order ----------------------------------------------------------------------------------
+// ---- a run of spheres ------------------------------------------------------------------------------------------------
+// What bounds this loop is instruction ISSUE, all kinds together: a SIMD issues one instruction per two cycles, and a scalar
+// instruction takes that slot like a vector one (PMC, 496-hittable scene: VALU 0.62 + SALU 0.26 + LDS/branch/waits of the
+// issue slots; hiding the LDS latency alone changed nothing).  So the scan is organised to need the fewest instructions per
+// sphere of ANY kind: no per-sphere "is it moving" test, no per-sphere loop control.
 // In front of a sphere run's records the flattener puts (pt_flatten.hpp: put_sphere_run_aux)
-//     [ceil(n/128) f4: bit i = sphere i of the run is moving]  [aux f4 = (time0, time1, number of mask f4, flags)]
-// flags bit 0: every moving sphere of the run has the shutter interval (time0, time1) — then the time fraction of
-// sphere.hpp:54 is ONE division per ray and run; bit 1: the run has a moving sphere at all.
-// Why: with the "moving" flag only inside the record (sign of R0.w) every sphere cost a full LDS round trip before the
-// wave knew whether to fetch R2 = center1 - center0, and a second one if so; the scan of the 496-hittable scene spent 48 %
-// of its wave-cycles in s_waitcnt with 60 % VALU issue.  The mask is read through the scalar cache (one dword per 32
-// spheres), so a trip knows up front which records it needs: it issues the first records of K spheres and the R2 of the
-// moving ones together (one exposed LDS latency per trip instead of one or two per sphere), evaluates the K discriminants
-// back to back and takes the roots in list order.  Same operations on the same operands as sphere.hpp:51-56,68-72.
-typedef const __attribute__((address_space(4))) int* cst_ip;
+//     [static list][moving list][aux f4 = (time0, time1, number of static spheres, flags)]
+// the record offsets (f4 units, relative to the run) of the run's static and of its moving spheres, each list in list order
+// and padded to a multiple of four entries by repeating its last entry.  flags bit 0: every moving sphere of the run has
+// the shutter interval (time0, time1) — then (time - time0) / (time1 - time0) of sphere.hpp:54 is ONE division per ray and
+// run.  The lists are read through the scalar cache, four offsets per s_load; a trip issues the first records (and for the
+// moving list the R2 = center1 - center0 records) of four spheres together, evaluates the discriminants and takes the roots.
+// Scanning the static spheres before the moving ones is not list order, so acceptance carries the reference's tie rule
+// explicitly: the sequential scan keeps the FIRST sphere in list order among equal t (sphere.hpp:77 needs t < max), i.e. a
+// candidate replaces an equal-t hit iff that hit is a record of this run with a larger offset (records stay in list order
+// in the blob, so offsets compare like list positions; a hit of an earlier run has a smaller offset and stays).  Repeating
+// a sphere (the padding) is therefore a no-op.  Every candidate's t is independent of max, so the result is
+// the sequential scan's, bit for bit.
+typedef const __attribute__((address_space(4))) i4* cst_i4p;
 
-template <int K, typename P, typename AcceptAt>
-__device__ __forceinline__ void sphere_trip(P recs, int o, unsigned int bits, float frac, const RayCtx& c, HitState& h,
-                                            AcceptAt accept_at) {
+// sphere_finish with the tie rule (see above); off_here = blob offset of this sphere's record
+template <typename Accept>
+__device__ __forceinline__ void sphere_finish_unordered(SphereEval e, const RayCtx& c, float mn, const HitState& h, int off_here,
+                                                        Accept accept) {
+#ifdef PT_STAMPS
+  { // diagnostic build: how often a wave enters the root block, and with how many lanes
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(e.disc > 0);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&g_stamps[5], 1ull); if (m) { atomicAdd(&g_stamps[4], 1ull); atomicAdd(&g_stamps[6], (unsigned long long)__builtin_popcountll(m)); } }
+  }
+#endif
+  if (e.disc > 0) {
+    const float mx = h.closest;
+    const bool later = (h.hit >= 0) & (hit_off(h.hit) > off_here);
+    float sq = sqrt_rn(e.disc);
+    float temp = (-e.b - sq) / c.a;
+    bool ok = (temp < mx || (temp == mx && later)) && temp > mn;
+    if (!ok) {
+      temp = (-e.b + sq) / c.a;
+      ok = (temp < mx || (temp == mx && later)) && temp > mn;
+    }
+    if (ok) accept(temp);
+  }
+}
+
+// K spheres of a list entry (K = 4: the whole entry; K = 2: half of it — the kernels that run at a 72-register budget)
+template <bool MOVING, int K, typename P, typename AcceptAt>
+__device__ __forceinline__ void sphere_list_trip(P recs, const int (&o)[K], int goff, float frac, const RayCtx& c, HitState& h,
+                                                 AcceptAt accept_at) {
   const Ray& r = c.r;
   f4 R0[K], R2[K];
+  // the run's base address held in a VGPR the compiler cannot see through: each record address is then ONE v_lshl_add_u32
+  // with the scalar offset as an operand, instead of s_lshl + s_add + v_mov (three issue slots)
+  P vrecs = recs;
+  asm volatile("" : "+v"(vrecs));
 #pragma unroll
-  for (int k = 0; k < K; k++) R0[k] = recs[o + k * SZ_SPHERE];
+  for (int k = 0; k < K; k++) R0[k] = vrecs[o[k]];
+  if (MOVING) {
 #pragma unroll
-  for (int k = 0; k < K; k++)
-    if ((bits >> k) & 1u) R2[k] = recs[o + k * SZ_SPHERE + 2]; // scalar condition: fetched only for the moving ones (and only read for them)
+    for (int k = 0; k < K; k++) R2[k] = vrecs[o[k] + 2];
+  }
   SphereEval e[K];
 #pragma unroll
   for (int k = 0; k < K; k++) {
     V3 center = xyz(R0[k]);
-    if ((bits >> k) & 1u) { // a real (scalar) branch: if-converted it costs every static sphere 6 VALU + 3 selects
-      asm volatile("" ::: "memory");
-      center = center + frac * xyz(R2[k]); // sphere.hpp:54-55
-    }
+    if (MOVING) center = center + frac * xyz(R2[k]); // sphere.hpp:54-55
     V3 oc = r.o - center;
     float b = dot(oc, r.d);
     float cc = dot(oc, oc) - __builtin_fabsf(R0[k].w);
     e[k] = SphereEval{b, b * b - c.a * cc};
   }
 #pragma unroll
-  for (int k = 0; k < K; k++) sphere_finish(e[k], c, PT_TMIN, h.closest, true, accept_at(o + k * SZ_SPHERE));
+  for (int k = 0; k < K; k++) sphere_finish_unordered(e[k], c, PT_TMIN, h, goff + o[k], accept_at(o[k]));
+}
+template <bool MOVING, int K, typename P, typename AcceptAt>
+__device__ __forceinline__ void sphere_list_entry(P recs, i4 o4, int goff, float frac, const RayCtx& c, HitState& h, AcceptAt accept_at) {
+  if constexpr (K >= 4) {
+    const int o[4] = {o4.x, o4.y, o4.z, o4.w};
+    sphere_list_trip<MOVING, 4>(recs, o, goff, frac, c, h, accept_at);
+  } else {
+    const int a[2] = {o4.x, o4.y}, b[2] = {o4.z, o4.w};
+    sphere_list_trip<MOVING, 2>(recs, a, goff, frac, c, h, accept_at);
+    sphere_list_trip<MOVING, 2>(recs, b, goff, frac, c, h, accept_at);
+  }
 }
 
-// n records at recs[0..); record i of this call is sphere (first + i) of the run whose records start at blob offset run_off.
-template <int TRIP, typename P, typename AcceptAt>
-__device__ __forceinline__ void sphere_scan(P recs, cst_f4p cblob, int n, int run_off, int first, const RayCtx& c, HitState& h,
-                                            AcceptAt accept_at) {
-  const f4 aux = cblob[run_off - 1];
-  const int flags = as_i(aux.w);
-  if (!(flags & 1)) { // moving spheres with different shutter intervals: one sphere at a time, fraction memoised
+// The whole run (recs = its first record, at blob offset goff).
+template <int K, typename P, typename AcceptAt>
+__device__ __forceinline__ void sphere_scan(P recs, cst_f4p cblob, int n, int goff, const RayCtx& c, HitState& h, AcceptAt accept_at) {
+  const f4 aux = cblob[goff - 1];
+  const int flags = as_i(aux.w), ns = as_i(aux.z), nm = n - ns;
+  if (!(flags & 1)) { // moving spheres with different shutter intervals: one sphere at a time in list order, fraction memoised
     TimeFrac tf = time_frac_none();
     for (int i = 0, off = 0; i < n; ++i, off += SZ_SPHERE) sphere_roots(recs, off, c, PT_TMIN, h.closest, true, tf, accept_at(off));
     return;
   }
-  float frac = 0.0f;
-  if (flags & 2) frac = (c.r.tm - aux.x) / (aux.y - aux.x); // (time - time0) / (time1 - time0)  sphere.hpp:54
-  const cst_ip maskw = (cst_ip)(cblob + (run_off - 1 - as_i(aux.z)));
-  for (int base = 0; base < n; base += 32) { // first is a multiple of 32 (whole run, or an LDS tile of 672 spheres)
-    const unsigned int m = (unsigned int)maskw[(first + base) >> 5];
-    asm volatile("" ::"s"(m)); // have the mask word in its SGPR here: scalar loads and LDS reads share lgkmcnt, and a wait for
-                               // it inside a trip would drain that trip's first-record reads before the R2 reads are issued
-    const int lim = min(32, n - base);
-    int q = 0;
-    if constexpr (TRIP >= 4)
-      for (; q + 3 < lim; q += 4) sphere_trip<4>(recs, (base + q) * SZ_SPHERE, m >> q, frac, c, h, accept_at);
-    if constexpr (TRIP >= 2)
-      for (; q + 1 < lim; q += 2) sphere_trip<2>(recs, (base + q) * SZ_SPHERE, m >> q, frac, c, h, accept_at);
-    for (; q < lim; ++q) sphere_trip<1>(recs, (base + q) * SZ_SPHERE, m >> q, frac, c, h, accept_at);
+  const int qs = (ns + 3) >> 2, qm = (nm + 3) >> 2;
+  const cst_i4p lists = (cst_i4p)(cblob + (goff - 1 - qs - qm));
+  // the next list entry is requested while the current one is processed (reading one entry past a list lands on the next
+  // list or on the aux record: valid memory, never used)
+  i4 cur = lists[0];
+  for (int q = 0; q < qs; ++q) {
+    const i4 nxt = lists[q + 1];
+    sphere_list_entry<false, K>(recs, cur, goff, 0.0f, c, h, accept_at);
+    cur = nxt;
+  }
+  if (qm) {
+    const float frac = (c.r.tm - aux.x) / (aux.y - aux.x); // (time - time0) / (time1 - time0)  sphere.hpp:54
+    for (int q = 0; q < qm; ++q) {
+      const i4 nxt = lists[qs + q + 1];
+      sphere_list_entry<true, K>(recs, cur, goff, frac, c, h, accept_at);
+      cur = nxt;
+    }
   }
 }
-
 
 // n records of one kind at recs[0..): record i is blob offset goff + i*size.  `recs` is either the resident
 // blob (LDS or scalar-cached) advanced to the run, or an LDS tile of a streamed run.
@@ -550,8 +596,10 @@ __device__ __forceinline__ void sphere_scan(P recs, cst_f4p cblob, int n, int ru
 // Every resident kernel contains all the loops, and the ones that run at a 72-register budget (7 waves) pay for a wide
 // triangle loop with spills around EVERY scan, triangles or not: they take TRIP = 1; the cooperative and the streaming
 // kernels, which have registers to spare, take 2 spheres / 4 triangles.
-template <bool IMG, int TRIP = 1, int TTRIP = TRIP, typename P>
-__device__ __forceinline__ void hit_records(P recs, cst_f4p cblob, int kind, int n, int goff, int run_off, int first,
+// WHOLE: recs[0..n) is a whole run (its aux records sit in front of it at cblob[goff - 1]); false for an LDS tile of a
+// streamed run, which takes the spheres one at a time in list order.
+template <bool IMG, int TRIP = 1, int TTRIP = TRIP, bool WHOLE = true, typename P>
+__device__ __forceinline__ void hit_records(P recs, cst_f4p cblob, int kind, int n, int goff,
                                             const RayCtx& c, bool fast, uint32_t& rng, HitState& h) {
   const Ray& r = c.r;
   int off = 0;
@@ -570,7 +618,11 @@ __device__ __forceinline__ void hit_records(P recs, cst_f4p cblob, int kind, int
         }
       };
     };
-    sphere_scan<TRIP>(recs, cblob, n, run_off, first, c, h, accept_at);
+    if constexpr (WHOLE) sphere_scan<(TRIP >= 2 ? 4 : 2)>(recs, cblob, n, goff, c, h, accept_at);
+    else {
+      TimeFrac tf = time_frac_none();
+      for (int i = 0; i < n; ++i, off += SZ_SPHERE) sphere_roots(recs, off, c, PT_TMIN, h.closest, true, tf, accept_at(off));
+    }
   } else if (kind == DK_RECT) {
     for (int i = 0; i < n; ++i, off += SZ_RECT) {
       f4 R0 = recs[off], R1 = recs[off + 1];
@@ -640,29 +692,58 @@ __device__ __forceinline__ void hit_records(P recs, cst_f4p cblob, int kind, int
 // tests the records whose hittable index is == j (mod G).  The loop itself stays wave-uniform — ceil(cnt / G) trips for
 // everybody, a lane without a record in a trip re-tests record 0 of the run and discards the outcome — so the only
 // per-lane things are the record address and one predicate (divergent trip counts cost ~10 SALU + 2 branches per trip).
-template <bool IMG, typename P>
-__device__ __forceinline__ void hit_records_strided(P recs, int kind, int cnt, int first, int goff, int j, int logG,
+template <bool IMG, bool WHOLE = true, typename P>
+__device__ __forceinline__ void hit_records_strided(P recs, cst_f4p cblob, int kind, int cnt, int first, int goff, int j, int logG,
                                                     const RayCtx& c, HitState& h) {
   const Ray& r = c.r;
   const int G = 1 << logG, trips = (cnt + G - 1) >> logG;
   int k = (j - first) & (G - 1);
   if (kind == DK_SPHERE) {
-    TimeFrac tf = time_frac_none();
-    for (int i = 0; i < trips; ++i, k += G) {
-      const bool valid = k < cnt;
-      const int off = (valid ? k : 0) * SZ_SPHERE;
-      sphere_roots(recs, off, c, PT_TMIN, h.closest, valid, tf, [&](float t) {
+    auto accept_at = [&](int o) {
+      return [&h, &r, recs, goff, o](float t) {
         h.closest = t;
-        h.hit = hit_pack(DK_SPHERE, 0, goff + off);
+        h.hit = hit_pack(DK_SPHERE, 0, goff + o);
         if (IMG) {
-          f4 R0 = recs[off], R1 = recs[off + 1], R2 = recs[off + 2];
+          f4 R0 = recs[o], R1 = recs[o + 1], R2 = recs[o + 2];
           V3 p = r.o + t * r.d;
           V3 n_ = (p - sphere_center(R0, R1, R2, r.tm)) / R1.x;
           bool ff = dot(r.d, n_) < 0;
           V3 nn = ff ? n_ : mk(0.0f, 0.0f, 0.0f) - n_;
           mercator(nn, h.u, h.v);
         }
-      });
+      };
+    };
+    bool listed = false;
+    if constexpr (WHOLE) {
+      // Lane j takes the list ENTRIES (four spheres each) j, j + G, ... of the run's static and then of its moving list
+      // (sphere_scan): four first records in flight per trip, no per-lane "is it moving" branch.  A lane past the end of a
+      // list repeats the last entry — a duplicate candidate, which the tie rule (own scan) and the merge (same t, same
+      // record) both ignore.
+      const f4 aux = cblob[goff - 1];
+      if (as_i(aux.w) & 1) {
+        listed = true;
+        const int ns = as_i(aux.z), nm = cnt - ns, qs = (ns + 3) >> 2, qm = (nm + 3) >> 2;
+        const P lists = recs - (1 + qs + qm);
+        auto entry = [&](int e) {
+          const f4 v = lists[e];
+          return i4{as_i(v.x), as_i(v.y), as_i(v.z), as_i(v.w)};
+        };
+        for (int e = j, i = 0; i < ((qs + G - 1) >> logG); ++i, e += G)
+          sphere_list_entry<false, PT_STRIDED_K>(recs, entry(min(e, qs - 1)), goff, 0.0f, c, h, accept_at);
+        if (qm) {
+          const float frac = (r.tm - aux.x) / (aux.y - aux.x); // sphere.hpp:54
+          for (int e = j, i = 0; i < ((qm + G - 1) >> logG); ++i, e += G)
+            sphere_list_entry<true, PT_STRIDED_K>(recs, entry(qs + min(e, qm - 1)), goff, frac, c, h, accept_at);
+        }
+      }
+    }
+    if (!listed) {
+      TimeFrac tf = time_frac_none();
+      for (int i = 0; i < trips; ++i, k += G) {
+        const bool valid = k < cnt;
+        const int off = (valid ? k : 0) * SZ_SPHERE;
+        sphere_roots(recs, off, c, PT_TMIN, h.closest, valid, tf, accept_at(off));
+      }
     }
   } else if (kind == DK_RECT) {
     for (int i = 0; i < trips; ++i, k += G) {
@@ -714,7 +795,7 @@ __device__ __forceinline__ void hit_world(P blob, cst_f4p cblob, int n_runs, con
   for (int ri = 0; ri < n_runs; ++ri) {
     f4 runf = cblob[ri];
     const int off = as_i(runf.y);
-    hit_records<IMG>(blob + off, cblob, as_i(runf.x), as_i(runf.z), off, off, 0, c, fast, rng, h);
+    hit_records<IMG>(blob + off, cblob, as_i(runf.x), as_i(runf.z), off, c, fast, rng, h);
   }
 }
 
@@ -851,10 +932,6 @@ __device__ __forceinline__ void hit_world_lds(P blob, cst_f4p cblob, const CoopS
   }
   const int G = 1 << logG;
   const int group = lane >> logG, j = lane & (G - 1);
-#ifdef PT_STAMPS
-  if (lane == 0) { atomicAdd(&g_stamps[4], (unsigned long long)(logG > 0)); atomicAdd(&g_stamps[5], (unsigned long long)(handoff ? 1 : 0)); atomicAdd(&g_stamps[6], (unsigned long long)nlive); }
-  const unsigned long long st0 = __builtin_amdgcn_s_memtime();
-#endif
   uint32_t rng = my_rng;
   if (handoff) { // hand every live ray (+ its context and RNG state) to a group of G lanes
     const int owner = nth_set_bit(live_mask, group < nlive ? group : 0); // surplus groups shadow ray 0 (outcome unused)
@@ -892,8 +969,8 @@ __device__ __forceinline__ void hit_world_lds(P blob, cst_f4p cblob, const CoopS
     if (cnt <= 0) continue;
     // (idle lanes scan too and their outcome is dropped: a per-lane skip would put the whole scan under exec-mask
     // branches — the ordinary kernels do the same)
-    if (merged) hit_records<IMG, PT_COOP_TRIP, 2>(blob + off, cblob, kind, cnt, off, off, 0, c, fast, rng, s);
-    else hit_records_strided<IMG>(blob + off, kind, cnt, first, off, j, logG, c, s);
+    if (merged) hit_records<IMG, 2>(blob + off, cblob, kind, cnt, off, c, fast, rng, s);
+    else hit_records_strided<IMG>(blob + off, cblob, kind, cnt, first, off, j, logG, c, s);
   }
   if (handoff) { // hand each owner its result: the r-th live lane reads from (a lane of) group r
     const int my_rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(live_mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)live_mask, 0u));
@@ -905,10 +982,6 @@ __device__ __forceinline__ void hit_world_lds(P blob, cst_f4p cblob, const CoopS
   }
   h = s;
   if (live) my_rng = rng;
-#ifdef PT_STAMPS
-  asm volatile("" ::"v"(h.closest), "v"(h.hit));
-  if (lane == 0 && logG > 0) atomicAdd(&g_stamps[7], __builtin_amdgcn_s_memtime() - st0);
-#endif
 }
 
 

@@ -25,7 +25,7 @@ inline float as_f(int32_t i) { float f; std::memcpy(&f, &i, 4); return f; }
 enum { DK_SPHERE = 0, DK_RECT = 1, DK_TRI = 2, DK_BOX = 3, DK_MEDIUM = 4 };
 
 struct Flat {
-  std::vector<F4> blob; // [n_runs run headers][records; a sphere run is preceded by its mask + aux F4s]
+  std::vector<F4> blob; // [n_runs run headers][records; a sphere run is preceded by its offset lists + aux F4]
   std::vector<F4> mats; // 4 F4 per material, texture inlined
   int32_t n_runs = 0;
   bool has_image = false;
@@ -91,26 +91,29 @@ inline void put_sphere(std::vector<F4>& b, const float* f, int32_t mat, int32_t 
   b.push_back({f[6], as_f(mat), f[7], f[8]});            // radius, material, time0, time1
   b.push_back({f[3] - f[0], f[4] - f[1], f[5] - f[2], as_f(hidx)}); // center1 - center0 (sphere.hpp:55), ray-independent
 }
-// In front of a sphere run's records: [ceil(n/128) F4 of "moving" bits, sphere i of the run = bit i][aux F4]
-// aux = (time0, time1, number of mask F4, flags); flags bit 0: every moving sphere of the run has the shutter interval
-// (time0, time1), so (time - time0) / (time1 - time0) is one division per ray and run (pt_device.hpp: sphere_scan);
-// bit 1: the run has a moving sphere.
+// In front of a sphere run's records: [static list][moving list][aux F4]  (pt_device.hpp: sphere_scan)
+// lists: record offsets (F4 units, relative to the run's first record) of the static / the moving spheres of the run, each in
+// list order, four per F4, padded to a multiple of four by repeating the last entry; aux = (time0, time1, number of static
+// spheres, flags); flags bit 0: every moving sphere of the run has the shutter interval (time0, time1); bit 1: something moves.
 inline void put_sphere_run_aux(std::vector<F4>& b, const PtHittable* h, int count) {
-  const int n_mask = (count + 127) / 128;
-  std::vector<uint32_t> bits((size_t)n_mask * 4, 0u);
-  bool any = false, uniform = true;
+  std::vector<int32_t> st, mv;
+  bool uniform = true;
   float t0 = 0.0f, t1 = 0.0f;
   for (int i = 0; i < count; i++) {
     const float* f = h[i].f;
     if (f[7] != f[8]) { // moving (sphere.hpp:52)
-      bits[(size_t)i >> 5] |= 1u << (i & 31);
-      if (!any) { t0 = f[7]; t1 = f[8]; any = true; }
+      if (mv.empty()) { t0 = f[7]; t1 = f[8]; }
       else if (std::memcmp(&t0, &f[7], 4) != 0 || std::memcmp(&t1, &f[8], 4) != 0) uniform = false;
-    }
+      mv.push_back(i * 3);
+    } else st.push_back(i * 3);
   }
-  for (int k = 0; k < n_mask; k++)
-    b.push_back({as_f((int32_t)bits[4 * k]), as_f((int32_t)bits[4 * k + 1]), as_f((int32_t)bits[4 * k + 2]), as_f((int32_t)bits[4 * k + 3])});
-  b.push_back({t0, t1, as_f(n_mask), as_f((uniform ? 1 : 0) | (any ? 2 : 0))});
+  const int ns = (int)st.size();
+  const bool any = !mv.empty();
+  for (std::vector<int32_t>* l : {&st, &mv}) {
+    while (l->size() % 4) l->push_back(l->back());
+    for (size_t k = 0; k < l->size(); k += 4) b.push_back({as_f((*l)[k]), as_f((*l)[k + 1]), as_f((*l)[k + 2]), as_f((*l)[k + 3])});
+  }
+  b.push_back({t0, t1, as_f(ns), as_f((uniform ? 1 : 0) | (any ? 2 : 0))});
 }
 inline void put_box(std::vector<F4>& b, const float* f, int32_t mat, int32_t hidx) {
   b.push_back({f[0], f[1], f[2], as_f(mat)});

@@ -414,8 +414,8 @@ __global__ __launch_bounds__(kBlock) void render_kernel_stream(KArgs a) {
       const int sz = record_size(kind);
       if (cnt * sz <= kSmallRunF4) {
         if (!wave_idle) {
-          if (logG) hit_records_strided<IMG>(a.blob + off, kind, cnt, 0, off, j, logG, c, h);
-          else hit_records<IMG, 4>(cblob + off, cblob, kind, cnt, off, off, 0, c, fast, L.rng, h);
+          if (logG) hit_records_strided<IMG>(a.blob + off, cblob, kind, cnt, 0, off, j, logG, c, h);
+          else hit_records<IMG, 4>(cblob + off, cblob, kind, cnt, off, c, fast, L.rng, h);
         }
         continue;
       }
@@ -426,8 +426,8 @@ __global__ __launch_bounds__(kBlock) void render_kernel_stream(KArgs a) {
         for (int i = threadIdx.x; i < nf4; i += kBlock) tile[i] = a.blob[base + i];
         __syncthreads();
         if (!wave_idle) {
-          if (logG) hit_records_strided<IMG>((lds_f4p)tile, kind, n, 0, base, j, logG, c, h);
-          else hit_records<IMG, 4>((lds_f4p)tile, cblob, kind, n, base, off, first, c, fast, L.rng, h);
+          if (logG) hit_records_strided<IMG, false>((lds_f4p)tile, cblob, kind, n, 0, base, j, logG, c, h);
+          else hit_records<IMG, 4, 4, false>((lds_f4p)tile, cblob, kind, n, base, c, fast, L.rng, h);
         }
         __syncthreads();
       }

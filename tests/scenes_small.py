@@ -91,6 +91,29 @@ def ties_scene():
     return pack(hs), cam
 
 
+def sphere_ties_scene():
+    """Equal-t ties between spheres that the device scans out of list order (static spheres of a run before its moving
+    ones): duplicates of one sphere as static / "moving" with center1 == center0 (same t at every ray time) in both list
+    orders, next to ordinary static and moving neighbours.  The reference keeps the FIRST in list order (sphere.hpp:77)."""
+    red, green, blue, white = (lambertian_material(c) for c in ((0.9, 0.1, 0.1), (0.1, 0.9, 0.1), (0.1, 0.1, 0.9), (0.8, 0.8, 0.8)))
+    light = lightsource_material((3, 3, 3))
+    hs = [
+        sphere((0, -100.5, -2), 100, white),
+        sphere((-1.2, 0, -2), (-1.2, 0, -2), 0.0, 1.0, 0.5, red),   # "moving", not displaced: first in list -> wins
+        sphere((-1.2, 0, -2), 0.5, green),                           # static duplicate, scanned FIRST on the device
+        sphere((0, 0, -2), 0.5, blue),                               # static first in list -> wins
+        sphere((0, 0, -2), (0, 0, -2), 0.0, 1.0, 0.5, red),          # "moving" duplicate
+        sphere((0, 0, -2), 0.5, green),                              # second static duplicate
+        sphere((1.2, 0, -2), (1.2, 0.3, -2), 0.0, 1.0, 0.5, green),  # really moving
+        sphere((1.2, 0, -2), (1.2, 0.3, -2), 0.0, 1.0, 0.5, light),  # its duplicate: loses
+        sphere((0.3, 0.9, -1.6), 0.25, metal_material((0.8, 0.8, 0.8), 0.1)),
+        sphere((-0.5, 0.8, -1.5), (-0.5, 1.0, -1.5), 0.0, 1.0, 0.2, dielectric_material(1.5, (1, 1, 1))),
+    ]
+    cam = dict(look_from=(0, 0.4, 1.5), look_at=(0, 0.1, -2), vup=(0, 1, 0), vfov=60.0, aperture=0.0, focus_dist=3.5,
+               time0=0.0, time1=1.0)
+    return pack(hs), cam
+
+
 def empty_scene():
     cam = dict(look_from=(0, 0, 1), look_at=(0, 0, -1), vup=(0, 1, 0), vfov=60.0, aperture=0.0, focus_dist=1.0,
                time0=0.0, time1=0.0)
@@ -102,4 +125,4 @@ def cornell_scene():
 
 
 ALL = {"cornell": cornell_scene, "mixed": mixed_scene, "spheres": spheres_scene, "triangles": triangles_scene,
-       "ties": ties_scene, "empty": empty_scene}
+       "ties": ties_scene, "sphere_ties": sphere_ties_scene, "empty": empty_scene}

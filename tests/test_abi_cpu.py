@@ -95,11 +95,12 @@ def test_flatten_preserves_list_order(lib):
     sizes = {0: 3, 1: 2, 2: 3, 3: 2, 4: 4}
     off = n_runs
     for kind, first, count, _ in runs:
-        if kind == 0:  # a sphere run is preceded by its "moving" bit mask (1 F4 per 128 spheres) and an aux F4
-            off += (int(count) + 127) // 128 + 1
+        if kind == 0:  # a sphere run is preceded by its static / moving offset lists (4 per F4) and an aux F4
+            off += (int(count) + 3) // 4 + 1  # nothing moves here: one list
             aux = blob[first - 1]
-            assert aux.view(np.int32)[2] == (int(count) + 127) // 128 and aux.view(np.int32)[3] == 1  # uniform interval, nothing moves
-            assert not blob[first - 2].view(np.uint32).any()
+            assert aux.view(np.int32)[2] == count and aux.view(np.int32)[3] == 1  # all static, uniform interval
+            lst = blob[first - 1 - (int(count) + 3) // 4:first - 1].view(np.int32).reshape(-1)
+            assert lst[:count].tolist() == [3 * i for i in range(count)] and (lst[count:] == 3 * (count - 1)).all()
         assert first == off
         off += sizes[int(kind)] * int(count)
     assert off == len(blob)
@@ -117,9 +118,10 @@ def test_flatten_preserves_list_order(lib):
     assert md.view(np.int32)[0] == 0 and md[1] == np.float32(-0.5)
 
 
-def test_flatten_sphere_run_masks(lib):
-    """pt_flatten.hpp put_sphere_run_aux: bit i of the mask = sphere i of the run moves (time0 != time1, sphere.hpp:52);
-    aux = (time0, time1, mask F4s, flags: 1 = one shutter interval for all moving spheres, 2 = something moves)."""
+def test_flatten_sphere_run_lists(lib):
+    """pt_flatten.hpp put_sphere_run_aux: the static and the moving spheres of a run as two lists of record offsets (list
+    order, padded to a multiple of four by repeating the last entry); aux = (time0, time1, number of static spheres,
+    flags: 1 = one shutter interval for all moving spheres, 2 = something moves)."""
     m = lambertian_material((0.5, 0.5, 0.5))
     def scene(intervals):
         hs = []
@@ -134,13 +136,15 @@ def test_flatten_sphere_run_masks(lib):
     rc, blob, mats, n_runs, flags = flatten(lib, scene(moving))
     assert rc == 0 and n_runs == 1
     first = int(blob[0].view(np.int32)[1])
-    assert first == 1 + 2 + 1  # header, two mask F4s (150 spheres), aux
+    qs, qm = (145 + 3) // 4, (5 + 3) // 4
+    assert first == 1 + qs + qm + 1  # header, static list, moving list, aux
     aux = blob[first - 1]
-    assert aux[0] == 0.0 and aux[1] == 1.0 and aux.view(np.int32)[2:].tolist() == [2, 3]
-    bits = blob[first - 3:first - 1].view(np.uint32).reshape(-1)
-    got = {i for i in range(150) if (int(bits[i >> 5]) >> (i & 31)) & 1}
-    assert got == set(moving)
-    for i in range(150):  # the per-record flag (sign of r^2) agrees with the mask
+    assert aux[0] == 0.0 and aux[1] == 1.0 and aux.view(np.int32)[2:].tolist() == [145, 3]
+    st = blob[first - 1 - qs - qm:first - 1 - qm].view(np.int32).reshape(-1)
+    mv = blob[first - 1 - qm:first - 1].view(np.int32).reshape(-1)
+    assert st[:145].tolist() == [3 * i for i in range(150) if i not in moving] and (st[145:] == st[144]).all()
+    assert mv[:5].tolist() == [3 * i for i in sorted(moving)] and (mv[5:] == mv[4]).all()
+    for i in range(150):  # the per-record flag (sign of r^2) agrees with the lists
         assert (blob[first + 3 * i, 3] < 0) == (i in moving)
     moving[77] = (0.25, 1.0)  # a second shutter interval: the run falls back to the one-sphere-at-a-time scan
     rc, blob, *_ = flatten(lib, scene(moving))

@@ -258,7 +258,7 @@ def test_cornell_bit_exact_vs_glibc_oracle(orc):
     assert_bit_identical(R.render_host(200, 112, 64, ps, c), orc.render(ps, c.c, 200, 112, 64))
 
 
-@pytest.mark.parametrize("name", ["cornell", "mixed", "triangles"])
+@pytest.mark.parametrize("name", ["cornell", "mixed", "triangles", "sphere_ties"])
 def test_lds_and_scalar_fetch_agree(name):
     ps, cam = S.ALL[name]()
     c = scenes.make_camera(cam, 64, 40)
@@ -267,7 +267,7 @@ def test_lds_and_scalar_fetch_agree(name):
     assert_bit_identical(a, b, name)
 
 
-@pytest.mark.parametrize("name", ["cornell", "mixed", "triangles", "spheres", "ties"])
+@pytest.mark.parametrize("name", ["cornell", "mixed", "triangles", "spheres", "ties", "sphere_ties"])
 def test_streaming_kernel_agrees(name):
     """The LDS-tile streaming kernel (used when the scene exceeds LDS) gives the resident kernel's frame."""
     ps, cam = S.ALL[name]()
@@ -277,7 +277,7 @@ def test_streaming_kernel_agrees(name):
     assert_bit_identical(a, b, name)
 
 
-@pytest.mark.parametrize("name", ["cornell", "spheres", "triangles", "ties", "mixed"])
+@pytest.mark.parametrize("name", ["cornell", "spheres", "triangles", "ties", "mixed", "sphere_ties"])
 @pytest.mark.parametrize("size", [(1, 1), (2, 1), (3, 1), (5, 1), (3, 3), (17, 1), (8, 4), (33, 1), (40, 2)])
 def test_streaming_kernel_cooperative_tail(orc, name, size):
     """The streaming kernel spreads the rays of a wave that is down to <= 32 live lanes over groups of G = 64 >>
@@ -388,7 +388,7 @@ def test_cost_sorted_tile_order_does_not_matter(orc, name, flags):
     assert_bit_identical(a, orc.render(ps, c.c, w, h, spp), name + " vs oracle")
 
 
-@pytest.mark.parametrize("name", ["cornell", "spheres", "triangles", "ties", "mixed"])
+@pytest.mark.parametrize("name", ["cornell", "spheres", "triangles", "ties", "mixed", "sphere_ties"])
 @pytest.mark.parametrize("size", [(37, 21), (64, 40), (9, 5)])
 def test_cooperative_traversal_agrees(orc, name, size):
     """Waves with <= 32 live lanes split each ray's list over idle lanes and merge the segment winners with the
@@ -405,7 +405,7 @@ def test_cooperative_traversal_agrees(orc, name, size):
     assert_bit_identical(a, orc.render(ps, c.c, w, h, 24), f"{name} {w}x{h} vs oracle")
 
 
-@pytest.mark.parametrize("name", ["cornell", "spheres", "triangles", "ties", "mixed"])
+@pytest.mark.parametrize("name", ["cornell", "spheres", "triangles", "ties", "mixed", "sphere_ties"])
 def test_wide_phase_every_group_size(orc, name, monkeypatch):
     """Heavy tiles are rendered G lanes per pixel: all G lanes hold the same pixel (same seed, same draws), each tests the
     hittables == its lane (mod G), a butterfly merges the partial winners with the scan's own tie rule.  Tuning knobs force

@@ -15,7 +15,8 @@ cam = scenes.make_camera(cam_args, W, H)
 ds = R.DeviceScene(packed)
 R.render(W, H, 16, ds, cam); torch.cuda.synchronize()
 def t():
-    return min(R.render(W, H, spp, ds, cam, shard_index=0, shard_count=n, timed=True)[1] for _ in range(2))
+    d = R.DeviceScene(packed)  # the tuning knobs are read when a scene is created
+    return min(R.render(W, H, spp, d, cam, shard_index=0, shard_count=n, timed=True)[1] for _ in range(2))
 tiles = (W // 8) * (H // 8) // n
 for k in ("PT_SPLIT_TILES", "PT_WIDE_LOGG"): os.environ.pop(k, None)
 print(f"{scene} {spp} spp shard 0/{n}: model {t():7.1f} ms", flush=True)

@@ -22,5 +22,5 @@ out = (C.c_ulonglong * 8)()
 lib.pt_debug_stamps(out, 0)
 prep, trav, shade, iters = out[0], out[1], out[2], out[3]
 tot = prep + trav + shade
-print(f"  cooperative iterations {out[4]/iters:.3f} of all (dynamic hand-off {out[5]/iters:.3f}); mean live lanes {out[6]/iters:.1f}; their traversal {out[7]/max(out[4],1):.0f} cycles each = {out[7]/max(trav,1):.2f} of all traversal cycles")
+print(f"  sphere tests per wave-iteration {out[5]/iters:.0f}; root block entered by {out[4]/max(out[5],1):.3f} of them, with {out[6]/max(out[4],1):.1f} lanes on average")
 print(f"{scene} {spp} spp: kernel {ms:.1f} ms; wave-iterations {iters:.3e}; cycles per wave-iteration: prepare {prep/iters:.0f}  traversal {trav/iters:.0f}  shade {shade/iters:.0f}  (total {tot/iters:.0f}); shares {prep/tot:.2f} {trav/tot:.2f} {shade/tot:.2f}")
