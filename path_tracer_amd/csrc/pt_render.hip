@@ -446,7 +446,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel_stream(KArgs a) {
 // WHEN a pixel is rendered, never its value, so the (atomic, run-to-run varying) order inside a class is harmless.
 constexpr int kLptClasses = 32;
 __global__ __launch_bounds__(1024) void lpt_order_kernel(const unsigned int* __restrict__ cost, int n, int* __restrict__ order,
-                                                        int n_waves, float trav_cost, float fixed_cost, int forced_logG,
+                                                        int n_waves, float trav_cost, float fixed_cost, float s_chain, int forced_logG,
                                                         int* __restrict__ n_split) {
   __shared__ float s_cost_sum[kLptClasses];
   __shared__ unsigned int s_max;
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(1024) void lpt_order_kernel(const unsigned int* __r
       // Fitted on the 496-hittable scene with every tile wide (tools/wide_chain.py): lane time grows as 1 + 0.037 (G - 1)
       // (unsplit ~420 of ~11 200 instructions per iteration), while a pixel's chain shortens only as if ~2 400 were unsplit
       // (latency of run headers, merge stages and shading counts there, not their instruction count).
-      const float G = (float)(1 << logG), s_chain = 2400.0f;
+      const float G = (float)(1 << logG);
       const float eff = (trav_cost + fixed_cost) / (trav_cost + G * fixed_cost);
       const float speedup = (trav_cost + s_chain) / (trav_cost / G + s_chain);
       float split_cost = 0.0f;
@@ -642,11 +642,14 @@ struct EnvKnobs {
   int wide_logG = 0;       // PT_WIDE_LOGG: forced log2 group size of the wide phase (0 = the model picks)
   bool has_split_tiles = false;
   int split_tiles = 0;     // PT_SPLIT_TILES: fixed number of tiles through the wide phase (< 0: all)
+  float model_fixed = 420.0f, model_chain = 1000.0f; // PT_MODEL_FIXED / PT_MODEL_CHAIN: constants of the makespan model (lpt_order_kernel)
   EnvKnobs() {
     if (const char* e = std::getenv("PT_BLOCKS_PER_CU")) blocks_per_cu = std::max(1, std::atoi(e));
     no_cold_lds = std::getenv("PT_NO_COLD_LDS") != nullptr;
     if (const char* e = std::getenv("PT_WIDE_LOGG")) wide_logG = std::min(6, std::max(1, std::atoi(e)));
     if (const char* e = std::getenv("PT_SPLIT_TILES")) { has_split_tiles = true; split_tiles = std::atoi(e); }
+    if (const char* e = std::getenv("PT_MODEL_FIXED")) model_fixed = (float)std::atof(e);
+    if (const char* e = std::getenv("PT_MODEL_CHAIN")) model_chain = (float)std::atof(e);
   }
 };
 
@@ -955,7 +958,7 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
     const int forced_logG = s->knobs.wide_logG; // 0: the model picks the group size of the wide phase
     // rough per-iteration instruction counts: traversal (splittable) vs shading + camera (not)
     hipLaunchKernelGGL(lpt_order_kernel, dim3(1), dim3(1024), 0, st, s->ws_cost, local_tiles, s->ws_order, n_waves_resident,
-                       std::max(1.0f, s->traversal_cost), 420.0f, forced_logG, coop ? s->ws_nsplit : nullptr);
+                       std::max(1.0f, s->traversal_cost), s->knobs.model_fixed, s->knobs.model_chain, forced_logG, coop ? s->ws_nsplit : nullptr);
     PT_HIP(hipGetLastError());
     if (s->knobs.has_split_tiles) { // tuning knob: fixed number of split tiles (< 0: all)
       if (coop) {
