@@ -158,7 +158,22 @@ enum {
   PT_FLAG_NO_COOP = 1u << 6,        /* never split a ray's primitive list over idle lanes (tail acceleration off) */
   PT_FLAG_NO_LPT = 1u << 5,         /* skip the cost-probe pass: tiles are dequeued in raster order */
   PT_FLAG_PIXEL_GRANULAR = 1u << 4, /* lanes dequeue single pixels (default for the LDS-tile streaming kernel) */
+  /* OPT-IN, NOT THE REFERENCE'S IMAGE: decorrelated RNG streams.  The reference gives a pixel ONE xorshift32 stream for all
+   * of its samples (render.hpp:95-101,130-133), which makes a pixel a sequential chain and bounds any schedule by the
+   * heaviest pixel.  With this flag a pixel's samples are cut into chunks of PT_FAST_CHUNK_SPP; chunk c of pixel id draws
+   * from its own stream seeded pt_fast_seed(id, c), chunks are rendered as independent work units and their sums are added
+   * in chunk order (deterministic run to run).  Same estimator, different random numbers: judged by PSNR / mean against
+   * the parity image, never bit for bit, never the default.                                                             */
+  PT_FLAG_FAST_RNG = 1u << 9,
 };
+
+/* PT_FLAG_FAST_RNG: samples per chunk, and the seed of chunk `chunk` of the pixel with linear id `pixel` (never 0). */
+#define PT_FAST_CHUNK_SPP 64
+static inline uint32_t pt_fast_seed(uint32_t pixel, uint32_t chunk) {
+  uint32_t h = pixel * 0x9E3779B1u + chunk * 0x85EBCA77u + 0x165667B1u;
+  h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+  return h ? h : 1u;
+}
 
 typedef struct PtRenderParams {
   int32_t width, height; /* template args of render<> (render.hpp:141)           */

@@ -85,8 +85,8 @@ def _fp(a: np.ndarray):
     return a.ctypes.data_as(_FP)
 
 
-def params(width, height, samples, depth=50, shard_index=0, shard_count=1) -> abi.PtRenderParams:
-    return abi.PtRenderParams(width, height, samples, depth, shard_index, shard_count, 0, 0)
+def params(width, height, samples, depth=50, shard_index=0, shard_count=1, flags=0) -> abi.PtRenderParams:
+    return abi.PtRenderParams(width, height, samples, depth, shard_index, shard_count, flags, 0)
 
 
 def camera_init(look_from, look_at, vup, vfov, aspect, aperture, focus_dist, t0=0.0, t1=0.0) -> abi.PtCamera:
@@ -98,9 +98,10 @@ def camera_init(look_from, look_at, vup, vfov, aspect, aperture, focus_dist, t0=
 
 
 def render(packed, cam: abi.PtCamera, width, height, samples, depth=50, shard_index=0, shard_count=1,
-           counters: bool = False):
+           counters: bool = False, flags: int = 0):
+    """flags: only PT_FLAG_FAST_RNG means anything to the oracle (the opt-in decorrelated mode's own checker)."""
     lib = load()
-    p = params(width, height, samples, depth, shard_index, shard_count)
+    p = params(width, height, samples, depth, shard_index, shard_count, flags)
     if shard_count == 1:
         fb = np.zeros((height, width, 3), dtype=np.float32)
     else:
@@ -125,9 +126,9 @@ def render_rows(packed, cam: abi.PtCamera, width, height, samples, y0, y1, depth
     return (fb, ctr) if counters else fb
 
 
-def render_pixels(packed, cam: abi.PtCamera, width, height, samples, xy: np.ndarray, depth=50) -> np.ndarray:
+def render_pixels(packed, cam: abi.PtCamera, width, height, samples, xy: np.ndarray, depth=50, flags: int = 0) -> np.ndarray:
     lib = load()
-    p = params(width, height, samples, depth)
+    p = params(width, height, samples, depth, flags=flags)
     xy = np.ascontiguousarray(xy, dtype=np.int32)
     out = np.zeros((len(xy), 3), dtype=np.float32)
     rc = lib.orc_render_pixels(C.byref(packed.desc), C.byref(cam), C.byref(p), xy.ctypes.data_as(C.POINTER(C.c_int32)),

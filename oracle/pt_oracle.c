@@ -526,6 +526,36 @@ static void render_pixel(const PtSceneDesc* sc, const PtCamera* cam, const PtRen
   vst(out, final_color);
 }
 
+/* PT_FLAG_FAST_RNG (include/pt_render.h): NOT the reference's image — the opt-in decorrelated mode, restated here so that
+ * the GPU's fast mode has a bit-exact checker of its own.  Chunks of PT_FAST_CHUNK_SPP samples, each with its own stream;
+ * chunk sums (sequential float adds from 0) are added in chunk order, then one division by the sample count.            */
+static void render_pixel_fast(const PtSceneDesc* sc, const PtCamera* cam, const PtRenderParams* p, int x, int y,
+                              float out[3], OrcCounters* ctr) {
+  ctx_t c;
+  c.sc = sc;
+  c.c = ctr;
+  const uint32_t id = (uint32_t)((uint64_t)y * (uint64_t)p->width + (uint64_t)x);
+  v3 total = V(0.0f, 0.0f, 0.0f);
+  for (int chunk = 0, s0 = 0; s0 < p->samples; chunk++, s0 += PT_FAST_CHUNK_SPP) {
+    const int n = p->samples - s0 < PT_FAST_CHUNK_SPP ? p->samples - s0 : PT_FAST_CHUNK_SPP;
+    c.rng = pt_fast_seed(id, (uint32_t)chunk);
+    v3 sum = V(0.0f, 0.0f, 0.0f);
+    for (int i = 0; i < n; i++) {
+      ray_t r = sample_ray(cam, x, y, p->width, p->height, &c);
+      sum = vadd(sum, get_color(&c, &r, p->depth));
+      if (ctr) ctr->samples++;
+    }
+    total = vadd(total, sum);
+  }
+  vst(out, vdivs(total, (float)p->samples));
+}
+
+static void render_pixel_any(const PtSceneDesc* sc, const PtCamera* cam, const PtRenderParams* p, int x, int y,
+                             float out[3], OrcCounters* ctr) {
+  if (p->flags & PT_FLAG_FAST_RNG) render_pixel_fast(sc, cam, p, x, y, out, ctr);
+  else render_pixel(sc, cam, p, x, y, out, ctr);
+}
+
 static int validate(const PtSceneDesc* sc) {
   if (!sc || sc->n_hittables < 0 || sc->n_materials < 0 || sc->n_textures < 0) return PT_ERR_INVALID_ARG;
   for (int i = 0; i < sc->n_textures; i++) {
@@ -593,7 +623,7 @@ static int render_rows(const PtSceneDesc* sc, const PtCamera* cam, const PtRende
       for (int x = 0; x < p->width; x++) {
         int64_t idx = fb_index(p, x, y);
         if (idx < 0) continue;
-        render_pixel(sc, cam, p, x, y, fb + idx - row_base, counters ? &local : NULL);
+        render_pixel_any(sc, cam, p, x, y, fb + idx - row_base, counters ? &local : NULL);
       }
     }
     if (counters) {
@@ -629,7 +659,7 @@ int orc_render_pixels(const PtSceneDesc* sc, const PtCamera* cam, const PtRender
   if (!cam || !p || !xy || !out || p->width <= 0 || p->height <= 0 || p->samples <= 0 || p->depth < 0)
     return PT_ERR_INVALID_ARG;
 #pragma omp parallel for schedule(dynamic, 4)
-  for (int32_t k = 0; k < n; k++) render_pixel(sc, cam, p, xy[2 * k], xy[2 * k + 1], out + 3 * (int64_t)k, NULL);
+  for (int32_t k = 0; k < n; k++) render_pixel_any(sc, cam, p, xy[2 * k], xy[2 * k + 1], out + 3 * (int64_t)k, NULL);
   return PT_OK;
 }
 
@@ -645,7 +675,7 @@ int orc_render_pixels_rays(const PtSceneDesc* sc, const PtCamera* cam, const PtR
   for (int32_t k = 0; k < n; k++) {
     OrcCounters c;
     memset(&c, 0, sizeof c);
-    render_pixel(sc, cam, p, xy[2 * k], xy[2 * k + 1], out + 3 * (int64_t)k, &c);
+    render_pixel_any(sc, cam, p, xy[2 * k], xy[2 * k + 1], out + 3 * (int64_t)k, &c);
     rays[k] = c.rays;
   }
   return PT_OK;

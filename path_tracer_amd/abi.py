@@ -34,6 +34,8 @@ PT_FLAG_NO_LPT = 32
 PT_FLAG_NO_COOP = 64
 PT_FLAG_FORCE_COOP = 128
 PT_FLAG_NO_SPLIT = 256
+PT_FLAG_FAST_RNG = 512  # opt-in decorrelated RNG streams: NOT the reference's image (include/pt_render.h)
+PT_FAST_CHUNK_SPP = 64
 
 PT_OK, PT_ERR_INVALID_ARG, PT_ERR_BAD_SCENE, PT_ERR_HIP, PT_ERR_NO_DEVICE, PT_ERR_TOO_LARGE = range(6)
 PT_BOUNCE_MISS, PT_BOUNCE_SCATTERED, PT_BOUNCE_ABSORBED = 0, 1, 2

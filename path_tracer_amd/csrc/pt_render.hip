@@ -83,6 +83,11 @@ struct KArgs {
   int n_hittables;
   int coop_prefix;     // >= 0: cooperative traversal allowed, list splittable up to this hittable; -1: disabled
   int fast_ok; // every rect/box coordinate finite and <= 2^60: rays may use the shared-reciprocal division
+  // PT_FLAG_FAST_RNG (opt-in, not the reference's image): a work unit is one CHUNK of a tile's pixels; `samples` above is
+  // then the chunk length, fast_chunks the chunks per pixel, samples_total the caller's spp, fb the partial-sum workspace
+  // [chunk][framebuffer layout] (fast_reduce_kernel adds the chunks in order and divides).  0 = the reference's single stream.
+  int fast_chunks, samples_total;
+  long long fast_stride; // floats per chunk plane of the workspace
 };
 
 // Per-lane state of the persistent loop.  A lane owns ONE pixel at a time, for all of its samples (the
@@ -101,7 +106,7 @@ template <> struct Cold<false> {
   int s, pix, x, y;
   unsigned int iters;
   __device__ __forceinline__ void init(lds_fp) { acc = mk(0.0f, 0.0f, 0.0f); s = 0; pix = -1; x = 0; y = 0; iters = 0; }
-  __device__ __forceinline__ void begin(int pix_, int x_, int y_) { acc = mk(0.0f, 0.0f, 0.0f); s = 0; iters = 0; pix = pix_; x = x_; y = y_; }
+  __device__ __forceinline__ void begin(int pix_, int x_, int y_, int s0 = 0) { acc = mk(0.0f, 0.0f, 0.0f); s = s0; iters = 0; pix = pix_; x = x_; y = y_; }
   __device__ __forceinline__ int add_sample(V3 o) { acc = acc + o; return ++s; }
   __device__ __forceinline__ void count_ray() { iters++; }
   __device__ __forceinline__ V3 get_acc() const { return acc; }
@@ -113,9 +118,9 @@ template <> struct Cold<false> {
 template <> struct Cold<true> {
   lds_fp p; // this thread's slots: field k at p[k * kBlock]
   __device__ __forceinline__ void init(lds_fp base) { p = base + threadIdx.x; }
-  __device__ __forceinline__ void begin(int pix_, int x_, int y_) {
+  __device__ __forceinline__ void begin(int pix_, int x_, int y_, int s0 = 0) {
     p[0] = 0.0f; p[kBlock] = 0.0f; p[2 * kBlock] = 0.0f;
-    p[3 * kBlock] = __int_as_float(0); p[4 * kBlock] = __int_as_float(pix_); p[5 * kBlock] = __int_as_float(x_);
+    p[3 * kBlock] = __int_as_float(s0); p[4 * kBlock] = __int_as_float(pix_); p[5 * kBlock] = __int_as_float(x_);
     p[6 * kBlock] = __int_as_float(y_); p[7 * kBlock] = __int_as_float(0);
   }
   __device__ __forceinline__ int add_sample(V3 o) {
@@ -157,6 +162,13 @@ __device__ __forceinline__ void lane_reset(Lane& L, lds_fp cold_base) {
   L.live = false; L.retired = false; L.need_new = true; L.split_done = false; L.wide = 0; L.split_pixels = 0;
 }
 
+// device copy of pt_fast_seed (include/pt_render.h; host inline there): tests compare the two through the oracle's fast mode
+__device__ __forceinline__ uint32_t fast_seed(uint32_t pixel, uint32_t chunk) {
+  uint32_t h = pixel * 0x9E3779B1u + chunk * 0x85EBCA77u + 0x165667B1u;
+  h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+  return h ? h : 1u;
+}
+
 // Wave-aggregated dequeue: one atomicAdd per wave for all lanes that need a pixel (ballot + prefix count),
 // pixels handed out in tile order so a fresh wave starts on one coherent 8x8 tile.
 //
@@ -165,7 +177,7 @@ __device__ __forceinline__ void lane_reset(Lane& L, lds_fp cold_base) {
 // pixel and compute everything redundantly — same seed, same RNG draws, same shading — except the traversal, where each
 // tests 1/G of the list (hit_world_lds) — so a pixel's sequential chain gets shorter without any state ever moving
 // between lanes.  A wave leaves the phase when that queue is empty and its last wide pixel is done.
-template <typename Lane>
+template <bool FAST = false, typename Lane>
 __device__ __forceinline__ void lane_acquire(Lane& L, const KArgs& a) {
   const bool want = !L.live && !L.retired;
   const unsigned long long mask = __builtin_amdgcn_ballot_w64(want);
@@ -202,20 +214,32 @@ __device__ __forceinline__ void lane_acquire(Lane& L, const KArgs& a) {
     i = split_pixels + base + rank;
   }
   if (i >= (unsigned int)a.n_local_pixels) { L.retired = true; return; }
+  // fast mode: the queue hands out (tile, chunk) units, a tile's chunks back to back
+  unsigned int unit = i >> 6;
+  int chunk = 0;
+  if constexpr (FAST) { chunk = (int)(unit % (unsigned int)a.fast_chunks); unit /= (unsigned int)a.fast_chunks; }
   // queue position -> local tile: identity, or the cost-sorted order of the probe pass (heaviest tiles first)
-  const int l = a.order ? a.order[i >> 6] : (int)(i >> 6), in_tile = (int)(i & 63);
+  const int l = a.order ? a.order[unit] : (int)unit, in_tile = (int)(i & 63);
   const long long g = (long long)l * a.shard_count + a.shard_index; // global tile (pt_render.h: round-robin shards)
   const int tx = (int)(g % a.tiles_x), ty = (int)(g / a.tiles_x);
   const int x = tx * PT_TILE + (in_tile & 7), y = ty * PT_TILE + (in_tile >> 3);
   if (g >= a.n_tiles || x >= a.width || y >= a.height) return; // padding pixel: stays 0, ask again next iteration
-  L.cold.begin(l * PT_TILE_PIXELS + in_tile, x, y);
   // render.hpp:130-132: seed = linear id of the pixel in the WHOLE frame, truncated to 32 bits
-  L.rng = (uint32_t)((unsigned long long)y * (unsigned long long)a.width + (unsigned long long)x);
+  const uint32_t id = (uint32_t)((unsigned long long)y * (unsigned long long)a.width + (unsigned long long)x);
+  if constexpr (FAST) {
+    // the last chunk of a pixel may be shorter: its sample counter starts ahead so that every chunk ends at a.samples
+    const int n_here = min(a.samples, a.samples_total - chunk * a.samples);
+    L.cold.begin((l * PT_TILE_PIXELS + in_tile) | (chunk << 24), x, y, a.samples - n_here);
+    L.rng = fast_seed(id, (uint32_t)chunk);
+  } else {
+    L.cold.begin(l * PT_TILE_PIXELS + in_tile, x, y);
+    L.rng = id;
+  }
   L.live = true;
   L.need_new = true;
 }
 
-template <typename Lane>
+template <bool FAST = false, typename Lane>
 __device__ __forceinline__ void lane_store(Lane& L, const KArgs& a) {
   L.live = false;
   if (L.wide && ((threadIdx.x & 63) & ((1 << L.wide) - 1))) return; // wide phase: one lane of the group writes
@@ -223,8 +247,17 @@ __device__ __forceinline__ void lane_store(Lane& L, const KArgs& a) {
     atomicAdd(&a.cost[L.cold.get_pix() >> 6], L.cold.get_iters());
     return;
   }
-  V3 acc = L.cold.get_acc() / (float)a.samples; // render.hpp:102
   long long idx;
+  if constexpr (FAST) { // fast mode: this chunk's plain sum into its plane of the workspace
+    const int packed = L.cold.get_pix(), pix = packed & 0xffffff;
+    if (a.shard_count == 1) idx = ((long long)L.cold.get_y() * a.width + L.cold.get_x()) * 3;
+    else idx = (long long)pix * 3;
+    idx += (long long)(packed >> 24) * a.fast_stride;
+    const V3 sum = L.cold.get_acc();
+    a.fb[idx] = sum.x; a.fb[idx + 1] = sum.y; a.fb[idx + 2] = sum.z;
+    return;
+  }
+  V3 acc = L.cold.get_acc() / (float)a.samples; // render.hpp:102
   if (a.shard_count == 1) idx = ((long long)L.cold.get_y() * a.width + L.cold.get_x()) * 3;
   else idx = (long long)L.cold.get_pix() * 3;
   a.fb[idx] = acc.x; a.fb[idx + 1] = acc.y; a.fb[idx + 2] = acc.z;
@@ -243,7 +276,7 @@ __device__ __forceinline__ void lane_regenerate(Lane& L, const KArgs& a) {
 }
 
 // emitted / scatter / sky for the nearest hit (render.hpp:60-88) and the sample bookkeeping (:100).
-template <int UV, typename Lane, typename PB, typename PM>
+template <int UV, bool FAST = false, typename Lane, typename PB, typename PM>
 __device__ __forceinline__ void lane_shade(Lane& L, const KArgs& a, const HitState& h, PB recs, PM mats) {
   if (!L.live) return;
   if (a.cost) L.cold.count_ray(); // cost-probe pass (wave-uniform)
@@ -270,15 +303,15 @@ __device__ __forceinline__ void lane_shade(Lane& L, const KArgs& a, const HitSta
   if (!cont) {
     L.need_new = true;
     // final_color += get_color(r)  render.hpp:100; pixel done: the lane is idle from here on
-    if (L.cold.add_sample(out) == a.samples) lane_store(L, a);
+    if (L.cold.add_sample(out) == a.samples) lane_store<FAST>(L, a);
   }
 }
 
 // One turn of the crank before tracing: finish/advance pixels, pull new ones, start new samples.
 // Returns false when this lane has nothing to trace this iteration.
-template <typename Lane>
+template <bool FAST = false, typename Lane>
 __device__ __forceinline__ void lane_prepare(Lane& L, const KArgs& a) {
-  lane_acquire(L, a);    // idle lanes pull their next pixel ...
+  lane_acquire<FAST>(L, a); // idle lanes pull their next pixel ...
   lane_regenerate(L, a); // ... and every lane whose path ended (or that is new) starts a sample
 }
 
@@ -294,7 +327,8 @@ __device__ __forceinline__ void lane_prepare(Lane& L, const KArgs& a) {
 // COOP: the traversal can split a ray's list over idle lanes (hit_world_lds); costs ~10 VGPRs and ~7 % of the
 // ordinary-mode throughput, so the launcher picks it only where the makespan floor matters (launch_render).
 // CL: the cold part of the lane state lives in LDS (Cold<true>); small scenes only (8 KB per workgroup).
-template <int UV, bool LDS, bool MLDS, bool COOP, bool CL = false>
+// FAST: PT_FLAG_FAST_RNG (opt-in decorrelated mode; its own instantiations, so the parity kernels carry none of it)
+template <int UV, bool LDS, bool MLDS, bool COOP, bool CL = false, bool FAST = false>
 __global__ __launch_bounds__(kBlock, CL ? PT_MIN_WAVES_CL : COOP ? (UV ? PT_MIN_WAVES_COOP_IMG : PT_MIN_WAVES_COOP) : (UV ? PT_MIN_WAVES_IMG : PT_MIN_WAVES))
 void render_kernel(KArgs a) {
   constexpr bool IMG = UV == UV_TRACKED;
@@ -320,7 +354,7 @@ void render_kernel(KArgs a) {
 #ifdef PT_STAMPS
     PT_STAMP(t0);
 #endif
-    lane_prepare(L, a);
+    lane_prepare<FAST>(L, a);
     if (__builtin_amdgcn_ballot_w64(L.live) == 0) {
       if (__builtin_amdgcn_ballot_w64(!L.retired) == 0) break; // queue drained for the whole wave
       continue;                                                 // only padding pixels this time: pull again
@@ -343,8 +377,8 @@ void render_kernel(KArgs a) {
       asm volatile("" ::"v"(h.closest), "v"(h.hit));
       PT_STAMP(t2);
 #endif
-      if constexpr (MLDS) lane_shade<UV>(L, a, h, (lds_f4p)smem, (lds_f4p)smem + a.blob_f4);
-      else lane_shade<UV>(L, a, h, (lds_f4p)smem, a.mats);
+      if constexpr (MLDS) lane_shade<UV, FAST>(L, a, h, (lds_f4p)smem, (lds_f4p)smem + a.blob_f4);
+      else lane_shade<UV, FAST>(L, a, h, (lds_f4p)smem, a.mats);
 #ifdef PT_STAMPS
       asm volatile("" ::"v"(L.att.x), "v"(L.ray.d.x));
       PT_STAMP(t3);
@@ -354,7 +388,7 @@ void render_kernel(KArgs a) {
       RayCtx c = make_ctx(L.ray, a.fast_ok != 0);
       const bool fast = wave_all_regular(c, L.live);
       hit_world<IMG>((cst_f4p)a.blob, (cst_f4p)a.blob, a.n_runs, c, fast, L.rng, h);
-      lane_shade<UV>(L, a, h, a.blob, a.mats);
+      lane_shade<UV, FAST>(L, a, h, a.blob, a.mats);
     }
   }
 #ifdef PT_STAMPS
@@ -379,7 +413,7 @@ constexpr int kSmallRunF4 = 48;    // runs this short are read through the scala
 // tests every G-th record of each tile; one butterfly merge with the reference's acceptance rule at the end: see
 // hit_world_lds), and a wave with no live ray only keeps the barriers.  Scenes with a constant_medium (in-traversal RNG
 // draw) or stale-u,v hazards scan the ordinary way.
-template <int UV>
+template <int UV, bool FAST = false>
 __global__ __launch_bounds__(kBlock) void render_kernel_stream(KArgs a) {
   constexpr bool IMG = UV == UV_TRACKED;
   __shared__ f4 tile[kTileF4];
@@ -390,7 +424,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel_stream(KArgs a) {
   const cst_f4p cblob = (cst_f4p)a.blob;
   const bool coop_scene = !IMG && a.coop_prefix >= a.n_hittables; // list splittable end to end (no medium)
   for (;;) {
-    lane_prepare(L, a);
+    lane_prepare<FAST>(L, a);
     if (!__syncthreads_or(L.live)) {
       if (!__syncthreads_or(!L.retired)) break;
       continue;
@@ -433,7 +467,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel_stream(KArgs a) {
       }
     }
     if (logG) coop_merge_handback<IMG>(h, live_mask, L.live, logG);
-    lane_shade<UV>(L, a, h, a.blob, a.mats);
+    lane_shade<UV, FAST>(L, a, h, a.blob, a.mats);
   }
 }
 
@@ -596,6 +630,17 @@ __global__ void math_kernel(int op, const float* __restrict__ a, const float* __
   out[i] = r;
 }
 
+// PT_FLAG_FAST_RNG: framebuffer = (chunk plane 0 + plane 1 + ... in order) / samples — a fixed order, so the mode is
+// deterministic run to run (and bit-comparable with the oracle's restatement of it).
+__global__ void fast_reduce_kernel(const float* __restrict__ partial, float* __restrict__ fb, long long n, long long stride,
+                                   int chunks, float samples) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float sum = 0.0f;
+  for (int c = 0; c < chunks; c++) sum = sum + partial[(long long)c * stride + i];
+  fb[i] = sum / samples;
+}
+
 // Root-side un-interleave of the gathered shard tiles -> [y][x][rgb].
 __global__ void unshard_kernel(const float* __restrict__ gathered, float* __restrict__ fb, int width, int height,
                                int tiles_x, int shard_count, int tiles_per_shard) {
@@ -687,6 +732,8 @@ struct PtScene {
   mutable int* ws_order = nullptr;         //                cost-sorted tile order
   mutable int ws_tiles = 0;
   int* ws_nsplit = nullptr;                //                number of leading tiles to split (device scalar)
+  mutable float* ws_partial = nullptr;     // PT_FLAG_FAST_RNG: per-chunk partial sums (grow-only)
+  mutable size_t ws_partial_floats = 0;
   unsigned int* queues = nullptr; // ring of per-launch pixel-queue counters
   mutable unsigned int next_queue = 0;
   int device = 0;
@@ -831,6 +878,7 @@ void pt_scene_destroy(PtScene* s) {
   if (s->ws_cost) (void)hipFree(s->ws_cost);
   if (s->ws_order) (void)hipFree(s->ws_order);
   if (s->ws_nsplit) (void)hipFree(s->ws_nsplit);
+  if (s->ws_partial) (void)hipFree(s->ws_partial);
   delete s;
 }
 
@@ -885,6 +933,8 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
   const bool resident = (blob_bytes <= kMaxLdsBlob || (p->flags & PT_FLAG_NO_LDS)) && !(p->flags & PT_FLAG_FORCE_STREAM);
   const bool lds = resident && !(p->flags & PT_FLAG_NO_LDS);
   a.n_local_pixels = local_tiles * PT_TILE_PIXELS;
+  a.fast_chunks = 0; a.samples_total = p->samples; a.fast_stride = 0;
+  long long launch_units = local_tiles; // waves worth of work in the queue (tiles; fast mode: tiles x chunks)
   // default: whole tiles for the resident kernels (coherent primary rays), single pixels for the lock-step
   // streaming kernel (a workgroup waits for its slowest lane); either can be forced
   a.tile_granular = (p->flags & PT_FLAG_TILE_GRANULAR) ? 1 : (p->flags & PT_FLAG_PIXEL_GRANULAR) ? 0 : (resident ? 1 : 0);
@@ -915,7 +965,7 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
     PT_HIP(hipMemsetAsync(a.queue, 0, 2 * sizeof(unsigned int), st));
     // one wave per tile is enough, except in the wide phase, where a split tile keeps G waves busy (how many tiles are
     // split is decided on the device, so such a launch simply fills the chip; surplus waves find the queues empty and exit)
-    const long long wanted = a.n_split ? (long long)resident_blocks : (long long)((local_tiles + kWavesPerBlock - 1) / kWavesPerBlock);
+    const long long wanted = a.n_split ? (long long)resident_blocks : (launch_units + kWavesPerBlock - 1) / kWavesPerBlock;
     n_waves_resident = (int)std::min<long long>(wanted, resident_blocks) * kWavesPerBlock;
     dim3 grid((unsigned int)std::min<long long>(wanted, resident_blocks)), block(kBlock);
     hipLaunchKernelGGL(kernel, grid, block, shmem, st, a);
@@ -924,6 +974,11 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
   };
   auto launch_uv = [&](auto uv) -> int {
     constexpr int UV = decltype(uv)::value;
+    if (a.fast_chunks) { // opt-in decorrelated mode: its own instantiations (no cooperative kernels: a chunk is short)
+      if (!resident) return launch(render_kernel_stream<UV, true>);
+      if (!lds) return launch(render_kernel<UV, false, false, false, false, true>);
+      return mlds ? launch(render_kernel<UV, true, true, false, false, true>) : launch(render_kernel<UV, true, false, false, false, true>);
+    }
     if (!resident) return launch(render_kernel_stream<UV>);
     if (!lds) return launch(render_kernel<UV, false, false, false>);
     if (coop) return mlds ? launch(render_kernel<UV, true, true, true>) : launch(render_kernel<UV, true, false, true>);
@@ -970,6 +1025,36 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
     a = main_args;
     a.order = s->ws_order;
     a.n_split = (coop && !(p->flags & PT_FLAG_NO_SPLIT)) ? s->ws_nsplit : nullptr;
+  }
+  if (p->flags & PT_FLAG_FAST_RNG) {
+    // OPT-IN decorrelated mode (include/pt_render.h): (tile, chunk) work units, per-chunk sums into a workspace, then
+    // one ordered reduction.  No wide phase (a chunk is short by construction); the tile order of the probe still applies.
+    const int chunks = (p->samples + PT_FAST_CHUNK_SPP - 1) / PT_FAST_CHUNK_SPP;
+    if (chunks > 127 || local_tiles >= (1 << 18))
+      return fail(PT_ERR_TOO_LARGE, "PT_FLAG_FAST_RNG supports up to 8128 samples per pixel and 2^24 pixels per shard");
+    const size_t plane = (size_t)pt_framebuffer_floats(p), need = plane * (size_t)chunks;
+    if (s->ws_partial_floats < need) { // grow-only workspace (first render at a new size only)
+      if (s->ws_partial) (void)hipFree(s->ws_partial);
+      s->ws_partial = nullptr; s->ws_partial_floats = 0;
+      PT_HIP(hipMalloc((void**)&s->ws_partial, need * sizeof(float)));
+      s->ws_partial_floats = need;
+    }
+    PT_HIP(hipMemsetAsync(s->ws_partial, 0, need * sizeof(float), st)); // pixels no lane owns add 0
+    a.fast_chunks = chunks;
+    a.samples = std::min(p->samples, (int)PT_FAST_CHUNK_SPP);
+    a.samples_total = p->samples;
+    a.fast_stride = (long long)plane;
+    a.fb = s->ws_partial;
+    a.n_local_pixels = local_tiles * PT_TILE_PIXELS * chunks;
+    a.n_split = nullptr;
+    launch_units = (long long)local_tiles * chunks;
+    s->last_had_wide_phase = false;
+    int rc = launch_variant();
+    if (rc) return rc;
+    hipLaunchKernelGGL(fast_reduce_kernel, dim3((unsigned int)((plane + 255) / 256)), dim3(256), 0, st, s->ws_partial, fb,
+                       (long long)plane, (long long)plane, chunks, (float)p->samples);
+    PT_HIP(hipGetLastError());
+    return PT_OK;
   }
   s->last_had_wide_phase = a.n_split != nullptr;
   int rc = launch_variant();

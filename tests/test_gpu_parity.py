@@ -730,6 +730,42 @@ def test_4k_frame_low_spp(orc):
     assert_bit_identical(R.render_host(3840, 2160, 1, ps, c), orc.render(ps, c.c, 3840, 2160, 1), "4K x 1spp")
 
 
+@pytest.mark.parametrize("name,w,h,spp", [("cornell", 64, 40, 200), ("mixed", 48, 32, 64), ("spheres", 40, 24, 130),
+                                          ("triangles", 33, 17, 65), ("sphere_ties", 32, 18, 20)])
+def test_fast_mode_matches_its_own_oracle(orc, name, w, h, spp):
+    """PT_FLAG_FAST_RNG — opt-in, NOT the reference's image: per-(pixel, chunk) RNG streams (pt_fast_seed), chunks of 64
+    samples summed in chunk order.  Deterministic, so it has a bit-exact checker of its own: the oracle's restatement of
+    the same mode.  Whole chunks, a short last chunk, fewer samples than one chunk; resident, streaming and sharded."""
+    ps, cam = S.ALL[name]()
+    c = scenes.make_camera(cam, w, h)
+    orc.set_math(True)
+    F = abi.PT_FLAG_FAST_RNG
+    ref = orc.render(ps, c.c, w, h, spp, flags=F)
+    assert not np.array_equal(ref, orc.render(ps, c.c, w, h, spp))  # it really is a different image
+    for flags in (F, F | abi.PT_FLAG_FORCE_STREAM, F | abi.PT_FLAG_NO_LDS, F | abi.PT_FLAG_NO_LPT):
+        assert_bit_identical(R.render_host(w, h, spp, ps, c, flags=flags), ref, f"fast mode {name} flags {flags}")
+    shard = R.render_host(w, h, spp, ps, c, flags=F, shard_index=1, shard_count=3)
+    assert_bit_identical(shard, orc.render(ps, c.c, w, h, spp, shard_index=1, shard_count=3, flags=F), "fast mode shard 1/3")
+
+
+@pytest.mark.parametrize("name,w,h,spp,ref_spp", [("cornell", 96, 54, 128, 4096), ("smoke", 96, 54, 64, 2048)])
+def test_fast_mode_is_statistically_the_parity_image(orc, name, w, h, spp, ref_spp):
+    """The tolerance of the opt-in fast mode, stated: against a converged image (the oracle at 32x the samples) the fast
+    frame and the parity frame are estimates of equal quality — their 8-bit PSNRs differ by < 0.75 dB (measured 0.1-0.4)
+    and the mean radiance of each is within 1.5 % of the converged mean."""
+    ps, cam = scenes.build(name)
+    c = scenes.make_camera(cam, w, h)
+    orc.set_math(True)
+    ref = orc.render(ps, c.c, w, h, ref_spp)
+    parity = R.render_host(w, h, spp, ps, c)
+    fast = R.render_host(w, h, spp, ps, c, flags=abi.PT_FLAG_FAST_RNG)
+    r8 = orc.tonemap_rgb8(ref)
+    pp, pf = psnr_8bit(orc.tonemap_rgb8(parity), r8), psnr_8bit(orc.tonemap_rgb8(fast), r8)
+    assert abs(pp - pf) < 0.75, f"PSNR vs converged: parity {pp:.2f} dB, fast {pf:.2f} dB"
+    assert abs(fast.mean() / ref.mean() - 1) < 0.015 and abs(parity.mean() / ref.mean() - 1) < 0.015
+    print(f"\n[fast mode {name}] PSNR vs converged: parity {pp:.2f} dB, fast {pf:.2f} dB")
+
+
 def test_rerender_is_deterministic(torch_gpu):
     ps, cam = scenes.build("smoke")
     c = scenes.make_camera(cam, 200, 112)

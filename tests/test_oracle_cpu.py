@@ -172,3 +172,32 @@ def test_bad_scene_rejected(orc):
     p = orc.params(8, 8, 1)
     rc = orc.load().orc_render(C.byref(ps.desc), C.byref(c.c), C.byref(p), fb.ctypes.data_as(C.POINTER(C.c_float)), None)
     assert rc == abi.PT_ERR_BAD_SCENE
+
+
+def test_fast_mode_restatement_is_deterministic_and_seeds_never_zero(orc):
+    """PT_FLAG_FAST_RNG's checker (NOT the reference's image): deterministic, differs from the parity image, equals it
+    nowhere by accident of a zero seed — pt_fast_seed(pixel, chunk) is never 0 (a zero xorshift32 state is stuck)."""
+    import ctypes as C
+    import re
+    from pathlib import Path
+    from path_tracer_amd import abi
+    hdr = (Path(__file__).resolve().parent.parent / "include" / "pt_render.h").read_text()
+    assert int(re.search(r"#define PT_FAST_CHUNK_SPP (\d+)", hdr).group(1)) == abi.PT_FAST_CHUNK_SPP == 64
+    assert f"PT_FLAG_FAST_RNG = 1u << {abi.PT_FLAG_FAST_RNG.bit_length() - 1}" in hdr
+    ps, cam = S.spheres_scene()
+    c = scenes.make_camera(cam, 24, 14)
+    orc.set_math(True)
+    a = orc.render(ps, c.c, 24, 14, 70, flags=abi.PT_FLAG_FAST_RNG)
+    b = orc.render(ps, c.c, 24, 14, 70, flags=abi.PT_FLAG_FAST_RNG)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and np.isfinite(a).all()
+    assert not np.array_equal(a, orc.render(ps, c.c, 24, 14, 70))
+    # the header's seed function, restated: murmur-style finaliser of (pixel, chunk), 0 mapped to 1
+    def seed(pixel, chunk):
+        h = (pixel * 0x9E3779B1 + chunk * 0x85EBCA77 + 0x165667B1) & 0xFFFFFFFF
+        h ^= h >> 16; h = (h * 0x7FEB352D) & 0xFFFFFFFF; h ^= h >> 15; h = (h * 0x846CA68B) & 0xFFFFFFFF; h ^= h >> 16
+        return h or 1
+    seen = {seed(p, k) for p in range(0, 4000) for k in range(16)}
+    assert 0 not in seen and len(seen) > 0.999 * 4000 * 16
+    # pixel (0,0), one chunk: the oracle's stream starts at seed(0, 0) — first sample of pixel 0 differs from the stuck parity stream
+    px = orc.render_pixels(ps, c.c, 24, 14, 3, np.array([[0, 0]], np.int32), flags=abi.PT_FLAG_FAST_RNG)
+    assert np.isfinite(px).all()
