@@ -170,3 +170,47 @@ def test_example_main_renders_the_python_frame(example_bin, tmp_path, images_dir
     ps, cam = scenes.build("smoke")
     fb = R.render_host(96, 54, 8, ps, scenes.make_camera(cam, 96, 54))
     np.testing.assert_array_equal(img, orc.tonemap_rgb8(fb))
+
+
+# ---- the N-GPU host path in C++ (pt/distributed.hpp + libpt_dist.so: RCCL gather + un-interleave, no Python) ------------
+
+@pytest.fixture(scope="module")
+def dist_bin(tmp_path_factory, lib):
+    out = tmp_path_factory.mktemp("dist") / "dist_main"
+    libdir = ROOT / "path_tracer_amd"
+    assert (libdir / "libpt_dist.so").exists(), "libpt_dist.so is built by __graft_entry__.build()"
+    subprocess.run(["g++", "-std=c++20", "-O1", "-ffp-contract=off", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                    f"-I{libdir / 'include'}", str(ROOT / "tests" / "cpp" / "dist_main.cpp"), "-o", str(out), f"-L{libdir}",
+                    "-lpt_dist", "-lpt_render", "-L/opt/rocm/lib", "-lrccl", "-lamdhip64", f"-Wl,-rpath,{libdir}",
+                    "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    return out
+
+
+def test_dist_library_exports_its_header(lib):
+    """include/pt_dist.h <-> libpt_dist.so (no compute: loadable without a GPU as long as RCCL's library is present)."""
+    import ctypes
+    import re
+    hdr = (ROOT / "include" / "pt_dist.h").read_text()
+    names = sorted(set(re.findall(r"\b(pt_dist_[a-z_]+)\s*\(", hdr)))
+    assert names == ["pt_dist_gather_floats", "pt_dist_gather_frame", "pt_dist_last_error", "pt_dist_render"]
+    d = ctypes.CDLL(str(ROOT / "path_tracer_amd" / "libpt_dist.so"))
+    for n in names:
+        assert hasattr(d, n), n
+    d.pt_dist_gather_floats.restype = ctypes.c_int64
+    p = abi.PtRenderParams(21, 13, 1, 50, 0, 4, 0, 0)  # 3x2 tiles -> 2 per shard x 4 shards x 64 pixels x 3
+    assert d.pt_dist_gather_floats(ctypes.byref(p)) == 4 * 2 * 64 * 3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,n", [("multi", 1), ("shards", 1), ("shards", 3), ("shards", 8)])
+def test_cpp_multi_gpu_host_path(dist_bin, tmp_path, orc, mode, n):
+    """render_multi_gpu (ncclCommInitAll + thread per GPU + pt_dist_render; one device on this box) and the shard replay
+    (n ranks' pt_render outputs placed where ncclGather puts them, then pt_unshard_tiles) give the oracle's frame."""
+    w, h, spp = 70, 42, 5
+    out = tmp_path / "frame.f32"
+    subprocess.run([str(dist_bin), mode, str(w), str(h), str(spp), str(out), str(n)], check=True, timeout=300)
+    fb = np.fromfile(out, dtype=np.float32).reshape(h, w, 3)
+    ps, cam = S.cornell_scene()
+    c = scenes.make_camera(cam, w, h)
+    orc.set_math(True)
+    assert_bit_identical(fb, orc.render(ps, c.c, w, h, spp), f"C++ {mode} n={n}")
