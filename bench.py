@@ -315,6 +315,7 @@ def main() -> None:
                                  "frac": round(pmc[0] / (kern_ms * 1e-3) / 8e12, 6)} if pmc else None,
                          "valu_issue_occupancy_pmc": round(pmc[2].get("valu_issue_occupancy", 0.0), 3) if pmc else None,
                          "valu_lane_utilisation_pmc": round(pmc[2].get("valu_lane_utilisation", 0.0), 3) if pmc else None,
+                         "issue_slot_occupancy_pmc": round(pmc[2]["issue_slot_occupancy"], 3) if pmc and "issue_slot_occupancy" in pmc[2] else None,
                          "valu_lane_instr_per_sample_pmc": round(pmc[2].get("valu_lane_instr_per_sample", 0.0), 1) if pmc else None,
                          # how much more the kernel executes than the reference's arithmetic as written
                          "executed_over_algorithmic": round(pmc[2]["valu_lane_instr_per_sample"] / ops, 3)

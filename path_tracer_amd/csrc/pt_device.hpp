@@ -395,6 +395,47 @@ __device__ __forceinline__ bool box_fast(f4 R0, f4 R1, const RayCtx& c, float mx
   return hit;
 }
 
+// ---- the same six sides with the acceptance as an exec-narrowing chain ------------------------------------------------
+// A SIMD issues ONE instruction per two cycles whatever its kind, so the scalar instructions of a side count like its
+// vector ones.  rect_fast spends, besides the ten arithmetic instructions of t, a, b: 3 v_med3 + 3 v_cmp + 2 s_and + the
+// select of closest, and the box another ~9 for the side index and the hit flag — ~22 issue slots per side.  Here the
+// reference's own six comparisons (rectangle.hpp:36,40: !(t < min) !(t > max) !(a < a0) !(a > a1) !(b < b0) !(b > b1), NaN
+// behaviour included) narrow EXEC one after the other (v_cmpx writes EXEC), the two moves that record an accepted side
+// run under the narrowed mask, and one s_mov restores it: 10 + 6 + 2 + 1 = 19 slots per side and no epilogue.  The block
+// is ONE asm statement, so nothing the compiler schedules can run under the narrowed mask; it declares what it touches
+// (closest, hit in/out; vcc clobbered: v_cmpx_e32 also writes it; EXEC is restored before the block ends).
+// `hit_base` = hit id of this box with side 0, in a VGPR; side S adds S << 24 (hit_pack).
+template <int AX, int S>
+__device__ __forceinline__ void rect_side_cmpx(float a0, float a1, float b0, float b1, float k, const RayCtx& c,
+                                               unsigned long long exec_all, int hit_base, float& closest, int& hit) {
+  typedef AxisSel<AX> Sel;
+  const float n = k - Sel::ok(c);
+  const float t = div_exact(n, Sel::dk(c), Sel::yk(c), n * Sel::yk(c));
+  const float a = Sel::oa(c) + t * Sel::da(c);
+  const float b = Sel::ob(c) + t * Sel::db(c);
+  asm volatile(
+      "v_cmpx_ngt_f32_e32 vcc, %[tmin], %[t]\n\t"  // !(min > t)  ==  !(t < min)
+      "v_cmpx_ngt_f32_e32 vcc, %[t], %[cl]\n\t"    // !(t > max)
+      "v_cmpx_nlt_f32_e32 vcc, %[a], %[a0]\n\t"    // !(a < a0)
+      "v_cmpx_ngt_f32_e32 vcc, %[a], %[a1]\n\t"    // !(a > a1)
+      "v_cmpx_nlt_f32_e32 vcc, %[b], %[b0]\n\t"    // !(b < b0)
+      "v_cmpx_ngt_f32_e32 vcc, %[b], %[b1]\n\t"    // !(b > b1)
+      "v_mov_b32_e32 %[cl], %[t]\n\t"
+      "v_or_b32_e32 %[hit], %[sbits], %[base]\n\t"
+      "s_mov_b64 exec, %[all]"
+      : [cl] "+v"(closest), [hit] "+v"(hit)
+      : [t] "v"(t), [a] "v"(a), [b] "v"(b), [a0] "v"(a0), [a1] "v"(a1), [b0] "v"(b0), [b1] "v"(b1), [tmin] "s"(PT_TMIN),
+        [sbits] "n"(S << 24), [base] "v"(hit_base), [all] "s"(exec_all)
+      : "vcc");
+}
+
+// box.hpp:29-50 for a regular ray on a fast_ok scene; closest / hit are the traversal's own running state
+__device__ __forceinline__ void box_cmpx(f4 R0, f4 R1, const RayCtx& c, unsigned long long exec_all, int hit_base, float& closest, int& hit) {
+#define PT_BOX_SIDE(S, AX, A0, A1, B0, B1, K) rect_side_cmpx<AX, S>(A0, A1, B0, B1, K, c, exec_all, hit_base, closest, hit);
+  PT_BOX_SIDES(R0, R1)
+#undef PT_BOX_SIDE
+}
+
 // ---- triangle.hpp:58-100 (Moller-Trumbore) ---------------------------------------------------------
 // record: R0 = (v0.xyz, mat)  R1 = (edge1.xyz, hittable index)  R2 = (edge2.xyz, 0); edges = v1-v0, v2-v0
 // first half: a = e1.(d x e2), u = s.(d x e2) and the first two rejections of triangle.hpp:71-81 evaluated together
@@ -657,6 +698,16 @@ __device__ __forceinline__ void hit_records(P recs, cst_f4p cblob, int kind, int
     }
     for (; i < n; ++i, off += SZ_TRI) finish_at(off, eval_at(off));
   } else if (kind == DK_BOX) {
+#ifndef PT_NO_CMPX
+    if (fast && !IMG) {
+      const unsigned long long exec_all = __builtin_amdgcn_ballot_w64(true); // EXEC as it is around the scan
+      for (int i = 0; i < n; ++i, off += SZ_BOX) {
+        int hit_base = hit_pack(DK_BOX, 0, goff + off);
+        asm volatile("" : "+v"(hit_base)); // in a VGPR: the side's v_or takes the side bits as its literal
+        box_cmpx(recs[off], recs[off + 1], c, exec_all, hit_base, h.closest, h.hit);
+      }
+    } else
+#endif
     if (fast) {
       for (int i = 0; i < n; ++i, off += SZ_BOX) {
         float t, bu = 0.0f, bv = 0.0f;

@@ -31,6 +31,10 @@ def main():
         if "SQ_INSTS_VALU" in per:
             d["valu_lane_instr_per_sample"] = per["SQ_INSTS_VALU"] * 64 / samples
             d["valu_issue_occupancy"] = per["SQ_INSTS_VALU"] * 2 / (1024 * cyc)  # wave64 on SIMD-32: 2 cycles per instruction
+        if "SQ_INSTS_VALU" in per and "SQ_INSTS_SALU" in per:
+            # a SIMD issues one instruction per two cycles whatever its kind: scalar and LDS instructions
+            # take the same slots as vector ones
+            d["issue_slot_occupancy"] = (per["SQ_INSTS_VALU"] + per["SQ_INSTS_SALU"] + per.get("SQ_INSTS_LDS", 0.0)) * 2 / (1024 * cyc)
         if "SQ_WAVE_CYCLES" in per:
             d["mean_waves_per_simd"] = per["SQ_WAVE_CYCLES"] * 4 / (1024 * cyc)  # SQ_WAVE_CYCLES counts quad-cycles
     if "SQ_THREAD_CYCLES_VALU" in per and "SQ_ACTIVE_INST_VALU" in per:
