@@ -11,8 +11,11 @@
  * (include/texture.hpp:71,126-131,157).  This header states the same boundary as a
  * plain C ABI (pointers + sizes, no C++/torch types) so any host — the C++20
  * facade in path_tracer_amd/include/pt/, the Python ctypes mirror in
- * path_tracer_amd/, or the reference's own main.cpp with a one-line include swap —
- * can bind it.
+ * path_tracer_amd/, or the reference's own render.hpp through the adapter of
+ * INTEGRATION.md (which needs what the reference does not expose today: read access to
+ * camera's ten private fields, camera.hpp:23-51, and to image_texture's fields) — can
+ * bind it.  The facade's render<W,H,S>(frame_buf, hittables, cam) keeps the reference's
+ * argument order but has no sycl::queue& / sycl::buffer& (there is no SYCL here).
  *
  * The scene crosses the boundary as three small tables (hittables, materials,
  * textures) + the RGB8 atlas; tags keep the reference's std::variant index order
