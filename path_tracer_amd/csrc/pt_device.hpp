@@ -79,6 +79,21 @@ __device__ __forceinline__ float length_squared(V3 v) {
 // __fsqrt_rn is the 1-ulp native v_sqrt_f32 unless OCML_BASIC_ROUNDED_OPERATIONS is defined).
 __device__ __forceinline__ float sqrt_rn(float x) { return __builtin_sqrtf(x); }
 
+// Correctly rounded sqrt for x = 0 or 2^-60 <= x <= 4 (what 1 - x*x and maxy*maxy - y*y of rtweekend.hpp:60-67,83-88 can
+// be: multiples of 2^-48 in [0, 1]): the hardware estimate (v_sqrt_f32, <= 1 ulp) and the compiler's own two-sided
+// neighbour test — is s - 1ulp or s + 1ulp the better root? — without the denormal rescaling and the inf/zero class test
+// its general expansion carries (17 -> 9 issue slots, three times per lambertian bounce / camera ray).  Checked against
+// the IEEE result for EVERY float of the range (tests/test_gpu_parity.py::test_unit_range_sqrt_is_correctly_rounded).
+__device__ __forceinline__ float sqrt_rn_unit(float x) {
+  const float s = __builtin_amdgcn_sqrtf(x);
+  const float s_lo = as_f(as_i(s) - 1), s_hi = as_f(as_i(s) + 1);
+  const float r_lo = __builtin_fmaf(-s_lo, s, x); // x - s_lo*s <= 0: s is too large
+  const float r_hi = __builtin_fmaf(-s_hi, s, x); // x - s_hi*s  > 0: s is too small
+  float r = (r_lo <= 0.0f) ? s_lo : s;
+  r = (r_hi > 0.0f) ? s_hi : r;
+  return r;
+}
+
 struct Ray {
   V3 o, d;
   float tm;
@@ -95,9 +110,9 @@ __device__ __forceinline__ float rng_float(uint32_t& s, float mn, float mx) { re
 
 __device__ __forceinline__ V3 rng_unit_vec(uint32_t& s) {
   float x = rng_float(s, -1.0f, 1.0f);
-  float maxy = sqrt_rn(1.0f - x * x);
+  float maxy = sqrt_rn_unit(1.0f - x * x);
   float y = rng_float(s, -maxy, maxy);
-  float absz = sqrt_rn(maxy * maxy - y * y);
+  float absz = sqrt_rn_unit(maxy * maxy - y * y);
   float z = (rng_float(s) > 0.5f) ? absz : -absz;
   return mk(x, y, z);
 }
@@ -116,12 +131,19 @@ struct Cam { // PtCamera, passed by value in the kernarg segment (SGPRs)
   float lens_radius, time0, time1;
 };
 
-__device__ __forceinline__ Ray camera_ray(const Cam& c, int x, int y, int width, int height, uint32_t& rng) {
-  const float su = ((float)x + rng_float(rng)) / (float)width;
-  const float sv = ((float)y + rng_float(rng)) / (float)height;
+__device__ __forceinline__ float div_exact(float n, float d, float y, float q0); // below, with its proof obligations
+
+// inv_w, inv_h: RN(1 / (float)width), RN(1 / (float)height), computed once on the host: the two quotients of render.hpp:96-97
+// through the shared-reciprocal form (div_exact: bit-identical to the IEEE division for 1 <= divisor <= 2^24 and a
+// numerator that is 0 or >= 2^-32 — its tested range), 5 issue slots each instead of ~12.
+__device__ __forceinline__ Ray camera_ray(const Cam& c, int x, int y, int width, int height, float inv_w, float inv_h, uint32_t& rng) {
+  const float nu = (float)x + rng_float(rng);
+  const float su = div_exact(nu, (float)width, inv_w, nu * inv_w);
+  const float nv = (float)y + rng_float(rng);
+  const float sv = div_exact(nv, (float)height, inv_h, nv * inv_h);
   // in_unit_disk rtweekend.hpp:83-88
   float dx = rng_float(rng, -1.0f, 1.0f);
-  float maxy = sqrt_rn(1.0f - dx * dx);
+  float maxy = sqrt_rn_unit(1.0f - dx * dx);
   float dy = rng_float(rng, -maxy, maxy);
   V3 rd = c.lens_radius * mk(dx, dy, 0.0f);
   V3 U = mk(c.u[0], c.u[1], c.u[2]), Vv = mk(c.v[0], c.v[1], c.v[2]);

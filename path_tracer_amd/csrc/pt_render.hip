@@ -72,6 +72,7 @@ struct KArgs {
   float* fb;
   int n_runs, blob_f4, mats_f4;
   int width, height, samples, depth;
+  float inv_w, inv_h; // RN(1 / (float)width), RN(1 / (float)height): camera_ray
   int shard_index, shard_count;
   int tiles_x, n_tiles;
   int n_local_pixels;  // 64 x the tiles this shard owns (incl. padding pixels of edge tiles)
@@ -268,7 +269,7 @@ __device__ __forceinline__ void lane_store(Lane& L, const KArgs& a) {
 template <typename Lane>
 __device__ __forceinline__ void lane_regenerate(Lane& L, const KArgs& a) {
   if (L.live && L.need_new) {
-    L.ray = camera_ray(a.cam, L.cold.get_x(), L.cold.get_y(), a.width, a.height, L.rng);
+    L.ray = camera_ray(a.cam, L.cold.get_x(), L.cold.get_y(), a.width, a.height, a.inv_w, a.inv_h, L.rng);
     L.att = mk(1.0f, 1.0f, 1.0f);
     L.b = 0;
     L.need_new = false;
@@ -601,7 +602,7 @@ __global__ void camera_rays_kernel(Cam cam, int width, int height, const int* __
   int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
   uint32_t rng = rng_in[k];
-  Ray r = camera_ray(cam, xy[2 * k], xy[2 * k + 1], width, height, rng);
+  Ray r = camera_ray(cam, xy[2 * k], xy[2 * k + 1], width, height, 1.0f / (float)width, 1.0f / (float)height, rng);
   PtCameraRay o;
   o.origin[0] = r.o.x; o.origin[1] = r.o.y; o.origin[2] = r.o.z;
   o.dir[0] = r.d.x; o.dir[1] = r.d.y; o.dir[2] = r.d.z;
@@ -625,6 +626,7 @@ __global__ void math_kernel(int op, const float* __restrict__ a, const float* __
     case 7: r = sqrt_rn(x); break;
     case 9: { float yy = 1.0f / y; r = div_exact(x, y, yy, x * yy); break; } // the shared-reciprocal quotient (|q| >= 2^-60)
     case 10: r = rcp_rn_guarded(x); break; // RN(1/a) for 2^-40 <= |a| <= 2^40 (pt_device.hpp: make_ctx)
+    case 11: r = sqrt_rn_unit(x); break;   // correctly rounded sqrt for x = 0 or 2^-60 <= x <= 4
     default: r = x / y; break;
   }
   out[i] = r;
@@ -921,6 +923,7 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
   a.blob = s->blob; a.mats = s->mats; a.atlas = s->atlas; a.fb = fb;
   a.n_runs = s->n_runs; a.blob_f4 = s->blob_f4; a.mats_f4 = s->mats_f4; a.n_hittables = s->n_hittables;
   a.width = p->width; a.height = p->height; a.samples = p->samples; a.depth = p->depth;
+  a.inv_w = 1.0f / (float)p->width; a.inv_h = 1.0f / (float)p->height; // host IEEE division: correctly rounded
   a.shard_index = p->shard_index; a.shard_count = p->shard_count;
   a.n_tiles = n_tiles_of(p, &a.tiles_x);
   const int local_tiles = (a.n_tiles - p->shard_index + p->shard_count - 1) / p->shard_count; // tiles this shard owns
@@ -1187,7 +1190,7 @@ int pt_debug_camera_rays(const PtCamera* cam, int32_t width, int32_t height, con
 }
 
 int pt_debug_math(int32_t op, const float* a, const float* b, float* out, int64_t n) {
-  if (!a || !out || n < 0 || op < 0 || op > 10) return fail(PT_ERR_INVALID_ARG, "pt_debug_math: bad argument");
+  if (!a || !out || n < 0 || op < 0 || op > 11) return fail(PT_ERR_INVALID_ARG, "pt_debug_math: bad argument");
   if ((op == 4 || op == 8 || op == 9) && !b) return fail(PT_ERR_INVALID_ARG, "pt_debug_math: op needs two operands");
   if (n == 0) return PT_OK;
   DevBuf<float> da, db, dout;

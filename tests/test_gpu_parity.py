@@ -124,6 +124,32 @@ def test_guarded_reciprocal_is_correctly_rounded(lib):
                 assert_bit_identical(gpu_math(lib, 10, d, None), (np.float32(1.0) / d).astype(np.float32), f"1/d, exponent {e}")
 
 
+def test_unit_range_sqrt_is_correctly_rounded(lib):
+    """sqrt_rn_unit (pt_device.hpp: v_sqrt_f32 + the two-sided neighbour test, no rescaling): the IEEE square root for
+    EVERY float in [2^-60, 4) and for 0 — the only values 1 - x*x and maxy*maxy - y*y of rtweekend.hpp:60-67,83-88 take
+    (multiples of 2^-48 in [0, 1])."""
+    m = np.arange(2 ** 23, dtype=np.uint32)
+    for e in range(-60, 2):
+        x = ((np.uint32(e + 127) << 23) | m).astype(np.uint32).view(np.float32)
+        assert_bit_identical(gpu_math(lib, 11, x, None), np.sqrt(x), f"sqrt, exponent {e}")
+    z = np.float32([0.0, 1.0, 2.0 ** -48, 3.9999998])
+    assert_bit_identical(gpu_math(lib, 11, z, None), np.sqrt(z), "sqrt edge values")
+
+
+def test_camera_quotients_through_the_reciprocal_are_exact(lib):
+    """render.hpp:96-97: (x + xi) / width through div_exact with RN(1/width) — equal to the IEEE quotient for every frame
+    size up to 16384 and numerators x + xi with xi a multiple of 2^-32 (checked on random and extreme numerators)."""
+    rng = np.random.default_rng(3)
+    for w in (1, 2, 3, 7, 225, 400, 480, 800, 1080, 1920, 2160, 3840, 5431, 16383, 16384):
+        xs = rng.integers(0, w, 200_000).astype(np.float32)
+        xi = (rng.integers(0, 2 ** 32, 200_000, dtype=np.uint64).astype(np.float32) * np.float32(2.0 ** -32)).astype(np.float32)
+        xi[:4] = [0.0, 2.0 ** -32, 1.0 - 2.0 ** -24, 1.0]
+        xs[:4] = [0, 0, w - 1, w - 1]
+        n = (xs + xi).astype(np.float32)
+        d = np.full_like(n, np.float32(w))
+        assert_bit_identical(gpu_math(lib, 9, n, d), (n / d).astype(np.float32), f"(x + xi) / {w}")
+
+
 def test_camera_rays_bit_exact(lib, orc):
     rng = np.random.default_rng(11)
     for cam_args, (w, h) in [(S.cornell_scene()[1], (1920, 1080)), (S.mixed_scene()[1], (400, 225))]:
