@@ -523,9 +523,11 @@ __global__ __launch_bounds__(1024) void lpt_order_kernel(const unsigned int* __r
     unsigned int acc = 0;
     for (int k = 0; k < kLptClasses; k++) { s_cursor[k] = acc; acc += s_count[k]; }
     for (int logG = (forced_logG > 0 ? forced_logG : 1); logG <= (forced_logG > 0 ? forced_logG : 6); logG++) {
-      // Fitted on the 496-hittable scene with every tile wide (tools/wide_chain.py): lane time grows as 1 + 0.037 (G - 1)
-      // (unsplit ~420 of ~11 200 instructions per iteration), while a pixel's chain shortens only as if ~2 400 were unsplit
-      // (latency of run headers, merge stages and shading counts there, not their instruction count).
+      // Per iteration ~2 400 instruction slots are not split (camera, shading, run headers, merge stages — every lane of a
+      // group runs them redundantly) against the list scan's T: lane time of a wide tile grows as (T + G*2400) / (T + 2400),
+      // its chain shortens as (T + 2400) / (T/G + 2400).  Refit in round 2 on the 496-hittable scene after the scan got
+      // cheaper (tools/model_sweep.py; the round-1 fit charged only 420 slots for the lane time and over-split shards:
+      // shard 0/8 of the 1080p frame 113 -> 102 ms, 4K x 512 spp 365 -> 348 ms, whole frames unchanged).
       const float G = (float)(1 << logG);
       const float eff = (trav_cost + fixed_cost) / (trav_cost + G * fixed_cost);
       const float speedup = (trav_cost + s_chain) / (trav_cost / G + s_chain);
@@ -689,7 +691,7 @@ struct EnvKnobs {
   int wide_logG = 0;       // PT_WIDE_LOGG: forced log2 group size of the wide phase (0 = the model picks)
   bool has_split_tiles = false;
   int split_tiles = 0;     // PT_SPLIT_TILES: fixed number of tiles through the wide phase (< 0: all)
-  float model_fixed = 420.0f, model_chain = 1000.0f; // PT_MODEL_FIXED / PT_MODEL_CHAIN: constants of the makespan model (lpt_order_kernel)
+  float model_fixed = 2400.0f, model_chain = 2400.0f; // PT_MODEL_FIXED / PT_MODEL_CHAIN: constants of the makespan model (lpt_order_kernel)
   EnvKnobs() {
     if (const char* e = std::getenv("PT_BLOCKS_PER_CU")) blocks_per_cu = std::max(1, std::atoi(e));
     no_cold_lds = std::getenv("PT_NO_COLD_LDS") != nullptr;

@@ -19,8 +19,8 @@ def t(W, H, spp, n):
     return ms, out[0], out[1]
 R.render(400, 225, 16, R.DeviceScene(packed), scenes.make_camera(cam_args, 400, 225)); torch.cuda.synchronize()
 print("workloads:", work, flush=True)
-for fixed in (420, 250, 150):
-    for chain in (2400, 1500, 1000, 600):
+for fixed in (1200, 2400, 3600):
+    for chain in (2400, 1000, 600):
         os.environ["PT_MODEL_FIXED"] = str(fixed); os.environ["PT_MODEL_CHAIN"] = str(chain)
         row = [t(*w) for w in work]
         print(f"fixed {fixed:4d} chain {chain:5d}: " + "  ".join(f"{ms:7.1f} ms ({tiles} tiles G={g})" for ms, tiles, g in row), flush=True)
