@@ -55,6 +55,10 @@ enum {
   PT_HIT_KIND_COUNT = 7
 };
 
+/* _triangle<IntersectionStrategy> (triangle.hpp:102-103): moller_trumbore_triangle_intersec is the default and the only one
+ * main.cpp instantiates; badouel_ray_triangle_intersec (triangle.hpp:14-56) is the alternative the header ships.        */
+enum { PT_TRI_MOLLER_TRUMBORE = 0, PT_TRI_BADOUEL = 1 };
+
 /* material_t = variant<lambertian, metal, dielectric, lightsource, isotropic>  material.hpp:133-135 */
 enum {
   PT_MAT_LAMBERTIAN = 0,
@@ -85,7 +89,8 @@ typedef struct PtHittable {
   int32_t kind;
   int32_t material;      /* index into PtSceneDesc.materials */
   int32_t boundary_kind; /* CONSTANT_MEDIUM only: PT_HIT_SPHERE or PT_HIT_BOX */
-  int32_t reserved;
+  int32_t strategy;      /* TRIANGLE only: the template argument of _triangle<> (triangle.hpp:102-103): PT_TRI_MOLLER_TRUMBORE
+                          * (= `triangle`, what main.cpp builds) or PT_TRI_BADOUEL (triangle.hpp:14-56); 0 elsewhere      */
   float f[12];
 } PtHittable;
 
@@ -168,15 +173,18 @@ enum {
    * in chunk order (deterministic run to run).  Same estimator, different random numbers: judged by PSNR / mean against
    * the parity image, never bit for bit, never the default.                                                             */
   PT_FLAG_FAST_RNG = 1u << 9,
+  /* The reference's OTHER executor (render.hpp:113-122, built with USE_SINGLE_TASK for FPGA targets): ONE LocalPseudoRNG
+   * with its default seed (xorshift.hpp:18) shared by all pixels, visited x-outer / y-inner, every draw of every sample of
+   * every pixel taken from that one stream in order.  Sequential by definition — a pixel's first state depends on how
+   * many numbers all earlier pixels drew — so it runs as ONE lane; offered for parity completeness on small frames
+   * (width * height * samples <= 2^22), not for speed.  Needs shard_count == 1.                                         */
+  PT_FLAG_SINGLE_STREAM = 1u << 10,
 };
 
-/* PT_FLAG_FAST_RNG: samples per chunk, and the seed of chunk `chunk` of the pixel with linear id `pixel` (never 0). */
+/* PT_FLAG_FAST_RNG: samples per chunk; pt_fast_seed() below gives the xorshift32 seed of chunk `chunk` of the pixel with
+ * linear id `pixel`: h = pixel * 0x9E3779B1 + chunk * 0x85EBCA77 + 0x165667B1; h ^= h >> 16; h *= 0x7FEB352D; h ^= h >> 15;
+ * h *= 0x846CA68B; h ^= h >> 16; 0 is mapped to 1 (a zero xorshift state is stuck).                                       */
 #define PT_FAST_CHUNK_SPP 64
-static inline uint32_t pt_fast_seed(uint32_t pixel, uint32_t chunk) {
-  uint32_t h = pixel * 0x9E3779B1u + chunk * 0x85EBCA77u + 0x165667B1u;
-  h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
-  return h ? h : 1u;
-}
 
 typedef struct PtRenderParams {
   int32_t width, height; /* template args of render<> (render.hpp:141)           */
@@ -225,6 +233,9 @@ void pt_scene_destroy(PtScene* scene);
  * (render.hpp:105, main.cpp:41).  shard_count>1: pt_shard_tiles()*64*3 laid
  * out [local_tile][ly*8+lx][rgb].                                              */
 int64_t pt_framebuffer_floats(const PtRenderParams* p);
+/* Seed of the fast mode's stream for (pixel, chunk) — see PT_FLAG_FAST_RNG; never 0. Host function, no GPU needed. */
+uint32_t pt_fast_seed(uint32_t pixel, uint32_t chunk);
+
 int32_t pt_shard_tiles(const PtRenderParams* p); /* ceil(n_tiles / shard_count) */
 
 /* The hot path.  Asynchronous on `stream` (a hipStream_t, or NULL for the

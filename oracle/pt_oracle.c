@@ -259,6 +259,37 @@ static int triangle_hit(ctx_t* c, const float* f, const ray_t* r, float mn, floa
   return 1; /* rec->u, rec->v left as they were (stale) */
 }
 
+/* ---- triangle, Badouel strategy (triangle.hpp:14-56): the alternative _triangle<> can be instantiated with ---------- */
+static int triangle_hit_badouel(ctx_t* c, const float* f, const ray_t* r, float mn, float mx, hit_record* rec) {
+  (void)c;
+  v3 v0 = vld(f), v1 = vld(f + 3), v2 = vld(f + 6);
+  v3 u = vsub(v1, v0);
+  v3 v = vsub(v2, v0);
+  v3 outward_normal = vcross(u, v);
+  v3 w0 = vsub(r->orig, v0);
+  float a = -vdot(outward_normal, w0);
+  float b = vdot(outward_normal, r->dir);
+  if (fabsf(b) < 0.000001f) return 0; /* ray parallel to the plane */
+  float length = a / b;
+  if (length < 0) return 0;
+  else if (length < mn || length > mx) return 0;
+  v3 hit_pt = ray_at(r, length);
+  float uu = vdot(u, u);
+  float uv = vdot(u, v);
+  float vv = vdot(v, v);
+  v3 w = vsub(hit_pt, v0);
+  float wu = vdot(w, u);
+  float wv = vdot(w, v);
+  float D = uv * uv - uu * vv;
+  float s = (uv * wv - vv * wu) / D;
+  float t = (uv * wu - uu * wv) / D;
+  if (s < 0.0f || s > 1.0f || t < 0.0f || (s + t) > 1.0f) return 0;
+  set_face_normal(rec, r, outward_normal);
+  rec->t = length;
+  rec->p = hit_pt;
+  return 1; /* rec->u, rec->v left as they were */
+}
+
 /* ---- box (box.hpp:15-50): nearest of six sides in constructor order ------------------------ */
 static int box_hit(ctx_t* c, const float* f, const ray_t* r, float mn, float mx, hit_record* rec) {
   float x0 = f[0], y0 = f[1], z0 = f[2], x1 = f[3], y1 = f[4], z1 = f[5];
@@ -327,7 +358,10 @@ static int hit_world(ctx_t* c, const ray_t* r, hit_record* rec, int* material, i
       case PT_HIT_XY_RECT: hit = rect_hit(c, 0, h->f[0], h->f[1], h->f[2], h->f[3], h->f[4], r, 0.001f, closest_so_far, &temp_rec); break;
       case PT_HIT_XZ_RECT: hit = rect_hit(c, 1, h->f[0], h->f[1], h->f[2], h->f[3], h->f[4], r, 0.001f, closest_so_far, &temp_rec); break;
       case PT_HIT_YZ_RECT: hit = rect_hit(c, 2, h->f[0], h->f[1], h->f[2], h->f[3], h->f[4], r, 0.001f, closest_so_far, &temp_rec); break;
-      case PT_HIT_TRIANGLE: hit = triangle_hit(c, h->f, r, 0.001f, closest_so_far, &temp_rec); break;
+      case PT_HIT_TRIANGLE: /* _triangle<IntersectionStrategy>::hit triangle.hpp:113-117 */
+        hit = h->strategy == PT_TRI_BADOUEL ? triangle_hit_badouel(c, h->f, r, 0.001f, closest_so_far, &temp_rec)
+                                            : triangle_hit(c, h->f, r, 0.001f, closest_so_far, &temp_rec);
+        break;
       case PT_HIT_BOX: hit = box_hit(c, h->f, r, 0.001f, closest_so_far, &temp_rec); break;
       default: hit = medium_hit(c, h, r, 0.001f, closest_so_far, &temp_rec); break;
     }
@@ -529,6 +563,13 @@ static void render_pixel(const PtSceneDesc* sc, const PtCamera* cam, const PtRen
 /* PT_FLAG_FAST_RNG (include/pt_render.h): NOT the reference's image — the opt-in decorrelated mode, restated here so that
  * the GPU's fast mode has a bit-exact checker of its own.  Chunks of PT_FAST_CHUNK_SPP samples, each with its own stream;
  * chunk sums (sequential float adds from 0) are added in chunk order, then one division by the sample count.            */
+/* the oracle's own statement of pt_fast_seed (include/pt_render.h): nothing of the product is linked here */
+static inline uint32_t orc_fast_seed(uint32_t pixel, uint32_t chunk) {
+  uint32_t h = pixel * 0x9E3779B1u + chunk * 0x85EBCA77u + 0x165667B1u;
+  h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+  return h ? h : 1u;
+}
+
 static void render_pixel_fast(const PtSceneDesc* sc, const PtCamera* cam, const PtRenderParams* p, int x, int y,
                               float out[3], OrcCounters* ctr) {
   ctx_t c;
@@ -538,7 +579,7 @@ static void render_pixel_fast(const PtSceneDesc* sc, const PtCamera* cam, const 
   v3 total = V(0.0f, 0.0f, 0.0f);
   for (int chunk = 0, s0 = 0; s0 < p->samples; chunk++, s0 += PT_FAST_CHUNK_SPP) {
     const int n = p->samples - s0 < PT_FAST_CHUNK_SPP ? p->samples - s0 : PT_FAST_CHUNK_SPP;
-    c.rng = pt_fast_seed(id, (uint32_t)chunk);
+    c.rng = orc_fast_seed(id, (uint32_t)chunk);
     v3 sum = V(0.0f, 0.0f, 0.0f);
     for (int i = 0; i < n; i++) {
       ray_t r = sample_ray(cam, x, y, p->width, p->height, &c);
@@ -548,6 +589,25 @@ static void render_pixel_fast(const PtSceneDesc* sc, const PtCamera* cam, const 
     total = vadd(total, sum);
   }
   vst(out, vdivs(total, (float)p->samples));
+}
+
+/* render.hpp:113-122 (USE_SINGLE_TASK): one LocalPseudoRNG, default-seeded (xorshift.hpp:18), shared by every pixel; the
+ * loops run x outer, y inner; render_pixel is the same function, it just receives the shared context.                  */
+static void render_single_stream(const PtSceneDesc* sc, const PtCamera* cam, const PtRenderParams* p, float* fb, OrcCounters* ctr) {
+  ctx_t c;
+  c.rng = 2463534242u;
+  c.sc = sc;
+  c.c = ctr;
+  for (int x = 0; x != p->width; ++x)
+    for (int y = 0; y != p->height; ++y) {
+      v3 final_color = V(0.0f, 0.0f, 0.0f);
+      for (int i = 0; i < p->samples; i++) {
+        ray_t r = sample_ray(cam, x, y, p->width, p->height, &c);
+        final_color = vadd(final_color, get_color(&c, &r, p->depth));
+        if (ctr) ctr->samples++;
+      }
+      vst(fb + ((int64_t)y * p->width + x) * 3, vdivs(final_color, (float)p->samples));
+    }
 }
 
 static void render_pixel_any(const PtSceneDesc* sc, const PtCamera* cam, const PtRenderParams* p, int x, int y,
@@ -578,6 +638,7 @@ static int validate(const PtSceneDesc* sc) {
     if (h->material < 0 || h->material >= sc->n_materials) return PT_ERR_BAD_SCENE;
     if (h->kind == PT_HIT_CONSTANT_MEDIUM && h->boundary_kind != PT_HIT_SPHERE && h->boundary_kind != PT_HIT_BOX)
       return PT_ERR_BAD_SCENE;
+    if (h->kind == PT_HIT_TRIANGLE && h->strategy != PT_TRI_MOLLER_TRUMBORE && h->strategy != PT_TRI_BADOUEL) return PT_ERR_BAD_SCENE;
   }
   return PT_OK;
 }
@@ -614,6 +675,11 @@ static int render_rows(const PtSceneDesc* sc, const PtCamera* cam, const PtRende
       p->shard_count < 1 || p->shard_index < 0 || p->shard_index >= p->shard_count)
     return PT_ERR_INVALID_ARG;
   if (counters) memset(counters, 0, sizeof *counters);
+  if (p->flags & PT_FLAG_SINGLE_STREAM) { /* the reference's single-task executor: one stream, inherently sequential */
+    if (p->shard_count != 1 || y0 != 0 || y1 != p->height) return PT_ERR_INVALID_ARG;
+    render_single_stream(sc, cam, p, fb, counters);
+    return PT_OK;
+  }
 #pragma omp parallel
   {
     OrcCounters local;

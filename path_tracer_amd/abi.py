@@ -24,6 +24,7 @@ PT_TEX_CHECKER, PT_TEX_SOLID, PT_TEX_IMAGE = 0, 1, 2
 
 PT_TILE = 8
 PT_TILE_PIXELS = 64
+PT_TRI_MOLLER_TRUMBORE, PT_TRI_BADOUEL = 0, 1  # PtHittable.strategy of a triangle (triangle.hpp:102-103)
 PT_FLAG_NONE = 0
 PT_FLAG_NO_LDS = 1
 PT_FLAG_FORCE_STREAM = 2
@@ -36,6 +37,7 @@ PT_FLAG_FORCE_COOP = 128
 PT_FLAG_NO_SPLIT = 256
 PT_FLAG_FAST_RNG = 512  # opt-in decorrelated RNG streams: NOT the reference's image (include/pt_render.h)
 PT_FAST_CHUNK_SPP = 64
+PT_FLAG_SINGLE_STREAM = 1024  # the reference's USE_SINGLE_TASK executor: one RNG stream for the whole frame (small frames)
 
 PT_OK, PT_ERR_INVALID_ARG, PT_ERR_BAD_SCENE, PT_ERR_HIP, PT_ERR_NO_DEVICE, PT_ERR_TOO_LARGE = range(6)
 PT_BOUNCE_MISS, PT_BOUNCE_SCATTERED, PT_BOUNCE_ABSORBED = 0, 1, 2
@@ -43,7 +45,7 @@ PT_BOUNCE_MISS, PT_BOUNCE_SCATTERED, PT_BOUNCE_ABSORBED = 0, 1, 2
 
 class PtHittable(C.Structure):
     _fields_ = [("kind", C.c_int32), ("material", C.c_int32), ("boundary_kind", C.c_int32),
-                ("reserved", C.c_int32), ("f", C.c_float * 12)]
+                ("strategy", C.c_int32), ("f", C.c_float * 12)]
 
 
 class PtMaterial(C.Structure):
@@ -109,6 +111,7 @@ SIGNATURES = {
                                  C.c_float, C.c_float]),
     "pt_scene_create": (C.c_int, [C.POINTER(PtSceneDesc), C.POINTER(_SCENE_P)]),
     "pt_scene_destroy": (None, [_SCENE_P]),
+    "pt_fast_seed": (C.c_uint32, [C.c_uint32, C.c_uint32]),
     "pt_framebuffer_floats": (C.c_int64, [C.POINTER(PtRenderParams)]),
     "pt_shard_tiles": (C.c_int32, [C.POINTER(PtRenderParams)]),
     "pt_render": (C.c_int, [_SCENE_P, C.POINTER(PtCamera), C.POINTER(PtRenderParams), C.c_void_p, C.c_void_p]),

@@ -36,7 +36,7 @@ typedef const __attribute__((address_space(3))) f4* lds_f4p; // LDS-resident blo
 typedef const __attribute__((address_space(4))) f4* cst_f4p; // global blob via scalar (SMEM) loads
 
 // device kinds of a run / hit id (not the ABI tags: the three rect axes share one kind)
-enum { DK_SPHERE = 0, DK_RECT = 1, DK_TRI = 2, DK_BOX = 3, DK_MEDIUM = 4 };
+enum { DK_SPHERE = 0, DK_RECT = 1, DK_TRI = 2, DK_BOX = 3, DK_MEDIUM = 4, DK_TRI_B = 5 /* Badouel-strategy triangles */ };
 
 // record sizes in f4 units
 enum { SZ_SPHERE = 3, SZ_RECT = 2, SZ_TRI = 3, SZ_BOX = 2, SZ_MEDIUM = 4, SZ_MATERIAL = 4 };
@@ -499,6 +499,32 @@ __device__ __forceinline__ bool tri_t(f4 R0, f4 R1, f4 R2, const Ray& r, float m
   return hit;
 }
 
+// ---- triangle.hpp:14-56 (Badouel strategy: the alternative argument of _triangle<>) -----------------------------------
+// Same record as the Moller-Trumbore triangle (edges precomputed with the same subtractions, triangle.hpp:19-20).  A
+// parity-completeness path (main.cpp never instantiates it): one triangle at a time, compiled only into the kernels that
+// scenes with such triangles run (template flag BADOUEL), so it costs the others neither code nor registers.
+template <typename Accept>
+__device__ __forceinline__ void badouel_test(f4 R0, f4 R1, f4 R2, const Ray& r, float mn, float mx, Accept accept) {
+  const V3 u = xyz(R1), v = xyz(R2);
+  const V3 outward_normal = cross(u, v);
+  const V3 w0 = r.o - xyz(R0);
+  const float a = -dot(outward_normal, w0);
+  const float b = dot(outward_normal, r.d);
+  if (__builtin_fabsf(b) < 0.000001f) return; // parallel to the plane
+  const float length = a / b;
+  if (length < 0) return;
+  if (length < mn || length > mx) return;
+  const V3 hit_pt = r.o + length * r.d;
+  const float uu = dot(u, u), uv = dot(u, v), vv = dot(v, v);
+  const V3 w = hit_pt - xyz(R0);
+  const float wu = dot(w, u), wv = dot(w, v);
+  const float D = uv * uv - uu * vv;
+  const float s = (uv * wv - vv * wu) / D;
+  const float t = (uv * wu - uu * wv) / D;
+  if (s < 0.0f || s > 1.0f || t < 0.0f || (s + t) > 1.0f) return;
+  accept(length);
+}
+
 // ---- constant_medium.hpp:28-78 -------------------------------------------------------------------------
 // record: R0 = (boundary kind, neg_inv_density, mat, hittable index)  R1.. = boundary (sphere 3 f4 | box 2 f4)
 template <typename P>
@@ -661,7 +687,8 @@ __device__ __forceinline__ void sphere_scan(P recs, cst_f4p cblob, int n, int go
 // kernels, which have registers to spare, take 2 spheres / 4 triangles.
 // WHOLE: recs[0..n) is a whole run (its aux records sit in front of it at cblob[goff - 1]); false for an LDS tile of a
 // streamed run, which takes the spheres one at a time in list order.
-template <bool IMG, int TRIP = 1, int TTRIP = TRIP, bool WHOLE = true, typename P>
+// BADOUEL: the kernel also knows Badouel-strategy triangle runs (DK_TRI_B).
+template <bool IMG, int TRIP = 1, int TTRIP = TRIP, bool WHOLE = true, bool BADOUEL = false, typename P>
 __device__ __forceinline__ void hit_records(P recs, cst_f4p cblob, int kind, int n, int goff,
                                             const RayCtx& c, bool fast, uint32_t& rng, HitState& h) {
   const Ray& r = c.r;
@@ -719,6 +746,10 @@ __device__ __forceinline__ void hit_records(P recs, cst_f4p cblob, int kind, int
       }
     }
     for (; i < n; ++i, off += SZ_TRI) finish_at(off, eval_at(off));
+  } else if (BADOUEL && kind == DK_TRI_B) {
+    for (int i = 0; i < n; ++i, off += SZ_TRI)
+      badouel_test(recs[off], recs[off + 1], recs[off + 2], r, PT_TMIN, h.closest,
+                   [&](float t) { h.closest = t; h.hit = hit_pack(DK_TRI_B, 0, goff + off); });
   } else if (kind == DK_BOX) {
 #ifndef PT_NO_CMPX
     if (fast && !IMG) {
@@ -854,7 +885,7 @@ __device__ __forceinline__ void hit_records_strided(P recs, cst_f4p cblob, int k
 }
 
 __device__ __forceinline__ int record_size(int kind) {
-  return kind == DK_SPHERE ? SZ_SPHERE : kind == DK_RECT ? SZ_RECT : kind == DK_TRI ? SZ_TRI : kind == DK_BOX ? SZ_BOX : SZ_MEDIUM;
+  return kind == DK_SPHERE ? SZ_SPHERE : kind == DK_RECT ? SZ_RECT : (kind == DK_TRI || kind == DK_TRI_B) ? SZ_TRI : kind == DK_BOX ? SZ_BOX : SZ_MEDIUM;
 }
 
 // Whole list, blob resident (LDS or scalar cache): blob = [n_runs x (kind, first record offset, count, -)] [records]
@@ -862,13 +893,13 @@ __device__ __forceinline__ int record_size(int kind) {
 // kernel constants: an s_load lands in SGPRs directly, no LDS round trip + v_readfirstlane per run) and the records from LDS.
 // `cblob`: the blob in global memory through the scalar cache (run headers, sphere-run masks); `blob`: where the records are
 // read from (LDS copy, or the same global blob).
-template <bool IMG, typename P>
+template <bool IMG, bool BADOUEL = false, typename P>
 __device__ __forceinline__ void hit_world(P blob, cst_f4p cblob, int n_runs, const RayCtx& c, bool fast, uint32_t& rng, HitState& h) {
   hit_begin(h);
   for (int ri = 0; ri < n_runs; ++ri) {
     f4 runf = cblob[ri];
     const int off = as_i(runf.y);
-    hit_records<IMG>(blob + off, cblob, as_i(runf.x), as_i(runf.z), off, c, fast, rng, h);
+    hit_records<IMG, 1, 1, true, BADOUEL>(blob + off, cblob, as_i(runf.x), as_i(runf.z), off, c, fast, rng, h);
   }
 }
 
@@ -1090,9 +1121,9 @@ __device__ __forceinline__ Rec resolve_hit(P blob, int hit, const Ray& r, float 
     else { axis = hit_side(hit) >> 1; rec.mat = as_i(R0.w); rec.hittable = as_i(R1.w); }
     V3 n = axis == 0 ? mk(0, 0, 1) : axis == 1 ? mk(0, 1, 0) : mk(1, 0, 0);
     set_face_normal(rec, r, n);
-  } else if (kind == DK_TRI) {
+  } else if (kind == DK_TRI || kind == DK_TRI_B) {
     f4 R2 = blob[off + 2];
-    set_face_normal(rec, r, cross(xyz(R1), xyz(R2))); // not normalised, triangle.hpp:96
+    set_face_normal(rec, r, cross(xyz(R1), xyz(R2))); // not normalised, triangle.hpp:96 (Badouel: the same cross(u, v), :21,52)
     rec.mat = as_i(R0.w);
     rec.hittable = as_i(R1.w);
   } else {

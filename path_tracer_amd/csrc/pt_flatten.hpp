@@ -22,7 +22,7 @@ static_assert(sizeof(F4) == 16);
 
 inline float as_f(int32_t i) { float f; std::memcpy(&f, &i, 4); return f; }
 
-enum { DK_SPHERE = 0, DK_RECT = 1, DK_TRI = 2, DK_BOX = 3, DK_MEDIUM = 4 };
+enum { DK_SPHERE = 0, DK_RECT = 1, DK_TRI = 2, DK_BOX = 3, DK_MEDIUM = 4, DK_TRI_B = 5 /* Badouel-strategy triangles */ };
 
 struct Flat {
   std::vector<F4> blob; // [n_runs run headers][records; a sphere run is preceded by its offset lists + aux F4]
@@ -33,6 +33,7 @@ struct Flat {
   bool coop_ok = true; // no triangle/medium carries an image texture (stale u,v cannot matter): pt_device.hpp coop
   int32_t coop_prefix = 0; // hittables before the first constant_medium
   bool fast_ok = true; // all rect/box coordinates finite with |v| <= 2^60 (pt_device.hpp: RayCtx)
+  bool has_badouel = false; // some triangle uses the Badouel strategy (its own device kind and kernel instantiations)
 };
 
 inline int device_kind(int32_t k) {
@@ -46,8 +47,13 @@ inline int device_kind(int32_t k) {
   }
 }
 
+inline int device_kind(const PtHittable& h) { // a Badouel-strategy triangle is a device kind of its own (own run, own loop)
+  if (h.kind == PT_HIT_TRIANGLE && h.strategy == PT_TRI_BADOUEL) return DK_TRI_B;
+  return device_kind(h.kind);
+}
+
 inline int record_size(int dk) {
-  switch (dk) { case DK_SPHERE: return 3; case DK_RECT: return 2; case DK_TRI: return 3; case DK_BOX: return 2; default: return 4; }
+  switch (dk) { case DK_SPHERE: return 3; case DK_RECT: return 2; case DK_TRI: case DK_TRI_B: return 3; case DK_BOX: return 2; default: return 4; }
 }
 
 inline int validate(const PtSceneDesc* sc, std::string& err) {
@@ -80,6 +86,9 @@ inline int validate(const PtSceneDesc* sc, std::string& err) {
     if (h.material < 0 || h.material >= sc->n_materials) { err = "hittable " + std::to_string(i) + ": material index out of range"; return PT_ERR_BAD_SCENE; }
     if (h.kind == PT_HIT_CONSTANT_MEDIUM && h.boundary_kind != PT_HIT_SPHERE && h.boundary_kind != PT_HIT_BOX) {
       err = "hittable " + std::to_string(i) + ": constant_medium boundary must be a sphere or a box"; return PT_ERR_BAD_SCENE;
+    }
+    if (h.kind == PT_HIT_TRIANGLE && h.strategy != PT_TRI_MOLLER_TRUMBORE && h.strategy != PT_TRI_BADOUEL) {
+      err = "hittable " + std::to_string(i) + ": unknown triangle strategy"; return PT_ERR_BAD_SCENE;
     }
   }
   return PT_OK;
@@ -146,7 +155,8 @@ inline int flatten(const PtSceneDesc* sc, Flat& out, std::string& err) {
   struct Run { int kind, first, count; };
   std::vector<Run> runs;
   for (int i = 0; i < sc->n_hittables; i++) {
-    int dk = device_kind(sc->hittables[i].kind);
+    int dk = device_kind(sc->hittables[i]);
+    if (dk == DK_TRI_B) out.has_badouel = true;
     if (runs.empty() || runs.back().kind != dk) runs.push_back({dk, i, 0});
     runs.back().count++;
   }

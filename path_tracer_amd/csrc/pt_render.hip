@@ -163,8 +163,8 @@ __device__ __forceinline__ void lane_reset(Lane& L, lds_fp cold_base) {
   L.live = false; L.retired = false; L.need_new = true; L.split_done = false; L.wide = 0; L.split_pixels = 0;
 }
 
-// device copy of pt_fast_seed (include/pt_render.h; host inline there): tests compare the two through the oracle's fast mode
-__device__ __forceinline__ uint32_t fast_seed(uint32_t pixel, uint32_t chunk) {
+// pt_fast_seed (include/pt_render.h), device and host
+__host__ __device__ __forceinline__ uint32_t fast_seed(uint32_t pixel, uint32_t chunk) {
   uint32_t h = pixel * 0x9E3779B1u + chunk * 0x85EBCA77u + 0x165667B1u;
   h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
   return h ? h : 1u;
@@ -329,7 +329,8 @@ __device__ __forceinline__ void lane_prepare(Lane& L, const KArgs& a) {
 // ordinary-mode throughput, so the launcher picks it only where the makespan floor matters (launch_render).
 // CL: the cold part of the lane state lives in LDS (Cold<true>); small scenes only (8 KB per workgroup).
 // FAST: PT_FLAG_FAST_RNG (opt-in decorrelated mode; its own instantiations, so the parity kernels carry none of it)
-template <int UV, bool LDS, bool MLDS, bool COOP, bool CL = false, bool FAST = false>
+// BADOUEL: the scene has Badouel-strategy triangles (their loop is compiled only into these instantiations)
+template <int UV, bool LDS, bool MLDS, bool COOP, bool CL = false, bool FAST = false, bool BADOUEL = false>
 __global__ __launch_bounds__(kBlock, CL ? PT_MIN_WAVES_CL : COOP ? (UV ? PT_MIN_WAVES_COOP_IMG : PT_MIN_WAVES_COOP) : (UV ? PT_MIN_WAVES_IMG : PT_MIN_WAVES))
 void render_kernel(KArgs a) {
   constexpr bool IMG = UV == UV_TRACKED;
@@ -372,7 +373,7 @@ void render_kernel(KArgs a) {
       } else {
         RayCtx c = make_ctx(L.ray, a.fast_ok != 0);
         const bool fast = wave_all_regular(c, L.live);
-        hit_world<IMG>((lds_f4p)smem, (cst_f4p)a.blob, a.n_runs, c, fast, L.rng, h);
+        hit_world<IMG, BADOUEL>((lds_f4p)smem, (cst_f4p)a.blob, a.n_runs, c, fast, L.rng, h);
       }
 #ifdef PT_STAMPS
       asm volatile("" ::"v"(h.closest), "v"(h.hit));
@@ -388,7 +389,7 @@ void render_kernel(KArgs a) {
     } else {
       RayCtx c = make_ctx(L.ray, a.fast_ok != 0);
       const bool fast = wave_all_regular(c, L.live);
-      hit_world<IMG>((cst_f4p)a.blob, (cst_f4p)a.blob, a.n_runs, c, fast, L.rng, h);
+      hit_world<IMG, BADOUEL>((cst_f4p)a.blob, (cst_f4p)a.blob, a.n_runs, c, fast, L.rng, h);
       lane_shade<UV, FAST>(L, a, h, a.blob, a.mats);
     }
   }
@@ -414,7 +415,7 @@ constexpr int kSmallRunF4 = 48;    // runs this short are read through the scala
 // tests every G-th record of each tile; one butterfly merge with the reference's acceptance rule at the end: see
 // hit_world_lds), and a wave with no live ray only keeps the barriers.  Scenes with a constant_medium (in-traversal RNG
 // draw) or stale-u,v hazards scan the ordinary way.
-template <int UV, bool FAST = false>
+template <int UV, bool FAST = false, bool BADOUEL = false>
 __global__ __launch_bounds__(kBlock) void render_kernel_stream(KArgs a) {
   constexpr bool IMG = UV == UV_TRACKED;
   __shared__ f4 tile[kTileF4];
@@ -450,7 +451,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel_stream(KArgs a) {
       if (cnt * sz <= kSmallRunF4) {
         if (!wave_idle) {
           if (logG) hit_records_strided<IMG>(a.blob + off, cblob, kind, cnt, 0, off, j, logG, c, h);
-          else hit_records<IMG, 4>(cblob + off, cblob, kind, cnt, off, c, fast, L.rng, h);
+          else hit_records<IMG, 4, 4, true, BADOUEL>(cblob + off, cblob, kind, cnt, off, c, fast, L.rng, h);
         }
         continue;
       }
@@ -462,7 +463,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel_stream(KArgs a) {
         __syncthreads();
         if (!wave_idle) {
           if (logG) hit_records_strided<IMG, false>((lds_f4p)tile, cblob, kind, n, 0, base, j, logG, c, h);
-          else hit_records<IMG, 4, 4, false>((lds_f4p)tile, cblob, kind, n, base, c, fast, L.rng, h);
+          else hit_records<IMG, 4, 4, false, BADOUEL>((lds_f4p)tile, cblob, kind, n, base, c, fast, L.rng, h);
         }
         __syncthreads();
       }
@@ -470,6 +471,37 @@ __global__ __launch_bounds__(kBlock) void render_kernel_stream(KArgs a) {
     if (logG) coop_merge_handback<IMG>(h, live_mask, L.live, logG);
     lane_shade<UV, FAST>(L, a, h, a.blob, a.mats);
   }
+}
+
+// The reference's single-task executor (render.hpp:113-122, USE_SINGLE_TASK): one default-seeded RNG for the whole frame,
+// pixels x-outer / y-inner.  One sequential chain by definition, so one lane runs it (launch <<<1, 64>>>, lane 0 works);
+// u,v are tracked through the scan as the reference's temp_rec does (no per-scene kernel choice for a parity-only mode).
+__global__ __launch_bounds__(64) void render_single_stream_kernel(KArgs a) {
+  if (threadIdx.x != 0) return;
+  const cst_f4p cblob = (cst_f4p)a.blob;
+  uint32_t rng = 2463534242u; // xorshift.hpp:18
+  for (int x = 0; x != a.width; ++x)
+    for (int y = 0; y != a.height; ++y) {
+      V3 acc = mk(0.0f, 0.0f, 0.0f);
+      for (int s = 0; s < a.samples; ++s) {
+        Ray ray = camera_ray(a.cam, x, y, a.width, a.height, a.inv_w, a.inv_h, rng);
+        V3 att = mk(1.0f, 1.0f, 1.0f), out = mk(0.0f, 0.0f, 0.0f); // depth exhausted: black (render.hpp:91)
+        for (int b = 0; b < a.depth; ++b) {
+          RayCtx c = make_ctx(ray, a.fast_ok != 0);
+          HitState h;
+          hit_world<true, true>(a.blob, cblob, a.n_runs, c, c.reg, rng, h);
+          if (h.hit < 0) { out = sky_color(ray, att); break; }
+          const Rec rec = resolve_hit(a.blob, h.hit, ray, h.closest);
+          auto uv = [&](float& u, float& v) { u = h.u; v = h.v; };
+          if (!shade(a.mats, a.atlas, rec, uv, ray, att, rng, out)) break;
+          out = mk(0.0f, 0.0f, 0.0f);
+        }
+        acc = acc + out;
+      }
+      const V3 mean = acc / (float)a.samples;
+      float* px = a.fb + ((long long)y * a.width + x) * 3;
+      px[0] = mean.x; px[1] = mean.y; px[2] = mean.z;
+    }
 }
 
 // ---- longest-processing-time-first tile order -------------------------------------------------------------
@@ -566,7 +598,7 @@ __global__ void bounce_kernel(const f4* __restrict__ blob, int n_runs, const f4*
   memset(&O, 0, sizeof O);
   RayCtx c = make_ctx(ray, fast_ok != 0);
   HitState h;
-  hit_world<IMG>(blob, (cst_f4p)blob, n_runs, c, wave_all_regular(c, true), rng, h);
+  hit_world<IMG, true>(blob, (cst_f4p)blob, n_runs, c, wave_all_regular(c, true), rng, h);
   const float closest = h.closest, hu = h.u, hv = h.v;
   const int hit = h.hit;
   if (hit < 0) {
@@ -725,6 +757,7 @@ struct PtScene {
   bool track_uv = false; // an image texture sits on a triangle or a medium: the stale u,v such hits inherit must be tracked
   bool fast_ok = false;
   bool coop_ok = false;
+  bool has_badouel = false; // Badouel-strategy triangles: the scalar-cache / streaming kernels compiled with their loop
   int coop_prefix = 0;
   int n_hittables = 0;
   mutable bool last_had_wide_phase = false;
@@ -843,7 +876,8 @@ int pt_scene_create(const PtSceneDesc* desc, PtScene** out_scene) {
   s->blob_f4 = (int)flat.blob.size();
   s->has_image = flat.has_image;
   s->fast_ok = flat.fast_ok;
-  s->coop_ok = flat.coop_ok;
+  s->coop_ok = flat.coop_ok && !flat.has_badouel; // the cooperative scans do not carry the Badouel loop
+  s->has_badouel = flat.has_badouel;
   s->track_uv = flat.has_image && !flat.coop_ok;
   s->coop_prefix = flat.coop_prefix;
   s->n_hittables = desc->n_hittables;
@@ -901,6 +935,8 @@ static int n_tiles_of(const PtRenderParams* p, int* tiles_x) {
   return tx * ty;
 }
 
+uint32_t pt_fast_seed(uint32_t pixel, uint32_t chunk) { return fast_seed(pixel, chunk); }
+
 int32_t pt_shard_tiles(const PtRenderParams* p) {
   if (check_params(p)) return -1;
   int n = n_tiles_of(p, nullptr);
@@ -933,6 +969,15 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
   PT_HIP(hipMemsetAsync(fb, 0, (size_t)pt_framebuffer_floats(p) * sizeof(float), st));
   if (local_tiles <= 0) return PT_OK;
   a.fast_ok = (s->fast_ok && !(p->flags & PT_FLAG_NO_FASTDIV)) ? 1 : 0;
+  if (p->flags & PT_FLAG_SINGLE_STREAM) { // the reference's single-task executor: one sequential chain, one lane
+    if (p->shard_count != 1) return fail(PT_ERR_INVALID_ARG, "PT_FLAG_SINGLE_STREAM needs shard_count == 1");
+    if ((long long)p->width * p->height * p->samples > (1ll << 22))
+      return fail(PT_ERR_TOO_LARGE, "PT_FLAG_SINGLE_STREAM is sequential by definition: width * height * samples <= 2^22");
+    if (p->depth <= 0) return PT_OK;
+    hipLaunchKernelGGL(render_single_stream_kernel, dim3(1), dim3(64), 0, st, a);
+    PT_HIP(hipGetLastError());
+    return PT_OK;
+  }
   a.coop_prefix = (s->coop_ok && a.fast_ok && !(p->flags & PT_FLAG_NO_COOP)) ? s->coop_prefix : -1;
   const size_t blob_bytes = (size_t)s->blob_f4 * 16;
   const bool resident = (blob_bytes <= kMaxLdsBlob || (p->flags & PT_FLAG_NO_LDS)) && !(p->flags & PT_FLAG_FORCE_STREAM);
@@ -979,6 +1024,11 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
   };
   auto launch_uv = [&](auto uv) -> int {
     constexpr int UV = decltype(uv)::value;
+    if (s->has_badouel) { // parity-completeness path: scalar-cache or streaming kernel with the Badouel loop compiled in
+      if (a.fast_chunks) return fail(PT_ERR_INVALID_ARG, "PT_FLAG_FAST_RNG is not offered for scenes with Badouel-strategy triangles");
+      if (!resident) return launch(render_kernel_stream<UV, false, true>);
+      return launch(render_kernel<UV, false, false, false, false, false, true>);
+    }
     if (a.fast_chunks) { // opt-in decorrelated mode: its own instantiations (no cooperative kernels: a chunk is short)
       if (!resident) return launch(render_kernel_stream<UV, true>);
       if (!lds) return launch(render_kernel<UV, false, false, false, false, true>);

@@ -214,12 +214,18 @@ struct yz_rect {
   real_t y0{}, y1{}, z0{}, z1{}, k{};
   material_t material_type;
 };
-struct triangle {
-  triangle() = default;
-  triangle(const point& v0, const point& v1, const point& v2, const material_t& m) : v0{v0}, v1{v1}, v2{v2}, material_type{m} {}
+// triangle.hpp:102-122: _triangle<IntersectionStrategy>; `triangle` = the Moller-Trumbore default (what main.cpp builds),
+// `badouel_triangle` = _triangle<badouel_ray_triangle_intersec> (triangle.hpp:14-56).
+template <int Strategy = PT_TRI_MOLLER_TRUMBORE>
+struct _triangle {
+  _triangle() = default;
+  _triangle(const point& v0, const point& v1, const point& v2, const material_t& m) : v0{v0}, v1{v1}, v2{v2}, material_type{m} {}
   point v0, v1, v2;
   material_t material_type;
+  static constexpr int strategy = Strategy;
 };
+using triangle = _triangle<>;
+using badouel_triangle = _triangle<PT_TRI_BADOUEL>;
 struct box {
   box() = default;
   box(const point& p0, const point& p1, const material_t& m) : box_min{p0}, box_max{p1}, material_type{m} {}
@@ -234,8 +240,8 @@ struct constant_medium {
   real_t neg_inv_density;
   material_t phase_function;
 };
-// The reference's five alternatives first (same indices); xz_rect/yz_rect are an extension.
-using hittable_t = std::variant<sphere, xy_rect, triangle, box, constant_medium, xz_rect, yz_rect>;
+// The reference's five alternatives first (same indices); xz_rect/yz_rect and the Badouel-strategy triangle are extensions.
+using hittable_t = std::variant<sphere, xy_rect, triangle, box, constant_medium, xz_rect, yz_rect, badouel_triangle>;
 
 // ---- camera (camera.hpp:67-87) -----------------------------------------------------------------------
 class camera {
@@ -326,7 +332,10 @@ struct flattener {
       else if constexpr (std::is_same_v<T, xy_rect>) { e.kind = PT_HIT_XY_RECT; e.material = material(a.material_type); float v[5] = {a.x0, a.x1, a.y0, a.y1, a.k}; std::copy(v, v + 5, e.f); }
       else if constexpr (std::is_same_v<T, xz_rect>) { e.kind = PT_HIT_XZ_RECT; e.material = material(a.material_type); float v[5] = {a.x0, a.x1, a.z0, a.z1, a.k}; std::copy(v, v + 5, e.f); }
       else if constexpr (std::is_same_v<T, yz_rect>) { e.kind = PT_HIT_YZ_RECT; e.material = material(a.material_type); float v[5] = {a.y0, a.y1, a.z0, a.z1, a.k}; std::copy(v, v + 5, e.f); }
-      else if constexpr (std::is_same_v<T, triangle>) { e.kind = PT_HIT_TRIANGLE; e.material = material(a.material_type); put3(e.f, a.v0); put3(e.f + 3, a.v1); put3(e.f + 6, a.v2); }
+      else if constexpr (std::is_same_v<T, triangle> || std::is_same_v<T, badouel_triangle>) {
+        e.kind = PT_HIT_TRIANGLE; e.strategy = T::strategy; e.material = material(a.material_type);
+        put3(e.f, a.v0); put3(e.f + 3, a.v1); put3(e.f + 6, a.v2);
+      }
       else if constexpr (std::is_same_v<T, box>) { e.kind = PT_HIT_BOX; e.material = material(a.material_type); fill(e.f, a); }
       else {
         e.kind = PT_HIT_CONSTANT_MEDIUM; e.material = material(a.phase_function);

@@ -45,12 +45,22 @@ def _params(width, height, samples, depth, shard_index=0, shard_count=1, flags=0
                               int(flags), 0)
 
 
-def _as_device_scene(scene) -> DeviceScene:
+def _as_device_scene(scene, cache_key=None) -> DeviceScene:
+    """DeviceScene of whatever the caller handed over.  With `cache_key` (the asynchronous torch path) the device scene of a
+    PackedScene is kept on it, per device: no re-flatten / re-upload / hipMalloc per call, and — the point — no temporary
+    whose destructor (pt_scene_destroy -> hipFree, an implicit device synchronisation) would run while the kernels it
+    launched are still in flight."""
     if isinstance(scene, DeviceScene):
         return scene
-    if isinstance(scene, PackedScene):
+    if not isinstance(scene, PackedScene):
+        scene = pack(scene)  # a list of hittables, like std::vector<hittable_t>
+        cache_key = None
+    if cache_key is None:
         return DeviceScene(scene)
-    return DeviceScene(pack(scene))  # a list of hittables, like std::vector<hittable_t>
+    cache = scene.__dict__.setdefault("_pt_device_scenes", {})
+    if cache_key not in cache:
+        cache[cache_key] = DeviceScene(scene)
+    return cache[cache_key]
 
 
 def _stream_ptr(torch) -> C.c_void_p:
@@ -60,7 +70,9 @@ def _stream_ptr(torch) -> C.c_void_p:
 def render(width: int, height: int, samples: int, scene, cam: camera, depth: int = 50, *, flags: int = 0,
            out=None, shard_index: int = 0, shard_count: int = 1, timed: bool = False):
     """Launch the render kernel on torch's current device/stream; asynchronous like queue.submit
-    (render.hpp:151) unless `timed`.  Returns the framebuffer tensor — [H][W][3] float32, y=0 bottom
+    (render.hpp:151) unless `timed`.  `scene`: a DeviceScene (reuse it across renders), a PackedScene (its device scene is
+    created once per device and kept on it) or a list of hittables (packed + uploaded for this call; kept alive by the
+    returned tensor).  Returns the framebuffer tensor — [H][W][3] float32, y=0 bottom
     row — or, for shard_count>1, this shard's tiles [tiles][64][3].  With `timed`, returns
     (tensor, kernel_ms) measured with HIP events on the launch stream."""
     import torch
@@ -68,7 +80,7 @@ def render(width: int, height: int, samples: int, scene, cam: camera, depth: int
     if not torch.cuda.is_available():
         raise RuntimeError("path_tracer_amd.render needs a HIP device: there is no CPU path in the product")
     lib = abi.load_library()
-    ds = _as_device_scene(scene)
+    ds = _as_device_scene(scene, cache_key=("cuda", torch.cuda.current_device()))
     p = _params(width, height, samples, depth, shard_index, shard_count, flags)
     n = lib.pt_framebuffer_floats(C.byref(p))
     if n < 0:
@@ -85,6 +97,7 @@ def render(width: int, height: int, samples: int, scene, cam: camera, depth: int
         return out, float(ms.value)
     abi.check(lib.pt_render(ds.handle, C.byref(cam.c), C.byref(p), C.c_void_p(out.data_ptr()), _stream_ptr(torch)),
               "pt_render")
+    out._pt_scene = ds  # a scene built from a list of hittables lives as long as the frame it is still rendering into
     return out
 
 

@@ -216,16 +216,22 @@ class yz_rect(_rect):
 
 @dataclass(frozen=True)
 class triangle:
+    """triangle.hpp:102-122.  `strategy` mirrors the class template's argument: "moller_trumbore" (the reference's
+    `triangle` alias, what main.cpp builds) or "badouel" (`_triangle<badouel_ray_triangle_intersec>`, triangle.hpp:14-56)."""
     v0: tuple
     v1: tuple
     v2: tuple
     material_type: object
+    strategy: str = "moller_trumbore"
 
-    def __init__(self, v0, v1, v2, mat):
+    def __init__(self, v0, v1, v2, mat, strategy: str = "moller_trumbore"):
+        if strategy not in ("moller_trumbore", "badouel"):
+            raise ValueError("triangle strategy must be 'moller_trumbore' or 'badouel'")
         object.__setattr__(self, "v0", _c3(v0))
         object.__setattr__(self, "v1", _c3(v1))
         object.__setattr__(self, "v2", _c3(v2))
         object.__setattr__(self, "material_type", mat)
+        object.__setattr__(self, "strategy", strategy)
 
 
 @dataclass(frozen=True)
@@ -368,6 +374,7 @@ def pack(hittables: Iterable, atlas: TextureAtlas | None = None) -> PackedScene:
             e.f[0:5] = (h.a0, h.a1, h.b0, h.b1, h.k)
         elif isinstance(h, triangle):
             e.kind, e.material = abi.PT_HIT_TRIANGLE, mat_id(h.material_type)
+            e.strategy = abi.PT_TRI_BADOUEL if h.strategy == "badouel" else abi.PT_TRI_MOLLER_TRUMBORE
             e.f[0:9] = h.v0 + h.v1 + h.v2
         elif isinstance(h, box):
             e.kind, e.material = abi.PT_HIT_BOX, mat_id(h.material_type)
@@ -405,6 +412,6 @@ def pack_tables(hittables: np.ndarray, materials: Sequence, textures: Sequence, 
     return ps
 
 
-hittable_dtype = np.dtype([("kind", "<i4"), ("material", "<i4"), ("boundary_kind", "<i4"), ("reserved", "<i4"),
+hittable_dtype = np.dtype([("kind", "<i4"), ("material", "<i4"), ("boundary_kind", "<i4"), ("strategy", "<i4"),
                            ("f", "<f4", (12,))])
 assert hittable_dtype.itemsize == 64

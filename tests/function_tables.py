@@ -34,6 +34,7 @@ def cases():
     out["xz_rect_light"] = ([xz_rect(-1.0, 1.0, -2.0, 0.0, 2.5, lightsource_material((4, 3, 2)))], ((0.0, 2.5, -1.0), 1.6))
     out["yz_rect_lambertian_checker"] = ([yz_rect(-0.5, 1.5, -2.5, -0.5, -2.2, lambertian_material(checker))], ((-2.2, 0.5, -1.5), 1.6))
     out["triangle_lambertian"] = ([triangle((-0.5, 0.6, -1.2), (0.5, 0.6, -1.2), (0.0, 1.3, -0.9), lambertian_material((0.1, 0.2, 0.9)))], ((0.0, 0.85, -1.1), 0.9))
+    out["triangle_badouel_lambertian"] = ([triangle((-0.5, 0.6, -1.2), (0.5, 0.6, -1.2), (0.0, 1.3, -0.9), lambertian_material((0.1, 0.2, 0.9)), "badouel")], ((0.0, 0.85, -1.1), 0.9))
     out["box_metal"] = ([box((1.2, -0.5, -2.5), (1.8, 0.7, -1.9), metal_material((0.7, 0.6, 0.5), 0.0))], ((1.5, 0.1, -2.2), 1.0))
     out["medium_sphere_isotropic"] = ([constant_medium(sphere((0.8, 0.9, -1.2), 0.6, lambertian_material((1, 1, 1))), 2.5, (0.9, 0.9, 1.0))], ((0.8, 0.9, -1.2), 1.0))
     out["medium_box_isotropic_checker"] = ([constant_medium(box((-1.9, -0.5, -0.9), (-1.3, 0.2, -0.3), lambertian_material((1, 1, 1))), 6.0, checker)], ((-1.6, -0.15, -0.6), 0.8))

@@ -114,6 +114,28 @@ def sphere_ties_scene():
     return pack(hs), cam
 
 
+def badouel_scene():
+    """Triangles with the Badouel intersection strategy (triangle.hpp:14-56, `_triangle<badouel_ray_triangle_intersec>`) next to
+    Moller-Trumbore ones and other kinds: separate runs in list order, a shared edge, a coplanar duplicate pair (the later
+    one wins the tie: both strategies accept t == max), a sliver, one behind a glass sphere."""
+    red, green, blue, white = (lambertian_material(c) for c in ((0.9, 0.1, 0.1), (0.1, 0.9, 0.1), (0.1, 0.1, 0.9), (0.8, 0.8, 0.8)))
+    B = "badouel"
+    hs = [
+        sphere((0, -100.5, -2), 100, lambertian_material(checker_texture((0.2, 0.3, 0.1), (0.9, 0.9, 0.9)))),
+        triangle((-1.6, -0.4, -2.0), (-0.4, -0.4, -2.0), (-1.0, 0.8, -2.2), red, B),
+        triangle((-0.4, -0.4, -2.0), (0.8, -0.4, -2.0), (-1.0, 0.8, -2.2), green, B),       # shares an edge with the first
+        triangle((0.2, 0.0, -1.6), (1.2, 0.0, -1.6), (0.7, 0.9, -1.6), blue),                 # Moller-Trumbore
+        triangle((0.2, 0.0, -1.6), (1.2, 0.0, -1.6), (0.7, 0.9, -1.6), red, B),               # the same triangle, Badouel, later in the list
+        triangle((-0.2, 0.9, -1.8), (0.2, 0.9, -1.8), (0.0, 0.9001, -1.2), metal_material((0.8, 0.8, 0.8), 0.1), B),  # sliver
+        sphere((-0.9, 0.1, -1.2), 0.35, dielectric_material(1.5, (1, 1, 1))),
+        triangle((-2.0, 1.2, -3.0), (2.0, 1.2, -3.0), (0.0, 2.4, -2.0), lightsource_material((3, 3, 2.5)), B),
+        box((1.3, -0.5, -2.4), (1.8, 0.2, -1.9), white),
+    ]
+    cam = dict(look_from=(0.1, 0.5, 1.2), look_at=(0, 0.2, -2), vup=(0, 1, 0), vfov=65.0, aperture=0.02, focus_dist=3.2,
+               time0=0.0, time1=1.0)
+    return pack(hs), cam
+
+
 def empty_scene():
     cam = dict(look_from=(0, 0, 1), look_at=(0, 0, -1), vup=(0, 1, 0), vfov=60.0, aperture=0.0, focus_dist=1.0,
                time0=0.0, time1=0.0)
@@ -125,4 +147,4 @@ def cornell_scene():
 
 
 ALL = {"cornell": cornell_scene, "mixed": mixed_scene, "spheres": spheres_scene, "triangles": triangles_scene,
-       "ties": ties_scene, "sphere_ties": sphere_ties_scene, "empty": empty_scene}
+       "ties": ties_scene, "sphere_ties": sphere_ties_scene, "badouel": badouel_scene, "empty": empty_scene}

@@ -151,6 +151,23 @@ def test_flatten_sphere_run_lists(lib):
     assert blob[int(blob[0].view(np.int32)[1]) - 1].view(np.int32)[3] == 2
 
 
+def test_flatten_badouel_triangles_are_runs_of_their_own(lib):
+    """PtHittable.strategy (triangle.hpp:102-103): a Badouel-strategy triangle gets device kind 5 — its own run, in list
+    order, same record as a Moller-Trumbore triangle; an unknown strategy is a malformed scene."""
+    m = lambertian_material((0.5, 0.5, 0.5))
+    t = lambda z, st="moller_trumbore": triangle((0, 0, z), (1, 0, z), (0, 1, z), m, st)  # noqa: E731
+    ps = pack([t(0), t(1, "badouel"), t(2, "badouel"), t(3), sphere((0, 0, 0), 1, m)])
+    assert [ps.hittables[i].strategy for i in range(5)] == [0, 1, 1, 0, 0]
+    rc, blob, mats, n_runs, flags = flatten(lib, ps)
+    assert rc == 0 and n_runs == 4
+    runs = blob[:n_runs].view(np.int32)
+    assert runs[:, 0].tolist() == [2, 5, 2, 0] and runs[:, 2].tolist() == [1, 2, 1, 1] and runs[:, 3].tolist() == [0, 1, 3, 4]
+    rec = blob[runs[1, 1]: runs[1, 1] + 3]
+    assert rec[0, :3].tolist() == [0, 0, 1] and rec[1, :3].tolist() == [1, 0, 0] and rec[2, :3].tolist() == [0, 1, 0]
+    ps.hittables[1].strategy = 7
+    assert flatten(lib, ps)[0] == abi.PT_ERR_BAD_SCENE
+
+
 def test_flatten_flags_and_materials(lib):
     ps, _ = S.mixed_scene()
     rc, blob, mats, n_runs, flags = flatten(lib, ps)

@@ -202,7 +202,8 @@ def compare_bounce(got, ref, n, what, has_image):
 
 @pytest.mark.parametrize("name,center,extent", [("cornell", (278, 278, 278), 700.0), ("mixed", (0, 0.3, -1), 3.0),
                                                 ("spheres", (0, 0.5, 0), 5.0), ("triangles", (0, 1.5, 0), 4.0),
-                                                ("ties", (0, 0, -2), 3.0), ("empty", (0, 0, 0), 1.0)])
+                                                ("ties", (0, 0, -2), 3.0), ("empty", (0, 0, 0), 1.0),
+                                                ("badouel", (0, 0.3, -2), 3.0), ("sphere_ties", (0, 0.2, -2), 3.0)])
 def test_bounce_bit_exact(lib, orc, name, center, extent):
     """hit_world + emitted + scatter of one ray (render.hpp:58-89): every hit_record field, the scattered
     ray, the attenuation and the RNG state after, for thousands of random rays."""
@@ -293,7 +294,7 @@ def test_lds_and_scalar_fetch_agree(name):
     assert_bit_identical(a, b, name)
 
 
-@pytest.mark.parametrize("name", ["cornell", "mixed", "triangles", "spheres", "ties", "sphere_ties"])
+@pytest.mark.parametrize("name", ["cornell", "mixed", "triangles", "spheres", "ties", "sphere_ties", "badouel"])
 def test_streaming_kernel_agrees(name):
     """The LDS-tile streaming kernel (used when the scene exceeds LDS) gives the resident kernel's frame."""
     ps, cam = S.ALL[name]()
@@ -790,6 +791,56 @@ def test_fast_mode_is_statistically_the_parity_image(orc, name, w, h, spp, ref_s
     assert abs(pp - pf) < 0.75, f"PSNR vs converged: parity {pp:.2f} dB, fast {pf:.2f} dB"
     assert abs(fast.mean() / ref.mean() - 1) < 0.015 and abs(parity.mean() / ref.mean() - 1) < 0.015
     print(f"\n[fast mode {name}] PSNR vs converged: parity {pp:.2f} dB, fast {pf:.2f} dB")
+
+
+@pytest.mark.parametrize("name,w,h,spp", [("mixed", 24, 14, 3), ("cornell", 20, 12, 4), ("spheres", 18, 10, 3), ("sphere_ties", 16, 9, 2),
+                                          ("triangles", 12, 7, 2), ("empty", 5, 3, 2)])
+def test_single_stream_executor(orc, lib, name, w, h, spp):
+    """PT_FLAG_SINGLE_STREAM = the reference's USE_SINGLE_TASK executor (render.hpp:113-122): ONE default-seeded RNG stream
+    for the whole frame, pixels x-outer / y-inner — a different image from the parallel executor's, bit-exact against the
+    oracle's restatement of it.  Sequential by definition: one lane, small frames only, no shards."""
+    ps, cam = S.ALL[name]()
+    c = scenes.make_camera(cam, w, h)
+    orc.set_math(True)
+    ref = orc.render(ps, c.c, w, h, spp, flags=abi.PT_FLAG_SINGLE_STREAM)
+    if name != "empty":
+        assert not np.array_equal(ref, orc.render(ps, c.c, w, h, spp))
+    assert_bit_identical(R.render_host(w, h, spp, ps, c, flags=abi.PT_FLAG_SINGLE_STREAM), ref, f"single stream {name}")
+    ds = R.DeviceScene(ps)
+    fb = np.zeros(4096 * 4096 * 3, np.float32)
+    big = abi.PtRenderParams(4096, 4096, 1, 50, 0, 1, abi.PT_FLAG_SINGLE_STREAM, 0)
+    assert lib.pt_render_host(ds.handle, C.byref(c.c), C.byref(big), fb.ctypes.data_as(FP)) == abi.PT_ERR_TOO_LARGE
+    sharded = abi.PtRenderParams(w, h, spp, 50, 0, 2, abi.PT_FLAG_SINGLE_STREAM, 0)
+    assert lib.pt_render_host(ds.handle, C.byref(c.c), C.byref(sharded), fb.ctypes.data_as(FP)) == abi.PT_ERR_INVALID_ARG
+
+
+def test_badouel_strategy_triangles(orc, lib):
+    """_triangle<badouel_ray_triangle_intersec> (triangle.hpp:14-56; PtHittable.strategy = PT_TRI_BADOUEL): its own device
+    kind and kernel instantiations; bit-exact against the oracle through the resident, streaming and single-stream paths,
+    sharded, and with the cooperative / fast paths politely out of the way."""
+    ps, cam = S.badouel_scene()
+    orc.set_math(True)
+    for (w, h, spp) in ((96, 54, 12), (9, 5, 6)):
+        c = scenes.make_camera(cam, w, h)
+        ref = orc.render(ps, c.c, w, h, spp)
+        for flags in (0, abi.PT_FLAG_FORCE_STREAM, abi.PT_FLAG_FORCE_COOP, abi.PT_FLAG_NO_LPT, abi.PT_FLAG_PIXEL_GRANULAR):
+            assert_bit_identical(R.render_host(w, h, spp, ps, c, flags=flags), ref, f"badouel {w}x{h} flags {flags}")
+    c = scenes.make_camera(cam, 40, 24)
+    assert_bit_identical(R.render_host(40, 24, 5, ps, c, shard_index=2, shard_count=3),
+                         orc.render(ps, c.c, 40, 24, 5, shard_index=2, shard_count=3), "badouel shard 2/3")
+    assert_bit_identical(R.render_host(14, 8, 2, ps, c := scenes.make_camera(cam, 14, 8), flags=abi.PT_FLAG_SINGLE_STREAM),
+                         orc.render(ps, c.c, 14, 8, 2, flags=abi.PT_FLAG_SINGLE_STREAM), "badouel single stream")
+    # the two strategies are different arithmetic for the same geometry: close images, not identical ones
+    mt = S.badouel_scene()[0]
+    for i in range(mt.n_hittables):
+        mt.hittables[i].strategy = 0
+    c = scenes.make_camera(cam, 96, 54)
+    a, b = orc.render(ps, c.c, 96, 54, 12), orc.render(mt, c.c, 96, 54, 12)
+    assert not np.array_equal(a, b) and psnr_8bit(orc.tonemap_rgb8(a), orc.tonemap_rgb8(b)) > 20.0
+    ds = R.DeviceScene(ps)
+    p = abi.PtRenderParams(16, 8, 4, 50, 0, 1, abi.PT_FLAG_FAST_RNG, 0)
+    fb = np.zeros(16 * 8 * 3, np.float32)
+    assert lib.pt_render_host(ds.handle, C.byref(c.c), C.byref(p), fb.ctypes.data_as(FP)) == abi.PT_ERR_INVALID_ARG
 
 
 def test_rerender_is_deterministic(torch_gpu):
