@@ -176,6 +176,7 @@ struct RayCtx {
   float a;          // dot(d,d), hoisted (sphere.hpp:69)
   float yx, yy, yz; // RN(1/d_c) for regular rays
   bool reg;
+  bool live;        // this lane's ray is wanted (idle lanes scan along and their outcome is dropped: they must not vote)
 };
 
 // RN(1/d) for 2^-40 <= |d| <= 2^40: the hardware estimate (v_rcp_f32, <= 1 ulp) and ONE Newton step in fma arithmetic.
@@ -191,6 +192,7 @@ __device__ __forceinline__ float rcp_rn_guarded(float d) {
 __device__ __forceinline__ RayCtx make_ctx(const Ray& r, bool scene_fast_ok) {
   RayCtx c;
   c.r = r;
+  c.live = true;
   c.a = dot(r.d, r.d);
   const float lo = 9.094947017729282e-13f, hi = 1.099511627776e12f, ohi = 1.152921504606846976e18f; // 2^-40 2^40 2^60
   float ax = __builtin_fabsf(r.d.x), ay = __builtin_fabsf(r.d.y), az = __builtin_fabsf(r.d.z);
@@ -649,8 +651,75 @@ __device__ __forceinline__ void sphere_list_entry(P recs, i4 o4, int goff, float
   }
 }
 
+// dword i of an array of dwords packed four per f4 at `base` (cell table / candidate list of a sphere grid)
+__device__ __forceinline__ unsigned int dword_at(lds_f4p base, int i) { return ((const __attribute__((address_space(3))) unsigned int*)base)[i]; }
+__device__ __forceinline__ unsigned int dword_at(cst_f4p base, int i) { return ((const __attribute__((address_space(4))) unsigned int*)base)[i]; }
+__device__ __forceinline__ unsigned int dword_at(const f4* base, int i) { return ((const unsigned int*)base)[i]; }
+
+// Exact culling for the small spheres of a run (pt_flatten.hpp: build_sphere_grid states why it is exact): every lane walks
+// its own ray through a uniform grid (3-D DDA in cell units; t is the ray's own parameter, so it compares with closest
+// directly) and tests the spheres listed in the cells it crosses, each with the unordered acceptance rule — the order of
+// the tests does not matter and a sphere listed in several cells is simply re-tested.  The walk ends where the next cell's
+// entry lies beyond the nearest hit so far.  SIMD shape: the wave steps all walks together (a lane past its last cell idles)
+// and, per step, loops to the largest candidate count of the lanes' cells.
+template <typename P, typename AcceptAt>
+__device__ __forceinline__ void sphere_grid_walk(P recs, P cells, P cand, f4 g0, f4 g1, float frac, int goff, const RayCtx& c,
+                                                 HitState& h, AcceptAt accept_at) {
+  const Ray& r = c.r;
+  const float inv = g0.w, cell = g1.w;
+  const int nx = as_i(g1.x), ny = as_i(g1.y), nz = as_i(g1.z);
+  const float gx = (r.o.x - g0.x) * inv, gy = (r.o.y - g0.y) * inv, gz = (r.o.z - g0.z) * inv; // origin in cell units
+  const float rx = c.yx * cell, ry = c.yy * cell, rz = c.yz * cell;                           // 1 / (direction in cell units)
+  // slab clip of the line against the grid box [0, n]
+  const float ax = (0.0f - gx) * rx, bx = ((float)nx - gx) * rx;
+  const float ay = (0.0f - gy) * ry, by = ((float)ny - gy) * ry;
+  const float az = (0.0f - gz) * rz, bz = ((float)nz - gz) * rz;
+  const float t_in = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
+  const float t_out = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
+  const float t0 = __builtin_fmaxf(t_in, 0.0f);
+  auto limit = [&]() { const float m = __builtin_fminf(t_out, h.closest); return m + (__builtin_fabsf(m) * 1e-4f + 1e-4f); };
+  bool active = c.live && t0 <= limit();
+  // entry cell
+  const float px = gx + t0 * (r.d.x * inv), py = gy + t0 * (r.d.y * inv), pz = gz + t0 * (r.d.z * inv);
+  int ix = min(max((int)__builtin_floorf(px), 0), nx - 1);
+  int iy = min(max((int)__builtin_floorf(py), 0), ny - 1);
+  int iz = min(max((int)__builtin_floorf(pz), 0), nz - 1);
+  const bool fx = r.d.x > 0.0f, fy = r.d.y > 0.0f, fz = r.d.z > 0.0f; // walking towards larger indices?
+  float tmx = ((float)(ix + (fx ? 1 : 0)) - gx) * rx; // ray parameter at the next cell boundary, per axis
+  float tmy = ((float)(iy + (fy ? 1 : 0)) - gy) * ry;
+  float tmz = ((float)(iz + (fz ? 1 : 0)) - gz) * rz;
+  const float dtx = __builtin_fabsf(rx), dty = __builtin_fabsf(ry), dtz = __builtin_fabsf(rz);
+  while (__builtin_amdgcn_ballot_w64(active) != 0) {
+    unsigned int hdr = 0;
+    if (active) hdr = dword_at(cells, (iz * ny + iy) * nx + ix);
+    const int count = (int)(hdr & 255u), first = (int)(hdr >> 8);
+    for (int k = 0; __builtin_amdgcn_ballot_w64(k < count) != 0; ++k) {
+      if (k < count) {
+        const unsigned int e = dword_at(cand, first + k);
+        const int o = (int)(e & 0x7fffffffu);
+        const f4 R0 = recs[o];
+        V3 center = xyz(R0);
+        if ((int)e < 0) center = center + frac * xyz(recs[o + 2]); // moving: sphere.hpp:54-55
+        V3 oc = r.o - center;
+        float b = dot(oc, r.d);
+        float cc = dot(oc, oc) - __builtin_fabsf(R0.w);
+        sphere_finish_unordered(SphereEval{b, b * b - c.a * cc}, c, PT_TMIN, h, goff + o, accept_at(o));
+      }
+    }
+    if (active) { // next cell: the axis whose boundary comes first
+      const float tn = __builtin_fminf(tmx, __builtin_fminf(tmy, tmz));
+      if (tn > limit()) active = false;
+      else if (tmx == tn) { ix += fx ? 1 : -1; tmx += dtx; active = (unsigned)ix < (unsigned)nx; }
+      else if (tmy == tn) { iy += fy ? 1 : -1; tmy += dty; active = (unsigned)iy < (unsigned)ny; }
+      else { iz += fz ? 1 : -1; tmz += dtz; active = (unsigned)iz < (unsigned)nz; }
+    }
+  }
+}
+
 // The whole run (recs = its first record, at blob offset goff).
-template <int K, typename P, typename AcceptAt>
+// GRID = false: the kernel does not carry the grid walk (the streaming kernel: its register budget belongs to the triangle
+// loop); a run with a grid is then scanned through its full lists.
+template <int K, bool GRID, typename P, typename AcceptAt>
 __device__ __forceinline__ void sphere_scan(P recs, cst_f4p cblob, int n, int goff, const RayCtx& c, HitState& h, AcceptAt accept_at) {
   const f4 aux = cblob[goff - 1];
   const int flags = as_i(aux.w), ns = as_i(aux.z), nm = n - ns;
@@ -660,22 +729,37 @@ __device__ __forceinline__ void sphere_scan(P recs, cst_f4p cblob, int n, int go
     return;
   }
   const int qs = (ns + 3) >> 2, qm = (nm + 3) >> 2;
-  const cst_i4p lists = (cst_i4p)(cblob + (goff - 1 - qs - qm));
+  int lists_off = goff - 1 - qs - qm; // blob offset of the run's static list
+  float frac = 0.0f;
+  if (flags & 2) frac = (c.r.tm - aux.x) / (aux.y - aux.x); // (time - time0) / (time1 - time0)  sphere.hpp:54
+  int q_static = qs, q_moving = qm;
+  if (flags & 4) lists_off -= 4; // (a grid's four header records sit between the lists and aux)
+  if (GRID && (flags & 4)) { // the run has a grid for its small spheres
+    const f4 g0 = cblob[goff - 5], g1 = cblob[goff - 4], g2 = cblob[goff - 3], g3 = cblob[goff - 2];
+    const V3 dc = c.r.o - xyz(g2);
+    // the walk is exact for a regular ray that starts within rlimit of the grid and (if something moves) whose time lies in
+    // the run's shutter interval, so that centres stay between centre0 and centre1; one live lane outside -> full lists
+    const bool ok = c.reg && dot(dc, dc) <= g2.w && (!(flags & 2) || (c.r.tm >= aux.x && c.r.tm <= aux.y));
+    if (__builtin_amdgcn_ballot_w64(c.live && !ok) == 0) {
+      const int n_cell = as_i(g3.x), n_cand = as_i(g3.y), qbs = as_i(g3.z), qbm = as_i(g3.w);
+      const int big_off = lists_off - qbs - qbm, cand_off = big_off - n_cand, cell_off = cand_off - n_cell;
+      sphere_grid_walk(recs, recs + (cell_off - goff), recs + (cand_off - goff), g0, g1, frac, goff, c, h, accept_at);
+      lists_off = big_off; q_static = qbs; q_moving = qbm; // then only the spheres that are not in the grid
+    }
+  }
+  const cst_i4p lists = (cst_i4p)(cblob + lists_off);
   // the next list entry is requested while the current one is processed (reading one entry past a list lands on the next
-  // list or on the aux record: valid memory, never used)
+  // list or on the records behind it: valid memory, never used)
   i4 cur = lists[0];
-  for (int q = 0; q < qs; ++q) {
+  for (int q = 0; q < q_static; ++q) {
     const i4 nxt = lists[q + 1];
     sphere_list_entry<false, K>(recs, cur, goff, 0.0f, c, h, accept_at);
     cur = nxt;
   }
-  if (qm) {
-    const float frac = (c.r.tm - aux.x) / (aux.y - aux.x); // (time - time0) / (time1 - time0)  sphere.hpp:54
-    for (int q = 0; q < qm; ++q) {
-      const i4 nxt = lists[qs + q + 1];
-      sphere_list_entry<true, K>(recs, cur, goff, frac, c, h, accept_at);
-      cur = nxt;
-    }
+  for (int q = 0; q < q_moving; ++q) {
+    const i4 nxt = lists[q_static + q + 1];
+    sphere_list_entry<true, K>(recs, cur, goff, frac, c, h, accept_at);
+    cur = nxt;
   }
 }
 
@@ -688,7 +772,7 @@ __device__ __forceinline__ void sphere_scan(P recs, cst_f4p cblob, int n, int go
 // WHOLE: recs[0..n) is a whole run (its aux records sit in front of it at cblob[goff - 1]); false for an LDS tile of a
 // streamed run, which takes the spheres one at a time in list order.
 // BADOUEL: the kernel also knows Badouel-strategy triangle runs (DK_TRI_B).
-template <bool IMG, int TRIP = 1, int TTRIP = TRIP, bool WHOLE = true, bool BADOUEL = false, typename P>
+template <bool IMG, int TRIP = 1, int TTRIP = TRIP, bool WHOLE = true, bool BADOUEL = false, bool GRID = true, typename P>
 __device__ __forceinline__ void hit_records(P recs, cst_f4p cblob, int kind, int n, int goff,
                                             const RayCtx& c, bool fast, uint32_t& rng, HitState& h) {
   const Ray& r = c.r;
@@ -708,7 +792,7 @@ __device__ __forceinline__ void hit_records(P recs, cst_f4p cblob, int kind, int
         }
       };
     };
-    if constexpr (WHOLE) sphere_scan<(TRIP >= 2 ? 4 : 2)>(recs, cblob, n, goff, c, h, accept_at);
+    if constexpr (WHOLE) sphere_scan<(TRIP >= 2 ? 4 : 2), GRID>(recs, cblob, n, goff, c, h, accept_at);
     else {
       TimeFrac tf = time_frac_none();
       for (int i = 0; i < n; ++i, off += SZ_SPHERE) sphere_roots(recs, off, c, PT_TMIN, h.closest, true, tf, accept_at(off));
@@ -827,7 +911,7 @@ __device__ __forceinline__ void hit_records_strided(P recs, cst_f4p cblob, int k
       if (as_i(aux.w) & 1) {
         listed = true;
         const int ns = as_i(aux.z), nm = cnt - ns, qs = (ns + 3) >> 2, qm = (nm + 3) >> 2;
-        const P lists = recs - (1 + qs + qm);
+        const P lists = recs - (1 + ((as_i(aux.w) & 4) ? 4 : 0) + qs + qm); // (a grid's four header records sit between the lists and aux)
         auto entry = [&](int e) {
           const f4 v = lists[e];
           return i4{as_i(v.x), as_i(v.y), as_i(v.z), as_i(v.w)};
@@ -1047,6 +1131,7 @@ __device__ __forceinline__ void hit_world_lds(P blob, cst_f4p cblob, const CoopS
     c.reg = true; // fast == every live ray is regular
     rng = (uint32_t)shfl_i((int)rng, owner);
   }
+  c.live = handoff ? (group < nlive) : live;
   HitState s;
   hit_begin(s);
   bool merged = logG == 0;
@@ -1073,7 +1158,7 @@ __device__ __forceinline__ void hit_world_lds(P blob, cst_f4p cblob, const CoopS
     if (cnt <= 0) continue;
     // (idle lanes scan too and their outcome is dropped: a per-lane skip would put the whole scan under exec-mask
     // branches — the ordinary kernels do the same)
-    if (merged) hit_records<IMG, 2>(blob + off, cblob, kind, cnt, off, c, fast, rng, s);
+    if (merged) hit_records<IMG, 2, 2, true, false, false>(blob + off, cblob, kind, cnt, off, c, fast, rng, s); // (no grid walk here: lists + groups)
     else hit_records_strided<IMG>(blob + off, cblob, kind, cnt, first, off, j, logG, c, s);
   }
   if (handoff) { // hand each owner its result: the r-th live lane reads from (a lane of) group r

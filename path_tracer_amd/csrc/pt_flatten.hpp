@@ -5,6 +5,7 @@
 //
 // Replaces: the AoS sycl::buffer<hittable_t> of 624-byte variants (render.hpp:146-147).
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -34,6 +35,7 @@ struct Flat {
   int32_t coop_prefix = 0; // hittables before the first constant_medium
   bool fast_ok = true; // all rect/box coordinates finite with |v| <= 2^60 (pt_device.hpp: RayCtx)
   bool has_badouel = false; // some triangle uses the Badouel strategy (its own device kind and kernel instantiations)
+  int grid_spheres = 0;     // spheres that sit in a culling grid (pt_scene_create: their scan is cheap)
 };
 
 inline int device_kind(int32_t k) {
@@ -100,11 +102,127 @@ inline void put_sphere(std::vector<F4>& b, const float* f, int32_t mat, int32_t 
   b.push_back({f[6], as_f(mat), f[7], f[8]});            // radius, material, time0, time1
   b.push_back({f[3] - f[0], f[4] - f[1], f[5] - f[2], as_f(hidx)}); // center1 - center0 (sphere.hpp:55), ray-independent
 }
-// In front of a sphere run's records: [static list][moving list][aux F4]  (pt_device.hpp: sphere_scan)
-// lists: record offsets (F4 units, relative to the run's first record) of the static / the moving spheres of the run, each in
-// list order, four per F4, padded to a multiple of four by repeating the last entry; aux = (time0, time1, number of static
-// spheres, flags); flags bit 0: every moving sphere of the run has the shutter interval (time0, time1); bit 1: something moves.
-inline void put_sphere_run_aux(std::vector<F4>& b, const PtHittable* h, int count) {
+// In front of a sphere run's records (pt_device.hpp: sphere_scan / sphere_grid_scan), in address order:
+//   [grid cell table][grid candidates][big static list][big moving list]     only when the run has a grid (flags bit 2)
+//   [static list][moving list]                                                all spheres of the run
+//   [ghdr0..ghdr3]                                                            only with a grid
+//   [aux F4 = (time0, time1, number of static spheres, flags)]
+// lists: record offsets (F4 units, relative to the run's first record) of the static / the moving spheres, each in list
+// order, four per F4, padded to a multiple of four by repeating the last entry.  flags bit 0: every moving sphere of the run
+// has the shutter interval (time0, time1); bit 1: something moves; bit 2: grid.
+//
+// The grid is EXACT culling for the run's small spheres (the "big" lists hold the others): a uniform grid over their
+// bounds; a sphere is listed in every cell its box [centre range -+ (|r| + m)] touches.  Why that is enough: the reference's
+// discriminant b*b - a*cc (sphere.hpp:69-72), evaluated in binary32, differs from the exact a*(r^2 - p^2) (p = distance of
+// the centre from the ray's line) by less than 2^-18 * a * |o - c|^2 (21 roundings' worth, doubled), so a sphere can only
+// pass `discriminant > 0` if p^2 < r^2 + 2^-18 |o - c|^2, and then the accepted root's point lies within that same radius
+// of the centre.  A ray whose origin is within rlimit of the grid's centre has 2^-18 |o - c|^2 <= 2 r_min m + m^2 for
+// every small sphere, i.e. the inflated radius is <= |r| + m: the point of any acceptable hit lies inside the sphere's
+// box, hence in a cell that lists the sphere and that the ray's forward segment crosses.  Rays from farther away, rays
+// outside the run's shutter interval and irregular rays take the full lists (wave-level fallback).
+struct SphereGrid {
+  bool ok = false;
+  float origin[3], inv_cell, center[3], rlimit2;
+  int n[3];
+  std::vector<uint32_t> cells; // per cell: (first candidate << 8) | count
+  std::vector<uint32_t> cand;  // record offset (F4 units, run-relative) | moving << 31
+  std::vector<int32_t> big_st, big_mv;
+};
+
+inline SphereGrid build_sphere_grid(const PtHittable* h, int count, bool uniform) {
+  SphereGrid g;
+  if (count < 48 || !uniform) return g;
+  std::vector<float> rad;
+  for (int i = 0; i < count; i++) {
+    for (int k = 0; k < 9; k++) if (!std::isfinite(h[i].f[k])) return g;
+    rad.push_back(std::fabs(h[i].f[6]));
+  }
+  std::vector<float> sorted = rad;
+  std::nth_element(sorted.begin(), sorted.begin() + count / 2, sorted.end());
+  const float r_med = sorted[(size_t)count / 2];
+  if (!(r_med > 0.0f)) return g;
+  const float m = 1.5f * r_med, r_small = 4.0f * r_med;
+  double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+  float r_min = 3.4e38f;
+  int n_small = 0;
+  std::vector<char> small((size_t)count, 0);
+  auto box_of = [&](int i, double blo[3], double bhi[3]) {
+    const float* f = h[i].f;
+    const double e = (double)rad[(size_t)i] + m + 1e-3 * (r_med + m); // + slack for the walk's own rounding
+    for (int k = 0; k < 3; k++) {
+      const double c0 = f[k], c1 = (f[7] != f[8]) ? f[3 + k] : f[k];
+      blo[k] = std::min(c0, c1) - e; bhi[k] = std::max(c0, c1) + e;
+    }
+  };
+  for (int i = 0; i < count; i++) {
+    if (!(rad[(size_t)i] <= r_small) || !(rad[(size_t)i] > 0.0f)) continue;
+    small[(size_t)i] = 1; n_small++;
+    r_min = std::min(r_min, rad[(size_t)i]);
+    double blo[3], bhi[3];
+    box_of(i, blo, bhi);
+    for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], blo[k]); hi[k] = std::max(hi[k], bhi[k]); }
+  }
+  if (n_small < 48) return g;
+  const double cell = 2.8 * ((double)r_med + m);
+  long long total = 1;
+  for (int k = 0; k < 3; k++) {
+    g.n[k] = (int)std::min<double>(64.0, std::max<double>(1.0, std::ceil((hi[k] - lo[k]) / cell)));
+    total *= g.n[k];
+  }
+  // one cell size for all axes (the walk is in cell units); the box is grown to whole cells
+  const double kappa = 1.0 / 262144.0; // 2^-18
+  double half_diag2 = 0.0;
+  for (int k = 0; k < 3; k++) {
+    const double ext = g.n[k] * cell, mid = 0.5 * (lo[k] + hi[k]);
+    if (ext < hi[k] - lo[k]) return g; // more than 64 cells of this size along an axis: no grid
+    g.origin[k] = (float)(mid - 0.5 * ext);
+    g.center[k] = (float)mid;
+    half_diag2 += 0.25 * ext * ext;
+  }
+  const double allowed = std::sqrt((2.0 * r_min * m + (double)m * m) / kappa) - std::sqrt(half_diag2) - 1.0;
+  if (!(allowed > 0.0) || total > 16384) return g;
+  g.rlimit2 = (float)(allowed * allowed * 0.999);
+  g.inv_cell = (float)(1.0 / cell);
+  const double inv = (double)g.inv_cell; // assign with the float value the device uses
+  std::vector<std::vector<uint32_t>> lists((size_t)total);
+  for (int i = 0; i < count; i++) {
+    if (!small[(size_t)i]) { (h[i].f[7] != h[i].f[8] ? g.big_mv : g.big_st).push_back(i * 3); continue; }
+    double blo[3], bhi[3];
+    box_of(i, blo, bhi);
+    int c0[3], c1[3];
+    for (int k = 0; k < 3; k++) {
+      c0[k] = std::max(0, std::min(g.n[k] - 1, (int)std::floor((blo[k] - g.origin[k]) * inv)));
+      c1[k] = std::max(0, std::min(g.n[k] - 1, (int)std::floor((bhi[k] - g.origin[k]) * inv)));
+    }
+    const uint32_t entry = (uint32_t)(i * 3) | ((h[i].f[7] != h[i].f[8]) ? 0x80000000u : 0u);
+    for (int z = c0[2]; z <= c1[2]; z++)
+      for (int y = c0[1]; y <= c1[1]; y++)
+        for (int x = c0[0]; x <= c1[0]; x++) lists[((size_t)z * g.n[1] + y) * g.n[0] + x].push_back(entry);
+  }
+  for (auto& l : lists) {
+    if (l.size() > 255 || g.cand.size() + l.size() >= (1u << 24)) return g; // a cell this crowded: no grid
+    g.cells.push_back((uint32_t)(g.cand.size() << 8) | (uint32_t)l.size());
+    g.cand.insert(g.cand.end(), l.begin(), l.end());
+  }
+  g.ok = true;
+  return g;
+}
+
+inline void put_dwords(std::vector<F4>& b, const uint32_t* d, size_t n) {
+  for (size_t k = 0; k < n; k += 4) {
+    uint32_t v[4] = {0, 0, 0, 0};
+    for (size_t j = 0; j < 4 && k + j < n; j++) v[j] = d[k + j];
+    b.push_back({as_f((int32_t)v[0]), as_f((int32_t)v[1]), as_f((int32_t)v[2]), as_f((int32_t)v[3])});
+  }
+}
+inline int put_offset_list(std::vector<F4>& b, std::vector<int32_t> l) { // returns the number of F4 (entries of four)
+  if (l.empty()) return 0;
+  while (l.size() % 4) l.push_back(l.back());
+  for (size_t k = 0; k < l.size(); k += 4) b.push_back({as_f(l[k]), as_f(l[k + 1]), as_f(l[k + 2]), as_f(l[k + 3])});
+  return (int)(l.size() / 4);
+}
+
+inline int put_sphere_run_aux(std::vector<F4>& b, const PtHittable* h, int count, bool allow_grid) { // returns the spheres in the grid
   std::vector<int32_t> st, mv;
   bool uniform = true;
   float t0 = 0.0f, t1 = 0.0f;
@@ -118,18 +236,33 @@ inline void put_sphere_run_aux(std::vector<F4>& b, const PtHittable* h, int coun
   }
   const int ns = (int)st.size();
   const bool any = !mv.empty();
-  for (std::vector<int32_t>* l : {&st, &mv}) {
-    while (l->size() % 4) l->push_back(l->back());
-    for (size_t k = 0; k < l->size(); k += 4) b.push_back({as_f((*l)[k]), as_f((*l)[k + 1]), as_f((*l)[k + 2]), as_f((*l)[k + 3])});
+  SphereGrid g;
+  if (allow_grid) g = build_sphere_grid(h, count, uniform && (!any || t0 < t1));
+  int n_cell_f4 = 0, n_cand_f4 = 0, qbs = 0, qbm = 0;
+  if (g.ok) {
+    size_t before = b.size();
+    put_dwords(b, g.cells.data(), g.cells.size()); n_cell_f4 = (int)(b.size() - before); before = b.size();
+    put_dwords(b, g.cand.data(), g.cand.size());   n_cand_f4 = (int)(b.size() - before);
+    qbs = put_offset_list(b, g.big_st);
+    qbm = put_offset_list(b, g.big_mv);
   }
-  b.push_back({t0, t1, as_f(ns), as_f((uniform ? 1 : 0) | (any ? 2 : 0))});
+  put_offset_list(b, st);
+  put_offset_list(b, mv);
+  if (g.ok) {
+    b.push_back({g.origin[0], g.origin[1], g.origin[2], g.inv_cell});
+    b.push_back({as_f(g.n[0]), as_f(g.n[1]), as_f(g.n[2]), 1.0f / g.inv_cell});
+    b.push_back({g.center[0], g.center[1], g.center[2], g.rlimit2});
+    b.push_back({as_f(n_cell_f4), as_f(n_cand_f4), as_f(qbs), as_f(qbm)});
+  }
+  b.push_back({t0, t1, as_f(ns), as_f((uniform ? 1 : 0) | (any ? 2 : 0) | (g.ok ? 4 : 0))});
+  return g.ok ? count - (int)g.big_st.size() - (int)g.big_mv.size() : 0;
 }
 inline void put_box(std::vector<F4>& b, const float* f, int32_t mat, int32_t hidx) {
   b.push_back({f[0], f[1], f[2], as_f(mat)});
   b.push_back({f[3], f[4], f[5], as_f(hidx)});
 }
 
-inline int flatten(const PtSceneDesc* sc, Flat& out, std::string& err) {
+inline int flatten(const PtSceneDesc* sc, Flat& out, std::string& err, bool allow_grid = true) {
   int rc = validate(sc, err);
   if (rc) return rc;
   out = Flat();
@@ -188,7 +321,7 @@ inline int flatten(const PtSceneDesc* sc, Flat& out, std::string& err) {
   b.resize(runs.size());
   for (size_t ri = 0; ri < runs.size(); ri++) {
     const Run& run = runs[ri];
-    if (run.kind == DK_SPHERE) put_sphere_run_aux(b, &sc->hittables[run.first], run.count);
+    if (run.kind == DK_SPHERE) out.grid_spheres += put_sphere_run_aux(b, &sc->hittables[run.first], run.count, allow_grid);
     b[ri] = {as_f(run.kind), as_f((int32_t)b.size()), as_f(run.count), as_f(run.first)};
     for (int i = run.first; i < run.first + run.count; i++) {
       const PtHittable& h = sc->hittables[i];

@@ -62,6 +62,7 @@ constexpr size_t kMaxLdsBlob = 64 * 1024;   // blob staged in LDS when it fits
 constexpr size_t kMaxLdsWithMaterials = 16 * 1024; // stage the material table too when records + materials are this small
 constexpr size_t kMaxLdsColdScene = 10 * 1024;    // records + materials this small: the 8-wave kernel with LDS-resident cold lane state
 constexpr float kCoopMinTraversal = 2500.0f;        // estimated VALU instructions of one list scan (~110 spheres)
+constexpr int kGridMinTiles = 4096;                 // frames (shards) smaller than this are chain-bound: see launch_render
 constexpr unsigned kQueueRing = 256;        // launches in flight on one scene may not exceed this
 
 struct KArgs {
@@ -372,6 +373,7 @@ void render_kernel(KArgs a) {
         hit_world_lds<IMG>((lds_f4p)smem, (cst_f4p)a.blob, cs, L.ray, L.rng, L.live, true, a.fast_ok != 0, L.wide, h);
       } else {
         RayCtx c = make_ctx(L.ray, a.fast_ok != 0);
+        c.live = L.live;
         const bool fast = wave_all_regular(c, L.live);
         hit_world<IMG, BADOUEL>((lds_f4p)smem, (cst_f4p)a.blob, a.n_runs, c, fast, L.rng, h);
       }
@@ -388,6 +390,7 @@ void render_kernel(KArgs a) {
 #endif
     } else {
       RayCtx c = make_ctx(L.ray, a.fast_ok != 0);
+      c.live = L.live;
       const bool fast = wave_all_regular(c, L.live);
       hit_world<IMG, BADOUEL>((cst_f4p)a.blob, (cst_f4p)a.blob, a.n_runs, c, fast, L.rng, h);
       lane_shade<UV, FAST>(L, a, h, a.blob, a.mats);
@@ -432,6 +435,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel_stream(KArgs a) {
       continue;
     }
     RayCtx c = make_ctx(L.ray, a.fast_ok != 0);
+    c.live = L.live;
     const bool fast = wave_all_regular(c, L.live);
     const unsigned long long live_mask = __builtin_amdgcn_ballot_w64(L.live);
     const int nlive = __builtin_popcountll(live_mask);
@@ -440,6 +444,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel_stream(KArgs a) {
     if (coop_scene && fast && nlive >= 1 && nlive <= 32) {
       logG = coop_group_log(nlive);
       coop_handoff(c, live_mask, nlive, logG);
+      c.live = ((threadIdx.x & 63) >> logG) < nlive; // lanes of a group that serves a live ray
     }
     const int j = (threadIdx.x & 63) & ((1 << logG) - 1);
     HitState h;
@@ -451,7 +456,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel_stream(KArgs a) {
       if (cnt * sz <= kSmallRunF4) {
         if (!wave_idle) {
           if (logG) hit_records_strided<IMG>(a.blob + off, cblob, kind, cnt, 0, off, j, logG, c, h);
-          else hit_records<IMG, 4, 4, true, BADOUEL>(cblob + off, cblob, kind, cnt, off, c, fast, L.rng, h);
+          else hit_records<IMG, 4, 4, true, BADOUEL, false>(cblob + off, cblob, kind, cnt, off, c, fast, L.rng, h);
         }
         continue;
       }
@@ -463,7 +468,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel_stream(KArgs a) {
         __syncthreads();
         if (!wave_idle) {
           if (logG) hit_records_strided<IMG, false>((lds_f4p)tile, cblob, kind, n, 0, base, j, logG, c, h);
-          else hit_records<IMG, 4, 4, false, BADOUEL>((lds_f4p)tile, cblob, kind, n, base, c, fast, L.rng, h);
+          else hit_records<IMG, 4, 4, false, BADOUEL, false>((lds_f4p)tile, cblob, kind, n, base, c, fast, L.rng, h);
         }
         __syncthreads();
       }
@@ -762,7 +767,8 @@ struct PtScene {
   int n_hittables = 0;
   mutable bool last_had_wide_phase = false;
   mutable int nsplit_override = 0; // PT_SPLIT_TILES tuning knob (host copy must outlive the async upload)
-  float traversal_cost = 0.0f; // estimated VALU instructions of one ray's scan of the list
+  float traversal_cost = 0.0f; // estimated VALU instructions of one ray's scan of the list (sphere runs through their lists)
+  int grid_spheres = 0;        // spheres that sit in a culling grid (the resident non-cooperative kernels walk it)
   size_t blob_bytes = 0;
   int num_cus = 256;
   mutable unsigned int* ws_cost = nullptr; // LPT workspace: per-tile ray counts of the probe pass
@@ -858,7 +864,7 @@ int pt_scene_create(const PtSceneDesc* desc, PtScene** out_scene) {
   *out_scene = nullptr;
   ptf::Flat flat;
   std::string err;
-  int rc = ptf::flatten(desc, flat, err);
+  int rc = ptf::flatten(desc, flat, err, std::getenv("PT_NO_GRID") == nullptr); // PT_NO_GRID: A/B knob (brute-force sphere runs)
   if (rc) return fail(rc, err);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(PT_ERR_NO_DEVICE, "no HIP device visible");
@@ -883,13 +889,14 @@ int pt_scene_create(const PtSceneDesc* desc, PtScene** out_scene) {
   s->n_hittables = desc->n_hittables;
   for (int i = 0; i < desc->n_hittables; i++) {
     switch (desc->hittables[i].kind) {
-      case PT_HIT_SPHERE: s->traversal_cost += 22.0f; break;
+      case PT_HIT_SPHERE: s->traversal_cost += 22.0f; break; // (spheres that sit in a culling grid are discounted below)
       case PT_HIT_TRIANGLE: s->traversal_cost += 35.0f; break;
       case PT_HIT_BOX: s->traversal_cost += 120.0f; break;
       case PT_HIT_CONSTANT_MEDIUM: s->traversal_cost += 300.0f; break;
       default: s->traversal_cost += 20.0f; break;
     }
   }
+  s->grid_spheres = flat.grid_spheres;
   s->blob_bytes = flat.blob.size() * 16;
   s->mats_f4 = (int)flat.mats.size();
   // one buffer: [blob records][material table] so a kernel can stage both with one contiguous copy
@@ -999,7 +1006,13 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
   // ~4 500 cycles of a lone wave's 13 200 on the Cornell-style scene) bounds what they can win: there G = 8 shortens a
   // pixel's chain by 1.4x for 4.6x the lane time, so they pay only where the scan of the list dominates an iteration
   // (496-hittable scene, shard 0/8: 522 -> 229 ms).
-  const bool coop = lds && a.coop_prefix >= 0 && (s->traversal_cost >= kCoopMinTraversal || (p->flags & PT_FLAG_FORCE_COOP));
+  // Sphere runs with a culling grid: the ordinary resident kernels walk it (a ray then tests tens of spheres instead of
+  // hundreds: 496-hittable scene 1 660 -> 3 240 Msamples/s at 1080p), the cooperative kernels scan the lists with lane
+  // groups.  A lone wave's grid walk is a chain of dependent LDS loads, no shorter than a group's list scan, so small frames
+  // and small shards — where the heaviest pixel's chain, not the throughput, sets the time — keep the cooperative kernels
+  // (400x225x256 spp: 106 ms against 126 ms with the grid; shard 0/8 of the 1080p frame: 102 against 98).
+  const bool use_grid = s->grid_spheres > 0 && local_tiles >= kGridMinTiles && !(p->flags & PT_FLAG_FORCE_COOP);
+  const bool coop = lds && a.coop_prefix >= 0 && !use_grid && (s->traversal_cost >= kCoopMinTraversal || (p->flags & PT_FLAG_FORCE_COOP));
   // Persistent grid: no more workgroups than the chip holds at once; lanes pull pixels from the queue.
   auto launch = [&](auto kernel) -> int {
     int per_cu = 0;

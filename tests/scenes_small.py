@@ -136,6 +136,35 @@ def badouel_scene():
     return pack(hs), cam
 
 
+def sphere_field_scene(n=260, seed=31):
+    """Enough small spheres for the culling grid of pt_flatten.hpp (>= 48): a slab of static and moving ones (some touching,
+    some duplicated for equal-t ties, some overlapping cell borders), big spheres that stay outside the grid (ground, a glass
+    ball INSIDE the field, a mirror ball), a hollow (negative-radius) small sphere, and other kinds after the run."""
+    rng = scenes.HostRNG(seed)
+    hs = [sphere((0, -500, 0), 500, lambertian_material(checker_texture((0.2, 0.3, 0.1), (0.9, 0.9, 0.9))))]
+    for i in range(n):
+        c = (-6 + 12 * float(rng.float_t()), 0.15 + 0.5 * float(rng.float_t()), -6 + 12 * float(rng.float_t()))
+        r = 0.12 + 0.1 * float(rng.float_t())
+        k = float(rng.float_t())
+        mat = (lambertian_material(tuple(rng.vec_t())) if k < 0.5 else metal_material(tuple(rng.vec_t(0.5, 1)), 0.3 * float(rng.float_t()))
+               if k < 0.8 else dielectric_material(1.5, (1, 1, 1)))
+        if i % 3 == 1:
+            hs.append(sphere(c, (c[0] + 0.2 * float(rng.float_t()), c[1] + 0.4 * float(rng.float_t()), c[2]), 0.0, 1.0, r, mat))
+        else:
+            hs.append(sphere(c, r, mat))
+        if i % 41 == 7:
+            hs.append(sphere(c, r, lightsource_material((2, 2, 2))))  # exact duplicate later in the list: loses every tie
+    hs.append(sphere((1.0, 0.6, 0.5), -0.18, dielectric_material(1.5, (1, 1, 1))))   # hollow small sphere
+    hs.append(sphere((0.0, 1.0, 0.0), 1.0, dielectric_material(1.5, (1.0, 0.8, 0.8))))  # big, in the middle of the field
+    hs.append(sphere((-3.0, 1.2, 2.0), 1.2, metal_material((0.8, 0.8, 0.9), 0.0)))
+    hs.append(triangle((2, 0, 2), (3, 0, 2), (2.5, 1.2, 2.2), lambertian_material((0.9, 0.2, 0.2))))
+    hs.append(sphere((4, 2.5, -1), 0.3, lightsource_material((8, 8, 6))))
+    hs.append(constant_medium(sphere((-2, 0.8, -2), 0.9, lambertian_material((1, 1, 1))), 1.5, (0.9, 0.9, 1.0)))
+    cam = dict(look_from=(9, 3.5, 7), look_at=(0, 0.3, 0), vup=(0, 1, 0), vfov=40.0, aperture=0.05, focus_dist=11.0,
+               time0=0.0, time1=1.0)
+    return pack(hs), cam
+
+
 def empty_scene():
     cam = dict(look_from=(0, 0, 1), look_at=(0, 0, -1), vup=(0, 1, 0), vfov=60.0, aperture=0.0, focus_dist=1.0,
                time0=0.0, time1=0.0)
@@ -147,4 +176,4 @@ def cornell_scene():
 
 
 ALL = {"cornell": cornell_scene, "mixed": mixed_scene, "spheres": spheres_scene, "triangles": triangles_scene,
-       "ties": ties_scene, "sphere_ties": sphere_ties_scene, "badouel": badouel_scene, "empty": empty_scene}
+       "ties": ties_scene, "sphere_ties": sphere_ties_scene, "badouel": badouel_scene, "sphere_field": sphere_field_scene, "empty": empty_scene}

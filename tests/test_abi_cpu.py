@@ -96,7 +96,7 @@ def test_flatten_preserves_list_order(lib):
     off = n_runs
     for kind, first, count, _ in runs:
         if kind == 0:  # a sphere run is preceded by its static / moving offset lists (4 per F4) and an aux F4
-            off += (int(count) + 3) // 4 + 1  # nothing moves here: one list
+            off += (int(count) + 3) // 4 + 1  # nothing moves here: one list; a handful of spheres: no grid
             aux = blob[first - 1]
             assert aux.view(np.int32)[2] == count and aux.view(np.int32)[3] == 1  # all static, uniform interval
             lst = blob[first - 1 - (int(count) + 3) // 4:first - 1].view(np.int32).reshape(-1)
@@ -118,37 +118,94 @@ def test_flatten_preserves_list_order(lib):
     assert md.view(np.int32)[0] == 0 and md[1] == np.float32(-0.5)
 
 
+def decode_sphere_aux(blob, first, count):
+    """The records in front of a sphere run (pt_flatten.hpp: put_sphere_run_aux), decoded: dict with the aux fields, the
+    full static / moving offset lists and, when the run has one, the grid (dims, cell table, candidates, big lists)."""
+    aux = blob[first - 1]
+    flags, ns = int(aux.view(np.int32)[3]), int(aux.view(np.int32)[2])
+    qs, qm = (ns + 3) // 4, (count - ns + 3) // 4
+    end = first - 1 - (4 if flags & 4 else 0)
+    out = dict(t0=float(aux[0]), t1=float(aux[1]), ns=ns, flags=flags,
+               static=blob[end - qs - qm:end - qm].view(np.int32).reshape(-1), moving=blob[end - qm:end].view(np.int32).reshape(-1))
+    if flags & 4:
+        g0, g1, g2, g3 = blob[first - 5], blob[first - 4], blob[first - 3], blob[first - 2]
+        n_cell, n_cand, qbs, qbm = (int(v) for v in g3.view(np.int32))
+        big = end - qs - qm
+        cand0 = big - qbs - qbm - n_cand
+        out.update(origin=g0[:3].copy(), inv_cell=float(g0[3]), dims=[int(v) for v in g1.view(np.int32)[:3]], cell=float(g1[3]),
+                   center=g2[:3].copy(), rlimit2=float(g2[3]),
+                   cells=blob[cand0 - n_cell:cand0].view(np.uint32).reshape(-1), cand=blob[cand0:cand0 + n_cand].view(np.uint32).reshape(-1),
+                   big_static=blob[big - qbs - qbm:big - qbm].view(np.int32).reshape(-1), big_moving=blob[big - qbm:big].view(np.int32).reshape(-1),
+                   start=cand0 - n_cell)
+    else:
+        out["start"] = end - qs - qm
+    return out
+
+
 def test_flatten_sphere_run_lists(lib):
     """pt_flatten.hpp put_sphere_run_aux: the static and the moving spheres of a run as two lists of record offsets (list
     order, padded to a multiple of four by repeating the last entry); aux = (time0, time1, number of static spheres,
-    flags: 1 = one shutter interval for all moving spheres, 2 = something moves)."""
+    flags: 1 = one shutter interval for all moving spheres, 2 = something moves, 4 = the run has a culling grid)."""
     m = lambertian_material((0.5, 0.5, 0.5))
-    def scene(intervals):
+    def scene(intervals, n=40):
         hs = []
-        for i in range(150):
+        for i in range(n):
             if i in intervals:
                 t0, t1 = intervals[i]
                 hs.append(sphere((i, 0, 0), (i, 1, 0), t0, t1, 0.5, m))
             else:
                 hs.append(sphere((i, 0, 0), 0.5, m))
         return pack(hs)
-    moving = {3: (0.0, 1.0), 31: (0.0, 1.0), 32: (0.0, 1.0), 129: (0.0, 1.0), 149: (0.0, 1.0)}
+    moving = {3: (0.0, 1.0), 31: (0.0, 1.0), 32: (0.0, 1.0), 39: (0.0, 1.0)}
     rc, blob, mats, n_runs, flags = flatten(lib, scene(moving))
     assert rc == 0 and n_runs == 1
     first = int(blob[0].view(np.int32)[1])
-    qs, qm = (145 + 3) // 4, (5 + 3) // 4
-    assert first == 1 + qs + qm + 1  # header, static list, moving list, aux
-    aux = blob[first - 1]
-    assert aux[0] == 0.0 and aux[1] == 1.0 and aux.view(np.int32)[2:].tolist() == [145, 3]
-    st = blob[first - 1 - qs - qm:first - 1 - qm].view(np.int32).reshape(-1)
-    mv = blob[first - 1 - qm:first - 1].view(np.int32).reshape(-1)
-    assert st[:145].tolist() == [3 * i for i in range(150) if i not in moving] and (st[145:] == st[144]).all()
-    assert mv[:5].tolist() == [3 * i for i in sorted(moving)] and (mv[5:] == mv[4]).all()
-    for i in range(150):  # the per-record flag (sign of r^2) agrees with the lists
+    d = decode_sphere_aux(blob, first, 40)
+    assert d["flags"] == 3 and (d["t0"], d["t1"], d["ns"]) == (0.0, 1.0, 36)  # fewer than 48 spheres: no grid
+    assert d["start"] == 1  # right behind the run header
+    assert d["static"][:36].tolist() == [3 * i for i in range(40) if i not in moving] and (d["static"][36:] == d["static"][35]).all()
+    assert d["moving"].tolist() == [3 * i for i in sorted(moving)]
+    for i in range(40):  # the per-record flag (sign of r^2) agrees with the lists
         assert (blob[first + 3 * i, 3] < 0) == (i in moving)
-    moving[77] = (0.25, 1.0)  # a second shutter interval: the run falls back to the one-sphere-at-a-time scan
+    moving[17] = (0.25, 1.0)  # a second shutter interval: the run falls back to the one-sphere-at-a-time scan
     rc, blob, *_ = flatten(lib, scene(moving))
     assert blob[int(blob[0].view(np.int32)[1]) - 1].view(np.int32)[3] == 2
+
+
+def test_flatten_sphere_grid(lib):
+    """pt_flatten.hpp build_sphere_grid: a run of >= 48 small spheres gets a uniform grid; every small sphere is listed in
+    every cell its box [centre range -+ (|r| + margin)] touches, large spheres go to the "big" lists, and the full lists
+    still name every sphere (the fallback scan)."""
+    ps, _ = scenes.build("smoke", textures="procedural")
+    rc, blob, mats, n_runs, flags = flatten(lib, ps)
+    assert rc == 0
+    runs = blob[:n_runs].view(np.int32)
+    kind, first, count, first_h = (int(v) for v in runs[0])
+    assert kind == 0 and count == 483 and first_h == 0
+    d = decode_sphere_aux(blob, first, count)
+    assert d["flags"] == 7
+    nx, ny, nz = d["dims"]
+    assert len(d["cells"]) >= nx * ny * nz and ny == 1 and nx >= 10 and nz >= 10
+    assert abs(d["cell"] * d["inv_cell"] - 1) < 1e-6 and abs(d["cell"] - 2.8 * (0.2 + 0.3)) < 1e-4
+    assert d["big_static"][:1].tolist() == [0] and len(set(d["big_static"].tolist())) == 1 and len(d["big_moving"]) == 0  # the ground sphere
+    listed = set()
+    for c in range(nx * ny * nz):
+        hdr = int(d["cells"][c])
+        cnt, off = hdr & 255, hdr >> 8
+        for e in d["cand"][off:off + cnt]:
+            o = int(e) & 0x7FFFFFFF
+            listed.add(o)
+            assert o % 3 == 0 and 0 < o < 3 * count and ((int(e) >> 31) & 1) == int(blob[first + o, 3] < 0)  # moving bit = the record's flag
+            # the cell really touches the sphere's inflated box
+            i = o // 3
+            f = np.array(ps.hittables[i].f[:9], np.float32)
+            lo = np.minimum(f[0:3], f[3:6]) - (0.2 + 0.3 + 1e-3); hi = np.maximum(f[0:3], f[3:6]) + (0.2 + 0.3 + 1e-3)
+            cx, cz = c % nx, c // (nx * ny)
+            cell_lo = d["origin"] + np.array([cx, 0, cz]) * d["cell"]; cell_hi = cell_lo + d["cell"]
+            assert (cell_lo[[0, 2]] <= hi[[0, 2]] + 1e-4).all() and (cell_hi[[0, 2]] >= lo[[0, 2]] - 1e-4).all()
+    assert listed == {3 * i for i in range(1, count)}  # every small sphere sits in some cell
+    assert set(d["static"].tolist()) | set(d["moving"].tolist()) == {3 * i for i in range(count)}
+    assert d["rlimit2"] > 100.0 ** 2  # rays starting within > 100 units of the field may use the grid
 
 
 def test_flatten_badouel_triangles_are_runs_of_their_own(lib):

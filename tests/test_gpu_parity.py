@@ -203,7 +203,8 @@ def compare_bounce(got, ref, n, what, has_image):
 @pytest.mark.parametrize("name,center,extent", [("cornell", (278, 278, 278), 700.0), ("mixed", (0, 0.3, -1), 3.0),
                                                 ("spheres", (0, 0.5, 0), 5.0), ("triangles", (0, 1.5, 0), 4.0),
                                                 ("ties", (0, 0, -2), 3.0), ("empty", (0, 0, 0), 1.0),
-                                                ("badouel", (0, 0.3, -2), 3.0), ("sphere_ties", (0, 0.2, -2), 3.0)])
+                                                ("badouel", (0, 0.3, -2), 3.0), ("sphere_ties", (0, 0.2, -2), 3.0),
+                                                ("sphere_field", (0, 0.4, 0), 9.0)])
 def test_bounce_bit_exact(lib, orc, name, center, extent):
     """hit_world + emitted + scatter of one ray (render.hpp:58-89): every hit_record field, the scattered
     ray, the attenuation and the RNG state after, for thousands of random rays."""
@@ -841,6 +842,28 @@ def test_badouel_strategy_triangles(orc, lib):
     p = abi.PtRenderParams(16, 8, 4, 50, 0, 1, abi.PT_FLAG_FAST_RNG, 0)
     fb = np.zeros(16 * 8 * 3, np.float32)
     assert lib.pt_render_host(ds.handle, C.byref(c.c), C.byref(p), fb.ctypes.data_as(FP)) == abi.PT_ERR_INVALID_ARG
+
+
+def test_sphere_grid_is_exact(orc, monkeypatch):
+    """The culling grid of sphere runs (pt_flatten.hpp: build_sphere_grid; pt_device.hpp: sphere_grid_walk) against the
+    oracle's linear scan, bit for bit: the ordinary view; a camera 3 000 units away (primary rays start beyond the grid's
+    rlimit: the wave takes the full lists, bounces come back to the grid); a shutter wider than the spheres' interval (ray
+    times outside [time0, time1]: full lists); from inside the field looking along it (long walks); every kernel family."""
+    ps, cam = S.sphere_field_scene()
+    orc.set_math(True)
+    views = [dict(cam), dict(cam, look_from=(2000.0, 900.0, 2000.0), vfov=0.4, focus_dist=3000.0, aperture=0.0),
+             dict(cam, time0=-0.5, time1=1.5), dict(cam, look_from=(-5.5, 0.4, -5.5), look_at=(6, 0.3, 6), vfov=70.0, aperture=0.0)]
+    for vi, view in enumerate(views):
+        c = scenes.make_camera(view, 64, 36)
+        ref = orc.render(ps, c.c, 64, 36, 6)
+        for flags in (0, abi.PT_FLAG_FORCE_COOP, abi.PT_FLAG_NO_LDS, abi.PT_FLAG_FORCE_STREAM, abi.PT_FLAG_FORCE_COOP | abi.PT_FLAG_NO_SPLIT,
+                      abi.PT_FLAG_PIXEL_GRANULAR):
+            assert_bit_identical(R.render_host(64, 36, 6, ps, c, flags=flags), ref, f"view {vi} flags {flags}")
+    c = scenes.make_camera(cam, 48, 27)
+    fast = R.render_host(48, 27, 70, ps, c, flags=abi.PT_FLAG_FAST_RNG)
+    assert_bit_identical(fast, orc.render(ps, c.c, 48, 27, 70, flags=abi.PT_FLAG_FAST_RNG), "grid + fast mode")
+    monkeypatch.setenv("PT_NO_GRID", "1")  # read at scene creation: the brute-force lists for the same scene
+    assert_bit_identical(R.render_host(64, 36, 6, ps, scenes.make_camera(cam, 64, 36)), orc.render(ps, scenes.make_camera(cam, 64, 36).c, 64, 36, 6), "PT_NO_GRID")
 
 
 def test_rerender_is_deterministic(torch_gpu):
