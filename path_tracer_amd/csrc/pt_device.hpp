@@ -655,6 +655,9 @@ __device__ __forceinline__ void sphere_list_entry(P recs, i4 o4, int goff, float
 __device__ __forceinline__ unsigned int dword_at(lds_f4p base, int i) { return ((const __attribute__((address_space(3))) unsigned int*)base)[i]; }
 __device__ __forceinline__ unsigned int dword_at(cst_f4p base, int i) { return ((const __attribute__((address_space(4))) unsigned int*)base)[i]; }
 __device__ __forceinline__ unsigned int dword_at(const f4* base, int i) { return ((const unsigned int*)base)[i]; }
+__device__ __forceinline__ unsigned int ushort_at(lds_f4p base, int i) { return ((const __attribute__((address_space(3))) unsigned short*)base)[i]; }
+__device__ __forceinline__ unsigned int ushort_at(cst_f4p base, int i) { return ((const __attribute__((address_space(4))) unsigned short*)base)[i]; }
+__device__ __forceinline__ unsigned int ushort_at(const f4* base, int i) { return ((const unsigned short*)base)[i]; }
 
 // Exact culling for the small spheres of a run (pt_flatten.hpp: build_sphere_grid states why it is exact): every lane walks
 // its own ray through a uniform grid (3-D DDA in cell units; t is the ray's own parameter, so it compares with closest
@@ -695,11 +698,11 @@ __device__ __forceinline__ void sphere_grid_walk(P recs, P cells, P cand, f4 g0,
     const int count = (int)(hdr & 255u), first = (int)(hdr >> 8);
     for (int k = 0; __builtin_amdgcn_ballot_w64(k < count) != 0; ++k) {
       if (k < count) {
-        const unsigned int e = dword_at(cand, first + k);
-        const int o = (int)(e & 0x7fffffffu);
+        const unsigned int e = ushort_at(cand, first + k); // sphere index in the run | moving << 15
+        const int o = (int)(e & 0x7fffu) * SZ_SPHERE;
         const f4 R0 = recs[o];
         V3 center = xyz(R0);
-        if ((int)e < 0) center = center + frac * xyz(recs[o + 2]); // moving: sphere.hpp:54-55
+        if (e & 0x8000u) center = center + frac * xyz(recs[o + 2]); // moving: sphere.hpp:54-55
         V3 oc = r.o - center;
         float b = dot(oc, r.d);
         float cc = dot(oc, oc) - __builtin_fabsf(R0.w);

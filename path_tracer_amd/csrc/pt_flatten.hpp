@@ -125,13 +125,13 @@ struct SphereGrid {
   float origin[3], inv_cell, center[3], rlimit2;
   int n[3];
   std::vector<uint32_t> cells; // per cell: (first candidate << 8) | count
-  std::vector<uint32_t> cand;  // record offset (F4 units, run-relative) | moving << 31
+  std::vector<uint16_t> cand;  // index of the sphere in the run | moving << 15 (two per dword: LDS space sets the occupancy)
   std::vector<int32_t> big_st, big_mv;
 };
 
 inline SphereGrid build_sphere_grid(const PtHittable* h, int count, bool uniform) {
   SphereGrid g;
-  if (count < 48 || !uniform) return g;
+  if (count < 48 || count > 32767 || !uniform) return g;
   std::vector<float> rad;
   for (int i = 0; i < count; i++) {
     for (int k = 0; k < 9; k++) if (!std::isfinite(h[i].f[k])) return g;
@@ -184,7 +184,7 @@ inline SphereGrid build_sphere_grid(const PtHittable* h, int count, bool uniform
   g.rlimit2 = (float)(allowed * allowed * 0.999);
   g.inv_cell = (float)(1.0 / cell);
   const double inv = (double)g.inv_cell; // assign with the float value the device uses
-  std::vector<std::vector<uint32_t>> lists((size_t)total);
+  std::vector<std::vector<uint16_t>> lists((size_t)total);
   for (int i = 0; i < count; i++) {
     if (!small[(size_t)i]) { (h[i].f[7] != h[i].f[8] ? g.big_mv : g.big_st).push_back(i * 3); continue; }
     double blo[3], bhi[3];
@@ -194,7 +194,7 @@ inline SphereGrid build_sphere_grid(const PtHittable* h, int count, bool uniform
       c0[k] = std::max(0, std::min(g.n[k] - 1, (int)std::floor((blo[k] - g.origin[k]) * inv)));
       c1[k] = std::max(0, std::min(g.n[k] - 1, (int)std::floor((bhi[k] - g.origin[k]) * inv)));
     }
-    const uint32_t entry = (uint32_t)(i * 3) | ((h[i].f[7] != h[i].f[8]) ? 0x80000000u : 0u);
+    const uint16_t entry = (uint16_t)((uint32_t)i | ((h[i].f[7] != h[i].f[8]) ? 0x8000u : 0u));
     for (int z = c0[2]; z <= c1[2]; z++)
       for (int y = c0[1]; y <= c1[1]; y++)
         for (int x = c0[0]; x <= c1[0]; x++) lists[((size_t)z * g.n[1] + y) * g.n[0] + x].push_back(entry);
@@ -242,7 +242,9 @@ inline int put_sphere_run_aux(std::vector<F4>& b, const PtHittable* h, int count
   if (g.ok) {
     size_t before = b.size();
     put_dwords(b, g.cells.data(), g.cells.size()); n_cell_f4 = (int)(b.size() - before); before = b.size();
-    put_dwords(b, g.cand.data(), g.cand.size());   n_cand_f4 = (int)(b.size() - before);
+    std::vector<uint32_t> packed((g.cand.size() + 1) / 2, 0u);
+    for (size_t k = 0; k < g.cand.size(); k++) packed[k / 2] |= (uint32_t)g.cand[k] << (16 * (k & 1));
+    put_dwords(b, packed.data(), packed.size());   n_cand_f4 = (int)(b.size() - before);
     qbs = put_offset_list(b, g.big_st);
     qbm = put_offset_list(b, g.big_mv);
   }

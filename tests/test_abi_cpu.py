@@ -134,7 +134,7 @@ def decode_sphere_aux(blob, first, count):
         cand0 = big - qbs - qbm - n_cand
         out.update(origin=g0[:3].copy(), inv_cell=float(g0[3]), dims=[int(v) for v in g1.view(np.int32)[:3]], cell=float(g1[3]),
                    center=g2[:3].copy(), rlimit2=float(g2[3]),
-                   cells=blob[cand0 - n_cell:cand0].view(np.uint32).reshape(-1), cand=blob[cand0:cand0 + n_cand].view(np.uint32).reshape(-1),
+                   cells=blob[cand0 - n_cell:cand0].view(np.uint32).reshape(-1), cand=blob[cand0:cand0 + n_cand].view(np.uint16).reshape(-1),
                    big_static=blob[big - qbs - qbm:big - qbm].view(np.int32).reshape(-1), big_moving=blob[big - qbm:big].view(np.int32).reshape(-1),
                    start=cand0 - n_cell)
     else:
@@ -193,9 +193,9 @@ def test_flatten_sphere_grid(lib):
         hdr = int(d["cells"][c])
         cnt, off = hdr & 255, hdr >> 8
         for e in d["cand"][off:off + cnt]:
-            o = int(e) & 0x7FFFFFFF
+            o = 3 * (int(e) & 0x7FFF)  # candidates: 16-bit sphere index in the run | moving << 15
             listed.add(o)
-            assert o % 3 == 0 and 0 < o < 3 * count and ((int(e) >> 31) & 1) == int(blob[first + o, 3] < 0)  # moving bit = the record's flag
+            assert 0 < o < 3 * count and ((int(e) >> 15) & 1) == int(blob[first + o, 3] < 0)  # moving bit = the record's flag
             # the cell really touches the sphere's inflated box
             i = o // 3
             f = np.array(ps.hittables[i].f[:9], np.float32)
