@@ -590,12 +590,6 @@ typedef const __attribute__((address_space(4))) i4* cst_i4p;
 template <typename Accept>
 __device__ __forceinline__ void sphere_finish_unordered(SphereEval e, const RayCtx& c, float mn, const HitState& h, int off_here,
                                                         Accept accept) {
-#ifdef PT_STAMPS
-  { // diagnostic build: how often a wave enters the root block, and with how many lanes
-    const unsigned long long m = __builtin_amdgcn_ballot_w64(e.disc > 0);
-    if ((threadIdx.x & 63) == 0) { atomicAdd(&g_stamps[5], 1ull); if (m) { atomicAdd(&g_stamps[4], 1ull); atomicAdd(&g_stamps[6], (unsigned long long)__builtin_popcountll(m)); } }
-  }
-#endif
   if (e.disc > 0) {
     const float mx = h.closest;
     const bool later = (h.hit >= 0) & (hit_off(h.hit) > off_here);
@@ -692,9 +686,18 @@ __device__ __forceinline__ void sphere_grid_walk(P recs, P cells, P cand, f4 g0,
   float tmy = ((float)(iy + (fy ? 1 : 0)) - gy) * ry;
   float tmz = ((float)(iz + (fz ? 1 : 0)) - gz) * rz;
   const float dtx = __builtin_fabsf(rx), dty = __builtin_fabsf(ry), dtz = __builtin_fabsf(rz);
+  const int stx = fx ? 1 : -1, sty = fy ? 1 : -1, stz = fz ? 1 : -1;
+  unsigned int hdr = 0;
+  if (active) hdr = dword_at(cells, (iz * ny + iy) * nx + ix);
   while (__builtin_amdgcn_ballot_w64(active) != 0) {
-    unsigned int hdr = 0;
-    if (active) hdr = dword_at(cells, (iz * ny + iy) * nx + ix);
+    // the next cell (the axis whose boundary comes first; branch-free) and its header, requested BEFORE this cell's tests:
+    // the walk of a lone wave is a chain of dependent LDS reads, this takes one of them off the chain
+    const float tn = __builtin_fminf(tmx, __builtin_fminf(tmy, tmz));
+    const bool sx = tmx == tn, sy = !sx & (tmy == tn), sz = !sx & !sy;
+    const int jx = ix + (sx ? stx : 0), jy = iy + (sy ? sty : 0), jz = iz + (sz ? stz : 0);
+    const bool inside = ((unsigned)jx < (unsigned)nx) & ((unsigned)jy < (unsigned)ny) & ((unsigned)jz < (unsigned)nz);
+    unsigned int hdr_next = 0;
+    if (active & inside) hdr_next = dword_at(cells, (jz * ny + jy) * nx + jx);
     const int count = (int)(hdr & 255u), first = (int)(hdr >> 8);
     for (int k = 0; __builtin_amdgcn_ballot_w64(k < count) != 0; ++k) {
       if (k < count) {
@@ -709,13 +712,11 @@ __device__ __forceinline__ void sphere_grid_walk(P recs, P cells, P cand, f4 g0,
         sphere_finish_unordered(SphereEval{b, b * b - c.a * cc}, c, PT_TMIN, h, goff + o, accept_at(o));
       }
     }
-    if (active) { // next cell: the axis whose boundary comes first
-      const float tn = __builtin_fminf(tmx, __builtin_fminf(tmy, tmz));
-      if (tn > limit()) active = false;
-      else if (tmx == tn) { ix += fx ? 1 : -1; tmx += dtx; active = (unsigned)ix < (unsigned)nx; }
-      else if (tmy == tn) { iy += fy ? 1 : -1; tmy += dty; active = (unsigned)iy < (unsigned)ny; }
-      else { iz += fz ? 1 : -1; tmz += dtz; active = (unsigned)iz < (unsigned)nz; }
-    }
+    // step: the walk ends where the next cell lies outside the grid or begins beyond the nearest hit so far
+    active = active & inside & !(tn > limit());
+    ix = jx; iy = jy; iz = jz;
+    tmx += sx ? dtx : 0.0f; tmy += sy ? dty : 0.0f; tmz += sz ? dtz : 0.0f;
+    hdr = active ? hdr_next : 0u;
   }
 }
 
@@ -743,6 +744,14 @@ __device__ __forceinline__ void sphere_scan(P recs, cst_f4p cblob, int n, int go
     // the walk is exact for a regular ray that starts within rlimit of the grid and (if something moves) whose time lies in
     // the run's shutter interval, so that centres stay between centre0 and centre1; one live lane outside -> full lists
     const bool ok = c.reg && dot(dc, dc) <= g2.w && (!(flags & 2) || (c.r.tm >= aux.x && c.r.tm <= aux.y));
+#ifdef PT_STAMPS
+    { // diagnostic build: how often a wave may walk the grid, and why not (far origin / irregular / shutter)
+      const unsigned long long bad = __builtin_amdgcn_ballot_w64(c.live && !ok);
+      const unsigned long long far = __builtin_amdgcn_ballot_w64(c.live && !(dot(dc, dc) <= g2.w));
+      if ((threadIdx.x & 63) == 0) { atomicAdd(&g_stamps[4], 1ull); if (bad) atomicAdd(&g_stamps[5], 1ull); if (far) atomicAdd(&g_stamps[6], 1ull);
+                                     atomicAdd(&g_stamps[7], (unsigned long long)__builtin_popcountll(bad)); }
+    }
+#endif
     if (__builtin_amdgcn_ballot_w64(c.live && !ok) == 0) {
       const int n_cell = as_i(g3.x), n_cand = as_i(g3.y), qbs = as_i(g3.z), qbm = as_i(g3.w);
       const int big_off = lists_off - qbs - qbm, cand_off = big_off - n_cand, cell_off = cand_off - n_cell;

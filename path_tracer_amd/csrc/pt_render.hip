@@ -79,6 +79,7 @@ struct KArgs {
   int n_local_pixels;  // 64 x the tiles this shard owns (incl. padding pixels of edge tiles)
   unsigned int* queue; // per-launch dequeue counter, zeroed on the stream before the kernel
   unsigned int* cost;  // non-NULL: cost-probe pass, per local tile ray counts (nothing is written to fb)
+  int cost_max;        // probe: 1 = keep the tile's HEAVIEST pixel (x 64) instead of the sum over its pixels
   const int* order;    // non-NULL: queue position -> local tile, heaviest first
   const int* n_split;  // non-NULL (COOP kernels): [0] how many leading tiles of `order` go through the wide phase, [1] log2 G
   int tile_granular;   // PT_FLAG_TILE_GRANULAR
@@ -246,7 +247,10 @@ __device__ __forceinline__ void lane_store(Lane& L, const KArgs& a) {
   L.live = false;
   if (L.wide && ((threadIdx.x & 63) & ((1 << L.wide) - 1))) return; // wide phase: one lane of the group writes
   if (a.cost) { // cost-probe pass: only the tile's ray count is kept
-    atomicAdd(&a.cost[L.cold.get_pix() >> 6], L.cold.get_iters());
+    // a wave holds a tile until its last pixel is done, so a tile's duration follows its heaviest pixel; the cooperative
+    // kernels' model also needs the lane time, i.e. the sum
+    if (a.cost_max) atomicMax(&a.cost[L.cold.get_pix() >> 6], L.cold.get_iters() * PT_TILE_PIXELS);
+    else atomicAdd(&a.cost[L.cold.get_pix() >> 6], L.cold.get_iters());
     return;
   }
   long long idx;
@@ -728,12 +732,15 @@ struct EnvKnobs {
   int wide_logG = 0;       // PT_WIDE_LOGG: forced log2 group size of the wide phase (0 = the model picks)
   bool has_split_tiles = false;
   int split_tiles = 0;     // PT_SPLIT_TILES: fixed number of tiles through the wide phase (< 0: all)
+  int lpt_max = -1, probe_spp_max = 16; // PT_LPT_MAX / PT_PROBE_SPP_MAX: order tiles by their heaviest pixel; probe depth cap
   float model_fixed = 2400.0f, model_chain = 2400.0f; // PT_MODEL_FIXED / PT_MODEL_CHAIN: constants of the makespan model (lpt_order_kernel)
   EnvKnobs() {
     if (const char* e = std::getenv("PT_BLOCKS_PER_CU")) blocks_per_cu = std::max(1, std::atoi(e));
     no_cold_lds = std::getenv("PT_NO_COLD_LDS") != nullptr;
     if (const char* e = std::getenv("PT_WIDE_LOGG")) wide_logG = std::min(6, std::max(1, std::atoi(e)));
     if (const char* e = std::getenv("PT_SPLIT_TILES")) { has_split_tiles = true; split_tiles = std::atoi(e); }
+    if (const char* e = std::getenv("PT_LPT_MAX")) lpt_max = std::atoi(e);
+    if (const char* e = std::getenv("PT_PROBE_SPP_MAX")) probe_spp_max = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("PT_MODEL_FIXED")) model_fixed = (float)std::atof(e);
     if (const char* e = std::getenv("PT_MODEL_CHAIN")) model_chain = (float)std::atof(e);
   }
@@ -996,6 +1003,7 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
   // streaming kernel (a workgroup waits for its slowest lane); either can be forced
   a.tile_granular = (p->flags & PT_FLAG_TILE_GRANULAR) ? 1 : (p->flags & PT_FLAG_PIXEL_GRANULAR) ? 0 : (resident ? 1 : 0);
   a.cost = nullptr;
+  a.cost_max = 0;
   a.order = nullptr;
   const bool mlds = lds && blob_bytes + (size_t)s->mats_f4 * 16 <= kMaxLdsWithMaterials;
   const size_t shmem = lds ? blob_bytes + (mlds ? (size_t)s->mats_f4 * 16 : 0) : 0;
@@ -1061,7 +1069,9 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
     return launch_uv(std::integral_constant<int, UV_NONE>{});
   };
   // Heaviest-first tile order from a probe pass (see lpt_order_kernel); pointless for short renders.
-  const int probe_spp = std::min(4, p->samples / 16);
+  int probe_spp = std::min(4, p->samples / 16);
+  const bool cost_by_max = s->knobs.lpt_max >= 0 ? s->knobs.lpt_max != 0 : false;
+  if (cost_by_max) probe_spp = std::min(std::max(probe_spp, p->samples / 64), s->knobs.probe_spp_max);
   if (probe_spp >= 1 && local_tiles >= 64 && !(p->flags & PT_FLAG_NO_LPT)) {
     if (s->ws_tiles < local_tiles) { // grow-only workspace (first render at a new size only)
       if (s->ws_cost) (void)hipFree(s->ws_cost);
@@ -1074,6 +1084,7 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
     PT_HIP(hipMemsetAsync(s->ws_cost, 0, (size_t)local_tiles * sizeof(unsigned int), st));
     KArgs main_args = a;
     a.cost = s->ws_cost;
+    a.cost_max = (cost_by_max && !coop) ? 1 : 0;
     a.samples = probe_spp;
     int rc = launch_variant();
     if (rc) return rc;

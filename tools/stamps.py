@@ -1,6 +1,6 @@
 """Reads the s_memtime shares of a diagnostic build (csrc built with -DPT_STAMPS -> libpt_stamps.so).
     PT_RENDER_LIB=path_tracer_amd/libpt_stamps.so python tools/stamps.py cornell 256"""
-import ctypes as C, sys
+import ctypes as C, os, sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import torch
@@ -10,17 +10,18 @@ scene, spp = sys.argv[1], int(sys.argv[2])
 flags = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 lib = abi.load_library()
 lib.pt_debug_stamps.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
-W, H = 1920, 1080
+W, H = (int(os.environ.get('PT_W', 1920)), int(os.environ.get('PT_H', 1080)))
+N = int(os.environ.get('PT_SHARDS', 1))
 packed, cam_args = scenes.build(scene)
 cam = scenes.make_camera(cam_args, W, H)
 ds = R.DeviceScene(packed)
-R.render(W, H, 8, ds, cam); torch.cuda.synchronize()
+R.render(W, H, 8, ds, cam, shard_index=0, shard_count=N); torch.cuda.synchronize()
 lib.pt_debug_stamps(None, 1)
 no_lpt = 0 if (len(sys.argv) > 4 and sys.argv[4] == 'lpt') else abi.PT_FLAG_NO_LPT
-fb, ms = R.render(W, H, spp, ds, cam, flags=flags | no_lpt, timed=True)
+fb, ms = R.render(W, H, spp, ds, cam, flags=flags | no_lpt, shard_index=0, shard_count=N, timed=True)
 out = (C.c_ulonglong * 8)()
 lib.pt_debug_stamps(out, 0)
 prep, trav, shade, iters = out[0], out[1], out[2], out[3]
 tot = prep + trav + shade
-print(f"  sphere tests per wave-iteration {out[5]/iters:.0f}; root block entered by {out[4]/max(out[5],1):.3f} of them, with {out[6]/max(out[4],1):.1f} lanes on average")
+print(f"  gridded sphere runs scanned {out[4]:.3e}; full-list fallback in {out[5]/max(out[4],1):.4f} of them (far origin in {out[6]/max(out[4],1):.4f}), {out[7]/max(out[5],1):.1f} lanes at fault on average")
 print(f"{scene} {spp} spp: kernel {ms:.1f} ms; wave-iterations {iters:.3e}; cycles per wave-iteration: prepare {prep/iters:.0f}  traversal {trav/iters:.0f}  shade {shade/iters:.0f}  (total {tot/iters:.0f}); shares {prep/tot:.2f} {trav/tot:.2f} {shade/tot:.2f}")
