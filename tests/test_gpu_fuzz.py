@@ -16,6 +16,7 @@ pytestmark = pytest.mark.gpu
 
 def random_scene(seed: int, allow_image_on_triangle: bool):
     rng = np.random.default_rng(seed)
+    seed = int(seed)
     atlas = TextureAtlas()
     img = image_texture.from_array(rng.integers(0, 256, (13, 17, 3), dtype=np.uint8), float(rng.choice([1.0, 2.5])), atlas)
 
@@ -58,7 +59,8 @@ def random_scene(seed: int, allow_image_on_triangle: bool):
             hs.append(cls(float(a[0]), float(a[1]), float(b[0]), float(b[1]), float(rng.random() * 3 - 1.5), material()))
         elif k == 3:
             v0 = np.array(pt())
-            hs.append(triangle(tuple(v0), tuple(v0 + (rng.random(3) - 0.5)), tuple(v0 + (rng.random(3) - 0.5)), material(True)))
+            hs.append(triangle(tuple(v0), tuple(v0 + (rng.random(3) - 0.5)), tuple(v0 + (rng.random(3) - 0.5)), material(True),
+                               "badouel" if (seed % 5 == 3 and rng.random() < 0.5) else "moller_trumbore"))
         elif k == 4:
             p0 = np.array(pt(1.5))
             hs.append(box(tuple(p0), tuple(p0 + 0.1 + rng.random(3)), material()))
@@ -107,3 +109,76 @@ def test_random_scene_sharded(orc, seed):
     ref = orc.render(ps, c.c, w, h, spp)
     parts = [R.render_host(w, h, spp, ps, c, shard_index=i, shard_count=3) for i in range(3)]
     assert_bit_identical(unshard_reference(np.stack(parts), w, h, 3), ref, f"seed {seed} 3 shards")
+
+
+def random_sphere_field(seed: int):
+    """Runs of small spheres big enough for the culling grid (>= 48), with everything the grid has to get right varied at
+    random: radii spread (so the "small" threshold and the margin differ), flat or tall fields, moving fractions, touching and
+    duplicated spheres, negative radii, big spheres inside the field, large coordinates, a second sphere run, other kinds
+    before / between / after, and cameras inside, near, far and very far (beyond the grid's rlimit: full-list fallback)."""
+    rng = np.random.default_rng(seed)
+
+    def color():
+        return tuple(float(x) for x in rng.random(3))
+
+    def material():
+        k = rng.integers(0, 4)
+        return (lambertian_material(color()) if k == 0 else metal_material(color(), float(0.4 * rng.random())) if k == 1
+                else dielectric_material(1.5, (1, 1, 1)) if k == 2 else lambertian_material(checker_texture(color(), color())))
+
+    scale = float(10.0 ** rng.integers(-1, 3))          # field size 0.1 .. 100
+    centre = np.array([(rng.random() - 0.5) * 50 * (seed % 3 == 0) for _ in range(3)])
+    r_med = 0.02 * scale * (0.5 + rng.random())
+    tall = rng.random() < 0.4
+    n = int(rng.integers(60, 400))
+    hs = [sphere(tuple(centre + [0, -1000 * scale, 0]), 1000 * scale - 0.01 * scale, lambertian_material(checker_texture((0.2, 0.3, 0.1), (0.9, 0.9, 0.9))))]
+    if rng.random() < 0.5:
+        hs.append(xz_rect(float(centre[0] - scale), float(centre[0] + scale), float(centre[2] - scale), float(centre[2] + scale),
+                          float(centre[1] + 1.5 * scale), lightsource_material((3, 3, 3))))
+    first_run = len(hs)
+    for i in range(n):
+        c = centre + np.array([(rng.random() - 0.5) * scale, rng.random() * scale * (1.0 if tall else 0.08), (rng.random() - 0.5) * scale])
+        r = float(r_med * (0.4 + 1.4 * rng.random()))
+        if rng.random() < 0.03:
+            r *= 6                                            # larger than 4 x the median: stays in the "big" list
+        if rng.random() < 0.04:
+            r = -r                                            # negative radius
+        if rng.random() < 0.35:
+            c1 = c + (rng.random(3) - 0.5) * 3 * r_med
+            hs.append(sphere(tuple(c), tuple(c1), 0.0, 1.0, r, material()))
+        else:
+            hs.append(sphere(tuple(c), r, material()))
+        if rng.random() < 0.03:
+            hs.append(hs[int(rng.integers(first_run, len(hs)))])  # duplicate: equal-t tie, the earlier one must win
+    if rng.random() < 0.6:                                      # interrupt the run, then a second (short or long) sphere run
+        p0 = centre + (rng.random(3) - 0.5) * scale * 0.5
+        hs.append(box(tuple(p0), tuple(p0 + 0.1 * scale), material()))
+        for i in range(int(rng.choice([3, 70]))):
+            c = centre + np.array([(rng.random() - 0.5) * scale, rng.random() * scale * 0.3, (rng.random() - 0.5) * scale])
+            hs.append(sphere(tuple(c), float(r_med * (0.5 + rng.random())), material()))
+    if rng.random() < 0.5:
+        hs.append(constant_medium(sphere(tuple(centre + [0, 0.2 * scale, 0]), float(0.2 * scale), lambertian_material((1, 1, 1))),
+                                  float(2.0 / scale), color()))
+    dist = float(rng.choice([0.3, 1.5, 40.0, 4000.0])) * scale
+    frm = centre + np.array([dist * 0.7, dist * 0.35 + 0.05 * scale, dist * 0.6])
+    cam = dict(look_from=tuple(float(x) for x in frm), look_at=tuple(float(x) for x in centre + [0, 0.05 * scale, 0]), vup=(0, 1, 0),
+               vfov=float(min(70.0, 2 * np.degrees(np.arctan(0.7 * scale / max(dist, 1e-6))) + 5.0)),
+               aperture=float(0.02 * scale * (rng.random() < 0.3)), focus_dist=float(max(dist, 0.1 * scale)),
+               time0=float(-0.3 * (seed % 7 == 5)), time1=1.0)
+    return pack(hs), cam
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_sphere_fields_through_the_culling_grid(orc, lib, seed):
+    ps, cam = random_sphere_field(3000 + seed)
+    w, h, spp = 40, 24, 8
+    c = scenes.make_camera(cam, w, h)
+    orc.set_math(True)
+    ref = orc.render(ps, c.c, w, h, spp)
+    # frames this small keep the cooperative kernels (lists) by default: PT_FLAG_NO_COOP / NO_LDS select the kernels that
+    # walk the grid (LDS-resident and scalar-cache), FAST_RNG has its own instantiations of them
+    for name, flags in (("grid, LDS", abi.PT_FLAG_NO_COOP), ("grid, scalar cache", abi.PT_FLAG_NO_LDS), ("default", 0),
+                        ("grid, pixel-granular", abi.PT_FLAG_NO_COOP | abi.PT_FLAG_PIXEL_GRANULAR), ("stream", abi.PT_FLAG_FORCE_STREAM)):
+        assert_bit_identical(R.render_host(w, h, spp, ps, c, flags=flags), ref, f"sphere field seed {seed} {name}")
+    F = abi.PT_FLAG_FAST_RNG
+    assert_bit_identical(R.render_host(w, h, 70, ps, c, flags=F), orc.render(ps, c.c, w, h, 70, flags=F), f"sphere field seed {seed} fast mode")

@@ -856,14 +856,21 @@ def test_sphere_grid_is_exact(orc, monkeypatch):
     for vi, view in enumerate(views):
         c = scenes.make_camera(view, 64, 36)
         ref = orc.render(ps, c.c, 64, 36, 6)
-        for flags in (0, abi.PT_FLAG_FORCE_COOP, abi.PT_FLAG_NO_LDS, abi.PT_FLAG_FORCE_STREAM, abi.PT_FLAG_FORCE_COOP | abi.PT_FLAG_NO_SPLIT,
-                      abi.PT_FLAG_PIXEL_GRANULAR):
+        # NO_COOP / NO_LDS: the kernels that walk the grid (a frame this small would otherwise keep the cooperative ones)
+        for flags in (abi.PT_FLAG_NO_COOP, abi.PT_FLAG_NO_LDS, abi.PT_FLAG_NO_COOP | abi.PT_FLAG_PIXEL_GRANULAR, 0, abi.PT_FLAG_FORCE_COOP,
+                      abi.PT_FLAG_FORCE_STREAM, abi.PT_FLAG_FORCE_COOP | abi.PT_FLAG_NO_SPLIT):
             assert_bit_identical(R.render_host(64, 36, 6, ps, c, flags=flags), ref, f"view {vi} flags {flags}")
     c = scenes.make_camera(cam, 48, 27)
     fast = R.render_host(48, 27, 70, ps, c, flags=abi.PT_FLAG_FAST_RNG)
     assert_bit_identical(fast, orc.render(ps, c.c, 48, 27, 70, flags=abi.PT_FLAG_FAST_RNG), "grid + fast mode")
+    # a frame large enough for the launcher to pick the grid kernels by itself (>= 4096 tiles), sampled pixels
+    c = scenes.make_camera(cam, 640, 520)
+    big = R.render_host(640, 520, 4, ps, c)
+    xy = np.stack([np.random.default_rng(1).integers(0, 640, 3000), np.random.default_rng(2).integers(0, 520, 3000)], axis=1).astype(np.int32)
+    assert_bit_identical(big[xy[:, 1], xy[:, 0]], orc.render_pixels(ps, c.c, 640, 520, 4, xy), "640x520 through the launcher's own choice")
     monkeypatch.setenv("PT_NO_GRID", "1")  # read at scene creation: the brute-force lists for the same scene
-    assert_bit_identical(R.render_host(64, 36, 6, ps, scenes.make_camera(cam, 64, 36)), orc.render(ps, scenes.make_camera(cam, 64, 36).c, 64, 36, 6), "PT_NO_GRID")
+    c = scenes.make_camera(cam, 64, 36)
+    assert_bit_identical(R.render_host(64, 36, 6, ps, c, flags=abi.PT_FLAG_NO_COOP), orc.render(ps, c.c, 64, 36, 6), "PT_NO_GRID")
 
 
 def test_rerender_is_deterministic(torch_gpu):

@@ -31,6 +31,14 @@ for name, fn in S.ALL.items():
         rc = san.orc_render(C.byref(ps.desc), C.byref(c.c), C.byref(p), fb.ctypes.data_as(C.POINTER(C.c_float)), None)
         assert rc == 0
         assert fb.tobytes() == ref.tobytes(), name
+    # the two extra executors of round 2: fast mode (own RNG streams per chunk) and the single-task stream
+    orc.set_math(True); san.orc_set_math(1)
+    for flags, spp in ((abi.PT_FLAG_FAST_RNG, 70), (abi.PT_FLAG_SINGLE_STREAM, 2)):
+        ref = orc.render(ps, c.c, 20, 12, spp, flags=flags)
+        fb = np.zeros((12, 20, 3), np.float32)
+        p = orc.params(20, 12, spp, flags=flags)
+        assert san.orc_render(C.byref(ps.desc), C.byref(c.c), C.byref(p), fb.ctypes.data_as(C.POINTER(C.c_float)), None) == 0
+        assert fb.tobytes() == ref.tobytes(), (name, flags)
 print("SANITIZED_OK")
 '''
 
