@@ -111,6 +111,7 @@ SIGNATURES = {
                                  C.c_float, C.c_float]),
     "pt_scene_create": (C.c_int, [C.POINTER(PtSceneDesc), C.POINTER(_SCENE_P)]),
     "pt_scene_destroy": (None, [_SCENE_P]),
+    "pt_scene_reserve": (C.c_int, [_SCENE_P, C.POINTER(PtRenderParams)]),
     "pt_fast_seed": (C.c_uint32, [C.c_uint32, C.c_uint32]),
     "pt_framebuffer_floats": (C.c_int64, [C.POINTER(PtRenderParams)]),
     "pt_shard_tiles": (C.c_int32, [C.POINTER(PtRenderParams)]),

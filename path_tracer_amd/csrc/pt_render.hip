@@ -963,6 +963,27 @@ int64_t pt_framebuffer_floats(const PtRenderParams* p) {
   return (int64_t)pt_shard_tiles(p) * PT_TILE_PIXELS * 3;
 }
 
+// grow-only per-scene workspaces (LPT cost / order arrays; fast mode's partial sums).  pt_scene_reserve() sizes them ahead of
+// time so that pt_render() neither allocates nor frees (hipMalloc / hipFree synchronise the device).
+static int reserve_tiles(const PtScene* s, int local_tiles) {
+  if (s->ws_tiles >= local_tiles) return PT_OK;
+  if (s->ws_cost) (void)hipFree(s->ws_cost);
+  if (s->ws_order) (void)hipFree(s->ws_order);
+  s->ws_cost = nullptr; s->ws_order = nullptr; s->ws_tiles = 0;
+  PT_HIP(hipMalloc((void**)&s->ws_cost, (size_t)local_tiles * sizeof(unsigned int)));
+  PT_HIP(hipMalloc((void**)&s->ws_order, (size_t)local_tiles * sizeof(int)));
+  s->ws_tiles = local_tiles;
+  return PT_OK;
+}
+static int reserve_partial(const PtScene* s, size_t floats) {
+  if (s->ws_partial_floats >= floats) return PT_OK;
+  if (s->ws_partial) (void)hipFree(s->ws_partial);
+  s->ws_partial = nullptr; s->ws_partial_floats = 0;
+  PT_HIP(hipMalloc((void**)&s->ws_partial, floats * sizeof(float)));
+  s->ws_partial_floats = floats;
+  return PT_OK;
+}
+
 static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderParams* p, float* fb, hipStream_t st) {
   int cur = -1;
   PT_HIP(hipGetDevice(&cur));
@@ -1073,14 +1094,7 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
   const bool cost_by_max = s->knobs.lpt_max >= 0 ? s->knobs.lpt_max != 0 : false;
   if (cost_by_max) probe_spp = std::min(std::max(probe_spp, p->samples / 64), s->knobs.probe_spp_max);
   if (probe_spp >= 1 && local_tiles >= 64 && !(p->flags & PT_FLAG_NO_LPT)) {
-    if (s->ws_tiles < local_tiles) { // grow-only workspace (first render at a new size only)
-      if (s->ws_cost) (void)hipFree(s->ws_cost);
-      if (s->ws_order) (void)hipFree(s->ws_order);
-      s->ws_cost = nullptr; s->ws_order = nullptr; s->ws_tiles = 0;
-      PT_HIP(hipMalloc((void**)&s->ws_cost, (size_t)local_tiles * sizeof(unsigned int)));
-      PT_HIP(hipMalloc((void**)&s->ws_order, (size_t)local_tiles * sizeof(int)));
-      s->ws_tiles = local_tiles;
-    }
+    if (int rc = reserve_tiles(s, local_tiles)) return rc; // first render at a new size only (or never: pt_scene_reserve)
     PT_HIP(hipMemsetAsync(s->ws_cost, 0, (size_t)local_tiles * sizeof(unsigned int), st));
     KArgs main_args = a;
     a.cost = s->ws_cost;
@@ -1112,12 +1126,7 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
     if (chunks > 127 || local_tiles >= (1 << 18))
       return fail(PT_ERR_TOO_LARGE, "PT_FLAG_FAST_RNG supports up to 8128 samples per pixel and 2^24 pixels per shard");
     const size_t plane = (size_t)pt_framebuffer_floats(p), need = plane * (size_t)chunks;
-    if (s->ws_partial_floats < need) { // grow-only workspace (first render at a new size only)
-      if (s->ws_partial) (void)hipFree(s->ws_partial);
-      s->ws_partial = nullptr; s->ws_partial_floats = 0;
-      PT_HIP(hipMalloc((void**)&s->ws_partial, need * sizeof(float)));
-      s->ws_partial_floats = need;
-    }
+    if (int rc = reserve_partial(s, need)) return rc; // first render at a new size only (or never: pt_scene_reserve)
     PT_HIP(hipMemsetAsync(s->ws_partial, 0, need * sizeof(float), st)); // pixels no lane owns add 0
     a.fast_chunks = chunks;
     a.samples = std::min(p->samples, (int)PT_FAST_CHUNK_SPP);
@@ -1139,6 +1148,25 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
   int rc = launch_variant();
   if (rc) return rc;
   PT_HIP(hipGetLastError());
+  return PT_OK;
+}
+
+int pt_scene_reserve(const PtScene* scene, const PtRenderParams* p) {
+  if (!scene) return fail(PT_ERR_INVALID_ARG, "pt_scene_reserve: NULL scene");
+  int rc = check_params(p);
+  if (rc) return rc;
+  int cur = -1;
+  PT_HIP(hipGetDevice(&cur));
+  if (cur != scene->device) return fail(PT_ERR_INVALID_ARG, "pt_scene_reserve: the scene lives on another device");
+  std::lock_guard<std::mutex> lock(scene->sched);
+  int tiles_x;
+  const int n_tiles = n_tiles_of(p, &tiles_x);
+  const int local_tiles = (n_tiles - p->shard_index + p->shard_count - 1) / p->shard_count;
+  if (local_tiles > 0 && (rc = reserve_tiles(scene, local_tiles))) return rc;
+  if (p->flags & PT_FLAG_FAST_RNG) {
+    const int chunks = (p->samples + PT_FAST_CHUNK_SPP - 1) / PT_FAST_CHUNK_SPP;
+    if ((rc = reserve_partial(scene, (size_t)pt_framebuffer_floats(p) * (size_t)chunks))) return rc;
+  }
   return PT_OK;
 }
 

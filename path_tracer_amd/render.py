@@ -28,6 +28,11 @@ class DeviceScene:
         self._packed = scene  # keep the host tables alive
         abi.check(self.lib.pt_scene_create(C.byref(scene.desc), C.byref(self.handle)), "pt_scene_create")
 
+    def reserve(self, width, height, samples, depth=50, shard_index=0, shard_count=1, flags=0) -> None:
+        """pt_scene_reserve: allocate the launch workspaces for these parameters now, so that render() never allocates."""
+        p = _params(width, height, samples, depth, shard_index, shard_count, flags)
+        abi.check(self.lib.pt_scene_reserve(self.handle, C.byref(p)), "pt_scene_reserve")
+
     def close(self):
         if self.handle:
             self.lib.pt_scene_destroy(self.handle)

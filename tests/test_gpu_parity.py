@@ -873,6 +873,23 @@ def test_sphere_grid_is_exact(orc, monkeypatch):
     assert_bit_identical(R.render_host(64, 36, 6, ps, c, flags=abi.PT_FLAG_NO_COOP), orc.render(ps, c.c, 64, 36, 6), "PT_NO_GRID")
 
 
+def test_scene_reserve_then_render(orc, lib):
+    """pt_scene_reserve sizes the launch workspaces ahead of time (the LPT arrays, the fast mode's partial sums); renders after
+    it give the same frames; bad arguments are codes."""
+    ps, cam = S.spheres_scene()
+    c = scenes.make_camera(cam, 136, 80)
+    ds = R.DeviceScene(ps)
+    ds.reserve(136, 80, 64, flags=abi.PT_FLAG_FAST_RNG)
+    ds.reserve(136, 80, 64)
+    orc.set_math(True)
+    assert_bit_identical(R.render_host(136, 80, 64, ds, c), orc.render(ps, c.c, 136, 80, 64), "after reserve")
+    F = abi.PT_FLAG_FAST_RNG
+    assert_bit_identical(R.render_host(136, 80, 64, ds, c, flags=F), orc.render(ps, c.c, 136, 80, 64, flags=F), "fast mode after reserve")
+    bad = abi.PtRenderParams(0, 8, 1, 50, 0, 1, 0, 0)
+    assert lib.pt_scene_reserve(ds.handle, C.byref(bad)) == abi.PT_ERR_INVALID_ARG
+    assert lib.pt_scene_reserve(None, C.byref(abi.PtRenderParams(8, 8, 1, 50, 0, 1, 0, 0))) == abi.PT_ERR_INVALID_ARG
+
+
 def test_rerender_is_deterministic(torch_gpu):
     ps, cam = scenes.build("smoke")
     c = scenes.make_camera(cam, 200, 112)
