@@ -36,6 +36,7 @@ struct Flat {
   bool fast_ok = true; // all rect/box coordinates finite with |v| <= 2^60 (pt_device.hpp: RayCtx)
   bool has_badouel = false; // some triangle uses the Badouel strategy (its own device kind and kernel instantiations)
   int grid_spheres = 0;     // spheres that sit in a culling grid (pt_scene_create: their scan is cheap)
+  int culled_boxes = 0;     // boxes in runs that are scanned through the slab test (pt_device.hpp: box_run_culled)
 };
 
 inline int device_kind(int32_t k) {
@@ -264,7 +265,7 @@ inline void put_box(std::vector<F4>& b, const float* f, int32_t mat, int32_t hid
   b.push_back({f[3], f[4], f[5], as_f(hidx)});
 }
 
-inline int flatten(const PtSceneDesc* sc, Flat& out, std::string& err, bool allow_grid = true) {
+inline int flatten(const PtSceneDesc* sc, Flat& out, std::string& err, bool allow_grid = true, bool allow_box_cull = true) {
   int rc = validate(sc, err);
   if (rc) return rc;
   out = Flat();
@@ -324,6 +325,14 @@ inline int flatten(const PtSceneDesc* sc, Flat& out, std::string& err, bool allo
   for (size_t ri = 0; ri < runs.size(); ri++) {
     const Run& run = runs[ri];
     if (run.kind == DK_SPHERE) out.grid_spheres += put_sphere_run_aux(b, &sc->hittables[run.first], run.count, allow_grid);
+    if (run.kind == DK_BOX) { // aux F4 in front of a box run: (largest |coordinate| of its boxes, 1 = cull the run exactly: box_run_culled)
+      float bmax = 0.0f;
+      for (int i = run.first; i < run.first + run.count; i++)
+        for (int k = 0; k < 6; k++) bmax = std::max(bmax, std::fabs(sc->hittables[i].f[k]));
+      const bool cull = allow_box_cull && out.fast_ok && run.count >= 2;
+      if (cull) out.culled_boxes += run.count;
+      b.push_back({bmax, as_f(cull ? 1 : 0), 0.0f, 0.0f});
+    }
     b[ri] = {as_f(run.kind), as_f((int32_t)b.size()), as_f(run.count), as_f(run.first)};
     for (int i = run.first; i < run.first + run.count; i++) {
       const PtHittable& h = sc->hittables[i];

@@ -871,7 +871,8 @@ int pt_scene_create(const PtSceneDesc* desc, PtScene** out_scene) {
   *out_scene = nullptr;
   ptf::Flat flat;
   std::string err;
-  int rc = ptf::flatten(desc, flat, err, std::getenv("PT_NO_GRID") == nullptr); // PT_NO_GRID: A/B knob (brute-force sphere runs)
+  // PT_NO_GRID / PT_NO_BOXCULL: A/B knobs (brute-force sphere runs / straight-line box runs)
+  int rc = ptf::flatten(desc, flat, err, std::getenv("PT_NO_GRID") == nullptr, std::getenv("PT_NO_BOXCULL") == nullptr);
   if (rc) return fail(rc, err);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(PT_ERR_NO_DEVICE, "no HIP device visible");

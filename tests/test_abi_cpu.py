@@ -101,6 +101,9 @@ def test_flatten_preserves_list_order(lib):
             assert aux.view(np.int32)[2] == count and aux.view(np.int32)[3] == 1  # all static, uniform interval
             lst = blob[first - 1 - (int(count) + 3) // 4:first - 1].view(np.int32).reshape(-1)
             assert lst[:count].tolist() == [3 * i for i in range(count)] and (lst[count:] == 3 * (count - 1)).all()
+        if kind == 3:  # a box run is preceded by one aux F4: (largest |coordinate|, cull flag: runs of >= 2 boxes)
+            off += 1
+            assert blob[first - 1, 0] == 1.0 and blob[first - 1].view(np.int32)[1] == 0
         assert first == off
         off += sizes[int(kind)] * int(count)
     assert off == len(blob)
@@ -116,6 +119,23 @@ def test_flatten_preserves_list_order(lib):
     # medium record: boundary kind, neg_inv_density = -1/2
     md = blob[runs[5, 1]]
     assert md.view(np.int32)[0] == 0 and md[1] == np.float32(-0.5)
+
+
+def test_flatten_box_run_aux(lib):
+    """Runs of two or more boxes on a fast_ok scene carry the cull flag and the largest |coordinate| of the run (the slab
+    test's error bound scales with it: pt_device.hpp box_run_culled); a non-finite / huge coordinate anywhere switches the
+    straight-line paths, and with them the culling, off."""
+    m = lambertian_material((0.5, 0.5, 0.5))
+    hs = [box((0, 0, 0), (1, 2, 3), m), box((-7, 0, 0), (1, 1, 1), m), box((0, 0, 0), (1, 1, 5.5), m), sphere((0, 0, 0), 1, m),
+          box((0, 0, 0), (9, 1, 1), m)]
+    rc, blob, mats, n_runs, flags = flatten(lib, pack(hs))
+    assert rc == 0 and n_runs == 3
+    runs = blob[:n_runs].view(np.int32)
+    assert blob[runs[0, 1] - 1, 0] == 7.0 and blob[runs[0, 1] - 1].view(np.int32)[1] == 1
+    assert blob[runs[2, 1] - 1, 0] == 9.0 and blob[runs[2, 1] - 1].view(np.int32)[1] == 0   # a single box: not worth it
+    hs[1] = box((-7, 0, 0), (1, 1, 3e18), m)
+    rc, blob, mats, n_runs, flags = flatten(lib, pack(hs))
+    assert rc == 0 and blob[blob[:n_runs].view(np.int32)[0, 1] - 1].view(np.int32)[1] == 0
 
 
 def decode_sphere_aux(blob, first, count):

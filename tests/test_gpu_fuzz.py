@@ -182,3 +182,79 @@ def test_random_sphere_fields_through_the_culling_grid(orc, lib, seed):
         assert_bit_identical(R.render_host(w, h, spp, ps, c, flags=flags), ref, f"sphere field seed {seed} {name}")
     F = abi.PT_FLAG_FAST_RNG
     assert_bit_identical(R.render_host(w, h, 70, ps, c, flags=F), orc.render(ps, c.c, w, h, 70, flags=F), f"sphere field seed {seed} fast mode")
+
+
+def random_box_field(seed: int):
+    """Runs of boxes for the exact slab culling (pt_device.hpp: box_run_culled), with what it has to get right varied at random:
+    more than 16 boxes (chunks), thin slabs, boxes sharing faces / edges / corners (equal-t ties: the later one wins), exact
+    duplicates, nested boxes (origins inside a box), stacks seen end-on (more than three candidates per ray: repeated passes),
+    large and tiny coordinates, rect runs between box runs, mirrors and glass (rays that start on and inside boxes), and
+    cameras inside, near and far."""
+    rng = np.random.default_rng(seed)
+
+    def color():
+        return tuple(float(x) for x in rng.random(3))
+
+    def material():
+        k = rng.integers(0, 5)
+        return (lambertian_material(color()) if k <= 1 else metal_material(color(), float(0.3 * rng.random())) if k == 2
+                else dielectric_material(1.5, (1, 1, 1)) if k == 3 else lightsource_material(tuple(float(3 * x) for x in rng.random(3))))
+
+    scale = float(10.0 ** rng.integers(-2, 4))          # scene size 0.01 .. 1000
+    centre = np.array([(rng.random() - 0.5) * 2000 * scale * (seed % 4 == 1) for _ in range(3)])
+    snap = scale / 8                                     # coordinates on a lattice: shared faces, edges and corners are exact
+    hs = []
+
+    def lattice_box():
+        p0 = centre + np.round((rng.random(3) - 0.5) * scale / snap) * snap
+        size = np.maximum(np.round(rng.random(3) * 0.35 * scale / snap), 1) * snap
+        if rng.random() < 0.25:
+            size[int(rng.integers(0, 3))] = snap * float(rng.choice([1e-3, 1 / 16]))   # a thin slab
+        return box(tuple(p0), tuple(p0 + size), material())
+
+    n = int(rng.integers(3, 40))
+    for _ in range(n):
+        hs.append(lattice_box())
+        if rng.random() < 0.08:
+            hs.append(hs[int(rng.integers(0, len(hs)))])                                  # exact duplicate
+    if rng.random() < 0.5:                                                                # a stack seen end-on
+        p0 = centre + np.array([0.3 * scale, 0, 0])
+        for i in range(int(rng.integers(4, 9))):
+            hs.append(box(tuple(p0 + [0, 0, i * snap]), tuple(p0 + [snap, snap, (i + 1) * snap]), material()))
+    if rng.random() < 0.6:                                                                # a room around everything
+        lo, hi = centre - 0.8 * scale, centre + 0.8 * scale
+        hs.insert(0, box(tuple(lo - 0.01 * scale), (float(hi[0] + 0.01 * scale), float(lo[1]), float(hi[2] + 0.01 * scale)), material()))
+        hs.append(box((float(lo[0] - 0.01 * scale), float(lo[1]), float(lo[2])), (float(lo[0]), float(hi[1]), float(hi[2])), material()))
+    if rng.random() < 0.7:                                                                # rects between box runs
+        k = int(rng.integers(1, len(hs)))
+        a = centre - 0.5 * scale
+        hs.insert(k, xy_rect(float(a[0]), float(a[0] + scale), float(a[1]), float(a[1] + scale), float(centre[2] + 0.5 * scale), material()))
+        if rng.random() < 0.5:
+            hs.insert(k, xz_rect(float(a[0]), float(a[0] + scale), float(a[2]), float(a[2] + scale), float(centre[1] - 0.5 * scale), material()))
+    if rng.random() < 0.4:
+        hs.append(sphere(tuple(centre), float(0.1 * scale), material()))
+        hs.append(lattice_box())
+        hs.append(lattice_box())
+    dist = float(rng.choice([0.0, 0.2, 1.5, 30.0])) * scale
+    frm = centre + np.array([dist * 0.6 + 0.01 * scale, dist * 0.45 + 0.013 * scale, dist * 0.65 + 0.017 * scale])
+    cam = dict(look_from=tuple(float(x) for x in frm), look_at=tuple(float(x) for x in centre), vup=(0, 1, 0),
+               vfov=float(70.0 if dist < scale else min(70.0, 2 * np.degrees(np.arctan(0.7 * scale / dist)) + 5.0)),
+               aperture=0.0, focus_dist=float(max(dist, 0.1 * scale)), time0=0.0, time1=1.0)
+    return pack(hs), cam
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_box_fields_through_the_slab_culling(orc, lib, seed):
+    ps, cam = random_box_field(4000 + seed)
+    w, h, spp = 40, 24, 8
+    c = scenes.make_camera(cam, w, h)
+    orc.set_math(True)
+    ref = orc.render(ps, c.c, w, h, spp)
+    # frames this small go to the cooperative kernels by default (straight-line box runs): NO_COOP / NO_LDS select the
+    # kernels with the culled box runs (LDS-resident and scalar-cache)
+    for name, flags in (("culled, LDS", abi.PT_FLAG_NO_COOP), ("culled, scalar cache", abi.PT_FLAG_NO_LDS), ("default", 0),
+                        ("culled, pixel-granular", abi.PT_FLAG_NO_COOP | abi.PT_FLAG_PIXEL_GRANULAR), ("stream", abi.PT_FLAG_FORCE_STREAM),
+                        ("plain division", abi.PT_FLAG_NO_FASTDIV | abi.PT_FLAG_NO_COOP)):
+        assert_bit_identical(R.render_host(w, h, spp, ps, c, flags=flags), ref, f"box field seed {seed} {name}")
+    F = abi.PT_FLAG_FAST_RNG | abi.PT_FLAG_NO_COOP
+    assert_bit_identical(R.render_host(w, h, 70, ps, c, flags=F), orc.render(ps, c.c, w, h, 70, flags=F), f"box field seed {seed} fast mode")
