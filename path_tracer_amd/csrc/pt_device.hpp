@@ -438,7 +438,7 @@ __device__ __forceinline__ void rect_side_cmpx(float a0, float a1, float b0, flo
   const float a = Sel::oa(c) + t * Sel::da(c);
   const float b = Sel::ob(c) + t * Sel::db(c);
   asm volatile(
-      "v_cmpx_ngt_f32_e32 vcc, %[tmin], %[t]\n\t"  // !(min > t)  ==  !(t < min)
+      "v_cmpx_le_f32_e32 vcc, %[tmin], %[t]\n\t"   // min <= t  ==  !(t < min): t is never NaN here (a slab pool's rect entry relies on NaN failing)
       "v_cmpx_ngt_f32_e32 vcc, %[t], %[cl]\n\t"    // !(t > max)
       "v_cmpx_nlt_f32_e32 vcc, %[a], %[a0]\n\t"    // !(a < a0)
       "v_cmpx_ngt_f32_e32 vcc, %[a], %[a1]\n\t"    // !(a > a1)
@@ -784,70 +784,97 @@ __device__ __forceinline__ void sphere_scan(P recs, cst_f4p cblob, int n, int go
 // WHOLE: recs[0..n) is a whole run (its aux records sit in front of it at cblob[goff - 1]); false for an LDS tile of a
 // streamed run, which takes the spheres one at a time in list order.
 // BADOUEL: the kernel also knows Badouel-strategy triangle runs (DK_TRI_B).
-// ---- a run of boxes, culled exactly ----------------------------------------------------------------------------------
-// The straight-line scan tests 6 sides x 19 issue slots for EVERY box although a ray's line passes through few of them.
-// Here each box first gets a conservative slab test in cheap arithmetic (~27 slots): the ray's parameter interval inside
-// the box, inflated by the rounding the reference itself can commit, which yields a lower bound L on the t of ANY side of that box the reference could accept, or
-// "cannot be hit".  The lane keeps its three smallest (L, box) keys; then, nearest first and only while L <= closest, the
-// box's six sides are tested EXACTLY as before (box_cmpx, records fetched per lane).  Everything skipped provably fails
-// the reference's own comparisons; every accepted t is computed by the same instructions as in the straight-line scan.
+// ---- consecutive runs of rects and boxes, culled exactly ("slab pool") ----------------------------------------------------
+// The straight-line scans test 19 issue slots per rect and 6 x 19 per box for EVERY record although a ray's line passes
+// through few of them.  For every maximal stretch of consecutive rect / box runs (>= 2 hittables, fast_ok scene) the
+// flattener adds a pool table (pt_flatten.hpp): per hittable a slab entry (lo, hi: a rect is a box of no thickness) and an
+// exact entry.  Each entry first gets a conservative slab test in cheap arithmetic (~30 slots): the ray's parameter
+// interval inside the box, inflated by the rounding the reference itself can commit, which yields a lower bound L on the t
+// of ANY side of that hittable the reference could accept, or "cannot be hit".  The lane keeps its three smallest
+// (L, entry) keys; then, nearest first and only while L <= closest, the entry's sides are tested EXACTLY (the same
+// rect_side_cmpx instructions as the straight-line box scan, records fetched per lane).  Everything skipped provably
+// fails the reference's own comparisons; every accepted t is computed by the same instructions as in the straight-line scan.
 //
 // Why the slab test is conservative (u = 2^-24).  A side on plane K of axis k is accepted by the reference
-// (rectangle.hpp:34-43 through box.hpp:29-50) only if t = RN(RN(K - o_k) / d_k) >= min and, for both in-plane axes a,
+// (rectangle.hpp:34-43, also through box.hpp:29-50) only if t = RN(RN(K - o_k) / d_k) >= min and, for both in-plane axes a,
 // A = RN(o_a + RN(t d_a)) lies in [lo_a, hi_a].  The two roundings move A by at most u (|t d_a| + |A|) <= u (2 B + |o_a|)
-// (B = the largest |coordinate| of the run's boxes), so in real arithmetic t lies in the ray's parameter interval over
+// (B = the largest |coordinate| in the pool), so in real arithmetic t lies in the ray's parameter interval over
 // [lo_a - e, hi_a + e], e = u (2 B + |o_a|); for the plane's own axis t is within 2u (relative) of an interval end.  The
 // interval ends are computed from an origin moved outwards by S = 3u |o| + 2.5u B per axis — RN(o +- S) moves o by at
-// least S - ulp(o +- S)/2 >= S - 2u |o| = u |o| + 2.5u B >= e — as (lo - (o + S)) * y and (hi - (o - S)) * y with y = RN(1 / d): three
-// roundings, each RELATIVE to the interval end (a difference of nearby floats is exact), covered by the factors 1 -+ 8u
-// applied to the entry and exit parameters.  So an accepted t satisfies max_c lo_c (1 - 8u) <= t <= min_c hi_c (1 + 8u)
-// and t >= min: L = max(entry (1 - 8u), min) is a lower bound of it and the box is a candidate iff L <= exit (1 + 8u).
-// (Regular rays on a fast_ok scene only: nothing here overflows or is NaN.  The margins matter: a ray leaving a box's face
-// has that box as a candidate whenever S / |d_k| reaches min, and every such lane costs its wave a trip.)
+// least S - ulp(o +- S)/2 >= S - 2u |o| = u |o| + 2.5u B >= e — as (lo - (o + S)) * y and (hi - (o - S)) * y with
+// y = RN(1 / d): three roundings, each RELATIVE to the interval end (a difference of nearby floats is exact), covered by the
+// factors 1 -+ 8u applied to the entry and exit parameters.  So an accepted t satisfies
+// max_c lo_c (1 - 8u) <= t <= min_c hi_c (1 + 8u) and t >= min: L = max(entry (1 - 8u), min) is a lower bound of it and the
+// hittable is a candidate iff L <= exit (1 + 8u).  (Regular rays on a fast_ok scene only: nothing here overflows or is NaN.
+// The margins matter: a ray leaving a box's face has that box as a candidate whenever S / |d_k| reaches min, and every
+// such lane costs its wave a trip.)
 //
-// Testing the boxes out of list order needs the tie rule spelled out, as for the sphere lists: the sequential scan accepts a
-// side on t <= closest, i.e. among equal t the LAST in list order wins.  A candidate box therefore compares against
-// closest when the current holder sits earlier in the list (or is this box), and against the next float below closest
-// (t <= nextbelow(closest)  <=>  t < closest) when the holder is a later box of this run that was tested first.
-// Keys: the float L with its low four bits replaced by the box's index in the chunk of 16 (L >= min > 0, so the keys order
-// like floats; truncation only lowers L); +inf = none.  More than three live candidates: another pass over the
+// Testing out of list order needs the tie rule spelled out, as for the sphere lists: the sequential scan accepts a side on
+// t <= closest, i.e. among equal t the LAST in list order wins.  A candidate therefore compares against closest when the
+// current holder sits earlier in the list (or is this hittable), and against the next float below closest
+// (t <= nextbelow(closest)  <=>  t < closest) when the holder is a later hittable of this pool that was tested first
+// (records stay in list order in the blob: offsets compare like list positions).
+// A rect's exact entry is a box whose other five sides cannot pass: X0 = (lo, hit id), X1 = (hi, -) with the plane in `lo`
+// and -inf in `hi` on the rect's own axis — the "hi" side of that axis has t = NaN (fails the ordered min <= t), the four
+// sides of the other axes have an empty in-plane interval [K, -inf], and the "lo" side IS the rect's test, instruction for
+// instruction (rect_side_cmpx<AX> with the same operands as rect_fast<AX>).  A rect hit carries junk side bits: nothing
+// reads them for DK_RECT.
+// Keys: the float L with its low four bits replaced by the entry's index in the chunk of 16 (L >= min > 0, so the keys
+// order like floats; truncation only lowers L); +inf = none.  More than three live candidates: another pass over the
 // chunk for the lanes concerned, restricted to keys above the last one handled.
 template <bool FILTER, typename P>
-__device__ __forceinline__ bool box_chunk_pass(P recs, cst_f4p crecs, int cn, int goff_chunk, const RayCtx& c, V3 om, V3 op,
-                                               float& kdone, HitState& h) {
+__device__ __forceinline__ bool slab_chunk_pass(P xrecs, cst_f4p srecs, int cn, const RayCtx& c, V3 om, V3 op, float& kdone, HitState& h) {
   const float none = PT_INF;
   float k1 = none, k2 = none, k3 = none;
-  for (int j = 0; j < cn; ++j) {
-    const f4 R0 = crecs[j * SZ_BOX], R1 = crecs[j * SZ_BOX + 1]; // wave-uniform: scalar loads, the bounds are SGPR operands
-    const float ax = (R0.x - om.x) * c.yx, bx = (R1.x - op.x) * c.yx;
-    const float ay = (R0.y - om.y) * c.yy, by = (R1.y - op.y) * c.yy;
-    const float az = (R0.z - om.z) * c.yz, bz = (R1.z - op.z) * c.yz;
+  // two entries per trip (the table is padded to an even count with an all-NaN entry: `L <= NaN` is false), one
+  // s_load_dwordx16 for both; wave-uniform, the bounds are SGPR operands
+  typedef float f16v __attribute__((ext_vector_type(16)));
+  typedef const __attribute__((address_space(4))) f16v* cst_f16p;
+  const cst_f16p pairs = (cst_f16p)srecs;
+  auto entry = [&](float lx, float ly, float lz, float hx, float hy, float hz, int j) {
+    const float ax = (lx - om.x) * c.yx, bx = (hx - op.x) * c.yx;
+    const float ay = (ly - om.y) * c.yy, by = (hy - op.y) * c.yy;
+    const float az = (lz - om.z) * c.yz, bz = (hz - op.z) * c.yz;
     const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
     const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
     const float L = __builtin_fmaxf(tn * (1.0f - 0x1p-21f), PT_TMIN);
-    const float key = as_f((as_i(L) & ~15) | j);
+    float key;
+    asm("v_bfi_b32 %0, 15, %1, %2" : "=v"(key) : "s"(j), "v"(L)); // (j & 15) | (L & ~15)
     bool cand = L <= tf * (1.0f + 0x1p-21f);
     if (FILTER) cand = cand & (key > kdone);
     const float kk = cand ? key : none;
-    const float n1 = __builtin_fminf(k1, kk), n2 = __builtin_amdgcn_fmed3f(k1, k2, kk), n3 = __builtin_amdgcn_fmed3f(k2, k3, kk);
-    k1 = n1; k2 = n2; k3 = n3;
+    // sorted insert into (k1 <= k2 <= k3), in place, as unsigned integers (positive floats and +inf order the same way; the
+    // float min / med3 would first canonicalise their operands: two more instructions per entry)
+    asm("v_med3_u32 %0, %1, %0, %2" : "+v"(k3) : "v"(k2), "v"(kk));
+    asm("v_med3_u32 %0, %1, %0, %2" : "+v"(k2) : "v"(k1), "v"(kk));
+    asm("v_min_u32_e32 %0, %0, %1" : "+v"(k1) : "v"(kk));
+  };
+  for (int j = 0; j < cn; j += 2) {
+    const f16v e = pairs[j >> 1];
+    entry(e[0], e[1], e[2], e[4], e[5], e[6], j);
+    entry(e[8], e[9], e[10], e[12], e[13], e[14], j + 1);
   }
   bool active = false;
 #pragma unroll 1
   for (int trip = 0; trip < 3; ++trip) {
     active = (k1 < none) & (as_f(as_i(k1) & ~15) <= h.closest) & c.live;
     if (!__builtin_amdgcn_ballot_w64(active)) break; // keys ascend: nothing further can be live either
-    const int offl = active ? (as_i(k1) & 15) * SZ_BOX : 0;
-    const f4 R0 = recs[offl], R1 = recs[offl + 1];
+#ifdef PT_STAMPS
+    if ((threadIdx.x & 63) == 0) { // diagnostic build: trips per pool scan, lanes busy per trip
+      atomicAdd(&g_stamps[5], 1ull);
+      atomicAdd(&g_stamps[7], (unsigned long long)__builtin_popcountll(__builtin_amdgcn_ballot_w64(active)));
+      if (FILTER && trip == 0) atomicAdd(&g_stamps[6], 1ull);
+    }
+#endif
+    const int offl = active ? (as_i(k1) & 15) * 2 : 0;
+    const f4 X0 = xrecs[offl], X1 = xrecs[offl + 1];
     if (active) {
       const unsigned long long exec_now = __builtin_amdgcn_ballot_w64(true);
-      const int off_here = goff_chunk + offl;
-      int hit_base = hit_pack(DK_BOX, 0, off_here);
-      asm volatile("" : "+v"(hit_base));
-      const bool holder_later = (h.hit >= 0) & (hit_off(h.hit) > off_here);
+      int hit_base = as_i(X0.w);
+      const bool holder_later = (h.hit >= 0) & (hit_off(h.hit) > hit_off(hit_base));
       float cl = holder_later ? as_f(as_i(h.closest) - 1) : h.closest;
       int hit_now = h.hit;
-      box_cmpx(R0, R1, c, exec_now, hit_base, cl, hit_now);
+      box_cmpx(X0, X1, c, exec_now, hit_base, cl, hit_now);
       h.closest = hit_now != h.hit ? cl : h.closest;
       h.hit = hit_now;
       kdone = k1;
@@ -857,20 +884,26 @@ __device__ __forceinline__ bool box_chunk_pass(P recs, cst_f4p crecs, int cn, in
   return active; // third candidate handled and still inside closest: there may be a fourth
 }
 
+// pool table at blob[pool_off]: n slab entries (2 f4 each; padded to an even count), then n exact entries (2 f4 each)
 template <typename P>
-__device__ __forceinline__ void box_run_culled(P recs, cst_f4p cblob, int n, int goff, float bmax, const RayCtx& c, HitState& h) {
+__device__ __forceinline__ void slab_pool(P blob, cst_f4p cblob, int pool_off, int n, float bmax, const RayCtx& c, HitState& h) {
   const float kP = 0x1.8p-23f;           // 3u
   const float bP = 0x1.4p-23f * bmax;    // 2.5u B
   const V3 pp = mk(__builtin_fmaf(__builtin_fabsf(c.r.o.x), kP, bP), __builtin_fmaf(__builtin_fabsf(c.r.o.y), kP, bP),
                    __builtin_fmaf(__builtin_fabsf(c.r.o.z), kP, bP));
   const V3 om = c.r.o + pp, op = c.r.o - pp;
+#ifdef PT_STAMPS
+  if ((threadIdx.x & 63) == 0) atomicAdd(&g_stamps[4], 1ull);
+#endif
   for (int base = 0; base < n; base += 16) {
     const int cn = n - base < 16 ? n - base : 16;
+    const P xrecs = blob + pool_off + 2 * (n + (n & 1)) + 2 * base;
+    const cst_f4p srecs = cblob + pool_off + 2 * base;
     float kdone = 0.0f;
-    bool more = box_chunk_pass<false>(recs + base * SZ_BOX, cblob + goff + base * SZ_BOX, cn, goff + base * SZ_BOX, c, om, op, kdone, h);
+    bool more = slab_chunk_pass<false>(xrecs, srecs, cn, c, om, op, kdone, h);
     while (__builtin_amdgcn_ballot_w64(more)) {
       if (!more) kdone = PT_INF; // lanes that are done: no key passes the filter
-      more = box_chunk_pass<true>(recs + base * SZ_BOX, cblob + goff + base * SZ_BOX, cn, goff + base * SZ_BOX, c, om, op, kdone, h);
+      more = slab_chunk_pass<true>(xrecs, srecs, cn, c, om, op, kdone, h);
     }
   }
 }
@@ -940,10 +973,6 @@ __device__ __forceinline__ void hit_records(P recs, cst_f4p cblob, int kind, int
   } else if (kind == DK_BOX) {
 #ifndef PT_NO_CMPX
     if (fast && !IMG) {
-      if constexpr (GRID && WHOLE) { // (GRID = this kernel carries the culling paths; the run's aux record sits in front of it)
-        const f4 aux = cblob[goff - 1];
-        if (as_i(aux.y) != 0) { box_run_culled(recs, cblob, n, goff, aux.x, c, h); return; }
-      }
       const unsigned long long exec_all = __builtin_amdgcn_ballot_w64(true); // EXEC as it is around the scan
       for (int i = 0; i < n; ++i, off += SZ_BOX) {
         int hit_base = hit_pack(DK_BOX, 0, goff + off);
@@ -1089,8 +1118,18 @@ __device__ __forceinline__ void hit_world(P blob, cst_f4p cblob, int n_runs, con
   hit_begin(h);
   for (int ri = 0; ri < n_runs; ++ri) {
     f4 runf = cblob[ri];
-    const int off = as_i(runf.y);
-    hit_records<IMG, 1, 1, true, BADOUEL>(blob + off, cblob, as_i(runf.x), as_i(runf.z), off, c, fast, rng, h);
+    const int off = as_i(runf.y), kind = as_i(runf.x);
+    if constexpr (!IMG) {
+      if (fast && (kind == DK_RECT || kind == DK_BOX)) { // head of a slab pool: the pool covers this run and the next span - 1
+        const f4 aux = cblob[off - 1];                   // (largest |coordinate|, span, pool offset, entries)
+        if (as_i(aux.y) != 0) {
+          slab_pool(blob, cblob, as_i(aux.z), as_i(aux.w), aux.x, c, h);
+          ri += as_i(aux.y) - 1;
+          continue;
+        }
+      }
+    }
+    hit_records<IMG, 1, 1, true, BADOUEL>(blob + off, cblob, kind, as_i(runf.z), off, c, fast, rng, h);
   }
 }
 

@@ -36,7 +36,7 @@ struct Flat {
   bool fast_ok = true; // all rect/box coordinates finite with |v| <= 2^60 (pt_device.hpp: RayCtx)
   bool has_badouel = false; // some triangle uses the Badouel strategy (its own device kind and kernel instantiations)
   int grid_spheres = 0;     // spheres that sit in a culling grid (pt_scene_create: their scan is cheap)
-  int culled_boxes = 0;     // boxes in runs that are scanned through the slab test (pt_device.hpp: box_run_culled)
+  int pooled = 0;           // rects and boxes that sit in a slab pool (pt_device.hpp: slab_pool)
 };
 
 inline int device_kind(int32_t k) {
@@ -322,21 +322,58 @@ inline int flatten(const PtSceneDesc* sc, Flat& out, std::string& err, bool allo
   out.n_runs = (int32_t)runs.size();
   std::vector<F4>& b = out.blob;
   b.resize(runs.size());
+  size_t pool_at = 0, pool_x = 0;  // the current slab pool: where its table / its exact entries start, its first hittable, its entries
+  int pool_first = 0, pool_n = 0;
   for (size_t ri = 0; ri < runs.size(); ri++) {
     const Run& run = runs[ri];
     if (run.kind == DK_SPHERE) out.grid_spheres += put_sphere_run_aux(b, &sc->hittables[run.first], run.count, allow_grid);
-    if (run.kind == DK_BOX) { // aux F4 in front of a box run: (largest |coordinate| of its boxes, 1 = cull the run exactly: box_run_culled)
+    // slab pools (pt_device.hpp: slab_pool): a maximal stretch of consecutive rect / box runs with >= 2 hittables gets a table
+    // [n slab entries (lo, -)(hi, -), padded to an even count][n exact entries (lo', hit id)(hi', -)] in front of its first run; every rect / box run
+    // carries an aux F4 at its first record - 1: (largest |coordinate| of the pool, runs the pool spans (0: not a pool head),
+    // pool offset, n).
+    if (run.kind == DK_BOX || run.kind == DK_RECT) {
+      const bool prev_rectish = ri > 0 && (runs[ri - 1].kind == DK_BOX || runs[ri - 1].kind == DK_RECT);
+      int span = 0, n = 0;
+      if (!prev_rectish) {
+        size_t rj = ri;
+        while (rj < runs.size() && (runs[rj].kind == DK_BOX || runs[rj].kind == DK_RECT)) { n += runs[rj].count; rj++; }
+        span = (int)(rj - ri);
+      }
+      const bool pool = allow_box_cull && out.fast_ok && span > 0 && n >= 2;
       float bmax = 0.0f;
-      for (int i = run.first; i < run.first + run.count; i++)
-        for (int k = 0; k < 6; k++) bmax = std::max(bmax, std::fabs(sc->hittables[i].f[k]));
-      const bool cull = allow_box_cull && out.fast_ok && run.count >= 2;
-      if (cull) out.culled_boxes += run.count;
-      b.push_back({bmax, as_f(cull ? 1 : 0), 0.0f, 0.0f});
+      int32_t pool_off = 0;
+      if (pool) {
+        pool_off = (int32_t)b.size();
+        pool_first = run.first;
+        pool_at = b.size();
+        const int ns = n + (n & 1); // slab entries, padded to an even count with an entry no ray can be a candidate for (NaN bounds)
+        b.resize(b.size() + 2 * (size_t)ns + 2 * (size_t)n);
+        pool_x = pool_at + 2 * (size_t)ns;
+        if (ns > n) { const float q = std::nanf(""); b[pool_at + 2 * n] = {q, q, q, 0}; b[pool_at + 2 * n + 1] = {q, q, q, 0}; }
+        const float ninf = -INFINITY;
+        for (int e = 0; e < n; e++) {
+          const PtHittable& h = sc->hittables[run.first + e];
+          const float* f = h.f;
+          F4 lo, hi, xhi;
+          if (h.kind == PT_HIT_BOX) { lo = {f[0], f[1], f[2], 0}; hi = {f[3], f[4], f[5], 0}; xhi = hi; }
+          else if (h.kind == PT_HIT_XY_RECT) { lo = {f[0], f[2], f[4], 0}; hi = {f[1], f[3], f[4], 0}; xhi = {f[1], f[3], ninf, 0}; }
+          else if (h.kind == PT_HIT_XZ_RECT) { lo = {f[0], f[4], f[2], 0}; hi = {f[1], f[4], f[3], 0}; xhi = {f[1], ninf, f[3], 0}; }
+          else { lo = {f[4], f[0], f[2], 0}; hi = {f[4], f[1], f[3], 0}; xhi = {ninf, f[1], f[3], 0}; }
+          for (float v : {lo.x, lo.y, lo.z, hi.x, hi.y, hi.z}) bmax = std::max(bmax, std::fabs(v));
+          b[pool_at + 2 * e] = lo; b[pool_at + 2 * e + 1] = hi;
+          b[pool_x + 2 * e] = lo; b[pool_x + 2 * e + 1] = xhi; // .w of the first = hit id: filled in with the record
+        }
+        pool_n = n;
+        out.pooled += n;
+      }
+      b.push_back({bmax, as_f(pool ? span : 0), as_f(pool_off), as_f(pool ? n : 0)});
     }
     b[ri] = {as_f(run.kind), as_f((int32_t)b.size()), as_f(run.count), as_f(run.first)};
     for (int i = run.first; i < run.first + run.count; i++) {
       const PtHittable& h = sc->hittables[i];
       const float* f = h.f;
+      if (pool_n > 0 && i >= pool_first && i < pool_first + pool_n && (run.kind == DK_BOX || run.kind == DK_RECT))
+        b[pool_x + 2 * (size_t)(i - pool_first)].w = as_f((int32_t)((run.kind << 27) | (int32_t)b.size())); // hit_pack(kind, 0, offset)
       switch (h.kind) {
         case PT_HIT_SPHERE: put_sphere(b, f, h.material, i); break;
         case PT_HIT_XY_RECT: case PT_HIT_XZ_RECT: case PT_HIT_YZ_RECT: {

@@ -101,9 +101,14 @@ def test_flatten_preserves_list_order(lib):
             assert aux.view(np.int32)[2] == count and aux.view(np.int32)[3] == 1  # all static, uniform interval
             lst = blob[first - 1 - (int(count) + 3) // 4:first - 1].view(np.int32).reshape(-1)
             assert lst[:count].tolist() == [3 * i for i in range(count)] and (lst[count:] == 3 * (count - 1)).all()
-        if kind == 3:  # a box run is preceded by one aux F4: (largest |coordinate|, cull flag: runs of >= 2 boxes)
+        if kind in (1, 3):  # rect and box runs carry one aux F4; a stretch of >= 2 rects / boxes a slab pool table before it
+            aux = blob[first - 1].view(np.int32)
+            if kind == 1:
+                assert aux[1] == 1 and aux[3] == 2 and aux[2] == off and blob[first - 1, 0] == 6.0  # (|coord| max, span, pool offset, n)
+                off += 4 * 2
+            else:
+                assert aux[1] == 0 and aux[3] == 0                                                 # a single box: no pool
             off += 1
-            assert blob[first - 1, 0] == 1.0 and blob[first - 1].view(np.int32)[1] == 0
         assert first == off
         off += sizes[int(kind)] * int(count)
     assert off == len(blob)
@@ -121,18 +126,29 @@ def test_flatten_preserves_list_order(lib):
     assert md.view(np.int32)[0] == 0 and md[1] == np.float32(-0.5)
 
 
-def test_flatten_box_run_aux(lib):
-    """Runs of two or more boxes on a fast_ok scene carry the cull flag and the largest |coordinate| of the run (the slab
-    test's error bound scales with it: pt_device.hpp box_run_culled); a non-finite / huge coordinate anywhere switches the
-    straight-line paths, and with them the culling, off."""
+def test_flatten_slab_pools(lib):
+    """A maximal stretch of consecutive rect / box runs with >= 2 hittables on a fast_ok scene gets a slab pool table (slab
+    entries, then exact entries carrying the hit id of the hittable's own record; a rect's exact entry has -inf on its own
+    axis: pt_device.hpp slab_pool); a non-finite / huge coordinate anywhere switches the straight-line paths, and with them
+    the pools, off."""
     m = lambertian_material((0.5, 0.5, 0.5))
-    hs = [box((0, 0, 0), (1, 2, 3), m), box((-7, 0, 0), (1, 1, 1), m), box((0, 0, 0), (1, 1, 5.5), m), sphere((0, 0, 0), 1, m),
-          box((0, 0, 0), (9, 1, 1), m)]
+    hs = [box((0, 0, 0), (1, 2, 3), m), box((-7, 0, 0), (1, 1, 1), m), xz_rect(0, 1, 2, 5.5, 4, m), box((0, 0, 0), (1, 1, 5), m),
+          sphere((0, 0, 0), 1, m), box((0, 0, 0), (9, 1, 1), m)]
     rc, blob, mats, n_runs, flags = flatten(lib, pack(hs))
-    assert rc == 0 and n_runs == 3
+    assert rc == 0 and n_runs == 5
     runs = blob[:n_runs].view(np.int32)
-    assert blob[runs[0, 1] - 1, 0] == 7.0 and blob[runs[0, 1] - 1].view(np.int32)[1] == 1
-    assert blob[runs[2, 1] - 1, 0] == 9.0 and blob[runs[2, 1] - 1].view(np.int32)[1] == 0   # a single box: not worth it
+    assert runs[:, 0].tolist() == [3, 1, 3, 0, 3]
+    aux = blob[runs[0, 1] - 1]
+    assert aux[0] == 7.0 and aux.view(np.int32)[1:].tolist() == [3, n_runs, 4]      # spans three runs, four entries, table first
+    pool = blob[n_runs:n_runs + 16]
+    assert pool[4].tolist()[:3] == [0, 4, 2] and pool[5].tolist()[:3] == [1, 4, 5.5]    # xz_rect: x, the plane y = 4, z
+    assert pool[8 + 4].tolist()[:3] == [0, 4, 2] and pool[8 + 5, 1] == -np.inf and pool[8 + 5, 0] == 1 and pool[8 + 5, 2] == 5.5
+    ids = pool[8::2].view(np.int32)[:, 3]
+    assert (ids >> 27).tolist() == [3, 3, 1, 3]
+    assert (ids & 0xffffff).tolist() == [runs[0, 1], runs[0, 1] + 2, runs[1, 1], runs[2, 1]]
+    for r in (1, 2):
+        assert blob[runs[r, 1] - 1].view(np.int32)[1] == 0                                # members, not heads
+    assert blob[runs[4, 1] - 1].view(np.int32)[1] == 0                                    # a single box: not worth it
     hs[1] = box((-7, 0, 0), (1, 1, 3e18), m)
     rc, blob, mats, n_runs, flags = flatten(lib, pack(hs))
     assert rc == 0 and blob[blob[:n_runs].view(np.int32)[0, 1] - 1].view(np.int32)[1] == 0

@@ -24,4 +24,6 @@ lib.pt_debug_stamps(out, 0)
 prep, trav, shade, iters = out[0], out[1], out[2], out[3]
 tot = prep + trav + shade
 print(f"  gridded sphere runs scanned {out[4]:.3e}; full-list fallback in {out[5]/max(out[4],1):.4f} of them (far origin in {out[6]/max(out[4],1):.4f}), {out[7]/max(out[5],1):.1f} lanes at fault on average")
+if os.environ.get("PT_STAMPS_POOL"):
+    print(f"  slab pool scans {out[4]:.3e}; exact trips per scan {out[5]/max(out[4],1):.3f}, lanes busy per trip {out[7]/max(out[5],1):.1f}, repeated passes per scan {out[6]/max(out[4],1):.4f}")
 print(f"{scene} {spp} spp: kernel {ms:.1f} ms; wave-iterations {iters:.3e}; cycles per wave-iteration: prepare {prep/iters:.0f}  traversal {trav/iters:.0f}  shade {shade/iters:.0f}  (total {tot/iters:.0f}); shares {prep/tot:.2f} {trav/tot:.2f} {shade/tot:.2f}")
