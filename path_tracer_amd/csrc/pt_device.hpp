@@ -823,7 +823,8 @@ __device__ __forceinline__ void sphere_scan(P recs, cst_f4p cblob, int n, int go
 // order like floats; truncation only lowers L); +inf = none.  More than three live candidates: another pass over the
 // chunk for the lanes concerned, restricted to keys above the last one handled.
 template <bool FILTER, typename P>
-__device__ __forceinline__ bool slab_chunk_pass(P xrecs, cst_f4p srecs, int cn, const RayCtx& c, V3 om, V3 op, float& kdone, HitState& h) {
+__device__ __forceinline__ bool slab_chunk_pass(P xrecs, P slrecs, cst_f4p srecs, int cn, float bmax, const RayCtx& c, V3 om, V3 op, float& kdone,
+                                                HitState& h) {
   const float none = PT_INF;
   float k1 = none, k2 = none, k3 = none;
   // two entries per trip (the table is padded to an even count with an all-NaN entry: `L <= NaN` is false), one
@@ -832,6 +833,8 @@ __device__ __forceinline__ bool slab_chunk_pass(P xrecs, cst_f4p srecs, int cn, 
   typedef const __attribute__((address_space(4))) f16v* cst_f16p;
   const cst_f16p pairs = (cst_f16p)srecs;
   auto entry = [&](float lx, float ly, float lz, float hx, float hy, float hz, int j) {
+    // (x and y through the packed fp32 pipe — v_pk_add_f32 / v_pk_mul_f32, 8 instead of 12 instructions — measured 5 % SLOWER
+    // on the same box: a packed fp32 instruction occupies the issue port for more than one slot)
     const float ax = (lx - om.x) * c.yx, bx = (hx - op.x) * c.yx;
     const float ay = (ly - om.y) * c.yy, by = (hy - op.y) * c.yy;
     const float az = (lz - om.z) * c.yz, bz = (hz - op.z) * c.yz;
@@ -854,16 +857,67 @@ __device__ __forceinline__ bool slab_chunk_pass(P xrecs, cst_f4p srecs, int cn, 
     entry(e[0], e[1], e[2], e[4], e[5], e[6], j);
     entry(e[8], e[9], e[10], e[12], e[13], e[14], j + 1);
   }
-  bool active = false;
+  // Every trip of the loop consumes the nearest key of every lane that still has a live one (tested exactly, or dropped by
+  // the proof below); a key beyond closest ends the lane's scan (keys ascend).  A lane that consumed all three keys it
+  // could hold may have a fourth candidate: it asks for another pass (`more`).
+  const bool had3 = k3 < none;
 #pragma unroll 1
-  for (int trip = 0; trip < 3; ++trip) {
-    active = (k1 < none) & (as_f(as_i(k1) & ~15) <= h.closest) & c.live;
-    if (!__builtin_amdgcn_ballot_w64(active)) break; // keys ascend: nothing further can be live either
-#ifdef PT_STAMPS
-    if ((threadIdx.x & 63) == 0) { // diagnostic build: trips per pool scan, lanes busy per trip
-      atomicAdd(&g_stamps[5], 1ull);
-      atomicAdd(&g_stamps[7], (unsigned long long)__builtin_popcountll(__builtin_amdgcn_ballot_w64(active)));
-      if (FILTER && trip == 0) atomicAdd(&g_stamps[6], 1ull);
+  for (;;) {
+    // A ray that leaves a face of a box has that box as its nearest candidate whenever the slab margins reach `min` along the
+    // face's axis (a few per cent of the lanes: nearly every wave), and the exact test then rejects all six sides: a whole
+    // trip for nothing.  For nearest keys with L == min (origin inside, on or next to the box) a proof is tried first.
+    // With the UNSHIFTED interval ends lw_c <= up_c of the three axes (relative error <= 3u each) and W_k >= the shifted
+    // upper end of axis k (up_k + S_k |y_k|): if for some axis k
+    //   (1) up_k (1 + 2^-20) < min: both planes of axis k have t < min — rejected;
+    //   (2) for both other axes a: lw_a (1 + 2^-20) < min — the near plane of a has t < min — and
+    //       up_a (1 - 2^-20) > W_k (1 + 2^-20): the far plane of a has a t beyond everything the slab bound admits for a
+    //       side whose in-plane coordinate k is inside [lo_k, hi_k] (accepted t <= shifted upper end of EVERY axis, above);
+    // then no side of the box can be accepted and the key is dropped without a trip: the ray leaves through the far plane
+    // of axis k before it reaches any other plane of the box.
+    {
+      bool inside = (k1 < none) & ((as_i(k1) & ~15) == (as_i(PT_TMIN) & ~15)) & c.live;
+#ifdef PT_NO_POOL_PROOF
+      inside = false; // A/B build
+#endif
+      if (__builtin_amdgcn_ballot_w64(inside)) {
+        const int offs = inside ? (as_i(k1) & 15) * 2 : 0;
+        const f4 S0 = slrecs[offs], S1 = slrecs[offs + 1]; // the slab entry: true bounds, a rect's plane in both
+        const float e = 0x1p-20f, tlo = PT_TMIN * (1.0f - 0x1p-20f);
+        auto ends = [&](float o, float y, float lo, float hi, float& lw, float& us, float& ws) { // returns (1) for this axis
+          const float a = (lo - o) * y, b = (hi - o) * y;
+          lw = __builtin_fminf(a, b);
+          const float up = __builtin_fmaxf(a, b);
+          // slab_pool's shift S = 3u |o| + 2.5u B as it can come out of RN(o +- S): up to ulp(o +- S)/2 <= u (|o| + S) more
+          const float S = __builtin_fmaf(__builtin_fabsf(o), 0x1.1p-21f, 0x1.6p-23f * bmax); // 4.25u |o| + 2.75u B
+          const float w = __builtin_fmaf(__builtin_fabsf(y), S, up);
+          us = __builtin_fmaf(__builtin_fabsf(up), -e, up); // up lowered
+          ws = __builtin_fmaf(__builtin_fabsf(w), e, w);    // W raised
+          return __builtin_fmaf(__builtin_fabsf(up), e, up) < PT_TMIN;
+        };
+        float lwx, lwy, lwz, usx, usy, usz, wsx, wsy, wsz;
+        const bool ownx = ends(c.r.o.x, c.yx, S0.x, S1.x, lwx, usx, wsx);
+        const bool owny = ends(c.r.o.y, c.yy, S0.y, S1.y, lwy, usy, wsy);
+        const bool ownz = ends(c.r.o.z, c.yz, S0.z, S1.z, lwz, usz, wsz);
+        const float lwm = __builtin_fmaxf(__builtin_fmaxf(lwx, lwy), lwz);
+        const bool near_behind = __builtin_fmaf(__builtin_fabsf(lwm), e, lwm) < PT_TMIN;
+        const bool kx = ownx & (usy > wsx) & (usz > wsx);
+        const bool ky = owny & (usx > wsy) & (usz > wsy);
+        const bool kz = ownz & (usx > wsz) & (usy > wsz);
+        const bool gone = inside & near_behind & (kx | ky | kz);
+        kdone = gone ? k1 : kdone;
+        k1 = gone ? k2 : k1; k2 = gone ? k3 : k2; k3 = gone ? none : k3;
+      }
+    }
+    const bool active = (k1 < none) & (as_f(as_i(k1) & ~15) <= h.closest) & c.live;
+    if (!__builtin_amdgcn_ballot_w64(active)) break;
+#ifdef PT_STAMPS_POOL
+    { // diagnostic build (make stamps EXTRA=-DPT_STAMPS_POOL): trips per pool scan, lanes busy per trip, repeated passes
+      const unsigned long long busy = __builtin_amdgcn_ballot_w64(active);
+      if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&g_stamps[5], 1ull);
+        atomicAdd(&g_stamps[7], (unsigned long long)__builtin_popcountll(busy));
+        if (FILTER) atomicAdd(&g_stamps[6], 1ull);
+      }
     }
 #endif
     const int offl = active ? (as_i(k1) & 15) * 2 : 0;
@@ -879,9 +933,9 @@ __device__ __forceinline__ bool slab_chunk_pass(P xrecs, cst_f4p srecs, int cn, 
       h.hit = hit_now;
       kdone = k1;
     }
-    k1 = k2; k2 = k3; k3 = none;
+    k1 = active ? k2 : k1; k2 = active ? k3 : k2; k3 = active ? none : k3;
   }
-  return active; // third candidate handled and still inside closest: there may be a fourth
+  return had3 & !(k1 < none) & c.live;
 }
 
 // pool table at blob[pool_off]: n slab entries (2 f4 each; padded to an even count), then n exact entries (2 f4 each)
@@ -892,18 +946,19 @@ __device__ __forceinline__ void slab_pool(P blob, cst_f4p cblob, int pool_off, i
   const V3 pp = mk(__builtin_fmaf(__builtin_fabsf(c.r.o.x), kP, bP), __builtin_fmaf(__builtin_fabsf(c.r.o.y), kP, bP),
                    __builtin_fmaf(__builtin_fabsf(c.r.o.z), kP, bP));
   const V3 om = c.r.o + pp, op = c.r.o - pp;
-#ifdef PT_STAMPS
+#ifdef PT_STAMPS_POOL
   if ((threadIdx.x & 63) == 0) atomicAdd(&g_stamps[4], 1ull);
 #endif
   for (int base = 0; base < n; base += 16) {
     const int cn = n - base < 16 ? n - base : 16;
     const P xrecs = blob + pool_off + 2 * (n + (n & 1)) + 2 * base;
-    const cst_f4p srecs = cblob + pool_off + 2 * base;
+    const cst_f4p srecs = cblob + pool_off + 2 * base; // the slab entries through the scalar cache (wave-uniform reads) ...
+    const P slrecs = blob + pool_off + 2 * base;       // ... and where the lanes read them individually
     float kdone = 0.0f;
-    bool more = slab_chunk_pass<false>(xrecs, srecs, cn, c, om, op, kdone, h);
+    bool more = slab_chunk_pass<false>(xrecs, slrecs, srecs, cn, bmax, c, om, op, kdone, h);
     while (__builtin_amdgcn_ballot_w64(more)) {
       if (!more) kdone = PT_INF; // lanes that are done: no key passes the filter
-      more = slab_chunk_pass<true>(xrecs, srecs, cn, c, om, op, kdone, h);
+      more = slab_chunk_pass<true>(xrecs, slrecs, srecs, cn, bmax, c, om, op, kdone, h);
     }
   }
 }

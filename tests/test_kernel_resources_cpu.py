@@ -44,9 +44,9 @@ def test_headline_kernels_fit_seven_waves_without_scratch(usage):
     assert len(hot) == 4, sorted(usage)
     for k, v in hot.items():
         # the kernel the headline config runs (cold lane state in LDS: CL = 1) has no scratch at all; the variants that keep
-        # the cold state in registers park three dwords around the culled box runs (once per iteration, outside every loop)
+        # the cold state in registers park up to seven dwords around the slab pool (once per iteration, outside every loop)
         cold_in_lds = re.search(r"render_kernelILi0ELb1ELb1ELb0ELb1E", k) is not None
-        assert v["ScratchSize [bytes/lane]"] <= (0 if cold_in_lds else 12), (k, v)
+        assert v["ScratchSize [bytes/lane]"] <= (0 if cold_in_lds else 28), (k, v)
         assert v["VGPRs"] <= 72 and v["Occupancy [waves/SIMD]"] >= 7, (k, v)
 
 
