@@ -800,10 +800,12 @@ __device__ __forceinline__ void sphere_scan(P recs, cst_f4p cblob, int n, int go
 // A = RN(o_a + RN(t d_a)) lies in [lo_a, hi_a].  The two roundings move A by at most u (|t d_a| + |A|) <= u (2 B + |o_a|)
 // (B = the largest |coordinate| in the pool), so in real arithmetic t lies in the ray's parameter interval over
 // [lo_a - e, hi_a + e], e = u (2 B + |o_a|); for the plane's own axis t is within 2u (relative) of an interval end.  The
-// interval ends are computed from an origin moved outwards by S = 3u |o| + 2.5u B per axis — RN(o +- S) moves o by at
-// least S - ulp(o +- S)/2 >= S - 2u |o| = u |o| + 2.5u B >= e — as (lo - (o + S)) * y and (hi - (o - S)) * y with
-// y = RN(1 / d): three roundings, each RELATIVE to the interval end (a difference of nearby floats is exact), covered by the
-// factors 1 -+ 8u applied to the entry and exit parameters.  So an accepted t satisfies
+// interval ends are computed from an origin moved outwards by S = 4u |o| + 2.5u B per axis, as fma(lo, y, -(o + S) y) and
+// fma(hi, y, -(o - S) y) with y = RN(1 / d) (two instructions per axis and entry fewer than subtract-then-multiply): RN(o +- S)
+// moves o by at least S - ulp(o +- S)/2 >= S - u |o| - u S, and rounding the product (o +- S) y once more is another
+// absolute u |o +- S| |y| in the parameter, i.e. u |o| (1 + ...) in position: what is left, 2u |o| + 2.5u B - ..., still
+// covers e.  The remaining roundings (y itself, the fma) are RELATIVE to the interval end and covered by the factors 1 -+ 8u
+// applied to the entry and exit parameters.  So an accepted t satisfies
 // max_c lo_c (1 - 8u) <= t <= min_c hi_c (1 + 8u) and t >= min: L = max(entry (1 - 8u), min) is a lower bound of it and the
 // hittable is a candidate iff L <= exit (1 + 8u).  (Regular rays on a fast_ok scene only: nothing here overflows or is NaN.
 // The margins matter: a ray leaving a box's face has that box as a candidate whenever S / |d_k| reaches min, and every
@@ -835,9 +837,9 @@ __device__ __forceinline__ bool slab_chunk_pass(P xrecs, P slrecs, cst_f4p srecs
   auto entry = [&](float lx, float ly, float lz, float hx, float hy, float hz, int j) {
     // (x and y through the packed fp32 pipe — v_pk_add_f32 / v_pk_mul_f32, 8 instead of 12 instructions — measured 5 % SLOWER
     // on the same box: a packed fp32 instruction occupies the issue port for more than one slot)
-    const float ax = (lx - om.x) * c.yx, bx = (hx - op.x) * c.yx;
-    const float ay = (ly - om.y) * c.yy, by = (hy - op.y) * c.yy;
-    const float az = (lz - om.z) * c.yz, bz = (hz - op.z) * c.yz;
+    const float ax = __builtin_fmaf(lx, c.yx, om.x), bx = __builtin_fmaf(hx, c.yx, op.x); // om = -(o + S) y, op = -(o - S) y
+    const float ay = __builtin_fmaf(ly, c.yy, om.y), by = __builtin_fmaf(hy, c.yy, op.y);
+    const float az = __builtin_fmaf(lz, c.yz, om.z), bz = __builtin_fmaf(hz, c.yz, op.z);
     const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
     const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
     const float L = __builtin_fmaxf(tn * (1.0f - 0x1p-21f), PT_TMIN);
@@ -887,8 +889,9 @@ __device__ __forceinline__ bool slab_chunk_pass(P xrecs, P slrecs, cst_f4p srecs
           const float a = (lo - o) * y, b = (hi - o) * y;
           lw = __builtin_fminf(a, b);
           const float up = __builtin_fmaxf(a, b);
-          // slab_pool's shift S = 3u |o| + 2.5u B as it can come out of RN(o +- S): up to ulp(o +- S)/2 <= u (|o| + S) more
-          const float S = __builtin_fmaf(__builtin_fabsf(o), 0x1.1p-21f, 0x1.6p-23f * bmax); // 4.25u |o| + 2.75u B
+          // slab_pool's shift S = 4u |o| + 2.5u B as it can come out of RN(o +- S) and of rounding (o +- S) y: up to
+          // ulp(o +- S)/2 <= u (|o| + S) and u |o +- S| more
+          const float S = __builtin_fmaf(__builtin_fabsf(o), 0x1.9p-21f, 0x1.6p-23f * bmax); // 6.25u |o| + 2.75u B
           const float w = __builtin_fmaf(__builtin_fabsf(y), S, up);
           us = __builtin_fmaf(__builtin_fabsf(up), -e, up); // up lowered
           ws = __builtin_fmaf(__builtin_fabsf(w), e, w);    // W raised
@@ -941,11 +944,12 @@ __device__ __forceinline__ bool slab_chunk_pass(P xrecs, P slrecs, cst_f4p srecs
 // pool table at blob[pool_off]: n slab entries (2 f4 each; padded to an even count), then n exact entries (2 f4 each)
 template <typename P>
 __device__ __forceinline__ void slab_pool(P blob, cst_f4p cblob, int pool_off, int n, float bmax, const RayCtx& c, HitState& h) {
-  const float kP = 0x1.8p-23f;           // 3u
+  const float kP = 0x1p-22f;             // 4u
   const float bP = 0x1.4p-23f * bmax;    // 2.5u B
   const V3 pp = mk(__builtin_fmaf(__builtin_fabsf(c.r.o.x), kP, bP), __builtin_fmaf(__builtin_fabsf(c.r.o.y), kP, bP),
                    __builtin_fmaf(__builtin_fabsf(c.r.o.z), kP, bP));
-  const V3 om = c.r.o + pp, op = c.r.o - pp;
+  const V3 yv = mk(c.yx, c.yy, c.yz);
+  const V3 om = (mk(0.0f, 0.0f, 0.0f) - (c.r.o + pp)) * yv, op = (mk(0.0f, 0.0f, 0.0f) - (c.r.o - pp)) * yv; // the fma addends of the slab test
 #ifdef PT_STAMPS_POOL
   if ((threadIdx.x & 63) == 0) atomicAdd(&g_stamps[4], 1ull);
 #endif
