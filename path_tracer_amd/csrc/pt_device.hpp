@@ -799,17 +799,16 @@ __device__ __forceinline__ void sphere_scan(P recs, cst_f4p cblob, int n, int go
 // (rectangle.hpp:34-43, also through box.hpp:29-50) only if t = RN(RN(K - o_k) / d_k) >= min and, for both in-plane axes a,
 // A = RN(o_a + RN(t d_a)) lies in [lo_a, hi_a].  The two roundings move A by at most u (|t d_a| + |A|) <= u (2 B + |o_a|)
 // (B = the largest |coordinate| in the pool), so in real arithmetic t lies in the ray's parameter interval over
-// [lo_a - e, hi_a + e], e = u (2 B + |o_a|); for the plane's own axis t is within 2u (relative) of an interval end.  The
-// interval ends are computed from an origin moved outwards by S = 4u |o| + 2.5u B per axis, as fma(lo, y, -(o + S) y) and
-// fma(hi, y, -(o - S) y) with y = RN(1 / d) (two instructions per axis and entry fewer than subtract-then-multiply): RN(o +- S)
-// moves o by at least S - ulp(o +- S)/2 >= S - u |o| - u S, and rounding the product (o +- S) y once more is another
-// absolute u |o +- S| |y| in the parameter, i.e. u |o| (1 + ...) in position: what is left, 2u |o| + 2.5u B - ..., still
-// covers e.  The remaining roundings (y itself, the fma) are RELATIVE to the interval end and covered by the factors 1 -+ 8u
-// applied to the entry and exit parameters.  So an accepted t satisfies
-// max_c lo_c (1 - 8u) <= t <= min_c hi_c (1 + 8u) and t >= min: L = max(entry (1 - 8u), min) is a lower bound of it and the
-// hittable is a candidate iff L <= exit (1 + 8u).  (Regular rays on a fast_ok scene only: nothing here overflows or is NaN.
-// The margins matter: a ray leaving a box's face has that box as a candidate whenever S / |d_k| reaches min, and every
-// such lane costs its wave a trip.)
+// [lo_a - e, hi_a + e], e = u (2 B + |o_a|); for the plane's own axis t is within 2u (relative) of an interval end, i.e.
+// within 2u |K - o_k| <= 2u (B + |o_k|) in position.  The interval ends are computed from an origin moved outwards by
+// S = 9u |o| + 7u B per axis, as fma(lo, y, -(o + S) y) and fma(hi, y, -(o - S) y) with y = RN(1 / d) (two instructions per
+// axis and entry fewer than subtract-then-multiply).  What S has to cover, in position: e (or the 2u (B + |o|) of the
+// plane's own axis); ulp(o +- S)/2 <= u (|o| + S) lost when o +- S is rounded; u |o +- S| for rounding the product
+// (o +- S) y; and the roundings that are relative to the interval end — y itself and the fma, 3u |lo - o| <= 3u (B + |o|)
+// with room: together u (5 B + 6 |o|) (1 + ...) < S.  So an accepted t satisfies max_c lo_c <= t <= min_c hi_c over the
+// computed ends, and t >= min: L = max(entry, min) is a lower bound of it and the hittable is a candidate iff L <= exit.
+// (Regular rays on a fast_ok scene only: nothing here overflows or is NaN.  The margins matter little: a ray leaving a
+// box's face keeps that box as a candidate when S / |d_k| reaches min — the proof in slab_chunk_pass drops those.)
 //
 // Testing out of list order needs the tie rule spelled out, as for the sphere lists: the sequential scan accepts a side on
 // t <= closest, i.e. among equal t the LAST in list order wins.  A candidate therefore compares against closest when the
@@ -842,10 +841,10 @@ __device__ __forceinline__ bool slab_chunk_pass(P xrecs, P slrecs, cst_f4p srecs
     const float az = __builtin_fmaf(lz, c.yz, om.z), bz = __builtin_fmaf(hz, c.yz, op.z);
     const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
     const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
-    const float L = __builtin_fmaxf(tn * (1.0f - 0x1p-21f), PT_TMIN);
+    const float L = __builtin_fmaxf(tn, PT_TMIN);
     float key;
     asm("v_bfi_b32 %0, 15, %1, %2" : "=v"(key) : "s"(j), "v"(L)); // (j & 15) | (L & ~15)
-    bool cand = L <= tf * (1.0f + 0x1p-21f);
+    bool cand = L <= tf;
     if (FILTER) cand = cand & (key > kdone);
     const float kk = cand ? key : none;
     // sorted insert into (k1 <= k2 <= k3), in place, as unsigned integers (positive floats and +inf order the same way; the
@@ -889,9 +888,9 @@ __device__ __forceinline__ bool slab_chunk_pass(P xrecs, P slrecs, cst_f4p srecs
           const float a = (lo - o) * y, b = (hi - o) * y;
           lw = __builtin_fminf(a, b);
           const float up = __builtin_fmaxf(a, b);
-          // slab_pool's shift S = 4u |o| + 2.5u B as it can come out of RN(o +- S) and of rounding (o +- S) y: up to
-          // ulp(o +- S)/2 <= u (|o| + S) and u |o +- S| more
-          const float S = __builtin_fmaf(__builtin_fabsf(o), 0x1.9p-21f, 0x1.6p-23f * bmax); // 6.25u |o| + 2.75u B
+          // slab_pool's shift S = 9u |o| + 7u B as it can come out of RN(o +- S) and of rounding (o +- S) y: up to
+          // ulp(o +- S)/2 <= u (|o| + S) and u |o +- S| more; the fma's own rounding is in the 2^-20 below
+          const float S = __builtin_fmaf(__builtin_fabsf(o), 0x1.7p-21f, 0x1.dp-22f * bmax); // 11.5u |o| + 7.25u B
           const float w = __builtin_fmaf(__builtin_fabsf(y), S, up);
           us = __builtin_fmaf(__builtin_fabsf(up), -e, up); // up lowered
           ws = __builtin_fmaf(__builtin_fabsf(w), e, w);    // W raised
@@ -944,8 +943,8 @@ __device__ __forceinline__ bool slab_chunk_pass(P xrecs, P slrecs, cst_f4p srecs
 // pool table at blob[pool_off]: n slab entries (2 f4 each; padded to an even count), then n exact entries (2 f4 each)
 template <typename P>
 __device__ __forceinline__ void slab_pool(P blob, cst_f4p cblob, int pool_off, int n, float bmax, const RayCtx& c, HitState& h) {
-  const float kP = 0x1p-22f;             // 4u
-  const float bP = 0x1.4p-23f * bmax;    // 2.5u B
+  const float kP = 0x1.2p-21f;           // 9u
+  const float bP = 0x1.cp-22f * bmax;    // 7u B
   const V3 pp = mk(__builtin_fmaf(__builtin_fabsf(c.r.o.x), kP, bP), __builtin_fmaf(__builtin_fabsf(c.r.o.y), kP, bP),
                    __builtin_fmaf(__builtin_fabsf(c.r.o.z), kP, bP));
   const V3 yv = mk(c.yx, c.yy, c.yz);
