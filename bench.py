@@ -296,7 +296,7 @@ def main() -> None:
         achieved = ops * kernel_samples_per_s / 1e12 / world  # per GPU
         headline = (scene_name, W1, H1, SPP) == ("cornell", 1920, 1080, 1024)
         at = "1080p 1024spp" if (W, H, SPP) == (1920, 1080, 1024) else f"{W}x{H} {SPP}spp"
-        scaling = args.scaling if world > 1 else "weak"  # N = 1: both modes coincide
+        scaling = args.scaling  # (at N = 1 both modes coincide; the label stays the one the N > 1 lines of the same sweep carry)
         line = {
             "metric": f"Msamples/s (W x H x spp / s) at {at}" + ("" if headline else f" [{args.config}: {scene_name}]")
                       + (" [fast mode: decorrelated RNG, not parity]" if args.mode == "fast" else ""),
