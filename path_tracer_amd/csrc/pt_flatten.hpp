@@ -265,7 +265,8 @@ inline void put_box(std::vector<F4>& b, const float* f, int32_t mat, int32_t hid
   b.push_back({f[3], f[4], f[5], as_f(hidx)});
 }
 
-inline int flatten(const PtSceneDesc* sc, Flat& out, std::string& err, bool allow_grid = true, bool allow_box_cull = true) {
+// box_cull: 0 = no slab pools, 1 = where the cost model says they pay, 2 = every stretch of >= 2 rects / boxes (tests)
+inline int flatten(const PtSceneDesc* sc, Flat& out, std::string& err, bool allow_grid = true, int box_cull = 1) {
   int rc = validate(sc, err);
   if (rc) return rc;
   out = Flat();
@@ -327,19 +328,25 @@ inline int flatten(const PtSceneDesc* sc, Flat& out, std::string& err, bool allo
   for (size_t ri = 0; ri < runs.size(); ri++) {
     const Run& run = runs[ri];
     if (run.kind == DK_SPHERE) out.grid_spheres += put_sphere_run_aux(b, &sc->hittables[run.first], run.count, allow_grid);
-    // slab pools (pt_device.hpp: slab_pool): a maximal stretch of consecutive rect / box runs with >= 2 hittables gets a table
+    // slab pools (pt_device.hpp: slab_pool): a maximal stretch of consecutive rect / box runs with enough boxes gets a table
     // [n slab entries (lo, -)(hi, -), padded to an even count][n exact entries (lo', hit id)(hi', -)] in front of its first run; every rect / box run
     // carries an aux F4 at its first record - 1: (largest |coordinate| of the pool, runs the pool spans (0: not a pool head),
     // pool offset, n).
     if (run.kind == DK_BOX || run.kind == DK_RECT) {
       const bool prev_rectish = ri > 0 && (runs[ri - 1].kind == DK_BOX || runs[ri - 1].kind == DK_RECT);
-      int span = 0, n = 0;
+      int span = 0, n = 0, n_box = 0;
       if (!prev_rectish) {
         size_t rj = ri;
-        while (rj < runs.size() && (runs[rj].kind == DK_BOX || runs[rj].kind == DK_RECT)) { n += runs[rj].count; rj++; }
+        while (rj < runs.size() && (runs[rj].kind == DK_BOX || runs[rj].kind == DK_RECT)) {
+          n += runs[rj].count;
+          if (runs[rj].kind == DK_BOX) n_box += runs[rj].count;
+          rj++;
+        }
         span = (int)(rj - ri);
       }
-      const bool pool = allow_box_cull && out.fast_ok && span > 0 && n >= 2;
+      // worth it?  issue slots per ray: straight-line 19 per rect + 114 per box; pool 26 per entry + ~50 (leave-behind proof)
+      // + ~150 (one exact trip).  Rects alone never pay; three boxes do.
+      const bool pool = box_cull && out.fast_ok && span > 0 && (box_cull == 2 ? n >= 2 : 88 * n_box - 7 * (n - n_box) > 200);
       float bmax = 0.0f;
       int32_t pool_off = 0;
       if (pool) {

@@ -871,8 +871,11 @@ int pt_scene_create(const PtSceneDesc* desc, PtScene** out_scene) {
   *out_scene = nullptr;
   ptf::Flat flat;
   std::string err;
-  // PT_NO_GRID / PT_NO_BOXCULL: A/B knobs (brute-force sphere runs / straight-line box runs)
-  int rc = ptf::flatten(desc, flat, err, std::getenv("PT_NO_GRID") == nullptr, std::getenv("PT_NO_BOXCULL") == nullptr);
+  // PT_NO_GRID / PT_NO_BOXCULL: A/B knobs (brute-force sphere runs / straight-line rect and box runs); PT_POOL_ALWAYS: a slab
+  // pool for every stretch of two or more rects / boxes, also where it does not pay (the tests' way to put the pools into
+  // small mixed scenes)
+  const int box_cull = std::getenv("PT_NO_BOXCULL") ? 0 : std::getenv("PT_POOL_ALWAYS") ? 2 : 1;
+  int rc = ptf::flatten(desc, flat, err, std::getenv("PT_NO_GRID") == nullptr, box_cull);
   if (rc) return fail(rc, err);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(PT_ERR_NO_DEVICE, "no HIP device visible");

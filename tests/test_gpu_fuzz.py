@@ -1,6 +1,9 @@
 """Randomised scenes (every hittable kind, material and texture, random order so that kinds interleave in short runs,
 media anywhere in the list, coincident surfaces) rendered by every kernel flavour and compared with the oracle
 bit for bit."""
+import contextlib
+import os
+
 import numpy as np
 import pytest
 
@@ -12,6 +15,16 @@ from path_tracer_amd.scene import (TextureAtlas, box, checker_texture, constant_
                                    sphere, triangle, xy_rect, xz_rect, yz_rect)
 
 pytestmark = pytest.mark.gpu
+
+
+@contextlib.contextmanager
+def forced_pools():
+    """PT_POOL_ALWAYS while a DeviceScene is created (pt_scene_create reads it): slab pools wherever two rects / boxes meet."""
+    os.environ["PT_POOL_ALWAYS"] = "1"
+    try:
+        yield
+    finally:
+        del os.environ["PT_POOL_ALWAYS"]
 
 
 def random_scene(seed: int, allow_image_on_triangle: bool):
@@ -97,6 +110,12 @@ def test_random_scene_every_kernel_flavour(orc, seed):
                         ("stream+tile", abi.PT_FLAG_FORCE_STREAM | abi.PT_FLAG_TILE_GRANULAR),
                         ("plain-div", abi.PT_FLAG_NO_FASTDIV), ("coop+pixel", abi.PT_FLAG_FORCE_COOP | abi.PT_FLAG_PIXEL_GRANULAR)):
         assert_bit_identical(R.render_host(w, h, spp, ps, c, flags=flags), ref, f"seed {seed} {name}")
+    # the same scene with a slab pool for every stretch of rects / boxes, however short (the cost model would not build them
+    # here): pools between sphere runs, triangles and media, ties against duplicates across kinds
+    with forced_pools():
+        ds = R.DeviceScene(ps)
+    for name, flags in (("pools, LDS", abi.PT_FLAG_NO_COOP), ("pools, scalar cache", abi.PT_FLAG_NO_LDS), ("pools, default", 0)):
+        assert_bit_identical(R.render_host(w, h, spp, ds, c, flags=flags), ref, f"seed {seed} {name}")
 
 
 @pytest.mark.parametrize("seed", range(4))
@@ -270,5 +289,6 @@ def test_path_rays_through_fuzz_scenes(orc, lib, kind, seed):
     from path_rays import follow_paths
     ps, cam = {"box": random_box_field, "sphere": random_sphere_field, "random": lambda s: random_scene(s, False)}[kind](seed)
     c = scenes.make_camera(cam, 40, 24)
-    checked, bad = follow_paths(lib, orc, ps, c.c, 40, 24, 15000, 12, seed)
+    with forced_pools() if kind == "random" else contextlib.nullcontext():
+        checked, bad = follow_paths(lib, orc, ps, c.c, 40, 24, 15000, 12, seed)
     assert checked >= 15000 and not bad, f"{len(bad)} of {checked} rays differ: " + " | ".join(bad[:3])

@@ -242,6 +242,31 @@ def test_framebuffer_bit_exact(orc, name, w, h, spp):
     assert_bit_identical(fb, orc.render(ps, c.c, w, h, spp), f"{name} {w}x{h}x{spp}")
 
 
+@pytest.mark.parametrize("name,w,h,spp", [("ties", 64, 64, 16), ("mixed", 128, 72, 24), ("cornell", 96, 54, 16), ("badouel", 64, 36, 8)])
+def test_small_scenes_with_slab_pools_forced(orc, lib, name, w, h, spp):
+    """The small hand-made scenes — coincident rect / box faces (`ties`), media and triangles between rects (`mixed`) — with a
+    slab pool for every stretch of two or more rects / boxes (PT_POOL_ALWAYS; the cost model builds none for scenes this
+    small): framebuffer and thousands of random rays, bit-identical."""
+    import os
+    ps, cam = S.ALL[name]()
+    c = scenes.make_camera(cam, w, h)
+    os.environ["PT_POOL_ALWAYS"] = "1"
+    try:
+        ds = R.DeviceScene(ps)
+    finally:
+        del os.environ["PT_POOL_ALWAYS"]
+    orc.set_math(True)
+    ref = orc.render(ps, c.c, w, h, spp)
+    for what, flags in (("LDS", abi.PT_FLAG_NO_COOP), ("scalar cache", abi.PT_FLAG_NO_LDS), ("default", 0)):
+        assert_bit_identical(R.render_host(w, h, spp, ds, c, flags=flags), ref, f"{name} pools forced, {what}")
+    rng = np.random.default_rng(5)
+    centre, extent = {"ties": ((0, 0, -2), 3.0), "mixed": ((0, 0.3, -1), 3.0), "cornell": ((278, 278, 278), 700.0), "badouel": ((0, 0.3, -2), 3.0)}[name]
+    recs = random_bounce_inputs(rng, 6000, np.float32(centre), np.float32(extent))
+    out = (abi.PtBounceOut * 6000)()
+    abi.check(lib.pt_debug_bounce(ds.handle, recs, out, 6000), "pt_debug_bounce")
+    compare_bounce(out, orc.bounce(ps, recs), 6000, name + " pools forced", False)
+
+
 def test_depth_edge_cases(orc):
     ps, cam = S.spheres_scene()
     c = scenes.make_camera(cam, 40, 24)
