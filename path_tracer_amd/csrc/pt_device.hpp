@@ -136,25 +136,41 @@ __device__ __forceinline__ float div_exact(float n, float d, float y, float q0);
 // inv_w, inv_h: RN(1 / (float)width), RN(1 / (float)height), computed once on the host: the two quotients of render.hpp:96-97
 // through the shared-reciprocal form (div_exact: bit-identical to the IEEE division for 1 <= divisor <= 2^24 and a
 // numerator that is 0 or >= 2^-32 — its tested range), 5 issue slots each instead of ~12.
-__device__ __forceinline__ Ray camera_ray(const Cam& c, int x, int y, int width, int height, float inv_w, float inv_h, uint32_t& rng) {
+// pinhole (wave-uniform, decided on the host: cam_is_pinhole): lens_radius == 0 and no component of the camera's origin is a
+// zero.  Then rd = 0 * (dx, dy, 0) is a vector of zeros, so is offset = rd.x u + rd.y v (dx, dy, u, v are finite), and
+// origin + offset == origin, (...) - origin - offset == (...) - origin bit for bit (x + (+-0) == x unless x is -0, and a
+// difference of floats is never -0 unless its first operand is): the lens arithmetic, and the square root that only scales
+// the second draw, are skipped — the three draws are not (the generator's state must advance as in camera.hpp:93-100).
+__device__ __forceinline__ Ray camera_ray(const Cam& c, int x, int y, int width, int height, float inv_w, float inv_h, uint32_t& rng,
+                                          bool pinhole = false) {
   const float nu = (float)x + rng_float(rng);
   const float su = div_exact(nu, (float)width, inv_w, nu * inv_w);
   const float nv = (float)y + rng_float(rng);
   const float sv = div_exact(nv, (float)height, inv_h, nv * inv_h);
-  // in_unit_disk rtweekend.hpp:83-88
-  float dx = rng_float(rng, -1.0f, 1.0f);
-  float maxy = sqrt_rn_unit(1.0f - dx * dx);
-  float dy = rng_float(rng, -maxy, maxy);
-  V3 rd = c.lens_radius * mk(dx, dy, 0.0f);
-  V3 U = mk(c.u[0], c.u[1], c.u[2]), Vv = mk(c.v[0], c.v[1], c.v[2]);
-  V3 offset = rd.x * U + rd.y * Vv;
   V3 origin = mk(c.origin[0], c.origin[1], c.origin[2]);
   Ray r;
-  r.o = origin + offset;
-  r.d = mk(c.llc[0], c.llc[1], c.llc[2]) + su * mk(c.horizontal[0], c.horizontal[1], c.horizontal[2]) +
-        sv * mk(c.vertical[0], c.vertical[1], c.vertical[2]) - origin - offset;
+  if (pinhole) {
+    (void)rng_float(rng); (void)rng_float(rng); // in_unit_disk's two draws
+    r.o = origin;
+    r.d = mk(c.llc[0], c.llc[1], c.llc[2]) + su * mk(c.horizontal[0], c.horizontal[1], c.horizontal[2]) +
+          sv * mk(c.vertical[0], c.vertical[1], c.vertical[2]) - origin;
+  } else {
+    // in_unit_disk rtweekend.hpp:83-88
+    float dx = rng_float(rng, -1.0f, 1.0f);
+    float maxy = sqrt_rn_unit(1.0f - dx * dx);
+    float dy = rng_float(rng, -maxy, maxy);
+    V3 rd = c.lens_radius * mk(dx, dy, 0.0f);
+    V3 U = mk(c.u[0], c.u[1], c.u[2]), Vv = mk(c.v[0], c.v[1], c.v[2]);
+    V3 offset = rd.x * U + rd.y * Vv;
+    r.o = origin + offset;
+    r.d = mk(c.llc[0], c.llc[1], c.llc[2]) + su * mk(c.horizontal[0], c.horizontal[1], c.horizontal[2]) +
+          sv * mk(c.vertical[0], c.vertical[1], c.vertical[2]) - origin - offset;
+  }
   r.tm = rng_float(rng, c.time0, c.time1);
   return r;
+}
+__host__ __device__ inline bool cam_is_pinhole(const Cam& c) {
+  return c.lens_radius == 0.0f && c.origin[0] != 0.0f && c.origin[1] != 0.0f && c.origin[2] != 0.0f;
 }
 
 // ---- per-ray context ------------------------------------------------------------------------------

@@ -74,6 +74,7 @@ struct KArgs {
   int n_runs, blob_f4, mats_f4;
   int width, height, samples, depth;
   float inv_w, inv_h; // RN(1 / (float)width), RN(1 / (float)height): camera_ray
+  int pinhole;        // cam_is_pinhole(cam): camera_ray skips the lens arithmetic
   int shard_index, shard_count;
   int tiles_x, n_tiles;
   int n_local_pixels;  // 64 x the tiles this shard owns (incl. padding pixels of edge tiles)
@@ -274,7 +275,7 @@ __device__ __forceinline__ void lane_store(Lane& L, const KArgs& a) {
 template <typename Lane>
 __device__ __forceinline__ void lane_regenerate(Lane& L, const KArgs& a) {
   if (L.live && L.need_new) {
-    L.ray = camera_ray(a.cam, L.cold.get_x(), L.cold.get_y(), a.width, a.height, a.inv_w, a.inv_h, L.rng);
+    L.ray = camera_ray(a.cam, L.cold.get_x(), L.cold.get_y(), a.width, a.height, a.inv_w, a.inv_h, L.rng, a.pinhole != 0);
     L.att = mk(1.0f, 1.0f, 1.0f);
     L.b = 0;
     L.need_new = false;
@@ -493,7 +494,7 @@ __global__ __launch_bounds__(64) void render_single_stream_kernel(KArgs a) {
     for (int y = 0; y != a.height; ++y) {
       V3 acc = mk(0.0f, 0.0f, 0.0f);
       for (int s = 0; s < a.samples; ++s) {
-        Ray ray = camera_ray(a.cam, x, y, a.width, a.height, a.inv_w, a.inv_h, rng);
+        Ray ray = camera_ray(a.cam, x, y, a.width, a.height, a.inv_w, a.inv_h, rng, a.pinhole != 0);
         V3 att = mk(1.0f, 1.0f, 1.0f), out = mk(0.0f, 0.0f, 0.0f); // depth exhausted: black (render.hpp:91)
         for (int b = 0; b < a.depth; ++b) {
           RayCtx c = make_ctx(ray, a.fast_ok != 0);
@@ -645,7 +646,7 @@ __global__ void camera_rays_kernel(Cam cam, int width, int height, const int* __
   int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
   uint32_t rng = rng_in[k];
-  Ray r = camera_ray(cam, xy[2 * k], xy[2 * k + 1], width, height, 1.0f / (float)width, 1.0f / (float)height, rng);
+  Ray r = camera_ray(cam, xy[2 * k], xy[2 * k + 1], width, height, 1.0f / (float)width, 1.0f / (float)height, rng, cam_is_pinhole(cam));
   PtCameraRay o;
   o.origin[0] = r.o.x; o.origin[1] = r.o.y; o.origin[2] = r.o.z;
   o.dir[0] = r.d.x; o.dir[1] = r.d.y; o.dir[2] = r.d.z;
@@ -1001,6 +1002,7 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
   a.n_runs = s->n_runs; a.blob_f4 = s->blob_f4; a.mats_f4 = s->mats_f4; a.n_hittables = s->n_hittables;
   a.width = p->width; a.height = p->height; a.samples = p->samples; a.depth = p->depth;
   a.inv_w = 1.0f / (float)p->width; a.inv_h = 1.0f / (float)p->height; // host IEEE division: correctly rounded
+  a.pinhole = cam_is_pinhole(a.cam) ? 1 : 0;
   a.shard_index = p->shard_index; a.shard_count = p->shard_count;
   a.n_tiles = n_tiles_of(p, &a.tiles_x);
   const int local_tiles = (a.n_tiles - p->shard_index + p->shard_count - 1) / p->shard_count; // tiles this shard owns

@@ -165,6 +165,35 @@ def test_camera_rays_bit_exact(lib, orc):
         assert bytes(out) == bytes(ref)
 
 
+def test_pinhole_camera_shortcut_is_exact(lib, orc):
+    """aperture 0 and no zero among the origin's components: the device skips the lens arithmetic (camera_ray, pt_device.hpp) —
+    same rays, same generator state after.  Cameras that must NOT take the shortcut sit beside: a zero origin component
+    (origin + (-0) is +0, not the origin, when the origin is -0), negative zeros, a tiny aperture; and the signs of the axes
+    vary so that the skipped products would be zeros of every sign."""
+    rng = np.random.default_rng(12)
+    w, h = 333, 187
+    cams = []
+    for frm, at, ap in [((278, 278, -800), (278, 278, 0), 0.0), ((-3.5, 2.25, 7.0), (1.0, -2.0, -4.0), 0.0), ((5.0, -1.0, 2.0), (-1.0, 3.0, 9.0), 0.0),
+                        ((0.0, 1.0, 5.0), (0.0, 1.0, 0.0), 0.0), ((-0.0, -0.0, 5.0), (0.0, 0.0, 0.0), 0.0), ((3.0, 0.0, -0.0), (0.0, 0.0, 1.0), 0.0),
+                        ((278, 278, -800), (278, 278, 0), 1e-30), ((1.0, 2.0, 3.0), (0.0, 0.0, 0.0), 0.5)]:
+        cams.append(dict(look_from=frm, look_at=at, vup=(0, 1, 0), vfov=40.0, aperture=ap, focus_dist=10.0, time0=0.0, time1=1.0))
+    for cam_args in cams:
+        cam = scenes.make_camera(cam_args, w, h)
+        n = 20_000
+        xy = np.stack([rng.integers(0, w, n), rng.integers(0, h, n)], axis=1).astype(np.int32)
+        st = rng.integers(1, 2 ** 32, n, dtype=np.uint64).astype(np.uint32)
+        out = (abi.PtCameraRay * n)()
+        abi.check(lib.pt_debug_camera_rays(C.byref(cam.c), w, h, xy.ctypes.data_as(C.POINTER(C.c_int32)),
+                                           st.ctypes.data_as(C.POINTER(C.c_uint32)), out, n), "pt_debug_camera_rays")
+        assert bytes(out) == bytes(orc.camera_rays(cam.c, w, h, xy, st)), cam_args
+    # and through the render kernels (lane_regenerate): a pinhole camera whose origin has a zero keeps the general path
+    ps, _ = S.cornell_scene()
+    for frm in ((278, 278, -800), (0.0, 278, -800)):
+        c = scenes.make_camera(dict(cams[0], look_from=frm), 64, 36)
+        orc.set_math(True)
+        assert_bit_identical(R.render_host(64, 36, 8, ps, c), orc.render(ps, c.c, 64, 36, 8), f"pinhole from {frm}")
+
+
 def random_bounce_inputs(rng, n, center, extent):
     recs = (abi.PtBounceIn * n)()
     o = (rng.random((n, 3), dtype=np.float32) - 0.5) * 2 * extent + center
