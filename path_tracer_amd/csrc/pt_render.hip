@@ -275,7 +275,20 @@ __device__ __forceinline__ void lane_store(Lane& L, const KArgs& a) {
 template <typename Lane>
 __device__ __forceinline__ void lane_regenerate(Lane& L, const KArgs& a) {
   if (L.live && L.need_new) {
-    L.ray = camera_ray(a.cam, L.cold.get_x(), L.cold.get_y(), a.width, a.height, a.inv_w, a.inv_h, L.rng, a.pinhole != 0);
+    // The camera is 30 floats of kernel argument.  Read through `a.cam` they sit in SGPRs for the whole loop, and the
+    // register allocator, out of SGPRs, parks others in VGPR lanes (v_writelane / v_readlane + hazard s_nops all over the
+    // loop).  KArgs starts with the camera, so here it is read from the kernarg segment where it is needed: four scalar
+    // loads per regeneration instead.  (The pointer is made opaque so that the loads are not hoisted out of the loop.)
+    static_assert(offsetof(KArgs, cam) == 0, "the camera leads the kernel arguments");
+#ifdef __HIP_DEVICE_COMPILE__
+    typedef const __attribute__((address_space(4))) Cam* kcam_p;
+    unsigned long long kp = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    const Cam cam = *(kcam_p)kp;
+#else
+    const Cam cam = a.cam; // (host pass of the single-source compile: never run)
+#endif
+    L.ray = camera_ray(cam, L.cold.get_x(), L.cold.get_y(), a.width, a.height, a.inv_w, a.inv_h, L.rng, a.pinhole != 0);
     L.att = mk(1.0f, 1.0f, 1.0f);
     L.b = 0;
     L.need_new = false;
