@@ -173,6 +173,19 @@ __host__ __device__ __forceinline__ uint32_t fast_seed(uint32_t pixel, uint32_t 
   return h ? h : 1u;
 }
 
+// Kernel arguments that only the rare paths read (queue, order, frame geometry, framebuffer ...): read through `a` they are
+// SGPR-resident for the whole loop and push other values out into VGPR lanes (v_readlane + hazard nops in the hot path).  The
+// rare paths therefore read them from the kernarg segment on the spot, through a pointer the optimiser cannot see through
+// (so that the loads stay where they are).  The kernels take KArgs as their only argument: the segment IS a KArgs.
+#ifdef __HIP_DEVICE_COMPILE__
+#define PT_COLD_ARGS(name, a)                                                            \
+  unsigned long long name##_p = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr(); \
+  asm volatile("" : "+s"(name##_p));                                                      \
+  const __attribute__((address_space(4))) KArgs& name = *(const __attribute__((address_space(4))) KArgs*)name##_p
+#else
+#define PT_COLD_ARGS(name, a) const KArgs& name = a
+#endif
+
 // Wave-aggregated dequeue: one atomicAdd per wave for all lanes that need a pixel (ballot + prefix count),
 // pixels handed out in tile order so a fresh wave starts on one coherent 8x8 tile.
 //
@@ -186,6 +199,7 @@ __device__ __forceinline__ void lane_acquire(Lane& L, const KArgs& a) {
   const bool want = !L.live && !L.retired;
   const unsigned long long mask = __builtin_amdgcn_ballot_w64(want);
   if (mask == 0) return;
+  PT_COLD_ARGS(k, a);
   const int lane = threadIdx.x & 63;
   const int leader = __builtin_ctzll(mask);
   const unsigned int rank = __builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mask, 0u));
@@ -198,7 +212,7 @@ __device__ __forceinline__ void lane_acquire(Lane& L, const KArgs& a) {
   if (L.wide) {
     const unsigned int groups = (unsigned int)__builtin_popcountll(mask) >> L.wide; // idle groups (all-or-none per group)
     unsigned int b = 0;
-    if (lane == leader) b = atomicAdd(a.queue + 1, groups);
+    if (lane == leader) b = atomicAdd(k.queue + 1, groups);
     b = __builtin_amdgcn_readlane(b, leader);
     if (b + groups >= split_pixels) L.split_done = true;
     i = b + (rank >> L.wide);
@@ -210,30 +224,30 @@ __device__ __forceinline__ void lane_acquire(Lane& L, const KArgs& a) {
   }
   if (!L.wide) {
     // tile-granular mode: a wave takes its next 64 pixels only when all of its lanes are idle
-    if (a.tile_granular && __builtin_amdgcn_ballot_w64(L.live) != 0) return;
+    if (k.tile_granular && __builtin_amdgcn_ballot_w64(L.live) != 0) return;
     unsigned int base = 0;
-    if (lane == leader) base = atomicAdd(a.queue, (unsigned int)__builtin_popcountll(mask));
+    if (lane == leader) base = atomicAdd(k.queue, (unsigned int)__builtin_popcountll(mask));
     base = __builtin_amdgcn_readlane(base, leader);
     if (!want) return;
     i = split_pixels + base + rank;
   }
-  if (i >= (unsigned int)a.n_local_pixels) { L.retired = true; return; }
+  if (i >= (unsigned int)k.n_local_pixels) { L.retired = true; return; }
   // fast mode: the queue hands out (tile, chunk) units, a tile's chunks back to back
   unsigned int unit = i >> 6;
   int chunk = 0;
-  if constexpr (FAST) { chunk = (int)(unit % (unsigned int)a.fast_chunks); unit /= (unsigned int)a.fast_chunks; }
+  if constexpr (FAST) { chunk = (int)(unit % (unsigned int)k.fast_chunks); unit /= (unsigned int)k.fast_chunks; }
   // queue position -> local tile: identity, or the cost-sorted order of the probe pass (heaviest tiles first)
-  const int l = a.order ? a.order[unit] : (int)unit, in_tile = (int)(i & 63);
-  const long long g = (long long)l * a.shard_count + a.shard_index; // global tile (pt_render.h: round-robin shards)
-  const int tx = (int)(g % a.tiles_x), ty = (int)(g / a.tiles_x);
+  const int l = k.order ? k.order[unit] : (int)unit, in_tile = (int)(i & 63);
+  const long long g = (long long)l * k.shard_count + k.shard_index; // global tile (pt_render.h: round-robin shards)
+  const int tx = (int)(g % k.tiles_x), ty = (int)(g / k.tiles_x);
   const int x = tx * PT_TILE + (in_tile & 7), y = ty * PT_TILE + (in_tile >> 3);
-  if (g >= a.n_tiles || x >= a.width || y >= a.height) return; // padding pixel: stays 0, ask again next iteration
+  if (g >= k.n_tiles || x >= k.width || y >= k.height) return; // padding pixel: stays 0, ask again next iteration
   // render.hpp:130-132: seed = linear id of the pixel in the WHOLE frame, truncated to 32 bits
-  const uint32_t id = (uint32_t)((unsigned long long)y * (unsigned long long)a.width + (unsigned long long)x);
+  const uint32_t id = (uint32_t)((unsigned long long)y * (unsigned long long)k.width + (unsigned long long)x);
   if constexpr (FAST) {
-    // the last chunk of a pixel may be shorter: its sample counter starts ahead so that every chunk ends at a.samples
-    const int n_here = min(a.samples, a.samples_total - chunk * a.samples);
-    L.cold.begin((l * PT_TILE_PIXELS + in_tile) | (chunk << 24), x, y, a.samples - n_here);
+    // the last chunk of a pixel may be shorter: its sample counter starts ahead so that every chunk ends at k.samples
+    const int n_here = min(k.samples, k.samples_total - chunk * k.samples);
+    L.cold.begin((l * PT_TILE_PIXELS + in_tile) | (chunk << 24), x, y, k.samples - n_here);
     L.rng = fast_seed(id, (uint32_t)chunk);
   } else {
     L.cold.begin(l * PT_TILE_PIXELS + in_tile, x, y);
@@ -246,28 +260,29 @@ __device__ __forceinline__ void lane_acquire(Lane& L, const KArgs& a) {
 template <bool FAST = false, typename Lane>
 __device__ __forceinline__ void lane_store(Lane& L, const KArgs& a) {
   L.live = false;
+  PT_COLD_ARGS(k, a);
   if (L.wide && ((threadIdx.x & 63) & ((1 << L.wide) - 1))) return; // wide phase: one lane of the group writes
-  if (a.cost) { // cost-probe pass: only the tile's ray count is kept
+  if (k.cost) { // cost-probe pass: only the tile's ray count is kept
     // a wave holds a tile until its last pixel is done, so a tile's duration follows its heaviest pixel; the cooperative
     // kernels' model also needs the lane time, i.e. the sum
-    if (a.cost_max) atomicMax(&a.cost[L.cold.get_pix() >> 6], L.cold.get_iters() * PT_TILE_PIXELS);
-    else atomicAdd(&a.cost[L.cold.get_pix() >> 6], L.cold.get_iters());
+    if (k.cost_max) atomicMax(&k.cost[L.cold.get_pix() >> 6], L.cold.get_iters() * PT_TILE_PIXELS);
+    else atomicAdd(&k.cost[L.cold.get_pix() >> 6], L.cold.get_iters());
     return;
   }
   long long idx;
   if constexpr (FAST) { // fast mode: this chunk's plain sum into its plane of the workspace
     const int packed = L.cold.get_pix(), pix = packed & 0xffffff;
-    if (a.shard_count == 1) idx = ((long long)L.cold.get_y() * a.width + L.cold.get_x()) * 3;
+    if (k.shard_count == 1) idx = ((long long)L.cold.get_y() * k.width + L.cold.get_x()) * 3;
     else idx = (long long)pix * 3;
-    idx += (long long)(packed >> 24) * a.fast_stride;
+    idx += (long long)(packed >> 24) * k.fast_stride;
     const V3 sum = L.cold.get_acc();
-    a.fb[idx] = sum.x; a.fb[idx + 1] = sum.y; a.fb[idx + 2] = sum.z;
+    k.fb[idx] = sum.x; k.fb[idx + 1] = sum.y; k.fb[idx + 2] = sum.z;
     return;
   }
-  V3 acc = L.cold.get_acc() / (float)a.samples; // render.hpp:102
-  if (a.shard_count == 1) idx = ((long long)L.cold.get_y() * a.width + L.cold.get_x()) * 3;
+  V3 acc = L.cold.get_acc() / (float)k.samples; // render.hpp:102
+  if (k.shard_count == 1) idx = ((long long)L.cold.get_y() * k.width + L.cold.get_x()) * 3;
   else idx = (long long)L.cold.get_pix() * 3;
-  a.fb[idx] = acc.x; a.fb[idx + 1] = acc.y; a.fb[idx + 2] = acc.z;
+  k.fb[idx] = acc.x; k.fb[idx + 1] = acc.y; k.fb[idx + 2] = acc.z;
 }
 
 // Start the next sample of a lane whose path ended (render.hpp:95-99); the pixel itself is finished where its last
