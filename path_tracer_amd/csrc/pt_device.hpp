@@ -753,6 +753,9 @@ __device__ __forceinline__ void sphere_scan(P recs, cst_f4p cblob, int n, int go
   float frac = 0.0f;
   if (flags & 2) frac = (c.r.tm - aux.x) / (aux.y - aux.x); // (time - time0) / (time1 - time0)  sphere.hpp:54
   int q_static = qs, q_moving = qm;
+  bool walk = false;
+  int w_cell = 0, w_cand = 0;
+  f4 wg0 = aux, wg1 = aux;
   if (flags & 4) lists_off -= 4; // (a grid's four header records sit between the lists and aux)
   if (GRID && (flags & 4)) { // the run has a grid for its small spheres
     const f4 g0 = cblob[goff - 5], g1 = cblob[goff - 4], g2 = cblob[goff - 3], g3 = cblob[goff - 2];
@@ -771,8 +774,8 @@ __device__ __forceinline__ void sphere_scan(P recs, cst_f4p cblob, int n, int go
     if (__builtin_amdgcn_ballot_w64(c.live && !ok) == 0) {
       const int n_cell = as_i(g3.x), n_cand = as_i(g3.y), qbs = as_i(g3.z), qbm = as_i(g3.w);
       const int big_off = lists_off - qbs - qbm, cand_off = big_off - n_cand, cell_off = cand_off - n_cell;
-      sphere_grid_walk(recs, recs + (cell_off - goff), recs + (cand_off - goff), g0, g1, frac, goff, c, h, accept_at);
-      lists_off = big_off; q_static = qbs; q_moving = qbm; // then only the spheres that are not in the grid
+      walk = true; w_cell = cell_off - goff; w_cand = cand_off - goff; wg0 = g0; wg1 = g1;
+      lists_off = big_off; q_static = qbs; q_moving = qbm; // only the spheres that are not in the grid go through the lists
     }
   }
   const cst_i4p lists = (cst_i4p)(cblob + lists_off);
@@ -789,6 +792,9 @@ __device__ __forceinline__ void sphere_scan(P recs, cst_f4p cblob, int n, int go
     sphere_list_entry<true, K>(recs, cur, goff, frac, c, h, accept_at);
     cur = nxt;
   }
+  // the walk comes after the big spheres (any order gives the same result: the tie rule is explicit): a ground hit found
+  // first ends the walks of the rays that go down where they reach it
+  if constexpr (GRID) { if (walk) sphere_grid_walk(recs, recs + w_cell, recs + w_cand, wg0, wg1, frac, goff, c, h, accept_at); }
 }
 
 // n records of one kind at recs[0..): record i is blob offset goff + i*size.  `recs` is either the resident
