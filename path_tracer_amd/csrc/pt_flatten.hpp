@@ -130,7 +130,12 @@ struct SphereGrid {
   std::vector<int32_t> big_st, big_mv;
 };
 
-inline SphereGrid build_sphere_grid(const PtHittable* h, int count, bool uniform) {
+// margin m in median radii; cell edge in (median radius + margin).  Swept on the 496-hittable scene at 1080p x 1024 spp
+// (tools/grid_sweep.sh, tools/grid_rep.sh): (1.5, 2.8) — round 2's first choice — 3 730 Msamples/s, (0.5, 3.0) 4 240,
+// (0.5, 3.33) 4 190, (0.75, 3.43) 4 070, (0.25, *) <= 3 360.  A smaller margin means fewer cells per sphere (a ray tests
+// fewer candidates) but a smaller rlimit (more waves fall back to the full lists for rays that start far out).
+struct GridTuning { float m = 0.5f, cell = 3.0f; };
+inline SphereGrid build_sphere_grid(const PtHittable* h, int count, bool uniform, GridTuning tune = GridTuning()) {
   SphereGrid g;
   if (count < 48 || count > 32767 || !uniform) return g;
   std::vector<float> rad;
@@ -142,7 +147,7 @@ inline SphereGrid build_sphere_grid(const PtHittable* h, int count, bool uniform
   std::nth_element(sorted.begin(), sorted.begin() + count / 2, sorted.end());
   const float r_med = sorted[(size_t)count / 2];
   if (!(r_med > 0.0f)) return g;
-  const float m = 1.5f * r_med, r_small = 4.0f * r_med;
+  const float m = tune.m * r_med, r_small = 4.0f * r_med;
   double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
   float r_min = 3.4e38f;
   int n_small = 0;
@@ -164,7 +169,7 @@ inline SphereGrid build_sphere_grid(const PtHittable* h, int count, bool uniform
     for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], blo[k]); hi[k] = std::max(hi[k], bhi[k]); }
   }
   if (n_small < 48) return g;
-  const double cell = 2.8 * ((double)r_med + m);
+  const double cell = (double)tune.cell * ((double)r_med + m);
   long long total = 1;
   for (int k = 0; k < 3; k++) {
     g.n[k] = (int)std::min<double>(64.0, std::max<double>(1.0, std::ceil((hi[k] - lo[k]) / cell)));
@@ -223,7 +228,7 @@ inline int put_offset_list(std::vector<F4>& b, std::vector<int32_t> l) { // retu
   return (int)(l.size() / 4);
 }
 
-inline int put_sphere_run_aux(std::vector<F4>& b, const PtHittable* h, int count, bool allow_grid) { // returns the spheres in the grid
+inline int put_sphere_run_aux(std::vector<F4>& b, const PtHittable* h, int count, bool allow_grid, GridTuning tune = GridTuning()) { // returns the spheres in the grid
   std::vector<int32_t> st, mv;
   bool uniform = true;
   float t0 = 0.0f, t1 = 0.0f;
@@ -238,7 +243,7 @@ inline int put_sphere_run_aux(std::vector<F4>& b, const PtHittable* h, int count
   const int ns = (int)st.size();
   const bool any = !mv.empty();
   SphereGrid g;
-  if (allow_grid) g = build_sphere_grid(h, count, uniform && (!any || t0 < t1));
+  if (allow_grid) g = build_sphere_grid(h, count, uniform && (!any || t0 < t1), tune);
   int n_cell_f4 = 0, n_cand_f4 = 0, qbs = 0, qbm = 0;
   if (g.ok) {
     size_t before = b.size();
@@ -266,7 +271,7 @@ inline void put_box(std::vector<F4>& b, const float* f, int32_t mat, int32_t hid
 }
 
 // box_cull: 0 = no slab pools, 1 = where the cost model says they pay, 2 = every stretch of >= 2 rects / boxes (tests)
-inline int flatten(const PtSceneDesc* sc, Flat& out, std::string& err, bool allow_grid = true, int box_cull = 1) {
+inline int flatten(const PtSceneDesc* sc, Flat& out, std::string& err, bool allow_grid = true, int box_cull = 1, GridTuning tune = GridTuning()) {
   int rc = validate(sc, err);
   if (rc) return rc;
   out = Flat();
@@ -327,7 +332,7 @@ inline int flatten(const PtSceneDesc* sc, Flat& out, std::string& err, bool allo
   int pool_first = 0, pool_n = 0;
   for (size_t ri = 0; ri < runs.size(); ri++) {
     const Run& run = runs[ri];
-    if (run.kind == DK_SPHERE) out.grid_spheres += put_sphere_run_aux(b, &sc->hittables[run.first], run.count, allow_grid);
+    if (run.kind == DK_SPHERE) out.grid_spheres += put_sphere_run_aux(b, &sc->hittables[run.first], run.count, allow_grid, tune);
     // slab pools (pt_device.hpp: slab_pool): a maximal stretch of consecutive rect / box runs with enough boxes gets a table
     // [n slab entries (lo, -)(hi, -), padded to an even count][n exact entries (lo', hit id)(hi', -)] in front of its first run; every rect / box run
     // carries an aux F4 at its first record - 1: (largest |coordinate| of the pool, runs the pool spans (0: not a pool head),

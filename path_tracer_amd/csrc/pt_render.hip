@@ -904,7 +904,10 @@ int pt_scene_create(const PtSceneDesc* desc, PtScene** out_scene) {
   // pool for every stretch of two or more rects / boxes, also where it does not pay (the tests' way to put the pools into
   // small mixed scenes)
   const int box_cull = std::getenv("PT_NO_BOXCULL") ? 0 : std::getenv("PT_POOL_ALWAYS") ? 2 : 1;
-  int rc = ptf::flatten(desc, flat, err, std::getenv("PT_NO_GRID") == nullptr, box_cull);
+  ptf::GridTuning tune; // PT_GRID_M / PT_GRID_CELL: the sphere grid's margin and cell size (tools/grid_sweep.sh)
+  if (const char* e = std::getenv("PT_GRID_M")) tune.m = (float)std::atof(e);
+  if (const char* e = std::getenv("PT_GRID_CELL")) tune.cell = (float)std::atof(e);
+  int rc = ptf::flatten(desc, flat, err, std::getenv("PT_NO_GRID") == nullptr, box_cull, tune);
   if (rc) return fail(rc, err);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(PT_ERR_NO_DEVICE, "no HIP device visible");

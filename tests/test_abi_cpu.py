@@ -218,7 +218,7 @@ def test_flatten_sphere_grid(lib):
     assert d["flags"] == 7
     nx, ny, nz = d["dims"]
     assert len(d["cells"]) >= nx * ny * nz and ny == 1 and nx >= 10 and nz >= 10
-    assert abs(d["cell"] * d["inv_cell"] - 1) < 1e-6 and abs(d["cell"] - 2.8 * (0.2 + 0.3)) < 1e-4
+    assert abs(d["cell"] * d["inv_cell"] - 1) < 1e-6 and abs(d["cell"] - 3.0 * (0.2 + 0.1)) < 1e-4   # margin 0.5 r, cell 3 (r + margin)
     assert d["big_static"][:1].tolist() == [0] and len(set(d["big_static"].tolist())) == 1 and len(d["big_moving"]) == 0  # the ground sphere
     listed = set()
     for c in range(nx * ny * nz):
@@ -231,13 +231,13 @@ def test_flatten_sphere_grid(lib):
             # the cell really touches the sphere's inflated box
             i = o // 3
             f = np.array(ps.hittables[i].f[:9], np.float32)
-            lo = np.minimum(f[0:3], f[3:6]) - (0.2 + 0.3 + 1e-3); hi = np.maximum(f[0:3], f[3:6]) + (0.2 + 0.3 + 1e-3)
+            lo = np.minimum(f[0:3], f[3:6]) - (0.2 + 0.1 + 1e-3); hi = np.maximum(f[0:3], f[3:6]) + (0.2 + 0.1 + 1e-3)
             cx, cz = c % nx, c // (nx * ny)
             cell_lo = d["origin"] + np.array([cx, 0, cz]) * d["cell"]; cell_hi = cell_lo + d["cell"]
             assert (cell_lo[[0, 2]] <= hi[[0, 2]] + 1e-4).all() and (cell_hi[[0, 2]] >= lo[[0, 2]] - 1e-4).all()
     assert listed == {3 * i for i in range(1, count)}  # every small sphere sits in some cell
     assert set(d["static"].tolist()) | set(d["moving"].tolist()) == {3 * i for i in range(count)}
-    assert d["rlimit2"] > 100.0 ** 2  # rays starting within > 100 units of the field may use the grid
+    assert d["rlimit2"] > 80.0 ** 2  # rays starting within > 80 units of the field may use the grid
 
 
 def test_flatten_badouel_triangles_are_runs_of_their_own(lib):
