@@ -62,7 +62,7 @@ constexpr size_t kMaxLdsBlob = 64 * 1024;   // blob staged in LDS when it fits
 constexpr size_t kMaxLdsWithMaterials = 16 * 1024; // stage the material table too when records + materials are this small
 constexpr size_t kMaxLdsColdScene = 10 * 1024;    // records + materials this small: the 8-wave kernel with LDS-resident cold lane state
 constexpr float kCoopMinTraversal = 2500.0f;        // estimated VALU instructions of one list scan (~110 spheres)
-constexpr int kGridMinTiles = 4096;                 // frames (shards) smaller than this are chain-bound: see launch_render
+constexpr int kGridMinTiles = 0;                    // since the grid's retuning it wins at every frame size: see launch_render
 constexpr unsigned kQueueRing = 256;        // launches in flight on one scene may not exceed this
 
 struct KArgs {
@@ -762,6 +762,7 @@ struct EnvKnobs {
   bool has_split_tiles = false;
   int split_tiles = 0;     // PT_SPLIT_TILES: fixed number of tiles through the wide phase (< 0: all)
   int lpt_max = -1, probe_spp_max = 16; // PT_LPT_MAX / PT_PROBE_SPP_MAX: order tiles by their heaviest pixel; probe depth cap
+  int grid_min_tiles = kGridMinTiles;    // PT_GRID_MIN_TILES: frames (shards) of fewer tiles keep the cooperative kernels and the lists
   float model_fixed = 2400.0f, model_chain = 2400.0f; // PT_MODEL_FIXED / PT_MODEL_CHAIN: constants of the makespan model (lpt_order_kernel)
   EnvKnobs() {
     if (const char* e = std::getenv("PT_BLOCKS_PER_CU")) blocks_per_cu = std::max(1, std::atoi(e));
@@ -769,6 +770,7 @@ struct EnvKnobs {
     if (const char* e = std::getenv("PT_WIDE_LOGG")) wide_logG = std::min(6, std::max(1, std::atoi(e)));
     if (const char* e = std::getenv("PT_SPLIT_TILES")) { has_split_tiles = true; split_tiles = std::atoi(e); }
     if (const char* e = std::getenv("PT_LPT_MAX")) lpt_max = std::atoi(e);
+    if (const char* e = std::getenv("PT_GRID_MIN_TILES")) grid_min_tiles = std::max(0, std::atoi(e));
     if (const char* e = std::getenv("PT_PROBE_SPP_MAX")) probe_spp_max = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("PT_MODEL_FIXED")) model_fixed = (float)std::atof(e);
     if (const char* e = std::getenv("PT_MODEL_CHAIN")) model_chain = (float)std::atof(e);
@@ -1074,10 +1076,11 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
   // (496-hittable scene, shard 0/8: 522 -> 229 ms).
   // Sphere runs with a culling grid: the ordinary resident kernels walk it (a ray then tests tens of spheres instead of
   // hundreds: 496-hittable scene 1 660 -> 3 240 Msamples/s at 1080p), the cooperative kernels scan the lists with lane
-  // groups.  A lone wave's grid walk is a chain of dependent LDS loads, no shorter than a group's list scan, so small frames
-  // and small shards — where the heaviest pixel's chain, not the throughput, sets the time — keep the cooperative kernels
-  // (400x225x256 spp: 106 ms against 126 ms with the grid; shard 0/8 of the 1080p frame: 102 against 98).
-  const bool use_grid = s->grid_spheres > 0 && local_tiles >= kGridMinTiles && !(p->flags & PT_FLAG_FORCE_COOP);
+  // groups.  With the grid as first tuned (margin 1.5 r) a lone wave's walk was no shorter than a group's list scan and small
+  // frames / shards kept the cooperative kernels; since the retuning (margin 0.5 r, walk after the big spheres) the walk wins
+  // everywhere (tools/grid_min_tiles.py: 400x225x256 spp 99 ms against 108; shard 0/8 of the 1080p frame at 256 spp 80
+  // against 102; shard 0/8 of 4K at 128 spp 61 against 102).  PT_GRID_MIN_TILES restores a threshold.
+  const bool use_grid = s->grid_spheres > 0 && local_tiles >= s->knobs.grid_min_tiles && !(p->flags & PT_FLAG_FORCE_COOP);
   const bool coop = lds && a.coop_prefix >= 0 && !use_grid && (s->traversal_cost >= kCoopMinTraversal || (p->flags & PT_FLAG_FORCE_COOP));
   // Persistent grid: no more workgroups than the chip holds at once; lanes pull pixels from the queue.
   auto launch = [&](auto kernel) -> int {
