@@ -300,10 +300,12 @@ __device__ __forceinline__ void lane_regenerate(Lane& L, const KArgs& a) {
     unsigned long long kp = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(kp));
     const Cam cam = *(kcam_p)kp;
+    const __attribute__((address_space(4))) KArgs& k = *(const __attribute__((address_space(4))) KArgs*)kp; // frame geometry: same reasoning
 #else
     const Cam cam = a.cam; // (host pass of the single-source compile: never run)
+    const KArgs& k = a;
 #endif
-    L.ray = camera_ray(cam, L.cold.get_x(), L.cold.get_y(), a.width, a.height, a.inv_w, a.inv_h, L.rng, a.pinhole != 0);
+    L.ray = camera_ray(cam, L.cold.get_x(), L.cold.get_y(), k.width, k.height, k.inv_w, k.inv_h, L.rng, k.pinhole != 0);
     L.att = mk(1.0f, 1.0f, 1.0f);
     L.b = 0;
     L.need_new = false;

@@ -519,9 +519,9 @@ def test_schedule_probe_reports_the_wide_phase(lib, monkeypatch):
     monkeypatch.setenv("PT_SPLIT_TILES", "40")
     monkeypatch.setenv("PT_WIDE_LOGG", "4")
     ds2 = R.DeviceScene(ps)  # the tuning knobs are read when a scene is created, never on the launch path
-    R.render(136, 72, 16, ds2, c)
+    R.render(136, 72, 16, ds2, c, flags=abi.PT_FLAG_FORCE_COOP)  # (by default a scene with a sphere grid runs the grid kernels)
     assert lib.pt_debug_schedule(ds2.handle, out) == 0 and (out[0], out[1]) == (40, 16)
-    R.render(136, 72, 16, ds, c)  # the scene created before the knobs were set still follows the model
+    R.render(136, 72, 16, ds, c, flags=abi.PT_FLAG_FORCE_COOP)  # the scene created before the knobs were set still follows the model
     assert lib.pt_debug_schedule(ds.handle, out) == 0 and 0 <= out[0] <= 153 and out[1] in (0, 2, 4, 8, 16, 32, 64)
     monkeypatch.delenv("PT_SPLIT_TILES"); monkeypatch.delenv("PT_WIDE_LOGG")
 
@@ -536,7 +536,7 @@ def test_wide_phase_smoke_scene(orc, monkeypatch):
     monkeypatch.setenv("PT_SPLIT_TILES", "-1")
     for log_g in (1, 3, 5, 6):
         monkeypatch.setenv("PT_WIDE_LOGG", str(log_g))
-        assert_bit_identical(R.render_host(w, h, 16, ps, c), ref, f"smoke G={1 << log_g}")
+        assert_bit_identical(R.render_host(w, h, 16, ps, c, flags=abi.PT_FLAG_FORCE_COOP), ref, f"smoke G={1 << log_g}")
 
 
 def test_cooperative_traversal_with_medium_suffix_and_image(orc):
