@@ -292,3 +292,15 @@ def test_path_rays_through_fuzz_scenes(orc, lib, kind, seed):
     with forced_pools() if kind == "random" else contextlib.nullcontext():
         checked, bad = follow_paths(lib, orc, ps, c.c, 40, 24, 15000, 12, seed)
     assert checked >= 15000 and not bad, f"{len(bad)} of {checked} rays differ: " + " | ".join(bad[:3])
+
+
+@pytest.mark.parametrize("name,n,gens", [("cornell", 40000, 16), ("smoke", 20000, 10)])
+def test_path_rays_on_the_baseline_scenes(orc, lib, name, n, gens):
+    """The same ray-level check on the scenes BASELINE.json names: the Cornell-style scene (slab pool: every ray of every
+    generation starts on a face of one of its boxes) and the 496-hittable scene (sphere grid, image textures, media)."""
+    from path_rays import follow_paths
+    ps, cam = scenes.build(name)
+    w, h = (192, 108) if name == "cornell" else (200, 112)
+    c = scenes.make_camera(cam, w, h)
+    checked, bad = follow_paths(lib, orc, ps, c.c, w, h, n, gens, 7)
+    assert checked >= 2 * n and not bad, f"{len(bad)} of {checked} rays differ: " + " | ".join(bad[:3])
