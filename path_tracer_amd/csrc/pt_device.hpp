@@ -1535,17 +1535,24 @@ __device__ __forceinline__ bool shade(PM mats, const uint8_t* __restrict__ atlas
   PM M = mats + rec.mat * SZ_MATERIAL;
   f4 M0 = M[0], M1 = M[1];
   const int mk_ = as_i(M0.x);
+  // A wave holds lanes of every material, and each `if` below runs once for the lanes that take it.  What several materials
+  // need — the unit direction of the incoming ray (metal, glass), a point in the unit ball (metal, isotropic: three draws and
+  // four transcendentals), the texture's value (lambertian, light, isotropic) — is therefore computed ONCE, for the union of
+  // the lanes that need it, ahead of the switch: one pass through that code per wave-iteration instead of one per
+  // material.  Per lane nothing moves: each lane takes exactly one material, its draws keep their order (the ball is the
+  // first thing metal and isotropic draw; texture values draw nothing).
+  V3 ud = mk(0.0f, 0.0f, 0.0f), ball = ud, tv = ud;
+  if (mk_ == 1 || mk_ == 2) ud = ray.d / sqrt_rn(dot(ray.d, ray.d));
+  if (mk_ == 1 || mk_ >= 4) ball = rng_in_unit_ball(rng);
+  if (mk_ == 0 || mk_ >= 3) tv = texture_value(M0, M1, M[2], M[3], rec.p, uv, atlas);
   if (mk_ == 0) { // lambertian material.hpp:18-28
     V3 dir = rec.normal + rng_unit_vec(rng);
-    V3 tv = texture_value(M0, M1, M[2], M[3], rec.p, uv, atlas);
     ray.o = rec.p; ray.d = dir;
     att = att * tv;
     return true;
   }
   if (mk_ == 1) { // metal material.hpp:39-48
-    V3 ud = ray.d / sqrt_rn(dot(ray.d, ray.d));
     V3 reflected = reflect(ud, rec.normal);
-    V3 ball = rng_in_unit_ball(rng);
     V3 dir = reflected + M0.z * ball;
     ray.o = rec.p; ray.d = dir;
     att = att * xyz(M1);
@@ -1557,7 +1564,6 @@ __device__ __forceinline__ bool shade(PM mats, const uint8_t* __restrict__ atlas
     att = att * xyz(M1);
     float ref_idx = M0.z;
     float ratio = rec.front_face ? (1.0f / ref_idx) : ref_idx;
-    V3 ud = ray.d / sqrt_rn(dot(ray.d, ray.d));
     float cos_theta = __builtin_fminf(-dot(ud, rec.normal), 1.0f);
     float sin_theta = sqrt_rn(1.0f - cos_theta * cos_theta);
     bool cannot_refract = ratio * sin_theta > 1.0f;
@@ -1568,12 +1574,10 @@ __device__ __forceinline__ bool shade(PM mats, const uint8_t* __restrict__ atlas
     return true;
   }
   if (mk_ == 3) { // lightsource material.hpp:104-108; returned un-attenuated (render.hpp:73)
-    out = texture_value(M0, M1, M[2], M[3], rec.p, uv, atlas);
+    out = tv;
     return false;
   }
   // isotropic material.hpp:119-126
-  V3 ball = rng_in_unit_ball(rng);
-  V3 tv = texture_value(M0, M1, M[2], M[3], rec.p, uv, atlas);
   ray.o = rec.p; ray.d = ball;
   att = att * tv;
   return true;
