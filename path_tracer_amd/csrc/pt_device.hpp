@@ -655,8 +655,15 @@ __device__ __forceinline__ void sphere_list_entry(P recs, i4 o4, int goff, float
     const int o[4] = {o4.x, o4.y, o4.z, o4.w};
     sphere_list_trip<MOVING, 4>(recs, o, goff, frac, c, h, accept_at);
   } else {
-    const int a[2] = {o4.x, o4.y}, b[2] = {o4.z, o4.w};
+    // Equal neighbouring offsets are the list's padding (its last entry repeated: two records never share an offset), and
+    // the offsets are scalars: the repeats are skipped by scalar branches.  Short lists are what a ray of a chain-bound
+    // frame spends its time on — the 496-hittable scene tests 7 spheres outside the grid (ground, glowing ball, the five
+    // big ones) and did so as 16.
+    const int a[2] = {o4.x, o4.y}, b[2] = {o4.z, o4.w}, a1[1] = {o4.x}, b1[1] = {o4.z};
+    if (o4.y == o4.x) { sphere_list_trip<MOVING, 1>(recs, a1, goff, frac, c, h, accept_at); return; }
     sphere_list_trip<MOVING, 2>(recs, a, goff, frac, c, h, accept_at);
+    if (o4.z == o4.y) return;
+    if (o4.w == o4.z) { sphere_list_trip<MOVING, 1>(recs, b1, goff, frac, c, h, accept_at); return; }
     sphere_list_trip<MOVING, 2>(recs, b, goff, frac, c, h, accept_at);
   }
 }
