@@ -1015,7 +1015,9 @@ __device__ __forceinline__ void hit_records(P recs, cst_f4p cblob, int kind, int
         }
       };
     };
-    if constexpr (WHOLE) sphere_scan<(TRIP >= 2 ? 4 : 2), GRID>(recs, cblob, n, goff, c, h, accept_at);
+    // (a run of one or two spheres — a lone ball between other kinds — is tested in place: the list machinery would cost it
+    // two dependent scalar loads before the first record is even requested)
+    if (WHOLE && n > 2) sphere_scan<(TRIP >= 2 ? 4 : 2), GRID>(recs, cblob, n, goff, c, h, accept_at);
     else {
       TimeFrac tf = time_frac_none();
       for (int i = 0; i < n; ++i, off += SZ_SPHERE) sphere_roots(recs, off, c, PT_TMIN, h.closest, true, tf, accept_at(off));
