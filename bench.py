@@ -81,18 +81,27 @@ def ops_per_sample(ctr: dict) -> float:
     return total / n
 
 
-def pmc_traffic(scene: str, w: int, h: int, spp: int):
-    """HBM bytes per launch of the render kernel from the newest committed rocprofv3 PMC summary of the same
-    workload (FETCH_SIZE and WRITE_SIZE are collected in their own --pmc passes: tools/pmc_summary.py).
-    Returns (bytes, file name, derived dict)."""
-    best = None
-    for f in sorted((ROOT / "profiles").glob("r*_pmc_summary.json")):
+def pmc_traffic(scene: str, w: int, h: int, spp: int, profiles_dir=None):
+    """HBM bytes per launch of the render kernel from the committed rocprofv3 PMC summary of the same workload
+    (FETCH_SIZE and WRITE_SIZE are collected in their own --pmc passes: tools/pmc_summary.py).
+    Selection is EXPLICIT, never by file name: only summaries that carry `"final": true` (written by
+    `tools/pmc_summary.py --final ROUND`: the counters of a round's final build) qualify, and among those the highest
+    `"round"` wins; two finals of one round for one workload are an error.  Returns (bytes, file name, derived dict)."""
+    best, best_round = None, None
+    for f in (Path(profiles_dir) if profiles_dir else ROOT / "profiles").glob("*_pmc_summary.json"):
         try:
             d = json.loads(f.read_text())
         except Exception:  # noqa: BLE001
             continue
-        if d.get("workload") == f"{w}x{h}x{spp}" and d.get("scene", "cornell") == scene and "hbm_bytes_per_launch" in d.get("derived", {}):
-            best = (d["derived"]["hbm_bytes_per_launch"], f.name, d["derived"])
+        if not d.get("final") or d.get("workload") != f"{w}x{h}x{spp}" or d.get("scene", "cornell") != scene:
+            continue
+        if "hbm_bytes_per_launch" not in d.get("derived", {}):
+            continue
+        rnd = int(d.get("round", 0))
+        if best is not None and rnd == best_round:
+            raise RuntimeError(f"two final PMC summaries of round {rnd} for {scene} {w}x{h}x{spp}: {best[1]} and {f.name}")
+        if best is None or rnd > best_round:
+            best, best_round = (d["derived"]["hbm_bytes_per_launch"], f.name, d["derived"]), rnd
     return best
 
 
@@ -273,9 +282,19 @@ def main() -> None:
             t1 = time.perf_counter()
             orc.render(packed, bcam.c, bw, bh, bs, DEPTH)
             dt = time.perf_counter() - t1
+            # the same sample with glibc's float libm (the reference's own libm semantics; transcendental-free scenes such as
+            # the Cornell-style one give the same image either way), half the sample: it rides beside, it is not `value`
+            orc.set_math(False)
+            gs = max(1, bs // 2)
+            t1 = time.perf_counter()
+            orc.render(packed, bcam.c, bw, bh, gs, DEPTH)
+            dtg = time.perf_counter() - t1
+            orc.set_math(True)
             cpu_line = {"value": round(bw * bh * bs / dt / 1e6, 3), "unit": "Msamples/s",
                         "cores": orc.load().orc_max_threads(), "kind": "port",
-                        "sample": f"same scene, {bw}x{bh}, {bs} spp, depth {DEPTH} ({bw * bh * bs / 1e6:.1f} Msamples, {dt:.1f} s), OpenMP CPU oracle, portable math"}
+                        "sample": f"same scene, {bw}x{bh}, {bs} spp, depth {DEPTH} ({bw * bh * bs / 1e6:.1f} Msamples, {dt:.1f} s), OpenMP CPU oracle, portable math",
+                        "value_glibc_math": round(bw * bh * gs / dtg / 1e6, 3),
+                        "sample_glibc_math": f"{bw}x{bh}, {gs} spp ({dtg:.1f} s), same oracle with glibc's float libm"}
             # the "PSNR vs CPU ref" half of the metric: sampled pixels of the LAST timed GPU frame re-rendered by the
             # oracle at full spp (a pixel depends only on its own RNG stream)
             import numpy as np
@@ -291,7 +310,8 @@ def main() -> None:
                       "psnr_db_8bit": None if mse == 0 else round(10 * np.log10(255.0 ** 2 / mse), 2),
                       "note": "GPU frame vs CPU oracle (portable math) at sampled pixels, full spp; null PSNR = identical"
                               + ("; fast mode is NOT expected to be bit-identical" if args.mode == "fast" else "")}
-        pmc = pmc_traffic(scene_name, W, H, SPP) if world == 1 else None
+        # the committed counters are those of the parity kernels with default flags: any other mode / flag set gets nulls
+        pmc = pmc_traffic(scene_name, W, H, SPP) if (world == 1 and args.flags == 0) else None
         kernel_samples_per_s = samples_per_step / (kern_ms * 1e-3)  # whole job; each rank renders 1/world of it
         achieved = ops * kernel_samples_per_s / 1e12 / world  # per GPU
         headline = (scene_name, W1, H1, SPP) == ("cornell", 1920, 1080, 1024)

@@ -257,6 +257,11 @@ __device__ __forceinline__ void lane_acquire(Lane& L, const KArgs& a) {
   L.need_new = true;
 }
 
+// One 12-byte store per finished pixel (render.hpp:105): global_store_dwordx3 needs dword alignment only.  Three scalar
+// dword stores made the write traffic 2.7x the algorithmic 12 B/pixel (partial-line writes; r02e_cornell_pmc_summary.json).
+struct __attribute__((packed, aligned(4))) Rgb12 { float r, g, b; };
+__device__ __forceinline__ void store_rgb(float* p, V3 c) { *(Rgb12*)p = Rgb12{c.x, c.y, c.z}; }
+
 template <bool FAST = false, typename Lane>
 __device__ __forceinline__ void lane_store(Lane& L, const KArgs& a) {
   L.live = false;
@@ -275,14 +280,13 @@ __device__ __forceinline__ void lane_store(Lane& L, const KArgs& a) {
     if (k.shard_count == 1) idx = ((long long)L.cold.get_y() * k.width + L.cold.get_x()) * 3;
     else idx = (long long)pix * 3;
     idx += (long long)(packed >> 24) * k.fast_stride;
-    const V3 sum = L.cold.get_acc();
-    k.fb[idx] = sum.x; k.fb[idx + 1] = sum.y; k.fb[idx + 2] = sum.z;
+    store_rgb(k.fb + idx, L.cold.get_acc());
     return;
   }
   V3 acc = L.cold.get_acc() / (float)k.samples; // render.hpp:102
   if (k.shard_count == 1) idx = ((long long)L.cold.get_y() * k.width + L.cold.get_x()) * 3;
   else idx = (long long)L.cold.get_pix() * 3;
-  k.fb[idx] = acc.x; k.fb[idx + 1] = acc.y; k.fb[idx + 2] = acc.z;
+  store_rgb(k.fb + idx, acc);
 }
 
 // Start the next sample of a lane whose path ended (render.hpp:95-99); the pixel itself is finished where its last
@@ -745,6 +749,29 @@ __global__ void tonemap_kernel(const float* __restrict__ fb, uint8_t* __restrict
 
 thread_local std::string g_last_error;
 
+// The flattening pt_scene_create uploads (pt_debug_flatten shows the same blob).
+// PT_NO_GRID / PT_NO_BOXCULL: A/B knobs (brute-force sphere runs / straight-line rect and box runs); PT_POOL_ALWAYS: a slab
+// pool for every stretch of two or more rects / boxes, also where it does not pay (the tests' way to put the pools into
+// small mixed scenes); PT_GRID_M / PT_GRID_CELL: the sphere grid's margin and cell size (tools/grid_sweep.sh).
+// LDS budget: the culling grid's tables ride in the blob, and only the LDS-resident kernels walk the grid.  A scene whose
+// blob exceeds kMaxLdsBlob WITH its grid but fits WITHOUT it (e.g. 1 200 small spheres: 101 KB against 62 KB) is flattened
+// without the grid, so that it keeps the resident kernels instead of falling to the streaming kernel with dead tables.
+static int flatten_with_env(const PtSceneDesc* desc, ptf::Flat& flat, std::string& err) {
+  const int box_cull = std::getenv("PT_NO_BOXCULL") ? 0 : std::getenv("PT_POOL_ALWAYS") ? 2 : 1;
+  ptf::GridTuning tune;
+  if (const char* e = std::getenv("PT_GRID_M")) tune.m = (float)std::atof(e);
+  if (const char* e = std::getenv("PT_GRID_CELL")) tune.cell = (float)std::atof(e);
+  const bool allow_grid = std::getenv("PT_NO_GRID") == nullptr;
+  int rc = ptf::flatten(desc, flat, err, allow_grid, box_cull, tune);
+  if (rc) return rc;
+  if (flat.grid_spheres > 0 && flat.blob.size() * 16 > kMaxLdsBlob) {
+    ptf::Flat plain;
+    std::string err2;
+    if (ptf::flatten(desc, plain, err2, false, box_cull, tune) == PT_OK && plain.blob.size() * 16 <= kMaxLdsBlob) flat = std::move(plain);
+  }
+  return PT_OK;
+}
+
 int fail(int code, const std::string& msg) {
   g_last_error = msg;
   return code;
@@ -819,10 +846,13 @@ struct PtScene {
   mutable size_t ws_partial_floats = 0;
   unsigned int* queues = nullptr; // ring of per-launch pixel-queue counters
   mutable unsigned int next_queue = 0;
+  mutable hipEvent_t ring_done[kQueueRing] = {}; // recorded behind the launch that uses a slot: a wrapped ring waits for it
   int device = 0;
   // Scheduling state above marked `mutable` (queue ring cursor, LPT workspace, last-launch info) changes per launch although
-  // the scene DATA is immutable: launches on one scene from several host threads serialise their enqueue on this mutex
-  // (the kernels themselves still overlap on their streams).
+  // the scene DATA is immutable: launches on one scene from several host threads serialise their ENQUEUE on this mutex.
+  // The per-scene workspaces (ws_cost / ws_order / ws_nsplit / ws_partial) are shared by every launch on the scene, so
+  // renders on ONE scene must also be stream-ordered (include/pt_render.h): callers that render one scene from several
+  // streams create one PtScene per stream (path_tracer_amd/render.py keys its cache by (device, stream)).
   mutable std::mutex sched;
   mutable std::map<const void*, int> occupancy; // resident workgroups per CU, per kernel variant (queried once)
   EnvKnobs knobs;                               // environment tuning knobs as they were when the scene was created
@@ -883,7 +913,7 @@ int pt_debug_flatten(const PtSceneDesc* desc, float* blob_out, int64_t blob_cap_
                      int32_t* n_runs, float* mats_out, int64_t mats_cap_f4, int32_t* flags_out) {
   ptf::Flat flat;
   std::string err;
-  int rc = ptf::flatten(desc, flat, err);
+  int rc = flatten_with_env(desc, flat, err); // the blob pt_scene_create would upload, knobs and LDS budget included
   if (rc) return fail(rc, err);
   if (n_blob_f4) *n_blob_f4 = (int32_t)flat.blob.size();
   if (n_runs) *n_runs = flat.n_runs;
@@ -904,14 +934,7 @@ int pt_scene_create(const PtSceneDesc* desc, PtScene** out_scene) {
   *out_scene = nullptr;
   ptf::Flat flat;
   std::string err;
-  // PT_NO_GRID / PT_NO_BOXCULL: A/B knobs (brute-force sphere runs / straight-line rect and box runs); PT_POOL_ALWAYS: a slab
-  // pool for every stretch of two or more rects / boxes, also where it does not pay (the tests' way to put the pools into
-  // small mixed scenes)
-  const int box_cull = std::getenv("PT_NO_BOXCULL") ? 0 : std::getenv("PT_POOL_ALWAYS") ? 2 : 1;
-  ptf::GridTuning tune; // PT_GRID_M / PT_GRID_CELL: the sphere grid's margin and cell size (tools/grid_sweep.sh)
-  if (const char* e = std::getenv("PT_GRID_M")) tune.m = (float)std::atof(e);
-  if (const char* e = std::getenv("PT_GRID_CELL")) tune.cell = (float)std::atof(e);
-  int rc = ptf::flatten(desc, flat, err, std::getenv("PT_NO_GRID") == nullptr, box_cull, tune);
+  int rc = flatten_with_env(desc, flat, err);
   if (rc) return fail(rc, err);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(PT_ERR_NO_DEVICE, "no HIP device visible");
@@ -936,7 +959,7 @@ int pt_scene_create(const PtSceneDesc* desc, PtScene** out_scene) {
   s->n_hittables = desc->n_hittables;
   for (int i = 0; i < desc->n_hittables; i++) {
     switch (desc->hittables[i].kind) {
-      case PT_HIT_SPHERE: s->traversal_cost += 22.0f; break; // (spheres that sit in a culling grid are discounted below)
+      case PT_HIT_SPHERE: s->traversal_cost += 22.0f; break;
       case PT_HIT_TRIANGLE: s->traversal_cost += 35.0f; break;
       case PT_HIT_BOX: s->traversal_cost += 120.0f; break;
       case PT_HIT_CONSTANT_MEDIUM: s->traversal_cost += 300.0f; break;
@@ -967,6 +990,7 @@ void pt_scene_destroy(PtScene* s) {
   if (s->blob) (void)hipFree(s->blob);
   if (s->atlas) (void)hipFree(s->atlas);
   if (s->queues) (void)hipFree(s->queues);
+  for (hipEvent_t e : s->ring_done) if (e) (void)hipEventDestroy(e);
   if (s->ws_cost) (void)hipFree(s->ws_cost);
   if (s->ws_order) (void)hipFree(s->ws_order);
   if (s->ws_nsplit) (void)hipFree(s->ws_nsplit);
@@ -1082,7 +1106,7 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
   // frames / shards kept the cooperative kernels; since the retuning (margin 0.5 r, walk after the big spheres) the walk wins
   // everywhere (tools/grid_min_tiles.py: 400x225x256 spp 99 ms against 108; shard 0/8 of the 1080p frame at 256 spp 80
   // against 102; shard 0/8 of 4K at 128 spp 61 against 102).  PT_GRID_MIN_TILES restores a threshold.
-  const bool use_grid = s->grid_spheres > 0 && local_tiles >= s->knobs.grid_min_tiles && !(p->flags & PT_FLAG_FORCE_COOP);
+  const bool use_grid = s->grid_spheres > 0 && resident /* the streaming kernel scans the full lists */ && local_tiles >= s->knobs.grid_min_tiles && !(p->flags & PT_FLAG_FORCE_COOP);
   const bool coop = lds && a.coop_prefix >= 0 && !use_grid && (s->traversal_cost >= kCoopMinTraversal || (p->flags & PT_FLAG_FORCE_COOP));
   // Persistent grid: no more workgroups than the chip holds at once; lanes pull pixels from the queue.
   auto launch = [&](auto kernel) -> int {
@@ -1095,7 +1119,13 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
     }
     if (s->knobs.blocks_per_cu) per_cu = std::min(per_cu, s->knobs.blocks_per_cu); // tuning knob
     const int resident_blocks = std::max(1, per_cu) * std::max(1, s->num_cus);
-    a.queue = s->queues + 2 * (s->next_queue++ % kQueueRing); // [0] ordinary queue, [1] wide-phase queue
+    // Queue counters come from a ring of kQueueRing slots.  A slot is reused only after the launch that last used it has
+    // finished: the host waits on that launch's event (more than kQueueRing launches in flight on one scene would
+    // otherwise share a dequeue counter and lose or duplicate pixels).
+    const unsigned int slot = s->next_queue++ % kQueueRing;
+    if (s->ring_done[slot]) PT_HIP(hipEventSynchronize(s->ring_done[slot]));
+    else PT_HIP(hipEventCreateWithFlags(&s->ring_done[slot], hipEventDisableTiming));
+    a.queue = s->queues + 2 * slot; // [0] ordinary queue, [1] wide-phase queue
     PT_HIP(hipMemsetAsync(a.queue, 0, 2 * sizeof(unsigned int), st));
     // one wave per tile is enough, except in the wide phase, where a split tile keeps G waves busy (how many tiles are
     // split is decided on the device, so such a launch simply fills the chip; surplus waves find the queues empty and exit)
@@ -1104,6 +1134,7 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
     dim3 grid((unsigned int)std::min<long long>(wanted, resident_blocks)), block(kBlock);
     hipLaunchKernelGGL(kernel, grid, block, shmem, st, a);
     PT_HIP(hipGetLastError());
+    PT_HIP(hipEventRecord(s->ring_done[slot], st));
     return PT_OK;
   };
   auto launch_uv = [&](auto uv) -> int {
@@ -1310,6 +1341,7 @@ int pt_debug_schedule(const PtScene* scene, int32_t out[2]) {
   if (!scene || !out) return fail(PT_ERR_INVALID_ARG, "pt_debug_schedule: NULL argument");
   out[0] = out[1] = 0;
   PT_HIP(hipDeviceSynchronize());
+  std::lock_guard<std::mutex> lock(scene->sched); // last_had_wide_phase / ws_nsplit belong to the launch path
   if (!scene->last_had_wide_phase) return PT_OK;
   int v[2] = {0, 0};
   PT_HIP(hipMemcpy(v, scene->ws_nsplit, sizeof v, hipMemcpyDeviceToHost));

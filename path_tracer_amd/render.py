@@ -52,7 +52,7 @@ def _params(width, height, samples, depth, shard_index=0, shard_count=1, flags=0
 
 def _as_device_scene(scene, cache_key=None) -> DeviceScene:
     """DeviceScene of whatever the caller handed over.  With `cache_key` (the asynchronous torch path) the device scene of a
-    PackedScene is kept on it, per device: no re-flatten / re-upload / hipMalloc per call, and — the point — no temporary
+    PackedScene is kept on it, per (device, stream): no re-flatten / re-upload / hipMalloc per call, and — the point — no temporary
     whose destructor (pt_scene_destroy -> hipFree, an implicit device synchronisation) would run while the kernels it
     launched are still in flight."""
     if isinstance(scene, DeviceScene):
@@ -85,7 +85,9 @@ def render(width: int, height: int, samples: int, scene, cam: camera, depth: int
     if not torch.cuda.is_available():
         raise RuntimeError("path_tracer_amd.render needs a HIP device: there is no CPU path in the product")
     lib = abi.load_library()
-    ds = _as_device_scene(scene, cache_key=("cuda", torch.cuda.current_device()))
+    # one device scene per (device, stream): a PtScene owns per-scene launch workspaces (tile costs / order / partial sums),
+    # so renders on ONE PtScene must be stream-ordered (include/pt_render.h); two streams get two scenes
+    ds = _as_device_scene(scene, cache_key=("cuda", torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream))
     p = _params(width, height, samples, depth, shard_index, shard_count, flags)
     n = lib.pt_framebuffer_floats(C.byref(p))
     if n < 0:

@@ -96,3 +96,41 @@ def test_weak_scaling_frames_keep_pixels_per_gpu_and_aspect():
         assert abs(w / h - 1920 / 1080) < 2e-3
         tiles = ((w + 7) // 8) * ((h + 7) // 8)
         assert abs(tiles / n / 32400 - 1.0) < 0.01  # one 1-GPU frame's worth of tiles per rank
+
+
+def test_pmc_summary_is_selected_by_explicit_final_marker(tmp_path):
+    """bench.py never picks "the newest file by name": only summaries marked `"final": true` qualify, the highest `round`
+    wins, and two finals of one round for one workload are an error (VERDICT r02 / ADVICE r02)."""
+    bench = load_bench()
+
+    def put(name, **kw):
+        d = {"scene": "smoke", "workload": "1920x1080x1024", "derived": {"hbm_bytes_per_launch": kw.pop("hbm")}}
+        d.update(kw)
+        (tmp_path / f"{name}_pmc_summary.json").write_text(json.dumps(d))
+
+    put("r02e_smoke", hbm=1.0, final=True, round=2)
+    put("r02g_smoke", hbm=2.0)                      # sorts later, not final: must be ignored
+    put("r09z_smoke", hbm=3.0, final=False, round=9)
+    assert bench.pmc_traffic("smoke", 1920, 1080, 1024, tmp_path)[:2] == (1.0, "r02e_smoke_pmc_summary.json")
+    put("r03_smoke", hbm=4.0, final=True, round=3)  # sorts EARLIER than r09z / r02g by tag, wins by round
+    assert bench.pmc_traffic("smoke", 1920, 1080, 1024, tmp_path)[0] == 4.0
+    assert bench.pmc_traffic("cornell", 1920, 1080, 1024, tmp_path) is None
+    assert bench.pmc_traffic("smoke", 1920, 1080, 256, tmp_path) is None
+    put("r03b_smoke", hbm=5.0, final=True, round=3)
+    with pytest.raises(RuntimeError):
+        bench.pmc_traffic("smoke", 1920, 1080, 1024, tmp_path)
+
+
+def test_committed_final_summaries_are_unambiguous():
+    """Every (scene, workload) of the committed profiles resolves to at most one final summary."""
+    bench = load_bench()
+    seen = set()
+    for f in (ROOT / "profiles").glob("*_pmc_summary.json"):
+        d = json.loads(f.read_text())
+        if d.get("final"):
+            w, h, spp = (int(x) for x in d["workload"].split("x"))
+            seen.add((d.get("scene", "cornell"), w, h, spp))
+    assert ("cornell", 1920, 1080, 1024) in seen
+    for key in seen:
+        got = bench.pmc_traffic(*key)
+        assert got is not None and got[0] > 0

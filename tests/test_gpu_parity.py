@@ -965,3 +965,45 @@ def test_errors_are_codes_not_crashes(lib):
     with pytest.raises(abi.PtError) as e:
         R.DeviceScene(ps)
     assert e.value.code == abi.PT_ERR_BAD_SCENE
+
+
+def test_more_launches_in_flight_than_queue_ring_slots(torch_gpu, orc):
+    """pt_render is asynchronous; each launch takes a slot of the scene's ring of dequeue counters (kQueueRing = 256).  600
+    back-to-back asynchronous 8x8 renders into 600 framebuffers on one scene and one stream (two slots each: none — the
+    frame is too small for a probe — so 600 slots, the ring wraps twice) must all be the oracle's frame: a wrapped ring
+    waits for the launch that last used the slot instead of sharing its counter."""
+    torch = torch_gpu
+    ps, cam = S.cornell_scene()
+    c = scenes.make_camera(cam, 8, 8)
+    ds = R.DeviceScene(ps)
+    orc.set_math(True)
+    ref = orc.render(ps, c.c, 8, 8, 24)
+    outs = torch.empty((600, 8, 8, 3), dtype=torch.float32, device="cuda")
+    for i in range(600):
+        R.render(8, 8, 24, ds, c, out=outs[i])
+    torch.cuda.synchronize()
+    got = outs.cpu().numpy()
+    for i in (0, 1, 255, 256, 257, 511, 512, 599):
+        assert_bit_identical(got[i], ref, f"launch {i}")
+    assert (got.view(np.uint32) == got[0].view(np.uint32)[None]).all()
+
+
+def test_two_streams_get_two_device_scenes(torch_gpu, orc):
+    """render() keeps one DeviceScene per (PackedScene, device, STREAM): a PtScene's launch workspaces (tile costs / order)
+    are per scene, so concurrent renders from two streams must not share one."""
+    torch = torch_gpu
+    ps, cam = scenes.build("smoke", textures="procedural")
+    c = scenes.make_camera(cam, 320, 184)
+    orc.set_math(True)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    frames = []
+    for rep in range(3):
+        for st in (s1, s2):
+            with torch.cuda.stream(st):
+                frames.append(R.render(320, 184, 64, ps, c))
+    torch.cuda.synchronize()
+    assert len(ps.__dict__["_pt_device_scenes"]) == 2
+    xy = np.stack([np.random.default_rng(4).integers(0, 320, 300), np.random.default_rng(5).integers(0, 184, 300)], axis=1).astype(np.int32)
+    ref = orc.render_pixels(ps, c.c, 320, 184, 64, xy)
+    for k, f in enumerate(frames):
+        assert_bit_identical(f.cpu().numpy()[xy[:, 1], xy[:, 0]], ref, f"frame {k}")

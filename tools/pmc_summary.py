@@ -1,7 +1,10 @@
 """Aggregate rocprofv3 --pmc counter_collection CSVs (one pass per CSV) into one JSON summary for the
 render kernel: per-launch counter sums plus the derived figures DESIGN.md quotes.
 
-  python tools/pmc_summary.py r02_smoke smoke 1920 1080 1024 profiles/r02_smoke_pmc_*.csv > profiles/r02_smoke_pmc_summary.json
+  python tools/pmc_summary.py [--final ROUND] r02_smoke smoke 1920 1080 1024 profiles/r02_smoke_pmc_*.csv > profiles/r02_smoke_pmc_summary.json
+
+--final ROUND marks the summary as THE counters of round ROUND's final build for this (scene, workload): bench.py's
+`pmc_traffic` only ever reads summaries so marked (highest round wins) — never "the newest file by name".
 """
 import collections
 import csv
@@ -10,6 +13,10 @@ import sys
 
 
 def main():
+    final_round = None
+    if sys.argv[1] == "--final":
+        final_round = int(sys.argv[2])
+        del sys.argv[1:3]
     tag, scene, w, h, spp = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
     # A render is two launches of the render kernel (a short cost-probe pass, then the frame): report the
     # frame launch = the dispatch with the largest value, per counter.
@@ -24,6 +31,8 @@ def main():
     per = {k: max(v.values()) for k, v in disp.items()}
     samples = w * h * spp
     out = {"tag": tag, "scene": scene, "workload": f"{w}x{h}x{spp}", "kernel": meta, "per_launch": per, "derived": {}}
+    if final_round is not None:
+        out["final"], out["round"] = True, final_round
     d = out["derived"]
     if "GRBM_GUI_ACTIVE" in per:
         cyc = per["GRBM_GUI_ACTIVE"] / 8  # summed over the 8 XCDs
