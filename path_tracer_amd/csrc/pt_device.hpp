@@ -27,6 +27,16 @@
 #ifdef PT_STAMPS
 extern __device__ unsigned long long g_stamps[8]; // diagnostic build only (pt_render.hip)
 #endif
+#ifdef PT_STAMPS_WALK
+// diagnostic build: per-workgroup counters of the sphere-grid walk in LDS (cheap ds_add; global atomics per step distort the
+// timing they are meant to explain), flushed once by render_kernel.  [0] cycles inside walks (wave leader's clock) [1] walks
+// (waves) [2] wave-steps [3] split phases [4] lane-steps (cells visited by live walks) [5] lane sphere tests [6] wave test trips
+extern __device__ unsigned long long g_walk[8];
+__device__ __forceinline__ unsigned long long* walk_ctr() { __shared__ unsigned long long c[8]; return c; }
+#define PT_WALK_COUNT(i, v) do { const unsigned long long v_ = (unsigned long long)(v); if ((threadIdx.x & 63) == 0) atomicAdd(&walk_ctr()[i], v_); } while (0)
+#else
+#define PT_WALK_COUNT(i, v) do { } while (0)
+#endif
 
 namespace ptd {
 
@@ -92,6 +102,16 @@ __device__ __forceinline__ float sqrt_rn_unit(float x) {
   float r = (r_lo <= 0.0f) ? s_lo : s;
   r = (r_hi > 0.0f) ? s_hi : r;
   return r;
+}
+
+// The same algorithm over the range the compiler's own expansion trusts it on (it rescales only below 2^-96): correctly rounded
+// for every normal x in [2^-96, 2^100] — sqrt is exactly scale-invariant by factors of 4, so the exhaustive check over two
+// adjacent binades carries to all; tests/test_gpu_parity.py::test_unit_range_sqrt_is_correctly_rounded sweeps every float of
+// exponents -96 ... 100 in steps anyway.  x > 0 on every active lane; one lane outside the range (denormal-tiny or huge
+// discriminants) sends the wave through the general expansion.
+__device__ __forceinline__ float sqrt_rn_pos(float x) {
+  if (__builtin_amdgcn_ballot_w64(!(x >= 0x1p-96f && x <= 0x1p100f)) != 0) return __builtin_sqrtf(x);
+  return sqrt_rn_unit(x);
 }
 
 struct Ray {
@@ -195,7 +215,8 @@ struct RayCtx {
   bool live;        // this lane's ray is wanted (idle lanes scan along and their outcome is dropped: they must not vote)
 };
 
-// RN(1/d) for 2^-40 <= |d| <= 2^40: the hardware estimate (v_rcp_f32, <= 1 ulp) and ONE Newton step in fma arithmetic.
+// RN(1/d) for 2^-40 <= |d| <= 2^40 (ray direction components) and for a = d.d of a regular ray (2^-79 <= a <= 2^82: the roots
+// of a culled sphere scan, SphereRoots): the hardware estimate (v_rcp_f32, <= 1 ulp) and ONE Newton step in fma arithmetic.
 // Correctly rounded for EVERY significand: checked exhaustively (all 2^23, both signs, eight exponents across the range;
 // the computation is scale-invariant while nothing over- or underflows) by tests/test_gpu_parity.py::
 // test_guarded_reciprocal_is_correctly_rounded against the IEEE quotient.  3 instructions instead of the ~10 of the full
@@ -602,18 +623,33 @@ __device__ __forceinline__ void hit_begin(HitState& h) { h.closest = PT_INF; h.h
 // the sequential scan's, bit for bit.
 typedef const __attribute__((address_space(4))) i4* cst_i4p;
 
+// How a run's roots (-b -+ sqrt(disc)) / a of sphere.hpp:76,92 are evaluated.  plain: the correctly rounded sqrt and division
+// as the compiler expands them (17 + 12 + 12 issue slots, in a block some lane of a wave enters for nearly every sphere a
+// culled scan still tests).  fast (wave-uniform: every live ray regular, so a = d.d lies in [2^-79, 2^82]): both quotients
+// share their divisor, so ONE correctly rounded reciprocal ya = RN(1/a) per ray and run + the Markstein correction of
+// div_exact give the IEEE quotient whenever the quotient's magnitude is in [2^-12, 2^100]
+// (tests/test_gpu_parity.py::test_fast_division_is_exact, the wide-divisor block); outside that range — and for infinite or
+// NaN numerators — both forms yield a value that fails `min < t < max` with min = 0.001 (a root below 2^-12 in magnitude is
+// below min either way; a root beyond 2^100 needs max = inf, and `inf < inf` and any comparison with NaN are false), so the
+// decision and every accepted t are the same bits.  The sqrt: sqrt_rn_pos.  9 + 5 + 5 slots.
+struct SphereRoots { bool fast; float ya; };
+__device__ __forceinline__ SphereRoots sphere_roots_plain() { return SphereRoots{false, 0.0f}; }
+__device__ __forceinline__ SphereRoots sphere_roots_for(const RayCtx& c, bool fast) { return SphereRoots{fast, fast ? rcp_rn_guarded(c.a) : 0.0f}; }
+
 // sphere_finish with the tie rule (see above); off_here = blob offset of this sphere's record
 template <typename Accept>
 __device__ __forceinline__ void sphere_finish_unordered(SphereEval e, const RayCtx& c, float mn, const HitState& h, int off_here,
-                                                        Accept accept) {
+                                                        SphereRoots rt, Accept accept) {
   if (e.disc > 0) {
     const float mx = h.closest;
     const bool later = (h.hit >= 0) & (hit_off(h.hit) > off_here);
-    float sq = sqrt_rn(e.disc);
-    float temp = (-e.b - sq) / c.a;
+    float sq, temp;
+    if (rt.fast) { sq = sqrt_rn_pos(e.disc); const float n = -e.b - sq; temp = div_exact(n, c.a, rt.ya, n * rt.ya); }
+    else { sq = sqrt_rn(e.disc); temp = (-e.b - sq) / c.a; }
     bool ok = (temp < mx || (temp == mx && later)) && temp > mn;
     if (!ok) {
-      temp = (-e.b + sq) / c.a;
+      if (rt.fast) { const float n = -e.b + sq; temp = div_exact(n, c.a, rt.ya, n * rt.ya); }
+      else temp = (-e.b + sq) / c.a;
       ok = (temp < mx || (temp == mx && later)) && temp > mn;
     }
     if (ok) accept(temp);
@@ -623,7 +659,7 @@ __device__ __forceinline__ void sphere_finish_unordered(SphereEval e, const RayC
 // K spheres of a list entry (K = 4: the whole entry; K = 2: half of it — the kernels that run at a 72-register budget)
 template <bool MOVING, int K, typename P, typename AcceptAt>
 __device__ __forceinline__ void sphere_list_trip(P recs, const int (&o)[K], int goff, float frac, const RayCtx& c, HitState& h,
-                                                 AcceptAt accept_at) {
+                                                 SphereRoots rt, AcceptAt accept_at) {
   const Ray& r = c.r;
   f4 R0[K], R2[K];
   // the run's base address held in a VGPR the compiler cannot see through: each record address is then ONE v_lshl_add_u32
@@ -647,24 +683,24 @@ __device__ __forceinline__ void sphere_list_trip(P recs, const int (&o)[K], int 
     e[k] = SphereEval{b, b * b - c.a * cc};
   }
 #pragma unroll
-  for (int k = 0; k < K; k++) sphere_finish_unordered(e[k], c, PT_TMIN, h, goff + o[k], accept_at(o[k]));
+  for (int k = 0; k < K; k++) sphere_finish_unordered(e[k], c, PT_TMIN, h, goff + o[k], rt, accept_at(o[k]));
 }
 template <bool MOVING, int K, typename P, typename AcceptAt>
-__device__ __forceinline__ void sphere_list_entry(P recs, i4 o4, int goff, float frac, const RayCtx& c, HitState& h, AcceptAt accept_at) {
+__device__ __forceinline__ void sphere_list_entry(P recs, i4 o4, int goff, float frac, const RayCtx& c, HitState& h, SphereRoots rt, AcceptAt accept_at) {
   if constexpr (K >= 4) {
     const int o[4] = {o4.x, o4.y, o4.z, o4.w};
-    sphere_list_trip<MOVING, 4>(recs, o, goff, frac, c, h, accept_at);
+    sphere_list_trip<MOVING, 4>(recs, o, goff, frac, c, h, rt, accept_at);
   } else {
     // Equal neighbouring offsets are the list's padding (its last entry repeated: two records never share an offset), and
     // the offsets are scalars: the repeats are skipped by scalar branches.  Short lists are what a ray of a chain-bound
     // frame spends its time on — the 496-hittable scene tests 7 spheres outside the grid (ground, glowing ball, the five
     // big ones) and did so as 16.
     const int a[2] = {o4.x, o4.y}, b[2] = {o4.z, o4.w}, a1[1] = {o4.x}, b1[1] = {o4.z};
-    if (o4.y == o4.x) { sphere_list_trip<MOVING, 1>(recs, a1, goff, frac, c, h, accept_at); return; }
-    sphere_list_trip<MOVING, 2>(recs, a, goff, frac, c, h, accept_at);
+    if (o4.y == o4.x) { sphere_list_trip<MOVING, 1>(recs, a1, goff, frac, c, h, rt, accept_at); return; }
+    sphere_list_trip<MOVING, 2>(recs, a, goff, frac, c, h, rt, accept_at);
     if (o4.z == o4.y) return;
-    if (o4.w == o4.z) { sphere_list_trip<MOVING, 1>(recs, b1, goff, frac, c, h, accept_at); return; }
-    sphere_list_trip<MOVING, 2>(recs, b, goff, frac, c, h, accept_at);
+    if (o4.w == o4.z) { sphere_list_trip<MOVING, 1>(recs, b1, goff, frac, c, h, rt, accept_at); return; }
+    sphere_list_trip<MOVING, 2>(recs, b, goff, frac, c, h, rt, accept_at);
   }
 }
 
@@ -682,9 +718,13 @@ __device__ __forceinline__ unsigned int ushort_at(const f4* base, int i) { retur
 // the tests does not matter and a sphere listed in several cells is simply re-tested.  The walk ends where the next cell's
 // entry lies beyond the nearest hit so far.  SIMD shape: the wave steps all walks together (a lane past its last cell idles)
 // and, per step, loops to the largest candidate count of the lanes' cells.
+// (Round 3 measured the walk with in-kernel counters — `make stamps EXTRA=-DPT_STAMPS_WALK`, tools/stamps.py — and tried a
+// split phase that hands the rest of the unfinished walks to idle lanes once <= 32 lanes still walk: DESIGN.md, rejected
+// experiments.  The walk is 48 % of a wave-iteration on the 496-hittable scene; 6.3 wave-steps and 17.3 test trips for 2.0
+// cells and 4.1 sphere tests per lane.)
 template <typename P, typename AcceptAt>
 __device__ __forceinline__ void sphere_grid_walk(P recs, P cells, P cand, f4 g0, f4 g1, float frac, int goff, const RayCtx& c,
-                                                 HitState& h, AcceptAt accept_at) {
+                                                 HitState& h, SphereRoots rt, AcceptAt accept_at) {
   const Ray& r = c.r;
   const float inv = g0.w, cell = g1.w;
   const int nx = as_i(g1.x), ny = as_i(g1.y), nz = as_i(g1.z);
@@ -713,6 +753,8 @@ __device__ __forceinline__ void sphere_grid_walk(P recs, P cells, P cand, f4 g0,
   unsigned int hdr = 0;
   if (active) hdr = dword_at(cells, (iz * ny + iy) * nx + ix);
   while (__builtin_amdgcn_ballot_w64(active) != 0) {
+    PT_WALK_COUNT(2, 1);
+    PT_WALK_COUNT(4, __builtin_popcountll(__builtin_amdgcn_ballot_w64(active)));
     // the next cell (the axis whose boundary comes first; branch-free) and its header, requested BEFORE this cell's tests:
     // the walk of a lone wave is a chain of dependent LDS reads, this takes one of them off the chain
     const float tn = __builtin_fminf(tmx, __builtin_fminf(tmy, tmz));
@@ -723,6 +765,8 @@ __device__ __forceinline__ void sphere_grid_walk(P recs, P cells, P cand, f4 g0,
     if (active & inside) hdr_next = dword_at(cells, (jz * ny + jy) * nx + jx);
     const int count = (int)(hdr & 255u), first = (int)(hdr >> 8);
     for (int k = 0; __builtin_amdgcn_ballot_w64(k < count) != 0; ++k) {
+      PT_WALK_COUNT(6, 1);
+      PT_WALK_COUNT(5, __builtin_popcountll(__builtin_amdgcn_ballot_w64(k < count)));
       if (k < count) {
         const unsigned int e = ushort_at(cand, first + k); // sphere index in the run | moving << 15
         const int o = (int)(e & 0x7fffu) * SZ_SPHERE;
@@ -732,7 +776,7 @@ __device__ __forceinline__ void sphere_grid_walk(P recs, P cells, P cand, f4 g0,
         V3 oc = r.o - center;
         float b = dot(oc, r.d);
         float cc = dot(oc, oc) - __builtin_fabsf(R0.w);
-        sphere_finish_unordered(SphereEval{b, b * b - c.a * cc}, c, PT_TMIN, h, goff + o, accept_at(o));
+        sphere_finish_unordered(SphereEval{b, b * b - c.a * cc}, c, PT_TMIN, h, goff + o, rt, accept_at(o));
       }
     }
     // step: the walk ends where the next cell lies outside the grid or begins beyond the nearest hit so far
@@ -747,8 +791,9 @@ __device__ __forceinline__ void sphere_grid_walk(P recs, P cells, P cand, f4 g0,
 // GRID = false: the kernel does not carry the grid walk (the streaming kernel: its register budget belongs to the triangle
 // loop); a run with a grid is then scanned through its full lists.
 template <int K, bool GRID, typename P, typename AcceptAt>
-__device__ __forceinline__ void sphere_scan(P recs, cst_f4p cblob, int n, int goff, const RayCtx& c, HitState& h, AcceptAt accept_at) {
+__device__ __forceinline__ void sphere_scan(P recs, cst_f4p cblob, int n, int goff, const RayCtx& c, bool fast, HitState& h, AcceptAt accept_at) {
   const f4 aux = cblob[goff - 1];
+  const SphereRoots rt = sphere_roots_for(c, fast); // one reciprocal of a = d.d per ray and run
   const int flags = as_i(aux.w), ns = as_i(aux.z), nm = n - ns;
   if (!(flags & 1)) { // moving spheres with different shutter intervals: one sphere at a time in list order, fraction memoised
     TimeFrac tf = time_frac_none();
@@ -770,7 +815,7 @@ __device__ __forceinline__ void sphere_scan(P recs, cst_f4p cblob, int n, int go
     // the walk is exact for a regular ray that starts within rlimit of the grid and (if something moves) whose time lies in
     // the run's shutter interval, so that centres stay between centre0 and centre1; one live lane outside -> full lists
     const bool ok = c.reg && dot(dc, dc) <= g2.w && (!(flags & 2) || (c.r.tm >= aux.x && c.r.tm <= aux.y));
-#ifdef PT_STAMPS
+#if defined(PT_STAMPS) && !defined(PT_STAMPS_WALK)
     { // diagnostic build: how often a wave may walk the grid, and why not (far origin / irregular / shutter)
       const unsigned long long bad = __builtin_amdgcn_ballot_w64(c.live && !ok);
       const unsigned long long far = __builtin_amdgcn_ballot_w64(c.live && !(dot(dc, dc) <= g2.w));
@@ -791,17 +836,26 @@ __device__ __forceinline__ void sphere_scan(P recs, cst_f4p cblob, int n, int go
   i4 cur = lists[0];
   for (int q = 0; q < q_static; ++q) {
     const i4 nxt = lists[q + 1];
-    sphere_list_entry<false, K>(recs, cur, goff, 0.0f, c, h, accept_at);
+    sphere_list_entry<false, K>(recs, cur, goff, 0.0f, c, h, rt, accept_at);
     cur = nxt;
   }
   for (int q = 0; q < q_moving; ++q) {
     const i4 nxt = lists[q_static + q + 1];
-    sphere_list_entry<true, K>(recs, cur, goff, frac, c, h, accept_at);
+    sphere_list_entry<true, K>(recs, cur, goff, frac, c, h, rt, accept_at);
     cur = nxt;
   }
   // the walk comes after the big spheres (any order gives the same result: the tie rule is explicit): a ground hit found
   // first ends the walks of the rays that go down where they reach it
-  if constexpr (GRID) { if (walk) sphere_grid_walk(recs, recs + w_cell, recs + w_cand, wg0, wg1, frac, goff, c, h, accept_at); }
+#ifdef PT_STAMPS_WALK
+  const unsigned long long walk_t0 = __builtin_amdgcn_s_memtime();
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+  if constexpr (GRID) { if (walk) sphere_grid_walk(recs, recs + w_cell, recs + w_cand, wg0, wg1, frac, goff, c, h, rt, accept_at); }
+#ifdef PT_STAMPS_WALK
+  asm volatile("" ::"v"(h.closest), "v"(h.hit));
+  __builtin_amdgcn_sched_barrier(0);
+  if (GRID && walk) { PT_WALK_COUNT(0, __builtin_amdgcn_s_memtime() - walk_t0); PT_WALK_COUNT(1, 1); }
+#endif
 }
 
 // n records of one kind at recs[0..): record i is blob offset goff + i*size.  `recs` is either the resident
@@ -1017,7 +1071,7 @@ __device__ __forceinline__ void hit_records(P recs, cst_f4p cblob, int kind, int
     };
     // (a run of one or two spheres — a lone ball between other kinds — is tested in place: the list machinery would cost it
     // two dependent scalar loads before the first record is even requested)
-    if (WHOLE && n > 2) sphere_scan<(TRIP >= 2 ? 4 : 2), GRID>(recs, cblob, n, goff, c, h, accept_at);
+    if (WHOLE && n > 2) sphere_scan<(TRIP >= 2 ? 4 : 2), GRID>(recs, cblob, n, goff, c, fast, h, accept_at);
     else {
       TimeFrac tf = time_frac_none();
       for (int i = 0; i < n; ++i, off += SZ_SPHERE) sphere_roots(recs, off, c, PT_TMIN, h.closest, true, tf, accept_at(off));
@@ -1142,11 +1196,11 @@ __device__ __forceinline__ void hit_records_strided(P recs, cst_f4p cblob, int k
           return i4{as_i(v.x), as_i(v.y), as_i(v.z), as_i(v.w)};
         };
         for (int e = j, i = 0; i < ((qs + G - 1) >> logG); ++i, e += G)
-          sphere_list_entry<false, PT_STRIDED_K>(recs, entry(min(e, qs - 1)), goff, 0.0f, c, h, accept_at);
+          sphere_list_entry<false, PT_STRIDED_K>(recs, entry(min(e, qs - 1)), goff, 0.0f, c, h, sphere_roots_plain(), accept_at);
         if (qm) {
           const float frac = (r.tm - aux.x) / (aux.y - aux.x); // sphere.hpp:54
           for (int e = j, i = 0; i < ((qm + G - 1) >> logG); ++i, e += G)
-            sphere_list_entry<true, PT_STRIDED_K>(recs, entry(qs + min(e, qm - 1)), goff, frac, c, h, accept_at);
+            sphere_list_entry<true, PT_STRIDED_K>(recs, entry(qs + min(e, qm - 1)), goff, frac, c, h, sphere_roots_plain(), accept_at);
         }
       }
     }
@@ -1202,7 +1256,7 @@ __device__ __forceinline__ int record_size(int kind) {
 // kernel constants: an s_load lands in SGPRs directly, no LDS round trip + v_readfirstlane per run) and the records from LDS.
 // `cblob`: the blob in global memory through the scalar cache (run headers, sphere-run masks); `blob`: where the records are
 // read from (LDS copy, or the same global blob).
-template <bool IMG, bool BADOUEL = false, typename P>
+template <bool IMG, bool BADOUEL = false, bool GRID = true, typename P>
 __device__ __forceinline__ void hit_world(P blob, cst_f4p cblob, int n_runs, const RayCtx& c, bool fast, uint32_t& rng, HitState& h) {
   hit_begin(h);
   for (int ri = 0; ri < n_runs; ++ri) {
@@ -1218,7 +1272,7 @@ __device__ __forceinline__ void hit_world(P blob, cst_f4p cblob, int n_runs, con
         }
       }
     }
-    hit_records<IMG, 1, 1, true, BADOUEL>(blob + off, cblob, kind, as_i(runf.z), off, c, fast, rng, h);
+    hit_records<IMG, 1, 1, true, BADOUEL, GRID>(blob + off, cblob, kind, as_i(runf.z), off, c, fast, rng, h);
   }
 }
 

@@ -31,6 +31,9 @@
 #ifdef PT_STAMPS
 __device__ unsigned long long g_stamps[8];
 #endif
+#ifdef PT_STAMPS_WALK
+__device__ unsigned long long g_walk[8];
+#endif
 
 using namespace ptd;
 
@@ -370,7 +373,10 @@ __device__ __forceinline__ void lane_prepare(Lane& L, const KArgs& a) {
 // CL: the cold part of the lane state lives in LDS (Cold<true>); small scenes only (8 KB per workgroup).
 // FAST: PT_FLAG_FAST_RNG (opt-in decorrelated mode; its own instantiations, so the parity kernels carry none of it)
 // BADOUEL: the scene has Badouel-strategy triangles (their loop is compiled only into these instantiations)
-template <int UV, bool LDS, bool MLDS, bool COOP, bool CL = false, bool FAST = false, bool BADOUEL = false>
+// GRID: the kernel carries the sphere-grid walk (pt_device.hpp: sphere_grid_walk).  Scenes without a culling grid and without
+// an image texture — the headline Cornell-style scene — run instantiations without it (less code in the hot kernel, and
+// nothing the walk needs can weigh on its 72-register budget).
+template <int UV, bool LDS, bool MLDS, bool COOP, bool CL = false, bool FAST = false, bool BADOUEL = false, bool GRID = true>
 __global__ __launch_bounds__(kBlock, CL ? PT_MIN_WAVES_CL : COOP ? (UV ? PT_MIN_WAVES_COOP_IMG : PT_MIN_WAVES_COOP) : (UV ? PT_MIN_WAVES_IMG : PT_MIN_WAVES))
 void render_kernel(KArgs a) {
   constexpr bool IMG = UV == UV_TRACKED;
@@ -382,6 +388,10 @@ void render_kernel(KArgs a) {
     for (int i = threadIdx.x; i < n; i += kBlock) smem[i] = a.blob[i];
     __syncthreads();
   }
+#ifdef PT_STAMPS_WALK
+  if (threadIdx.x < 8) walk_ctr()[threadIdx.x] = 0;
+  __syncthreads();
+#endif
   Lane L;
   lane_reset(L, (lds_fp)cold_slots);
   if (COOP && a.n_split) {
@@ -414,7 +424,7 @@ void render_kernel(KArgs a) {
         RayCtx c = make_ctx(L.ray, a.fast_ok != 0);
         c.live = L.live;
         const bool fast = wave_all_regular(c, L.live);
-        hit_world<IMG, BADOUEL>((lds_f4p)smem, (cst_f4p)a.blob, a.n_runs, c, fast, L.rng, h);
+        hit_world<IMG, BADOUEL, GRID>((lds_f4p)smem, (cst_f4p)a.blob, a.n_runs, c, fast, L.rng, h);
       }
 #ifdef PT_STAMPS
       asm volatile("" ::"v"(h.closest), "v"(h.hit));
@@ -431,10 +441,14 @@ void render_kernel(KArgs a) {
       RayCtx c = make_ctx(L.ray, a.fast_ok != 0);
       c.live = L.live;
       const bool fast = wave_all_regular(c, L.live);
-      hit_world<IMG, BADOUEL>((cst_f4p)a.blob, (cst_f4p)a.blob, a.n_runs, c, fast, L.rng, h);
+      hit_world<IMG, BADOUEL, GRID>((cst_f4p)a.blob, (cst_f4p)a.blob, a.n_runs, c, fast, L.rng, h);
       lane_shade<UV, FAST>(L, a, h, a.blob, a.mats);
     }
   }
+#ifdef PT_STAMPS_WALK
+  __syncthreads();
+  if (threadIdx.x < 8) atomicAdd(&g_walk[threadIdx.x], walk_ctr()[threadIdx.x]);
+#endif
 #ifdef PT_STAMPS
   if ((threadIdx.x & 63) == 0) {
     atomicAdd(&g_stamps[0], s_prep); atomicAdd(&g_stamps[1], s_trav); atomicAdd(&g_stamps[2], s_shade);
@@ -518,10 +532,11 @@ __global__ __launch_bounds__(kBlock) void render_kernel_stream(KArgs a) {
 }
 
 // The reference's single-task executor (render.hpp:113-122, USE_SINGLE_TASK): one default-seeded RNG for the whole frame,
-// pixels x-outer / y-inner.  One sequential chain by definition, so one lane runs it (launch <<<1, 64>>>, lane 0 works);
+// pixels x-outer / y-inner.  One sequential chain by definition, so one wave runs it (launch <<<1, 64>>>, every lane the same);
 // u,v are tracked through the scan as the reference's temp_rec does (no per-scene kernel choice for a parity-only mode).
 __global__ __launch_bounds__(64) void render_single_stream_kernel(KArgs a) {
-  if (threadIdx.x != 0) return;
+  // all 64 lanes run the same chain redundantly (the traversal's wave-level exchanges need a full wave); lane 0 stores
+  const bool writer = threadIdx.x == 0;
   const cst_f4p cblob = (cst_f4p)a.blob;
   uint32_t rng = 2463534242u; // xorshift.hpp:18
   for (int x = 0; x != a.width; ++x)
@@ -544,7 +559,7 @@ __global__ __launch_bounds__(64) void render_single_stream_kernel(KArgs a) {
       }
       const V3 mean = acc / (float)a.samples;
       float* px = a.fb + ((long long)y * a.width + x) * 3;
-      px[0] = mean.x; px[1] = mean.y; px[2] = mean.z;
+      if (writer) { px[0] = mean.x; px[1] = mean.y; px[2] = mean.z; }
     }
 }
 
@@ -630,7 +645,10 @@ __global__ void bounce_kernel(const f4* __restrict__ blob, int n_runs, const f4*
                               const uint8_t* __restrict__ atlas, const PtBounceIn* __restrict__ in,
                               PtBounceOut* __restrict__ outp, int n, int fast_ok) {
   int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= n) return;
+  // every lane of the wave stays active (the tail repeats the last record and does not store): the traversal exchanges data
+  // between lanes (grid walk split phase: ds_bpermute, DPP), and a lane that has exited reads as zero there
+  const bool valid_lane = k < n;
+  if (!valid_lane) k = n - 1;
   PtBounceIn I = in[k];
   Ray ray;
   ray.o = mk(I.origin[0], I.origin[1], I.origin[2]);
@@ -672,7 +690,7 @@ __global__ void bounce_kernel(const f4* __restrict__ blob, int n_runs, const f4*
     }
   }
   O.rng_state = rng;
-  outp[k] = O;
+  if (valid_lane) outp[k] = O;
 }
 
 __global__ void camera_rays_kernel(Cam cam, int width, int height, const int* __restrict__ xy,
@@ -705,6 +723,8 @@ __global__ void math_kernel(int op, const float* __restrict__ a, const float* __
     case 9: { float yy = 1.0f / y; r = div_exact(x, y, yy, x * yy); break; } // the shared-reciprocal quotient (|q| >= 2^-60)
     case 10: r = rcp_rn_guarded(x); break; // RN(1/a) for 2^-40 <= |a| <= 2^40 (pt_device.hpp: make_ctx)
     case 11: r = sqrt_rn_unit(x); break;   // correctly rounded sqrt for x = 0 or 2^-60 <= x <= 4
+    case 12: r = sqrt_rn_pos(x); break;    // the sphere roots' sqrt: x > 0, the fast form inside [2^-96, 2^100]
+    case 13: { float yy = rcp_rn_guarded(y); r = div_exact(x, y, yy, x * yy); break; } // a root's quotient as the fast sphere roots form it
     default: r = x / y; break;
   }
   out[i] = r;
@@ -1150,6 +1170,14 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
       return mlds ? launch(render_kernel<UV, true, true, false, false, true>) : launch(render_kernel<UV, true, false, false, false, true>);
     }
     if (!resident) return launch(render_kernel_stream<UV>);
+    if constexpr (UV == UV_NONE) { // no image texture and no sphere grid (the headline scene): kernels without the grid walk
+      if (s->grid_spheres == 0 && !coop) {
+        if (!lds) return launch(render_kernel<UV, false, false, false, false, false, false, false>);
+        if (mlds && shmem <= kMaxLdsColdScene && !s->knobs.no_cold_lds) return launch(render_kernel<UV, true, true, false, true, false, false, false>);
+        return mlds ? launch(render_kernel<UV, true, true, false, false, false, false, false>)
+                    : launch(render_kernel<UV, true, false, false, false, false, false, false>);
+      }
+    }
     if (!lds) return launch(render_kernel<UV, false, false, false>);
     if (coop) return mlds ? launch(render_kernel<UV, true, true, true>) : launch(render_kernel<UV, true, false, true>);
     if constexpr (UV == UV_NONE) { // small scene: cold lane state in LDS (7 workgroups x (scene + 8 KB) per CU)
@@ -1315,6 +1343,13 @@ int pt_debug_stamps(unsigned long long* out8, int reset) { // diagnostic build o
   if (reset) { unsigned long long z[8] = {0}; PT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof z)); }
   return PT_OK;
 }
+#ifdef PT_STAMPS_WALK
+int pt_debug_walk(unsigned long long* out8, int reset) { // -DPT_STAMPS_WALK: counters of the sphere-grid walk (pt_device.hpp: walk_ctr)
+  if (out8) PT_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_walk), 8 * sizeof(unsigned long long)));
+  if (reset) { unsigned long long z[8] = {0}; PT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_walk), z, sizeof z)); }
+  return PT_OK;
+}
+#endif
 #endif
 
 // ---- probes: host arrays in/out ------------------------------------------------------------------------
@@ -1371,8 +1406,8 @@ int pt_debug_camera_rays(const PtCamera* cam, int32_t width, int32_t height, con
 }
 
 int pt_debug_math(int32_t op, const float* a, const float* b, float* out, int64_t n) {
-  if (!a || !out || n < 0 || op < 0 || op > 11) return fail(PT_ERR_INVALID_ARG, "pt_debug_math: bad argument");
-  if ((op == 4 || op == 8 || op == 9) && !b) return fail(PT_ERR_INVALID_ARG, "pt_debug_math: op needs two operands");
+  if (!a || !out || n < 0 || op < 0 || op > 13) return fail(PT_ERR_INVALID_ARG, "pt_debug_math: bad argument");
+  if ((op == 4 || op == 8 || op == 9 || op == 13) && !b) return fail(PT_ERR_INVALID_ARG, "pt_debug_math: op needs two operands");
   if (n == 0) return PT_OK;
   DevBuf<float> da, db, dout;
   PT_HIP(da.alloc(n));

@@ -39,8 +39,9 @@ def usage():
 
 
 def test_headline_kernels_fit_seven_waves_without_scratch(usage):
-    # render_kernel<UV_NONE, LDS, MLDS, COOP=false, CL, FAST=false, BADOUEL=false>: mangled ...render_kernelILi0ELb?ELb?ELb0ELb?ELb0ELb0E...
-    hot = {k: v for k, v in usage.items() if re.search(r"render_kernelILi0ELb[01]ELb[01]ELb0ELb[01]ELb0ELb0E", k)}
+    # render_kernel<UV_NONE, LDS, MLDS, COOP=false, CL, FAST=false, BADOUEL=false, GRID=false>: the instantiations scenes without a
+    # sphere grid (the headline Cornell-style scene) run; mangled ...render_kernelILi0ELb?ELb?ELb0ELb?ELb0ELb0ELb0E...
+    hot = {k: v for k, v in usage.items() if re.search(r"render_kernelILi0ELb[01]ELb[01]ELb0ELb[01]ELb0ELb0ELb0E", k)}
     assert len(hot) == 4, sorted(usage)
     for k, v in hot.items():
         # the kernel the headline config runs (cold lane state in LDS: CL = 1) has no scratch at all; the variants that keep
@@ -48,6 +49,18 @@ def test_headline_kernels_fit_seven_waves_without_scratch(usage):
         cold_in_lds = re.search(r"render_kernelILi0ELb1ELb1ELb0ELb1E", k) is not None
         assert v["ScratchSize [bytes/lane]"] <= (0 if cold_in_lds else 28), (k, v)
         assert v["VGPRs"] <= 72 and v["Occupancy [waves/SIMD]"] >= 7, (k, v)
+
+
+def test_grid_walk_kernels_keep_five_waves(usage):
+    """The kernels that carry the sphere-grid walk and its split phase (GRID = true; cfg1 / cfg3 / cfg4 run the UV_WINNER one)
+    hold 5 waves per SIMD — what the scene's 31 KB LDS image allows anyway — and their scratch traffic stays outside the
+    walk: a few dwords parked per loop iteration (checked in the ISA when the split phase went in: no scratch instruction
+    between the walk's first and last block)."""
+    grid = {k: v for k, v in usage.items() if re.search(r"render_kernelILi[01]ELb[01]ELb[01]ELb0ELb[01]ELb0ELb0ELb1E", k)}
+    assert len(grid) >= 7, sorted(usage)
+    for k, v in grid.items():
+        assert v["Occupancy [waves/SIMD]"] >= 5 and v["VGPRs"] <= 96, (k, v)
+        assert v["ScratchSize [bytes/lane]"] <= 72, (k, v)
 
 
 def test_streaming_and_cooperative_kernels_without_image_textures(usage):
