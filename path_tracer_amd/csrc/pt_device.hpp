@@ -104,16 +104,6 @@ __device__ __forceinline__ float sqrt_rn_unit(float x) {
   return r;
 }
 
-// The same algorithm over the range the compiler's own expansion trusts it on (it rescales only below 2^-96): correctly rounded
-// for every normal x in [2^-96, 2^100] — sqrt is exactly scale-invariant by factors of 4, so the exhaustive check over two
-// adjacent binades carries to all; tests/test_gpu_parity.py::test_unit_range_sqrt_is_correctly_rounded sweeps every float of
-// exponents -96 ... 100 in steps anyway.  x > 0 on every active lane; one lane outside the range (denormal-tiny or huge
-// discriminants) sends the wave through the general expansion.
-__device__ __forceinline__ float sqrt_rn_pos(float x) {
-  if (__builtin_amdgcn_ballot_w64(!(x >= 0x1p-96f && x <= 0x1p100f)) != 0) return __builtin_sqrtf(x);
-  return sqrt_rn_unit(x);
-}
-
 struct Ray {
   V3 o, d;
   float tm;
@@ -215,8 +205,7 @@ struct RayCtx {
   bool live;        // this lane's ray is wanted (idle lanes scan along and their outcome is dropped: they must not vote)
 };
 
-// RN(1/d) for 2^-40 <= |d| <= 2^40 (ray direction components) and for a = d.d of a regular ray (2^-79 <= a <= 2^82: the roots
-// of a culled sphere scan, SphereRoots): the hardware estimate (v_rcp_f32, <= 1 ulp) and ONE Newton step in fma arithmetic.
+// RN(1/d) for 2^-40 <= |d| <= 2^40: the hardware estimate (v_rcp_f32, <= 1 ulp) and ONE Newton step in fma arithmetic.
 // Correctly rounded for EVERY significand: checked exhaustively (all 2^23, both signs, eight exponents across the range;
 // the computation is scale-invariant while nothing over- or underflows) by tests/test_gpu_parity.py::
 // test_guarded_reciprocal_is_correctly_rounded against the IEEE quotient.  3 instructions instead of the ~10 of the full
@@ -623,33 +612,22 @@ __device__ __forceinline__ void hit_begin(HitState& h) { h.closest = PT_INF; h.h
 // the sequential scan's, bit for bit.
 typedef const __attribute__((address_space(4))) i4* cst_i4p;
 
-// How a run's roots (-b -+ sqrt(disc)) / a of sphere.hpp:76,92 are evaluated.  plain: the correctly rounded sqrt and division
-// as the compiler expands them (17 + 12 + 12 issue slots, in a block some lane of a wave enters for nearly every sphere a
-// culled scan still tests).  fast (wave-uniform: every live ray regular, so a = d.d lies in [2^-79, 2^82]): both quotients
-// share their divisor, so ONE correctly rounded reciprocal ya = RN(1/a) per ray and run + the Markstein correction of
-// div_exact give the IEEE quotient whenever the quotient's magnitude is in [2^-12, 2^100]
-// (tests/test_gpu_parity.py::test_fast_division_is_exact, the wide-divisor block); outside that range — and for infinite or
-// NaN numerators — both forms yield a value that fails `min < t < max` with min = 0.001 (a root below 2^-12 in magnitude is
-// below min either way; a root beyond 2^100 needs max = inf, and `inf < inf` and any comparison with NaN are false), so the
-// decision and every accepted t are the same bits.  The sqrt: sqrt_rn_pos.  9 + 5 + 5 slots.
-struct SphereRoots { bool fast; float ya; };
-__device__ __forceinline__ SphereRoots sphere_roots_plain() { return SphereRoots{false, 0.0f}; }
-__device__ __forceinline__ SphereRoots sphere_roots_for(const RayCtx& c, bool fast) { return SphereRoots{fast, fast ? rcp_rn_guarded(c.a) : 0.0f}; }
-
 // sphere_finish with the tie rule (see above); off_here = blob offset of this sphere's record
+// (Round 3 tried the roots through ONE reciprocal of a = d.d per ray and run + div_exact's correction and a range-guarded
+// v_sqrt + neighbour test — 19 issue slots instead of 41, bit-exact in an exhaustive sweep — and the 496-hittable scene got
+// 2.5 % SLOWER: its frames follow the dependent chain of an iteration, and the corrected quotient is five dependent fma
+// where the compiler's expansion overlaps its steps.  Not kept; DESIGN.md, rejected experiments.)
 template <typename Accept>
 __device__ __forceinline__ void sphere_finish_unordered(SphereEval e, const RayCtx& c, float mn, const HitState& h, int off_here,
-                                                        SphereRoots rt, Accept accept) {
+                                                        Accept accept) {
   if (e.disc > 0) {
     const float mx = h.closest;
     const bool later = (h.hit >= 0) & (hit_off(h.hit) > off_here);
-    float sq, temp;
-    if (rt.fast) { sq = sqrt_rn_pos(e.disc); const float n = -e.b - sq; temp = div_exact(n, c.a, rt.ya, n * rt.ya); }
-    else { sq = sqrt_rn(e.disc); temp = (-e.b - sq) / c.a; }
+    float sq = sqrt_rn(e.disc);
+    float temp = (-e.b - sq) / c.a;
     bool ok = (temp < mx || (temp == mx && later)) && temp > mn;
     if (!ok) {
-      if (rt.fast) { const float n = -e.b + sq; temp = div_exact(n, c.a, rt.ya, n * rt.ya); }
-      else temp = (-e.b + sq) / c.a;
+      temp = (-e.b + sq) / c.a;
       ok = (temp < mx || (temp == mx && later)) && temp > mn;
     }
     if (ok) accept(temp);
@@ -659,7 +637,7 @@ __device__ __forceinline__ void sphere_finish_unordered(SphereEval e, const RayC
 // K spheres of a list entry (K = 4: the whole entry; K = 2: half of it — the kernels that run at a 72-register budget)
 template <bool MOVING, int K, typename P, typename AcceptAt>
 __device__ __forceinline__ void sphere_list_trip(P recs, const int (&o)[K], int goff, float frac, const RayCtx& c, HitState& h,
-                                                 SphereRoots rt, AcceptAt accept_at) {
+                                                 AcceptAt accept_at) {
   const Ray& r = c.r;
   f4 R0[K], R2[K];
   // the run's base address held in a VGPR the compiler cannot see through: each record address is then ONE v_lshl_add_u32
@@ -683,24 +661,24 @@ __device__ __forceinline__ void sphere_list_trip(P recs, const int (&o)[K], int 
     e[k] = SphereEval{b, b * b - c.a * cc};
   }
 #pragma unroll
-  for (int k = 0; k < K; k++) sphere_finish_unordered(e[k], c, PT_TMIN, h, goff + o[k], rt, accept_at(o[k]));
+  for (int k = 0; k < K; k++) sphere_finish_unordered(e[k], c, PT_TMIN, h, goff + o[k], accept_at(o[k]));
 }
 template <bool MOVING, int K, typename P, typename AcceptAt>
-__device__ __forceinline__ void sphere_list_entry(P recs, i4 o4, int goff, float frac, const RayCtx& c, HitState& h, SphereRoots rt, AcceptAt accept_at) {
+__device__ __forceinline__ void sphere_list_entry(P recs, i4 o4, int goff, float frac, const RayCtx& c, HitState& h, AcceptAt accept_at) {
   if constexpr (K >= 4) {
     const int o[4] = {o4.x, o4.y, o4.z, o4.w};
-    sphere_list_trip<MOVING, 4>(recs, o, goff, frac, c, h, rt, accept_at);
+    sphere_list_trip<MOVING, 4>(recs, o, goff, frac, c, h, accept_at);
   } else {
     // Equal neighbouring offsets are the list's padding (its last entry repeated: two records never share an offset), and
     // the offsets are scalars: the repeats are skipped by scalar branches.  Short lists are what a ray of a chain-bound
     // frame spends its time on — the 496-hittable scene tests 7 spheres outside the grid (ground, glowing ball, the five
     // big ones) and did so as 16.
     const int a[2] = {o4.x, o4.y}, b[2] = {o4.z, o4.w}, a1[1] = {o4.x}, b1[1] = {o4.z};
-    if (o4.y == o4.x) { sphere_list_trip<MOVING, 1>(recs, a1, goff, frac, c, h, rt, accept_at); return; }
-    sphere_list_trip<MOVING, 2>(recs, a, goff, frac, c, h, rt, accept_at);
+    if (o4.y == o4.x) { sphere_list_trip<MOVING, 1>(recs, a1, goff, frac, c, h, accept_at); return; }
+    sphere_list_trip<MOVING, 2>(recs, a, goff, frac, c, h, accept_at);
     if (o4.z == o4.y) return;
-    if (o4.w == o4.z) { sphere_list_trip<MOVING, 1>(recs, b1, goff, frac, c, h, rt, accept_at); return; }
-    sphere_list_trip<MOVING, 2>(recs, b, goff, frac, c, h, rt, accept_at);
+    if (o4.w == o4.z) { sphere_list_trip<MOVING, 1>(recs, b1, goff, frac, c, h, accept_at); return; }
+    sphere_list_trip<MOVING, 2>(recs, b, goff, frac, c, h, accept_at);
   }
 }
 
@@ -724,7 +702,7 @@ __device__ __forceinline__ unsigned int ushort_at(const f4* base, int i) { retur
 // cells and 4.1 sphere tests per lane.)
 template <typename P, typename AcceptAt>
 __device__ __forceinline__ void sphere_grid_walk(P recs, P cells, P cand, f4 g0, f4 g1, float frac, int goff, const RayCtx& c,
-                                                 HitState& h, SphereRoots rt, AcceptAt accept_at) {
+                                                 HitState& h, AcceptAt accept_at) {
   const Ray& r = c.r;
   const float inv = g0.w, cell = g1.w;
   const int nx = as_i(g1.x), ny = as_i(g1.y), nz = as_i(g1.z);
@@ -776,7 +754,7 @@ __device__ __forceinline__ void sphere_grid_walk(P recs, P cells, P cand, f4 g0,
         V3 oc = r.o - center;
         float b = dot(oc, r.d);
         float cc = dot(oc, oc) - __builtin_fabsf(R0.w);
-        sphere_finish_unordered(SphereEval{b, b * b - c.a * cc}, c, PT_TMIN, h, goff + o, rt, accept_at(o));
+        sphere_finish_unordered(SphereEval{b, b * b - c.a * cc}, c, PT_TMIN, h, goff + o, accept_at(o));
       }
     }
     // step: the walk ends where the next cell lies outside the grid or begins beyond the nearest hit so far
@@ -791,9 +769,8 @@ __device__ __forceinline__ void sphere_grid_walk(P recs, P cells, P cand, f4 g0,
 // GRID = false: the kernel does not carry the grid walk (the streaming kernel: its register budget belongs to the triangle
 // loop); a run with a grid is then scanned through its full lists.
 template <int K, bool GRID, typename P, typename AcceptAt>
-__device__ __forceinline__ void sphere_scan(P recs, cst_f4p cblob, int n, int goff, const RayCtx& c, bool fast, HitState& h, AcceptAt accept_at) {
+__device__ __forceinline__ void sphere_scan(P recs, cst_f4p cblob, int n, int goff, const RayCtx& c, HitState& h, AcceptAt accept_at) {
   const f4 aux = cblob[goff - 1];
-  const SphereRoots rt = sphere_roots_for(c, fast); // one reciprocal of a = d.d per ray and run
   const int flags = as_i(aux.w), ns = as_i(aux.z), nm = n - ns;
   if (!(flags & 1)) { // moving spheres with different shutter intervals: one sphere at a time in list order, fraction memoised
     TimeFrac tf = time_frac_none();
@@ -836,12 +813,12 @@ __device__ __forceinline__ void sphere_scan(P recs, cst_f4p cblob, int n, int go
   i4 cur = lists[0];
   for (int q = 0; q < q_static; ++q) {
     const i4 nxt = lists[q + 1];
-    sphere_list_entry<false, K>(recs, cur, goff, 0.0f, c, h, rt, accept_at);
+    sphere_list_entry<false, K>(recs, cur, goff, 0.0f, c, h, accept_at);
     cur = nxt;
   }
   for (int q = 0; q < q_moving; ++q) {
     const i4 nxt = lists[q_static + q + 1];
-    sphere_list_entry<true, K>(recs, cur, goff, frac, c, h, rt, accept_at);
+    sphere_list_entry<true, K>(recs, cur, goff, frac, c, h, accept_at);
     cur = nxt;
   }
   // the walk comes after the big spheres (any order gives the same result: the tie rule is explicit): a ground hit found
@@ -850,7 +827,7 @@ __device__ __forceinline__ void sphere_scan(P recs, cst_f4p cblob, int n, int go
   const unsigned long long walk_t0 = __builtin_amdgcn_s_memtime();
   __builtin_amdgcn_sched_barrier(0);
 #endif
-  if constexpr (GRID) { if (walk) sphere_grid_walk(recs, recs + w_cell, recs + w_cand, wg0, wg1, frac, goff, c, h, rt, accept_at); }
+  if constexpr (GRID) { if (walk) sphere_grid_walk(recs, recs + w_cell, recs + w_cand, wg0, wg1, frac, goff, c, h, accept_at); }
 #ifdef PT_STAMPS_WALK
   asm volatile("" ::"v"(h.closest), "v"(h.hit));
   __builtin_amdgcn_sched_barrier(0);
@@ -1071,7 +1048,7 @@ __device__ __forceinline__ void hit_records(P recs, cst_f4p cblob, int kind, int
     };
     // (a run of one or two spheres — a lone ball between other kinds — is tested in place: the list machinery would cost it
     // two dependent scalar loads before the first record is even requested)
-    if (WHOLE && n > 2) sphere_scan<(TRIP >= 2 ? 4 : 2), GRID>(recs, cblob, n, goff, c, fast, h, accept_at);
+    if (WHOLE && n > 2) sphere_scan<(TRIP >= 2 ? 4 : 2), GRID>(recs, cblob, n, goff, c, h, accept_at);
     else {
       TimeFrac tf = time_frac_none();
       for (int i = 0; i < n; ++i, off += SZ_SPHERE) sphere_roots(recs, off, c, PT_TMIN, h.closest, true, tf, accept_at(off));
@@ -1196,11 +1173,11 @@ __device__ __forceinline__ void hit_records_strided(P recs, cst_f4p cblob, int k
           return i4{as_i(v.x), as_i(v.y), as_i(v.z), as_i(v.w)};
         };
         for (int e = j, i = 0; i < ((qs + G - 1) >> logG); ++i, e += G)
-          sphere_list_entry<false, PT_STRIDED_K>(recs, entry(min(e, qs - 1)), goff, 0.0f, c, h, sphere_roots_plain(), accept_at);
+          sphere_list_entry<false, PT_STRIDED_K>(recs, entry(min(e, qs - 1)), goff, 0.0f, c, h, accept_at);
         if (qm) {
           const float frac = (r.tm - aux.x) / (aux.y - aux.x); // sphere.hpp:54
           for (int e = j, i = 0; i < ((qm + G - 1) >> logG); ++i, e += G)
-            sphere_list_entry<true, PT_STRIDED_K>(recs, entry(qs + min(e, qm - 1)), goff, frac, c, h, sphere_roots_plain(), accept_at);
+            sphere_list_entry<true, PT_STRIDED_K>(recs, entry(qs + min(e, qm - 1)), goff, frac, c, h, accept_at);
         }
       }
     }

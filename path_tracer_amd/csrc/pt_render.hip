@@ -723,8 +723,6 @@ __global__ void math_kernel(int op, const float* __restrict__ a, const float* __
     case 9: { float yy = 1.0f / y; r = div_exact(x, y, yy, x * yy); break; } // the shared-reciprocal quotient (|q| >= 2^-60)
     case 10: r = rcp_rn_guarded(x); break; // RN(1/a) for 2^-40 <= |a| <= 2^40 (pt_device.hpp: make_ctx)
     case 11: r = sqrt_rn_unit(x); break;   // correctly rounded sqrt for x = 0 or 2^-60 <= x <= 4
-    case 12: r = sqrt_rn_pos(x); break;    // the sphere roots' sqrt: x > 0, the fast form inside [2^-96, 2^100]
-    case 13: { float yy = rcp_rn_guarded(y); r = div_exact(x, y, yy, x * yy); break; } // a root's quotient as the fast sphere roots form it
     default: r = x / y; break;
   }
   out[i] = r;
@@ -1406,8 +1404,8 @@ int pt_debug_camera_rays(const PtCamera* cam, int32_t width, int32_t height, con
 }
 
 int pt_debug_math(int32_t op, const float* a, const float* b, float* out, int64_t n) {
-  if (!a || !out || n < 0 || op < 0 || op > 13) return fail(PT_ERR_INVALID_ARG, "pt_debug_math: bad argument");
-  if ((op == 4 || op == 8 || op == 9 || op == 13) && !b) return fail(PT_ERR_INVALID_ARG, "pt_debug_math: op needs two operands");
+  if (!a || !out || n < 0 || op < 0 || op > 11) return fail(PT_ERR_INVALID_ARG, "pt_debug_math: bad argument");
+  if ((op == 4 || op == 8 || op == 9) && !b) return fail(PT_ERR_INVALID_ARG, "pt_debug_math: op needs two operands");
   if (n == 0) return PT_OK;
   DevBuf<float> da, db, dout;
   PT_HIP(da.alloc(n));
