@@ -318,9 +318,15 @@ int pt_debug_camera_rays(const PtCamera* cam, int32_t width, int32_t height,
 /* Host-only view of what pt_scene_create() uploads (no GPU needed): the flattened blob
  * ([n_runs run headers (device kind, first record offset, count, first hittable)] then the
  * per-kind 16-byte records) and the material table (4 x 16 bytes each, texture inlined).
- * Pass NULL buffers to query the sizes.  flags_out: bit0 = has image texture, bit1 = has medium. */
+ * Pass NULL buffers to query the sizes.  flags_out: bit0 = has image texture, bit1 = has medium, bit2 = a triangle run
+ * carries a triangle pool (exact culling tables for long runs of Moller-Trumbore triangles; csrc/pt_tripool.hpp).        */
 int pt_debug_flatten(const PtSceneDesc* desc, float* blob_out, int64_t blob_cap_f4, int32_t* n_blob_f4,
                      int32_t* n_runs, float* mats_out, int64_t mats_cap_f4, int32_t* flags_out);
+
+/* Host-only statistics of the triangle pool pt_scene_create() would build (no GPU needed): out[0] = triangles in pooled runs,
+ * out[1] = entries of the always list, out[2..4] = triangles on the three cube-map band levels, out[5] = 1000 x mean grid cells
+ * per triangle, out[6] = blob size in 16-byte records, out[7] = 0.  All zero when the scene gets no pool.                 */
+int pt_debug_tri_pool(const PtSceneDesc* desc, int32_t out[8]);
 
 /* What the scheduler decided for the LAST render of this scene (blocks until that render is done): out[0] = tiles sent
  * through the wide phase, out[1] = lanes per pixel there (0 when the render had no cost-probe pass or used a kernel

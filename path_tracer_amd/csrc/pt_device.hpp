@@ -27,6 +27,11 @@
 #ifdef PT_STAMPS
 extern __device__ unsigned long long g_stamps[8]; // diagnostic build only (pt_render.hip)
 #endif
+#ifdef PT_STAMPS_TRI
+// diagnostic build (triangle pool): [0] scans (waves) [1] lane grid tests [2] lane band (cheap) tests [3] lane exact tests from the
+// band / always list [4] wave grid-test trips [5] wave cheap-test trips [6] flushes [7] fallbacks to the full scan
+extern __device__ unsigned long long g_tri[8];
+#endif
 #ifdef PT_STAMPS_WALK
 // diagnostic build: per-workgroup counters of the sphere-grid walk in LDS (cheap ds_add; global atomics per step distort the
 // timing they are meant to explain), flushed once by render_kernel.  [0] cycles inside walks (wave leader's clock) [1] walks
@@ -44,6 +49,7 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 typedef int i4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(3))) f4* lds_f4p; // LDS-resident blob
 typedef const __attribute__((address_space(4))) f4* cst_f4p; // global blob via scalar (SMEM) loads
+typedef const __attribute__((address_space(1))) f4* glb_f4p; // the same blob for per-lane (VMEM) loads: the triangle pool
 
 // device kinds of a run / hit id (not the ABI tags: the three rect axes share one kind)
 enum { DK_SPHERE = 0, DK_RECT = 1, DK_TRI = 2, DK_BOX = 3, DK_MEDIUM = 4, DK_TRI_B = 5 /* Badouel-strategy triangles */ };
@@ -1026,7 +1032,206 @@ __device__ __forceinline__ void slab_pool(P blob, cst_f4p cblob, int pool_off, i
   }
 }
 
-template <bool IMG, int TRIP = 1, int TTRIP = TRIP, bool WHOLE = true, bool BADOUEL = false, bool GRID = true, typename P>
+// ---- a long run of Moller-Trumbore triangles, culled exactly ("triangle pool") ----------------------------------------------
+// pt_tripool.hpp states what the tables are and proves that the three candidate sources below — the grid walk for the
+// triangles a ray does not graze, the cube-map strips for the ones it does, the always list for slivers — contain every
+// triangle the reference's scan could accept.  Every candidate runs the reference's own instructions (tri_eval + the second
+// half below) with the scan's acceptance spelled out for any order: min <= t <= closest, and an equal t replaces the
+// holder unless the holder is a LATER record (triangle.hpp:91 accepts t == max: the last in list order wins; records keep
+// list order in the blob).  Re-testing a triangle is therefore a no-op, and a triangle found by two sources is harmless.
+// All table reads are per-lane global loads (each lane walks its own ray): this path belongs to scenes far beyond LDS.
+#ifdef PT_STAMPS_TRI
+#define PT_TRI_COUNT(i, v) do { const unsigned long long v_ = (unsigned long long)(v); if ((threadIdx.x & 63) == 0) atomicAdd(&g_tri[i], v_); } while (0)
+#else
+#define PT_TRI_COUNT(i, v) do { } while (0)
+#endif
+
+__device__ __forceinline__ void tri_test_unordered(glb_f4p gblob, int o, const Ray& r, HitState& h) {
+  const f4 R0 = gblob[o], R1 = gblob[o + 1], R2 = gblob[o + 2];
+  const TriEval e = tri_eval(R0, R1, R2, r);
+  if (e.pass) {
+    const float a_abs = __builtin_fabsf(e.a);
+    const bool a_pos = e.a > 0.0f;
+    const V3 edge1 = xyz(R1), edge2 = xyz(R2);
+    const V3 s = r.o - xyz(R0);
+    const V3 q = cross(s, edge1);
+    const float v = dot(r.d, q);
+    const bool v_pos = v > 0.0f;
+    if (!((v_pos != a_pos) | (__builtin_fabsf(e.u + v) > a_abs))) {
+      const float t = dot(edge2, q) / e.a;
+      // (pool scenes and regular rays: t is finite.)  the scan's `!(t < min || t > max)` with the tie rule for any order
+      const bool holder_later = (h.hit >= 0) & (hit_off(h.hit) > o);
+      if (!(t < PT_TMIN) && (t < h.closest || (t == h.closest && !holder_later))) { h.closest = t; h.hit = hit_pack(DK_TRI, 0, o); }
+    }
+  }
+}
+
+__device__ __forceinline__ unsigned int gdword(glb_f4p gblob, int base_f4, int i) { return ((const __attribute__((address_space(1))) unsigned int*)(gblob + base_f4))[i]; }
+
+// returns false when some live lane's ray is outside what the pool is exact for (irregular, or its origin beyond rlimit): the
+// caller then scans the whole run.
+// Memory shape: every list a lane streams (a cell's candidates, a strip row's candidates) is CONTIGUOUS and carries the
+// records its filters need inline, and the next entry is requested while the current one is tested; only the exact test of
+// the few survivors gathers (three records of the triangle itself), and those are parked and run for the whole wave at once.
+__device__ __forceinline__ bool tri_pool_scan(glb_f4p gblob, cst_f4p cblob, int hdr, int goff, const RayCtx& c, HitState& h) {
+  const Ray& r = c.r;
+  const f4 H0 = cblob[hdr], H1 = cblob[hdr + 1], H2 = cblob[hdr + 2], H3 = cblob[hdr + 3], H4 = cblob[hdr + 4], H5 = cblob[hdr + 5], H6 = cblob[hdr + 6];
+  const V3 oc = r.o - xyz(H2);
+  const float oc2 = dot(oc, oc);
+  if (__builtin_amdgcn_ballot_w64(c.live && !(c.reg && oc2 <= H3.x)) != 0) { PT_TRI_COUNT(7, 1); return false; }
+  PT_TRI_COUNT(0, 1);
+  const int cell_first = as_i(H4.x), cell_cand = as_i(H4.y), always_idx = as_i(H4.z), cell_ball = as_i(H4.w), acheap = as_i(H5.x);
+  // does the ray's LINE pass within `rad` of the point C?  (both filters of pt_tripool.hpp; necessary conditions)
+  auto near_line = [&](V3 C, float rad) {
+    const V3 x = cross(C - r.o, r.d);
+    return dot(x, x) <= rad * rad * c.a * 1.00001f;
+  };
+  // A lane whose candidate passes its filters parks the triangle; the exact test runs for the whole wave when some lane gets its
+  // second one (and at the end): once per ~10-50 trips instead of in nearly every one.
+  int pend = -1;
+  auto flush = [&]() {
+    PT_TRI_COUNT(6, 1);
+    PT_TRI_COUNT(3, __builtin_popcountll(__builtin_amdgcn_ballot_w64(pend >= 0)));
+    if (pend >= 0) tri_test_unordered(gblob, goff + 3 * pend, r, h);
+    pend = -1;
+  };
+  auto park = [&](bool pass, int i) {
+    if (__builtin_amdgcn_ballot_w64(pass && pend >= 0) != 0) flush();
+    pend = pass ? i : pend;
+  };
+  // ---- (1) the grid: cells of the segment [0, closest (1 + kappa)] -------------------------------------------------------------
+  {
+    const float inv = H0.w, cell = H1.w, kappa = H3.y;
+    const int nx = as_i(H1.x), ny = as_i(H1.y), nz = as_i(H1.z);
+    const float gx = (r.o.x - H0.x) * inv, gy = (r.o.y - H0.y) * inv, gz = (r.o.z - H0.z) * inv;
+    const float rx = c.yx * cell, ry = c.yy * cell, rz = c.yz * cell;
+    const float ax = (0.0f - gx) * rx, bx = ((float)nx - gx) * rx;
+    const float ay = (0.0f - gy) * ry, by = ((float)ny - gy) * ry;
+    const float az = (0.0f - gz) * rz, bz = ((float)nz - gz) * rz;
+    const float t_in = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
+    const float t_out = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
+    const float t0 = __builtin_fmaxf(t_in, 0.0f);
+    // closest (1 + kappa), then the walk's own slack as in the sphere grid (relative 1e-4: rounding of the boundaries' parameters)
+    auto limit = [&]() { const float m = __builtin_fminf(t_out, h.closest + h.closest * kappa); return m + (__builtin_fabsf(m) * 1e-4f + 1e-4f); };
+    bool active = c.live && t0 <= limit();
+    const float px = gx + t0 * (r.d.x * inv), py = gy + t0 * (r.d.y * inv), pz = gz + t0 * (r.d.z * inv);
+    int ix = min(max((int)__builtin_floorf(px), 0), nx - 1);
+    int iy = min(max((int)__builtin_floorf(py), 0), ny - 1);
+    int iz = min(max((int)__builtin_floorf(pz), 0), nz - 1);
+    const bool fx = r.d.x > 0.0f, fy = r.d.y > 0.0f, fz = r.d.z > 0.0f;
+    float tmx = ((float)(ix + (fx ? 1 : 0)) - gx) * rx, tmy = ((float)(iy + (fy ? 1 : 0)) - gy) * ry, tmz = ((float)(iz + (fz ? 1 : 0)) - gz) * rz;
+    const float dtx = __builtin_fabsf(rx), dty = __builtin_fabsf(ry), dtz = __builtin_fabsf(rz);
+    const int stx = fx ? 1 : -1, sty = fy ? 1 : -1, stz = fz ? 1 : -1;
+    int k0 = 0, k1 = 0;
+    if (active) { const int ci = (iz * ny + iy) * nx + ix; k0 = (int)gdword(gblob, cell_first, ci); k1 = (int)gdword(gblob, cell_first, ci + 1); }
+    while (__builtin_amdgcn_ballot_w64(active) != 0) {
+      // the next cell and its candidate range, requested before this cell's candidates are scanned
+      const float tn = __builtin_fminf(tmx, __builtin_fminf(tmy, tmz));
+      const bool sx = tmx == tn, sy = !sx & (tmy == tn), sz = !sx & !sy;
+      ix += sx ? stx : 0; iy += sy ? sty : 0; iz += sz ? stz : 0;
+      const bool inside = ((unsigned)ix < (unsigned)nx) & ((unsigned)iy < (unsigned)ny) & ((unsigned)iz < (unsigned)nz);
+      int n0 = 0, n1 = 0;
+      if (active & inside) { const int ci = (iz * ny + iy) * nx + ix; n0 = (int)gdword(gblob, cell_first, ci); n1 = (int)gdword(gblob, cell_first, ci + 1); }
+      f4 B = f4{0, 0, 0, 0};
+      int bi = 0;
+      if (k0 < k1) { B = gblob[cell_ball + k0]; bi = (int)gdword(gblob, cell_cand, k0); }
+      for (int k = k0; __builtin_amdgcn_ballot_w64(k < k1) != 0; ++k) {
+        PT_TRI_COUNT(4, 1);
+        PT_TRI_COUNT(1, __builtin_popcountll(__builtin_amdgcn_ballot_w64(k < k1)));
+        f4 Bn = f4{0, 0, 0, 0};
+        int bn = 0;
+        if (k + 1 < k1) { Bn = gblob[cell_ball + k + 1]; bn = (int)gdword(gblob, cell_cand, k + 1); }
+        park(k < k1 && near_line(xyz(B), B.w), bi); // within L (1 + 8.5 / (M - 1)) of the centroid (the radius rides in the record)
+        B = Bn; bi = bn;
+      }
+      // the walk ends where the next cell lies outside the grid or begins beyond the nearest hit so far (parked candidates
+      // have not lowered `closest` yet: the walk only runs a little longer for it)
+      active = active & inside & !(tn > limit());
+      tmx += sx ? dtx : 0.0f; tmy += sy ? dty : 0.0f; tmz += sz ? dtz : 0.0f;
+      k0 = active ? n0 : 0; k1 = active ? n1 : 0;
+    }
+  }
+  // ---- (2) + (3): the triangles this ray grazes -------------------------------------------------------------------------------
+  // band test of triangle i: |d . g_i| <= |d| (rho + c_i), (g_i, c_i) its band record; rho and |d| rounded up
+  const float rho = (__builtin_amdgcn_sqrtf(oc2) + H2.w) * 1.000002f;
+  const float dn = __builtin_amdgcn_sqrtf(c.a) * 1.000002f;
+  // band test, then the noise-radius filter: the line within L + kr rho |d| / (|a'| - ea |d|) of the centroid
+  auto band_pass = [&](f4 G, f4 Bc) {
+    const float dg = __builtin_fabsf(r.d.x * G.x + r.d.y * G.y + r.d.z * G.z);
+    if (!(dg <= dn * (rho + G.w))) return false;
+    const float L = Bc.w, L2 = L * L;
+    const float a1 = dg * (H5.z * L) - H6.w * L2 * dn;                 // |a'| - ea |d|   (|a'| = |d . g| P, P = (P / L) L)
+    const float rr = (H6.y + H6.z * L) * L2 * rho * dn / a1;           // the noise radius; a1 <= 0: no bound
+    return !(a1 > 0.0f) || near_line(xyz(Bc), L + rr + H6.x);
+  };
+  const V3 dh = __builtin_amdgcn_rsqf(c.a) * r.d; // unit direction (a few ulp: covered by the strips' absolute slack)
+  const int n_levels = as_i(H3.w);
+  for (int lv = 0; lv < n_levels; ++lv) {
+    const f4 L0 = cblob[hdr + 7 + 3 * lv], T0 = cblob[hdr + 8 + 3 * lv], T1 = cblob[hdr + 9 + 3 * lv];
+    const int R = as_i(L0.x);
+    if (as_i(L0.y) == 0) continue;
+    const float W = 1.7320509f * (rho * L0.z + L0.w) * 1.00001f + 2e-5f; // |A p + B q + C| <= sqrt(3) tau on the face of n's largest component
+    const float step = 2.0f / (float)R, halfR = 0.5f * (float)R;
+    for (int face = 0; face < 3; ++face) {
+      const float A = face == 0 ? dh.y : face == 1 ? dh.z : dh.x; // face k: (p, q) = (n_a, n_b) / n_k, a = k + 1, b = k + 2 (mod 3)
+      const float B = face == 0 ? dh.z : face == 1 ? dh.x : dh.y;
+      const float C = face == 0 ? dh.x : face == 1 ? dh.y : dh.z;
+      const bool reach = c.live && (__builtin_fabsf(A) + __builtin_fabsf(B) + W >= __builtin_fabsf(C)); // can the strip meet the square?
+      if (__builtin_amdgcn_ballot_w64(reach) == 0) continue;
+      // rows along the axis with the smaller coefficient; the other coordinate solved: y(x) = -(C + mn x) / mj.  Orientation 0
+      // (|A| >= |B|): rows are q-rows, cells contiguous in p; orientation 1: rows are p-columns, cells contiguous in q.
+      const bool swp = __builtin_fabsf(B) > __builtin_fabsf(A);
+      const float mj = swp ? B : A, mn = swp ? A : B;
+      const float ninv = -1.0f / mj;
+      const float hw = W * __builtin_fabsf(ninv) * 1.00001f + 2e-5f;
+      const int tf = swp ? as_i(T1.x) : as_i(T0.x), tc = swp ? as_i(T1.y) : as_i(T0.y), tr = swp ? as_i(T1.z) : as_i(T0.z);
+      auto row_range = [&](int rr, int& k0, int& k1) { // the candidate range of row rr of this lane's strip (two loads)
+        const float x0 = -1.0f + (float)rr * step, x1 = x0 + step;
+        const float y0 = (C + mn * x0) * ninv, y1 = (C + mn * x1) * ninv;
+        const float ylo = __builtin_fminf(y0, y1) - hw, yhi = __builtin_fmaxf(y0, y1) + hw;
+        const int c0 = (int)__builtin_floorf((__builtin_fmaxf(ylo, -1.0f) + 1.0f) * halfR);
+        const int c1 = min((int)__builtin_floorf((__builtin_fminf(yhi, 1.0f) + 1.0f) * halfR), R - 1);
+        k0 = 0; k1 = 0;
+        if (reach && yhi >= -1.0f && ylo <= 1.0f && c0 <= c1) { // (NaN: nothing)
+          const int base = (face * R + rr) * R;
+          k0 = (int)gdword(gblob, tf, base + c0); k1 = (int)gdword(gblob, tf, base + c1 + 1);
+        }
+      };
+      int k0, k1;
+      row_range(0, k0, k1);
+      for (int rr = 0; rr < R; ++rr) {
+        int n0 = 0, n1 = 0;
+        if (rr + 1 < R) row_range(rr + 1, n0, n1); // in flight while this row's candidates are scanned
+        f4 G = f4{0, 0, 0, 0}, Bc = G;
+        int gi = 0;
+        if (k0 < k1) { G = gblob[tr + 2 * k0]; Bc = gblob[tr + 2 * k0 + 1]; gi = (int)gdword(gblob, tc, k0); }
+        for (int k = k0; __builtin_amdgcn_ballot_w64(k < k1) != 0; ++k) {
+          PT_TRI_COUNT(5, 1);
+          PT_TRI_COUNT(2, __builtin_popcountll(__builtin_amdgcn_ballot_w64(k < k1)));
+          f4 Gn = f4{0, 0, 0, 0}, Bn = Gn;
+          int gn = 0;
+          if (k + 1 < k1) { Gn = gblob[tr + 2 * k + 2]; Bn = gblob[tr + 2 * k + 3]; gn = (int)gdword(gblob, tc, k + 1); }
+          park(k < k1 && band_pass(G, Bc), gi);
+          G = Gn; Bc = Bn; gi = gn;
+        }
+        k0 = n0; k1 = n1;
+      }
+    }
+  }
+  // (3) the always list: wave-uniform, its records through the scalar cache
+  const int n_always = as_i(H3.z);
+  for (int k = 0; k < n_always; ++k) {
+    const f4 G = cblob[acheap + 2 * k], Bc = cblob[acheap + 2 * k + 1];
+    const int i = (int)(((const __attribute__((address_space(4))) unsigned int*)(cblob + always_idx))[k]);
+    PT_TRI_COUNT(5, 1);
+    PT_TRI_COUNT(2, __builtin_popcountll(__builtin_amdgcn_ballot_w64(c.live)));
+    park(c.live && band_pass(G, Bc), i);
+  }
+  if (__builtin_amdgcn_ballot_w64(pend >= 0) != 0) flush();
+  return true;
+}
+
+template <bool IMG, int TRIP = 1, int TTRIP = TRIP, bool WHOLE = true, bool BADOUEL = false, bool GRID = true, bool TRIPOOL = false, typename P>
 __device__ __forceinline__ void hit_records(P recs, cst_f4p cblob, int kind, int n, int goff,
                                             const RayCtx& c, bool fast, uint32_t& rng, HitState& h) {
   const Ray& r = c.r;
@@ -1065,6 +1270,13 @@ __device__ __forceinline__ void hit_records(P recs, cst_f4p cblob, int kind, int
       }
     }
   } else if (kind == DK_TRI) {
+    if constexpr (TRIPOOL && WHOLE) { // a long run with a triangle pool (flag + header offset in the run's aux record)
+      const f4 aux = cblob[goff - 1];
+      if (as_i(aux.x) != 0 && fast) {
+        const glb_f4p gblob = (glb_f4p)(unsigned long long)cblob; // the same blob, for per-lane loads
+        if (tri_pool_scan(gblob, cblob, as_i(aux.y), goff, c, h)) return;
+      }
+    }
     auto accept_at = [&](int o) { return [&h, goff, o](float t) { h.closest = t; h.hit = hit_pack(DK_TRI, 0, goff + o); }; };
     int i = 0;
     // two triangles per trip: six record reads in flight together, two independent arithmetic chains, half the loop
@@ -1233,7 +1445,7 @@ __device__ __forceinline__ int record_size(int kind) {
 // kernel constants: an s_load lands in SGPRs directly, no LDS round trip + v_readfirstlane per run) and the records from LDS.
 // `cblob`: the blob in global memory through the scalar cache (run headers, sphere-run masks); `blob`: where the records are
 // read from (LDS copy, or the same global blob).
-template <bool IMG, bool BADOUEL = false, bool GRID = true, typename P>
+template <bool IMG, bool BADOUEL = false, bool GRID = true, bool TRIPOOL = false, typename P>
 __device__ __forceinline__ void hit_world(P blob, cst_f4p cblob, int n_runs, const RayCtx& c, bool fast, uint32_t& rng, HitState& h) {
   hit_begin(h);
   for (int ri = 0; ri < n_runs; ++ri) {
@@ -1249,7 +1461,7 @@ __device__ __forceinline__ void hit_world(P blob, cst_f4p cblob, int n_runs, con
         }
       }
     }
-    hit_records<IMG, 1, 1, true, BADOUEL, GRID>(blob + off, cblob, kind, as_i(runf.z), off, c, fast, rng, h);
+    hit_records<IMG, 1, 1, true, BADOUEL, GRID, TRIPOOL>(blob + off, cblob, kind, as_i(runf.z), off, c, fast, rng, h);
   }
 }
 

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/pt_render.h"
+#include "pt_tripool.hpp"
 
 namespace ptf {
 
@@ -37,6 +38,9 @@ struct Flat {
   bool has_badouel = false; // some triangle uses the Badouel strategy (its own device kind and kernel instantiations)
   int grid_spheres = 0;     // spheres that sit in a culling grid (pt_scene_create: their scan is cheap)
   int pooled = 0;           // rects and boxes that sit in a slab pool (pt_device.hpp: slab_pool)
+  int tri_pooled = 0;       // triangles that sit in a triangle pool (pt_tripool.hpp; pt_device.hpp: tri_pool_scan)
+  double tri_cells_per_triangle = 0; // statistics of the (last) triangle pool, for the tests
+  int tri_always = 0, tri_level_counts[3] = {0, 0, 0};
 };
 
 inline int device_kind(int32_t k) {
@@ -271,7 +275,58 @@ inline void put_box(std::vector<F4>& b, const float* f, int32_t mat, int32_t hid
 }
 
 // box_cull: 0 = no slab pools, 1 = where the cost model says they pay, 2 = every stretch of >= 2 rects / boxes (tests)
-inline int flatten(const PtSceneDesc* sc, Flat& out, std::string& err, bool allow_grid = true, int box_cull = 1, GridTuning tune = GridTuning()) {
+// In front of a triangle run's records: ONE aux F4 = (1 if the run has a triangle pool else 0, header offset, 0, 0), and for a
+// pooled run, before it, the pool's tables and its 11-F4 header (pt_device.hpp: tri_pool_scan reads them):
+//   H0 (grid origin xyz, 1 / cell)   H1 (nx, ny, nz, cell)   H2 (centre xyz, R)   H3 (rlimit^2, kappa, n_always, n_levels)
+//   H4 (cell_first, cell_cand, always index list, the grid candidates' inline (centroid, filter radius) records: blob offsets)
+//   H5 (band records of the always list, per-triangle (centroid, L) records: blob offsets; P / L, k_sigma)
+//   H6 (ball_abs, kr_a, kr_b, ea)
+//   per level k, three F4: (R, triangles, pn_max, qn_max) (first, cand, inline band records of orientation 0) (... of orientation 1)
+inline int32_t put_tri_pool(std::vector<F4>& b, const TriPool& tp) {
+  auto put_u32 = [&](const std::vector<uint32_t>& v) { const int32_t at = (int32_t)b.size(); put_dwords(b, v.data(), v.size()); if (v.empty()) b.push_back({0, 0, 0, 0}); b.push_back({0, 0, 0, 0}); return at; };
+  // records INLINE beside the candidate lists, in candidate order (a lane streams its cell's / its strip's candidates from
+  // consecutive addresses instead of gathering one record per index): grid candidates carry (centroid, filter radius), band
+  // candidates their band record (g, c).  Each array is followed by a spare entry (the scans request one ahead).
+  auto put_inline = [&](const std::vector<uint32_t>& idx, auto rec_of) {
+    const int32_t at = (int32_t)b.size();
+    for (uint32_t i : idx) rec_of(i);
+    b.push_back({0, 0, 0, 0}); b.push_back({0, 0, 0, 0}); b.push_back({0, 0, 0, 0}); b.push_back({0, 0, 0, 0});
+    return at;
+  };
+  // grid candidate: one F4 (centroid, L k_sigma + ball_abs); band candidate: two F4 (g, c) (centroid, L)
+  auto ball_rec = [&](uint32_t i) { b.push_back(F4{tp.ball[(size_t)i * 4], tp.ball[(size_t)i * 4 + 1], tp.ball[(size_t)i * 4 + 2], tp.ball[(size_t)i * 4 + 3] * tp.k_sigma + tp.ball_abs}); };
+  auto band_rec = [&](uint32_t i) {
+    b.push_back(F4{tp.cheap[(size_t)i * 4], tp.cheap[(size_t)i * 4 + 1], tp.cheap[(size_t)i * 4 + 2], tp.cheap[(size_t)i * 4 + 3]});
+    b.push_back(F4{tp.ball[(size_t)i * 4], tp.ball[(size_t)i * 4 + 1], tp.ball[(size_t)i * 4 + 2], tp.ball[(size_t)i * 4 + 3]});
+  };
+  const int32_t cell_first = put_u32(tp.cell_first), cell_cand = put_u32(tp.cell_cand), cell_ball = put_inline(tp.cell_cand, ball_rec);
+  const int32_t always = put_u32(tp.always), acheap = put_inline(tp.always, band_rec);
+  const int32_t ball = 0; // (every record the filters need rides inline)
+  int32_t lfirst[3][2], lcand[3][2], lrec[3][2];
+  for (int k = 0; k < 3; k++)
+    for (int o = 0; o < 2; o++) {
+      lfirst[k][o] = put_u32(tp.levels[(size_t)k].first[o]); lcand[k][o] = put_u32(tp.levels[(size_t)k].cand[o]);
+      lrec[k][o] = put_inline(tp.levels[(size_t)k].cand[o], band_rec);
+    }
+  const int32_t hdr = (int32_t)b.size();
+  b.push_back({tp.origin[0], tp.origin[1], tp.origin[2], tp.inv_cell});
+  b.push_back({as_f(tp.n[0]), as_f(tp.n[1]), as_f(tp.n[2]), tp.cell});
+  b.push_back({tp.centre[0], tp.centre[1], tp.centre[2], tp.R});
+  b.push_back({tp.rlimit2, tp.kappa, as_f((int32_t)tp.always.size()), as_f(3)});
+  b.push_back({as_f(cell_first), as_f(cell_cand), as_f(always), as_f(cell_ball)});
+  b.push_back({as_f(acheap), as_f(ball), tp.p_per_L, tp.k_sigma});
+  b.push_back({tp.ball_abs, tp.kr_a, tp.kr_b, tp.ea});
+  for (int k = 0; k < 3; k++) {
+    const TriPoolLevel& L = tp.levels[(size_t)k];
+    b.push_back({as_f(L.R), as_f((int32_t)L.cand[0].size()), L.pn_max, L.qn_max});
+    b.push_back({as_f(lfirst[k][0]), as_f(lcand[k][0]), as_f(lrec[k][0]), 0});
+    b.push_back({as_f(lfirst[k][1]), as_f(lcand[k][1]), as_f(lrec[k][1]), 0});
+  }
+  return hdr;
+}
+
+inline int flatten(const PtSceneDesc* sc, Flat& out, std::string& err, bool allow_grid = true, int box_cull = 1, GridTuning tune = GridTuning(),
+                   bool allow_tri_pool = true, TriPoolTuning tri_tune = TriPoolTuning()) {
   int rc = validate(sc, err);
   if (rc) return rc;
   out = Flat();
@@ -379,6 +434,22 @@ inline int flatten(const PtSceneDesc* sc, Flat& out, std::string& err, bool allo
         out.pooled += n;
       }
       b.push_back({bmax, as_f(pool ? span : 0), as_f(pool_off), as_f(pool ? n : 0)});
+    }
+    if (run.kind == DK_TRI) { // (Badouel-strategy runs have no pool: one parity-completeness loop)
+      int32_t hdr = 0;
+      bool pooled = false;
+      if (allow_tri_pool) {
+        const TriPool tp = build_tri_pool(&sc->hittables[run.first], run.count, tri_tune);
+        if (tp.ok) {
+          hdr = put_tri_pool(b, tp);
+          pooled = true;
+          out.tri_pooled += run.count;
+          out.tri_cells_per_triangle = tp.mean_cells_per_triangle;
+          out.tri_always = (int)tp.always.size();
+          for (int k = 0; k < 3; k++) out.tri_level_counts[k] = (int)tp.levels[(size_t)k].cand[0].size();
+        }
+      }
+      b.push_back({as_f(pooled ? 1 : 0), as_f(hdr), 0, 0});
     }
     b[ri] = {as_f(run.kind), as_f((int32_t)b.size()), as_f(run.count), as_f(run.first)};
     for (int i = run.first; i < run.first + run.count; i++) {

@@ -34,6 +34,9 @@ __device__ unsigned long long g_stamps[8];
 #ifdef PT_STAMPS_WALK
 __device__ unsigned long long g_walk[8];
 #endif
+#ifdef PT_STAMPS_TRI
+__device__ unsigned long long g_tri[8];
+#endif
 
 using namespace ptd;
 
@@ -53,6 +56,9 @@ namespace {
 #endif
 #ifndef PT_MIN_WAVES_COOP
 #define PT_MIN_WAVES_COOP 5 /* cooperative kernels: 93 VGPRs, no scratch (7 waves: 72 VGPRs + 76 B/lane of spills in the loop) */
+#endif
+#ifndef PT_MIN_WAVES_TRIPOOL
+#define PT_MIN_WAVES_TRIPOOL 4 /* triangle-pool kernels (per-lane walks + parked candidates): 128 VGPRs */
 #endif
 #ifndef PT_MIN_WAVES_COOP_IMG
 #define PT_MIN_WAVES_COOP_IMG 5 /* 96 VGPRs + 60 B/lane of spills; spill-free needs 116 VGPRs = 4 waves: 496-hittable scene -9 % (A/B) */
@@ -376,8 +382,10 @@ __device__ __forceinline__ void lane_prepare(Lane& L, const KArgs& a) {
 // GRID: the kernel carries the sphere-grid walk (pt_device.hpp: sphere_grid_walk).  Scenes without a culling grid and without
 // an image texture — the headline Cornell-style scene — run instantiations without it (less code in the hot kernel, and
 // nothing the walk needs can weigh on its 72-register budget).
-template <int UV, bool LDS, bool MLDS, bool COOP, bool CL = false, bool FAST = false, bool BADOUEL = false, bool GRID = true>
-__global__ __launch_bounds__(kBlock, CL ? PT_MIN_WAVES_CL : COOP ? (UV ? PT_MIN_WAVES_COOP_IMG : PT_MIN_WAVES_COOP) : (UV ? PT_MIN_WAVES_IMG : PT_MIN_WAVES))
+// TRIPOOL: the kernel carries the exact culling of long triangle runs (pt_device.hpp: tri_pool_scan); scalar-cache variant only
+// (such scenes are far beyond LDS), its own register budget.
+template <int UV, bool LDS, bool MLDS, bool COOP, bool CL = false, bool FAST = false, bool BADOUEL = false, bool GRID = true, bool TRIPOOL = false>
+__global__ __launch_bounds__(kBlock, TRIPOOL ? PT_MIN_WAVES_TRIPOOL : CL ? PT_MIN_WAVES_CL : COOP ? (UV ? PT_MIN_WAVES_COOP_IMG : PT_MIN_WAVES_COOP) : (UV ? PT_MIN_WAVES_IMG : PT_MIN_WAVES))
 void render_kernel(KArgs a) {
   constexpr bool IMG = UV == UV_TRACKED;
   typedef LaneT<CL> Lane;
@@ -441,7 +449,7 @@ void render_kernel(KArgs a) {
       RayCtx c = make_ctx(L.ray, a.fast_ok != 0);
       c.live = L.live;
       const bool fast = wave_all_regular(c, L.live);
-      hit_world<IMG, BADOUEL, GRID>((cst_f4p)a.blob, (cst_f4p)a.blob, a.n_runs, c, fast, L.rng, h);
+      hit_world<IMG, BADOUEL, GRID, TRIPOOL>((cst_f4p)a.blob, (cst_f4p)a.blob, a.n_runs, c, fast, L.rng, h);
       lane_shade<UV, FAST>(L, a, h, a.blob, a.mats);
     }
   }
@@ -660,7 +668,7 @@ __global__ void bounce_kernel(const f4* __restrict__ blob, int n_runs, const f4*
   memset(&O, 0, sizeof O);
   RayCtx c = make_ctx(ray, fast_ok != 0);
   HitState h;
-  hit_world<IMG, true>(blob, (cst_f4p)blob, n_runs, c, wave_all_regular(c, true), rng, h);
+  hit_world<IMG, true, true, true>(blob, (cst_f4p)blob, n_runs, c, wave_all_regular(c, true), rng, h); // every culling structure the scene has
   const float closest = h.closest, hu = h.u, hv = h.v;
   const int hit = h.hit;
   if (hit < 0) {
@@ -780,12 +788,23 @@ static int flatten_with_env(const PtSceneDesc* desc, ptf::Flat& flat, std::strin
   if (const char* e = std::getenv("PT_GRID_M")) tune.m = (float)std::atof(e);
   if (const char* e = std::getenv("PT_GRID_CELL")) tune.cell = (float)std::atof(e);
   const bool allow_grid = std::getenv("PT_NO_GRID") == nullptr;
-  int rc = ptf::flatten(desc, flat, err, allow_grid, box_cull, tune);
+  // PT_TRICULL=1: OPT-IN exact culling of long triangle runs (pt_tripool.hpp).  It is exact (the GPU suite runs it against the
+  // oracle's full scan, bit for bit) but on BASELINE config 5 — a random triangle soup — it is ~3x SLOWER than the SIMD-amortised
+  // full scan it replaces (per ray it must still look at ~3 000 band records and ~600 grid candidates, gathered
+  // per lane, where the full scan costs the equivalent of 1 560 tests per ray), so it is not the default; PT_NO_TRICULL wins.
+  // PT_TRI_M / PT_TRI_CELL / PT_TRI_MIN: the pool's barycentric slack 1/M, its grid cell (in median grown boxes), the shortest
+  // run that gets one (pt_tripool.hpp: TriPoolTuning)
+  const bool allow_tri = std::getenv("PT_TRICULL") != nullptr && std::getenv("PT_NO_TRICULL") == nullptr;
+  ptf::TriPoolTuning tri;
+  if (const char* e = std::getenv("PT_TRI_M")) tri.M = (float)std::atof(e);
+  if (const char* e = std::getenv("PT_TRI_CELL")) tri.cell = (float)std::atof(e);
+  if (const char* e = std::getenv("PT_TRI_MIN")) tri.min_run = std::max(1, std::atoi(e));
+  int rc = ptf::flatten(desc, flat, err, allow_grid, box_cull, tune, allow_tri, tri);
   if (rc) return rc;
   if (flat.grid_spheres > 0 && flat.blob.size() * 16 > kMaxLdsBlob) {
     ptf::Flat plain;
     std::string err2;
-    if (ptf::flatten(desc, plain, err2, false, box_cull, tune) == PT_OK && plain.blob.size() * 16 <= kMaxLdsBlob) flat = std::move(plain);
+    if (ptf::flatten(desc, plain, err2, false, box_cull, tune, allow_tri, tri) == PT_OK && plain.blob.size() * 16 <= kMaxLdsBlob) flat = std::move(plain);
   }
   return PT_OK;
 }
@@ -854,6 +873,7 @@ struct PtScene {
   mutable int nsplit_override = 0; // PT_SPLIT_TILES tuning knob (host copy must outlive the async upload)
   float traversal_cost = 0.0f; // estimated VALU instructions of one ray's scan of the list (sphere runs through their lists)
   int grid_spheres = 0;        // spheres that sit in a culling grid (the resident non-cooperative kernels walk it)
+  int tri_pooled = 0;          // triangles that sit in a triangle pool (the TRIPOOL kernels query it)
   size_t blob_bytes = 0;
   int num_cus = 256;
   mutable unsigned int* ws_cost = nullptr; // LPT workspace: per-tile ray counts of the probe pass
@@ -935,7 +955,7 @@ int pt_debug_flatten(const PtSceneDesc* desc, float* blob_out, int64_t blob_cap_
   if (rc) return fail(rc, err);
   if (n_blob_f4) *n_blob_f4 = (int32_t)flat.blob.size();
   if (n_runs) *n_runs = flat.n_runs;
-  if (flags_out) *flags_out = (flat.has_image ? 1 : 0) | (flat.has_medium ? 2 : 0);
+  if (flags_out) *flags_out = (flat.has_image ? 1 : 0) | (flat.has_medium ? 2 : 0) | (flat.tri_pooled ? 4 : 0);
   if (blob_out) {
     if (blob_cap_f4 < (int64_t)flat.blob.size()) return fail(PT_ERR_INVALID_ARG, "blob buffer too small");
     std::memcpy(blob_out, flat.blob.data(), flat.blob.size() * 16);
@@ -944,6 +964,18 @@ int pt_debug_flatten(const PtSceneDesc* desc, float* blob_out, int64_t blob_cap_
     if (mats_cap_f4 < (int64_t)flat.mats.size()) return fail(PT_ERR_INVALID_ARG, "material buffer too small");
     std::memcpy(mats_out, flat.mats.data(), flat.mats.size() * 16);
   }
+  return PT_OK;
+}
+
+int pt_debug_tri_pool(const PtSceneDesc* desc, int32_t out[8]) {
+  if (!out) return fail(PT_ERR_INVALID_ARG, "pt_debug_tri_pool: NULL argument");
+  ptf::Flat flat;
+  std::string err;
+  int rc = flatten_with_env(desc, flat, err);
+  if (rc) return fail(rc, err);
+  out[0] = flat.tri_pooled; out[1] = flat.tri_always;
+  for (int k = 0; k < 3; k++) out[2 + k] = flat.tri_level_counts[k];
+  out[5] = (int32_t)(1000.0 * flat.tri_cells_per_triangle); out[6] = (int32_t)flat.blob.size(); out[7] = 0;
   return PT_OK;
 }
 
@@ -985,6 +1017,7 @@ int pt_scene_create(const PtSceneDesc* desc, PtScene** out_scene) {
     }
   }
   s->grid_spheres = flat.grid_spheres;
+  s->tri_pooled = flat.has_badouel ? 0 : flat.tri_pooled; // (scenes with Badouel-strategy triangles keep the round-2 kernels)
   s->blob_bytes = flat.blob.size() * 16;
   s->mats_f4 = (int)flat.mats.size();
   // one buffer: [blob records][material table] so a kernel can stage both with one contiguous copy
@@ -1098,14 +1131,18 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
   }
   a.coop_prefix = (s->coop_ok && a.fast_ok && !(p->flags & PT_FLAG_NO_COOP)) ? s->coop_prefix : -1;
   const size_t blob_bytes = (size_t)s->blob_f4 * 16;
-  const bool resident = (blob_bytes <= kMaxLdsBlob || (p->flags & PT_FLAG_NO_LDS)) && !(p->flags & PT_FLAG_FORCE_STREAM);
-  const bool lds = resident && !(p->flags & PT_FLAG_NO_LDS);
+  // a scene with a triangle pool is queried through per-lane loads from the global blob: the scalar-cache resident kernels,
+  // whatever its size (PT_FLAG_FORCE_STREAM: the streaming kernel, which scans every triangle, as the A/B)
+  const bool tri_pool = s->tri_pooled > 0 && !(p->flags & PT_FLAG_FORCE_STREAM);
+  const bool resident = (blob_bytes <= kMaxLdsBlob || (p->flags & PT_FLAG_NO_LDS) || tri_pool) && !(p->flags & PT_FLAG_FORCE_STREAM);
+  const bool lds = resident && !(p->flags & PT_FLAG_NO_LDS) && !tri_pool;
   a.n_local_pixels = local_tiles * PT_TILE_PIXELS;
   a.fast_chunks = 0; a.samples_total = p->samples; a.fast_stride = 0;
   long long launch_units = local_tiles; // waves worth of work in the queue (tiles; fast mode: tiles x chunks)
   // default: whole tiles for the resident kernels (coherent primary rays), single pixels for the lock-step
   // streaming kernel (a workgroup waits for its slowest lane); either can be forced
-  a.tile_granular = (p->flags & PT_FLAG_TILE_GRANULAR) ? 1 : (p->flags & PT_FLAG_PIXEL_GRANULAR) ? 0 : (resident ? 1 : 0);
+  // (the triangle-pool kernels' iterations are long and per-lane: single pixels, like the streaming kernel)
+  a.tile_granular = (p->flags & PT_FLAG_TILE_GRANULAR) ? 1 : (p->flags & PT_FLAG_PIXEL_GRANULAR) ? 0 : ((resident && !tri_pool) ? 1 : 0);
   a.cost = nullptr;
   a.cost_max = 0;
   a.order = nullptr;
@@ -1163,10 +1200,12 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
       return launch(render_kernel<UV, false, false, false, false, false, true>);
     }
     if (a.fast_chunks) { // opt-in decorrelated mode: its own instantiations (no cooperative kernels: a chunk is short)
+      if (tri_pool) return launch(render_kernel<UV, false, false, false, false, true, false, true, true>);
       if (!resident) return launch(render_kernel_stream<UV, true>);
       if (!lds) return launch(render_kernel<UV, false, false, false, false, true>);
       return mlds ? launch(render_kernel<UV, true, true, false, false, true>) : launch(render_kernel<UV, true, false, false, false, true>);
     }
+    if (tri_pool) return launch(render_kernel<UV, false, false, false, false, false, false, true, true>);
     if (!resident) return launch(render_kernel_stream<UV>);
     if constexpr (UV == UV_NONE) { // no image texture and no sphere grid (the headline scene): kernels without the grid walk
       if (s->grid_spheres == 0 && !coop) {
@@ -1341,6 +1380,13 @@ int pt_debug_stamps(unsigned long long* out8, int reset) { // diagnostic build o
   if (reset) { unsigned long long z[8] = {0}; PT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof z)); }
   return PT_OK;
 }
+#ifdef PT_STAMPS_TRI
+int pt_debug_tri(unsigned long long* out8, int reset) { // -DPT_STAMPS_TRI: counters of the triangle pool (pt_device.hpp: PT_TRI_COUNT)
+  if (out8) PT_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_tri), 8 * sizeof(unsigned long long)));
+  if (reset) { unsigned long long z[8] = {0}; PT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_tri), z, sizeof z)); }
+  return PT_OK;
+}
+#endif
 #ifdef PT_STAMPS_WALK
 int pt_debug_walk(unsigned long long* out8, int reset) { // -DPT_STAMPS_WALK: counters of the sphere-grid walk (pt_device.hpp: walk_ctr)
   if (out8) PT_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_walk), 8 * sizeof(unsigned long long)));

@@ -27,6 +27,22 @@ def forced_pools():
         del os.environ["PT_POOL_ALWAYS"]
 
 
+@contextlib.contextmanager
+def tri_pools(**knobs):
+    """PT_TRICULL=1 (+ PT_TRI_* knobs) while scenes are created: the opt-in exact culling of long triangle runs."""
+    env = {"PT_TRICULL": "1", **{k: str(v) for k, v in knobs.items()}}
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        yield
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 def random_scene(seed: int, allow_image_on_triangle: bool):
     rng = np.random.default_rng(seed)
     seed = int(seed)
@@ -279,28 +295,200 @@ def test_random_box_fields_through_the_slab_culling(orc, lib, seed):
     assert_bit_identical(R.render_host(w, h, 70, ps, c, flags=F), orc.render(ps, c.c, w, h, 70, flags=F), f"box field seed {seed} fast mode")
 
 
+def random_triangle_field(seed: int):
+    """Long runs of Moller-Trumbore triangles for the exact triangle pool (csrc/pt_tripool.hpp; pt_device.hpp: tri_pool_scan),
+    with what it has to get right varied at random: small random triangles, SLIVERS (edges nearly parallel: wide grazing
+    bands, the always list), degenerate triangles (repeated vertices, collinear vertices), exact duplicates and coplanar
+    re-orderings (equal-t ties: the later one wins), meshes with shared edges and vertices (rays through edges), triangles in
+    the coordinate planes seen by cameras that look along those planes (every primary ray grazes them), huge and tiny
+    scales, off-origin centres, a second triangle run behind another kind, and cameras inside, near, far and beyond the
+    pool's rlimit (fallback to the full scan)."""
+    rng = np.random.default_rng(seed)
+
+    def color():
+        return tuple(float(x) for x in rng.random(3))
+
+    def material():
+        k = rng.integers(0, 6)
+        return (lambertian_material(color()) if k <= 2 else metal_material(color(), float(0.3 * rng.random())) if k == 3
+                else dielectric_material(1.5, (1, 1, 1)) if k == 4 else lightsource_material(tuple(float(3 * x) for x in rng.random(3))))
+
+    scale = float(10.0 ** rng.integers(-2, 3))          # field size 0.01 .. 100
+    centre = np.array([(rng.random() - 0.5) * 300 * scale * (seed % 4 == 1) for _ in range(3)])
+    size = scale * float(rng.choice([0.03, 0.1, 0.3]))   # typical edge
+    n = int(rng.integers(300, 2500))
+    mats = [material() for _ in range(12)]
+    hs = [sphere(tuple(centre + [0, -1000 * scale - 0.5 * scale, 0]), 1000 * scale, lambertian_material(checker_texture((0.2, 0.3, 0.1), (0.9, 0.9, 0.9))))]
+    first = len(hs)
+
+    def P():
+        return centre + (rng.random(3) - 0.5) * scale
+
+    def add(v0, v1, v2):
+        hs.append(triangle(tuple(float(x) for x in v0), tuple(float(x) for x in v1), tuple(float(x) for x in v2), mats[int(rng.integers(0, len(mats)))]))
+
+    while len(hs) - first < n:
+        k = rng.integers(0, 12)
+        v0 = P()
+        if k <= 4:                                          # small random triangle
+            add(v0, v0 + (rng.random(3) - 0.5) * size, v0 + (rng.random(3) - 0.5) * size)
+        elif k == 5:                                        # sliver: second edge nearly parallel to the first
+            e = (rng.random(3) - 0.5) * size
+            add(v0, v0 + e, v0 + e * float(rng.random() * 1.5) + (rng.random(3) - 0.5) * size * float(10.0 ** rng.integers(-7, -2)))
+        elif k == 6:                                        # degenerate: repeated or collinear vertices
+            e = (rng.random(3) - 0.5) * size
+            add(v0, v0 + e, v0 + e * 0.5) if rng.random() < 0.5 else add(v0, v0, v0 + e)
+        elif k == 7 and len(hs) > first:                    # exact duplicate / same triangle with its vertices rotated or flipped
+            t = hs[int(rng.integers(first, len(hs)))]
+            if rng.random() < 0.5:
+                hs.append(t)
+            else:
+                a, b, c_ = (np.array(t.v0), np.array(t.v1), np.array(t.v2)) if hasattr(t, "v0") else (v0, v0 + size, v0 - size)
+                add(b, c_, a) if rng.random() < 0.5 else add(a, c_, b)
+        elif k == 8:                                        # a strip of quads: shared edges and vertices, exactly
+            u_, v_ = (rng.random(3) - 0.5) * size, (rng.random(3) - 0.5) * size
+            for i in range(int(rng.integers(2, 7))):
+                a = v0 + i * u_
+                add(a, a + u_, a + v_)
+                add(a + u_, a + u_ + v_, a + v_)
+        elif k == 9:                                        # in a coordinate plane through the centre (lattice-snapped)
+            ax = int(rng.integers(0, 3))
+            a = v0.copy(); a[ax] = centre[ax]
+            b = a + (rng.random(3) - 0.5) * size; b[ax] = centre[ax]
+            c_ = a + (rng.random(3) - 0.5) * size; c_[ax] = centre[ax]
+            add(a, b, c_)
+        elif k == 10:                                       # a big one
+            add(v0, v0 + (rng.random(3) - 0.5) * scale, v0 + (rng.random(3) - 0.5) * scale)
+        else:                                               # tiny
+            add(v0, v0 + (rng.random(3) - 0.5) * size * 1e-3, v0 + (rng.random(3) - 0.5) * size * 1e-3)
+    if rng.random() < 0.6:                                  # interrupt the run; a second run (long or short) behind it
+        p0 = centre + (rng.random(3) - 0.5) * scale * 0.5
+        hs.append(box(tuple(p0), tuple(p0 + 0.1 * scale), material()))
+        for _ in range(int(rng.choice([5, 400]))):
+            v0 = P()
+            add(v0, v0 + (rng.random(3) - 0.5) * size, v0 + (rng.random(3) - 0.5) * size)
+    if rng.random() < 0.5:
+        hs.append(xy_rect(float(centre[0] - scale), float(centre[0] + scale), float(centre[1] - scale), float(centre[1] + scale),
+                          float(centre[2] - 0.7 * scale), lightsource_material((4, 4, 4))))
+    mode = int(rng.integers(0, 5))
+    dist = float([0.05, 0.6, 2.0, 40.0, 30000.0][mode]) * scale
+    frm = centre + np.array([dist * 0.55, dist * 0.3, dist * 0.75])
+    at = centre.copy()
+    if seed % 3 == 0:                                       # look ALONG a coordinate plane through the centre
+        frm = centre + np.array([dist + 0.3 * scale, 0.0, 0.0])
+        at = centre + np.array([0.0, 0.0, 0.0])
+    cam = dict(look_from=tuple(float(x) for x in frm), look_at=tuple(float(x) for x in at), vup=(0, 1, 0),
+               vfov=float(70.0 if dist < scale else min(70.0, 2 * np.degrees(np.arctan(0.7 * scale / dist)) + 5.0)),
+               aperture=0.0, focus_dist=float(max(dist, 0.1 * scale)), time0=0.0, time1=1.0)
+    return pack(hs), cam
+
+
+@pytest.mark.parametrize("seed", range(14))
+def test_random_triangle_fields_through_the_triangle_pool(orc, lib, seed):
+    ps, cam = random_triangle_field(8000 + seed)
+    import ctypes as C
+    st = (C.c_int32 * 8)()
+    w, h, spp = 40, 24, 8
+    c = scenes.make_camera(cam, w, h)
+    orc.set_math(True)
+    ref = orc.render(ps, c.c, w, h, spp)
+    with tri_pools():
+        abi.check(lib.pt_debug_tri_pool(C.byref(ps.desc), st), "pt_debug_tri_pool")
+        assert st[0] >= 300, "the field's long run must get a pool"
+        ds = R.DeviceScene(ps)
+    for name, flags in (("pool", 0), ("pool, tile-granular", abi.PT_FLAG_TILE_GRANULAR), ("full scan (stream)", abi.PT_FLAG_FORCE_STREAM),
+                        ("plain division: every ray irregular -> full scan in the pool kernel", abi.PT_FLAG_NO_FASTDIV)):
+        assert_bit_identical(R.render_host(w, h, spp, ds, c, flags=flags), ref, f"triangle field seed {seed} {name}")
+    F = abi.PT_FLAG_FAST_RNG
+    assert_bit_identical(R.render_host(w, h, 70, ds, c, flags=F), orc.render(ps, c.c, w, h, 70, flags=F), f"triangle field seed {seed} fast mode")
+
+
+def test_triangle_pool_is_opt_in_and_small_runs(orc, lib, monkeypatch):
+    """Without PT_TRICULL no pool is built (the default: on BASELINE config 5 the pool is exact but slower than the full scan);
+    PT_NO_TRICULL overrides PT_TRICULL; PT_TRI_MIN=4 puts pools into the small mixed scenes (triangle runs of a handful, between
+    spheres, boxes and media; Badouel-strategy scenes keep their kernels)."""
+    import ctypes as C
+    ps, cam = random_triangle_field(8003)
+    st = (C.c_int32 * 8)()
+    abi.check(lib.pt_debug_tri_pool(C.byref(ps.desc), st), "pt_debug_tri_pool")
+    assert list(st)[:6] == [0] * 6
+    with tri_pools(PT_NO_TRICULL=1):
+        abi.check(lib.pt_debug_tri_pool(C.byref(ps.desc), st), "pt_debug_tri_pool")
+        assert list(st)[:6] == [0] * 6
+    c = scenes.make_camera(cam, 40, 24)
+    orc.set_math(True)
+    assert_bit_identical(R.render_host(40, 24, 6, ps, c), orc.render(ps, c.c, 40, 24, 6), "default: no pool")
+    for seed in (1001, 1003, 1004, 1006):
+        ps, cam = random_scene(seed, allow_image_on_triangle=(seed % 2 == 0))
+        c = scenes.make_camera(cam, 45, 27)
+        ref = orc.render(ps, c.c, 45, 27, 12)
+        with tri_pools(PT_TRI_MIN=4):
+            ds = R.DeviceScene(ps)
+        for flags in (0, abi.PT_FLAG_NO_LDS, abi.PT_FLAG_FORCE_STREAM):
+            assert_bit_identical(R.render_host(45, 27, 12, ds, c, flags=flags), ref, f"PT_TRI_MIN=4 seed {seed} flags {flags}")
+
+
+def test_rays_that_graze_triangles(orc, lib):
+    """Ray-level check aimed at the band: rays that lie ALMOST IN THE PLANE of a triangle of the 100 k-triangle mesh (tilted out of
+    it by 1e-8 ... 1e-2) and pass near it — the rays for which the reference's binary32 test accepts triangles by rounding
+    noise — from 0.01 to 12 units away, every one checked against the oracle's full scan (hit, t, scattered ray, RNG)."""
+    ps, cam = scenes.build("triangles", n_triangles=100_000)
+    hd = np.frombuffer(ps.hittables, dtype=scenes.hittable_dtype)
+    f = hd["f"][1:-1].astype(np.float64)
+    rng = np.random.default_rng(11)
+    n = 24000
+    recs = (abi.PtBounceIn * n)()
+    for k in range(n):
+        i = int(rng.integers(0, len(f)))
+        v0, e1, e2 = f[i, 0:3], f[i, 3:6] - f[i, 0:3], f[i, 6:9] - f[i, 0:3]
+        nn = np.cross(e1, e2)
+        nn /= max(np.linalg.norm(nn), 1e-30)
+        t1 = e1 / max(np.linalg.norm(e1), 1e-30)
+        t2 = np.cross(nn, t1)
+        ang = rng.uniform(0, 2 * np.pi)
+        d = np.cos(ang) * t1 + np.sin(ang) * t2 + nn * (10.0 ** rng.uniform(-8, -2)) * rng.choice([-1.0, 1.0])
+        d *= rng.uniform(0.3, 2.0)
+        target = v0 + rng.uniform(-0.2, 1.2) * e1 + rng.uniform(-0.2, 1.2) * e2 + rng.normal(size=3) * 10.0 ** rng.uniform(-7, -3)
+        o = target - d / np.linalg.norm(d) * rng.uniform(0.01, 12.0)
+        recs[k].origin[:] = [float(x) for x in o]; recs[k].dir[:] = [float(x) for x in d]; recs[k].time = 0.5
+        recs[k].rng_state = int(rng.integers(1, 2 ** 32)); recs[k].attenuation[:] = [1.0, 1.0, 1.0]
+    with tri_pools():
+        ds = R.DeviceScene(ps)
+    out = (abi.PtBounceOut * n)()
+    abi.check(lib.pt_debug_bounce(ds.handle, recs, out, n), "pt_debug_bounce")
+    orc.set_math(True)
+    ref = orc.bounce(ps, recs)
+    bad = [k for k in range(n) if (out[k].status, out[k].hittable, np.float32(out[k].t).tobytes(), out[k].rng_state)
+           != (ref[k].status, ref[k].hittable, np.float32(ref[k].t).tobytes(), ref[k].rng_state)]
+    assert not bad, f"{len(bad)} of {n} grazing rays differ; first: ray {bad[0]} device {out[bad[0]].hittable} t {out[bad[0]].t!r} oracle {ref[bad[0]].hittable} t {ref[bad[0]].t!r}"
+    hits = sum(1 for k in range(n) if ref[k].status != abi.PT_BOUNCE_MISS)
+    assert hits > n // 2
+
+
 @pytest.mark.parametrize("kind,seed", [("box", 4001), ("box", 4004), ("box", 4005), ("box", 4012), ("box", 4015), ("sphere", 3001),
-                                       ("sphere", 3007), ("random", 1003), ("random", 1004)])
+                                       ("sphere", 3007), ("random", 1003), ("random", 1004), ("triangle", 8001), ("triangle", 8002), ("triangle", 8006)])
 def test_path_rays_through_fuzz_scenes(orc, lib, kind, seed):
     """Paths followed with the oracle, the device checked on every ray of every generation (tests/path_rays.py): 15 000 camera
     rays and everything they scatter into — rays that start ON faces, in glass, next to shared faces and duplicates.  (The
     slab pool's key accounting once lost a fourth candidate after a dropped key: three framebuffer fuzz suites did not see it,
     this did within 100 000 rays.)"""
     from path_rays import follow_paths
-    ps, cam = {"box": random_box_field, "sphere": random_sphere_field, "random": lambda s: random_scene(s, False)}[kind](seed)
+    ps, cam = {"box": random_box_field, "sphere": random_sphere_field, "random": lambda s: random_scene(s, False),
+               "triangle": random_triangle_field}[kind](seed)
     c = scenes.make_camera(cam, 40, 24)
-    with forced_pools() if kind == "random" else contextlib.nullcontext():
+    with forced_pools() if kind == "random" else tri_pools() if kind == "triangle" else contextlib.nullcontext():
         checked, bad = follow_paths(lib, orc, ps, c.c, 40, 24, 15000, 12, seed)
     assert checked >= 15000 and not bad, f"{len(bad)} of {checked} rays differ: " + " | ".join(bad[:3])
 
 
-@pytest.mark.parametrize("name,n,gens", [("cornell", 40000, 16), ("smoke", 20000, 10)])
+@pytest.mark.parametrize("name,n,gens", [("cornell", 40000, 16), ("smoke", 20000, 10), ("triangles", 6000, 6)])
 def test_path_rays_on_the_baseline_scenes(orc, lib, name, n, gens):
     """The same ray-level check on the scenes BASELINE.json names: the Cornell-style scene (slab pool: every ray of every
     generation starts on a face of one of its boxes) and the 496-hittable scene (sphere grid, image textures, media)."""
     from path_rays import follow_paths
-    ps, cam = scenes.build(name)
+    ps, cam = scenes.build(name, **({"n_triangles": 100_000} if name == "triangles" else {}))
     w, h = (192, 108) if name == "cornell" else (200, 112)
     c = scenes.make_camera(cam, w, h)
-    checked, bad = follow_paths(lib, orc, ps, c.c, w, h, n, gens, 7)
-    assert checked >= 2 * n and not bad, f"{len(bad)} of {checked} rays differ: " + " | ".join(bad[:3])
+    with tri_pools() if name == "triangles" else contextlib.nullcontext():  # the 100 k-triangle mesh through its (opt-in) triangle pool
+        checked, bad = follow_paths(lib, orc, ps, c.c, w, h, n, gens, 7)
+    assert checked >= 1.5 * n and not bad, f"{len(bad)} of {checked} rays differ: " + " | ".join(bad[:3])

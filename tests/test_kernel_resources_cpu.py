@@ -51,16 +51,16 @@ def test_headline_kernels_fit_seven_waves_without_scratch(usage):
         assert v["VGPRs"] <= 72 and v["Occupancy [waves/SIMD]"] >= 7, (k, v)
 
 
-def test_grid_walk_kernels_keep_five_waves(usage):
-    """The kernels that carry the sphere-grid walk and its split phase (GRID = true; cfg1 / cfg3 / cfg4 run the UV_WINNER one)
-    hold 5 waves per SIMD — what the scene's 31 KB LDS image allows anyway — and their scratch traffic stays outside the
-    walk: a few dwords parked per loop iteration (checked in the ISA when the split phase went in: no scratch instruction
-    between the walk's first and last block)."""
-    grid = {k: v for k, v in usage.items() if re.search(r"render_kernelILi[01]ELb[01]ELb[01]ELb0ELb[01]ELb0ELb0ELb1E", k)}
-    assert len(grid) >= 7, sorted(usage)
-    for k, v in grid.items():
-        assert v["Occupancy [waves/SIMD]"] >= 5 and v["VGPRs"] <= 96, (k, v)
-        assert v["ScratchSize [bytes/lane]"] <= 72, (k, v)
+def test_grid_walk_and_triangle_pool_kernels(usage):
+    """The image-texture kernel cfg1 / cfg3 / cfg4 run (UV_WINNER, LDS, sphere-grid walk) holds 5 waves per SIMD — what the
+    scene's 31 KB LDS image allows anyway — without scratch; the (opt-in) triangle-pool kernels (TRIPOOL = true: per-lane walks
+    over global tables) hold 4, the ones without image textures without scratch."""
+    k1 = [v for k, v in usage.items() if re.search(r"render_kernelILi1ELb1ELb0ELb0ELb0ELb0ELb0ELb1ELb0E", k)]
+    assert len(k1) == 1 and k1[0]["Occupancy [waves/SIMD]"] >= 5 and k1[0]["ScratchSize [bytes/lane]"] == 0, k1
+    pool = {k: v for k, v in usage.items() if re.search(r"render_kernelILi[012]ELb0ELb0ELb0ELb0ELb[01]ELb0ELb1ELb1E", k)}
+    assert len(pool) == 6, sorted(usage)
+    for k, v in pool.items():
+        assert v["Occupancy [waves/SIMD]"] >= 4 and v["ScratchSize [bytes/lane]"] <= (0 if "ILi0E" in k else 32), (k, v)
 
 
 def test_streaming_and_cooperative_kernels_without_image_textures(usage):

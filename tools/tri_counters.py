@@ -1,0 +1,30 @@
+"""Counters of the triangle pool from a diagnostic build (make -C path_tracer_amd/csrc stamps EXTRA=-DPT_STAMPS_TRI):
+    PT_RENDER_LIB=path_tracer_amd/libpt_stamps.so python tools/tri_counters.py [spp] [width height]
+per ray: grid tests, band (cheap) tests, exact tests from the band / always list; lanes busy per trip; fallbacks."""
+import ctypes as C, os, sys
+os.environ.setdefault('PT_TRICULL', '1')
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import torch
+from path_tracer_amd import abi, scenes
+from path_tracer_amd import render as R
+spp = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+W, H = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (480, 270)
+lib = abi.load_library()
+lib.pt_debug_tri.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+packed, cam_args = scenes.build("triangles", n_triangles=100_000)
+cam = scenes.make_camera(cam_args, W, H)
+ds = R.DeviceScene(packed)
+st = (C.c_int32 * 8)()
+lib.pt_debug_tri_pool(C.byref(packed.desc), st)
+print("pool: triangles", st[0], "always", st[1], "levels", list(st)[2:5], "cells per triangle", st[5] / 1000, "blob MB", st[6] * 16 / 1e6)
+R.render(W, H, 1, ds, cam, flags=abi.PT_FLAG_NO_LPT); torch.cuda.synchronize()
+lib.pt_debug_tri(None, 1)
+fb, ms = R.render(W, H, spp, ds, cam, flags=abi.PT_FLAG_NO_LPT, timed=True)
+o = (C.c_ulonglong * 8)()
+lib.pt_debug_tri(o, 0)
+scans, lg, lc, lx, wg, wc, fl, fb_ = [o[i] for i in range(8)]
+print(f"{W}x{H}x{spp}: {ms:.1f} ms = {W*H*spp/ms/1e3:.2f} Msamples/s; wave scans {scans:.3e}, fallbacks {fb_:.3e}")
+rays = max(1, scans) * 64
+print(f"per scan (wave): grid trips {wg/max(scans,1):.1f} (lanes busy {lg/max(wg,1):.1f}), cheap trips {wc/max(scans,1):.1f} (lanes busy {lc/max(wc,1):.1f}), flushes {fl/max(scans,1):.1f} (lanes {lx/max(fl,1):.1f})")
+print(f"per lane-ray (upper bound, idle lanes included): grid tests {lg/rays:.1f}, cheap tests {lc/rays:.1f}, exact tests after the band {lx/rays:.1f}")
