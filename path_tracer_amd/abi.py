@@ -148,6 +148,12 @@ def library_path() -> Path:
     return Path(override) if override else Path(__file__).resolve().parent / LIB_NAME
 
 
+def override_is_older_build(path, lib, name) -> bool:
+    """A/B tooling only (tools/abn.sh loads an OLDER build of the extension through PT_RENDER_LIB): entry points added since
+    that build may be missing there.  The in-tree library must export everything include/pt_render.h declares."""
+    return bool(os.environ.get("PT_RENDER_LIB")) and os.environ.get("PT_RENDER_LIB_ALLOW_OLDER") == "1" and not hasattr(lib, name)
+
+
 def load_library() -> C.CDLL:
     """Open the HIP extension.  Fails loudly: the product has no CPU path."""
     global _lib
@@ -168,6 +174,8 @@ def load_library() -> C.CDLL:
         pass  # torch-free hosts bind to /opt/rocm/lib through the library's RUNPATH
     lib = C.CDLL(str(path))
     for name, (res, args) in SIGNATURES.items():
+        if override_is_older_build(path, lib, name):
+            continue
         fn = getattr(lib, name)  # AttributeError if the library does not export what the header declares
         fn.restype = res
         fn.argtypes = args

@@ -1736,8 +1736,15 @@ __device__ __forceinline__ uint32_t texel_index(float f, uint32_t maxv) {
   return (uint32_t)f;
 }
 
-template <typename UV>
+// MATS (compile-time, kernels specialised on what a scene contains): bit k = material kind k may occur (material.hpp:133-135
+// order: lambertian 0, metal 1, dielectric 2, lightsource 3, isotropic 4); bit 8 = a texture other than solid_texture may occur.
+// The generic kernels pass MATS_ALL; a scene of lambertian + lightsource materials over solid textures (the Cornell-style
+// headline scene) runs kernels compiled with MATS_LAMB_LIGHT_SOLID, which carry none of the other branches.
+enum { MATS_ALL = 0x11f, MATS_LAMB_LIGHT_SOLID = 0x009 };
+
+template <int MATS = MATS_ALL, typename UV>
 __device__ __forceinline__ V3 texture_value(f4 M0, f4 M1, f4 M2, f4 M3, V3 p, UV uv, const uint8_t* __restrict__ atlas) {
+  if constexpr (!(MATS & 0x100)) return xyz(M1); // every texture of the scene is a solid_texture (texture.hpp:25)
   const int tk = as_i(M0.y);
   if (tk == 1) return xyz(M1); // solid
   if (tk == 0) {               // checker
@@ -1781,12 +1788,13 @@ __device__ __forceinline__ V3 sky_color(const Ray& r, V3 att) {
 // One iteration of the bounce loop render.hpp:58-89 after hit_world: emitted + scatter.
 // Returns true if the path continues (ray/att updated); false if it ended with `out`.
 // `uv(u, v)` yields the hit's texture coordinates; it is called before the ray is overwritten.
-template <typename PM, typename UV>
+template <int MATS = MATS_ALL, typename PM, typename UV>
 __device__ __forceinline__ bool shade(PM mats, const uint8_t* __restrict__ atlas, const Rec& rec,
                                       UV uv, Ray& ray, V3& att, uint32_t& rng, V3& out) {
   PM M = mats + rec.mat * SZ_MATERIAL;
   f4 M0 = M[0], M1 = M[1];
   const int mk_ = as_i(M0.x);
+  constexpr bool LAMB = MATS & 1, METAL = (MATS >> 1) & 1, GLASS = (MATS >> 2) & 1, LIGHT = (MATS >> 3) & 1, ISO = (MATS >> 4) & 1;
   // A wave holds lanes of every material, and each `if` below runs once for the lanes that take it.  What several materials
   // need — the unit direction of the incoming ray (metal, glass), a point in the unit ball (metal, isotropic: three draws and
   // four transcendentals), the texture's value (lambertian, light, isotropic) — is therefore computed ONCE, for the union of
@@ -1794,38 +1802,43 @@ __device__ __forceinline__ bool shade(PM mats, const uint8_t* __restrict__ atlas
   // material.  Per lane nothing moves: each lane takes exactly one material, its draws keep their order (the ball is the
   // first thing metal and isotropic draw; texture values draw nothing).
   V3 ud = mk(0.0f, 0.0f, 0.0f), ball = ud, tv = ud;
-  if (mk_ == 1 || mk_ == 2) ud = ray.d / sqrt_rn(dot(ray.d, ray.d));
-  if (mk_ == 1 || mk_ >= 4) ball = rng_in_unit_ball(rng);
-  if (mk_ == 0 || mk_ >= 3) tv = texture_value(M0, M1, M[2], M[3], rec.p, uv, atlas);
-  if (mk_ == 0) { // lambertian material.hpp:18-28
+  if constexpr (METAL || GLASS) { if (mk_ == 1 || mk_ == 2) ud = ray.d / sqrt_rn(dot(ray.d, ray.d)); }
+  if constexpr (METAL || ISO) { if (mk_ == 1 || mk_ >= 4) ball = rng_in_unit_ball(rng); }
+  if constexpr (!(MATS & 0x100)) tv = xyz(M1); // solid textures only: every material's colour slot IS its texture value
+  else if (mk_ == 0 || mk_ >= 3) tv = texture_value<MATS>(M0, M1, M[2], M[3], rec.p, uv, atlas);
+  if (LAMB && (mk_ == 0 || !(METAL || GLASS || LIGHT || ISO))) { // lambertian material.hpp:18-28
     V3 dir = rec.normal + rng_unit_vec(rng);
     ray.o = rec.p; ray.d = dir;
     att = att * tv;
     return true;
   }
-  if (mk_ == 1) { // metal material.hpp:39-48
-    V3 reflected = reflect(ud, rec.normal);
-    V3 dir = reflected + M0.z * ball;
-    ray.o = rec.p; ray.d = dir;
-    att = att * xyz(M1);
-    if (dot(dir, rec.normal) > 0) return true;
-    out = mk(0.0f, 0.0f, 0.0f); // emitted of a non-light (material.hpp:50)
-    return false;
+  if constexpr (METAL) {
+    if (mk_ == 1) { // metal material.hpp:39-48
+      V3 reflected = reflect(ud, rec.normal);
+      V3 dir = reflected + M0.z * ball;
+      ray.o = rec.p; ray.d = dir;
+      att = att * xyz(M1);
+      if (dot(dir, rec.normal) > 0) return true;
+      out = mk(0.0f, 0.0f, 0.0f); // emitted of a non-light (material.hpp:50)
+      return false;
+    }
   }
-  if (mk_ == 2) { // dielectric material.hpp:68-88
-    att = att * xyz(M1);
-    float ref_idx = M0.z;
-    float ratio = rec.front_face ? (1.0f / ref_idx) : ref_idx;
-    float cos_theta = __builtin_fminf(-dot(ud, rec.normal), 1.0f);
-    float sin_theta = sqrt_rn(1.0f - cos_theta * cos_theta);
-    bool cannot_refract = ratio * sin_theta > 1.0f;
-    V3 dir;
-    if (cannot_refract || reflectance(cos_theta, ratio) > rng_float(rng)) dir = reflect(ud, rec.normal);
-    else dir = refract(ud, rec.normal, ratio);
-    ray.o = rec.p; ray.d = dir;
-    return true;
+  if constexpr (GLASS) {
+    if (mk_ == 2) { // dielectric material.hpp:68-88
+      att = att * xyz(M1);
+      float ref_idx = M0.z;
+      float ratio = rec.front_face ? (1.0f / ref_idx) : ref_idx;
+      float cos_theta = __builtin_fminf(-dot(ud, rec.normal), 1.0f);
+      float sin_theta = sqrt_rn(1.0f - cos_theta * cos_theta);
+      bool cannot_refract = ratio * sin_theta > 1.0f;
+      V3 dir;
+      if (cannot_refract || reflectance(cos_theta, ratio) > rng_float(rng)) dir = reflect(ud, rec.normal);
+      else dir = refract(ud, rec.normal, ratio);
+      ray.o = rec.p; ray.d = dir;
+      return true;
+    }
   }
-  if (mk_ == 3) { // lightsource material.hpp:104-108; returned un-attenuated (render.hpp:73)
+  if (LIGHT && (mk_ == 3 || !ISO)) { // lightsource material.hpp:104-108; returned un-attenuated (render.hpp:73)
     out = tv;
     return false;
   }

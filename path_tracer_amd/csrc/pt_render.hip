@@ -326,7 +326,7 @@ __device__ __forceinline__ void lane_regenerate(Lane& L, const KArgs& a) {
 }
 
 // emitted / scatter / sky for the nearest hit (render.hpp:60-88) and the sample bookkeeping (:100).
-template <int UV, bool FAST = false, typename Lane, typename PB, typename PM>
+template <int UV, bool FAST = false, int MATS = MATS_ALL, typename Lane, typename PB, typename PM>
 __device__ __forceinline__ void lane_shade(Lane& L, const KArgs& a, const HitState& h, PB recs, PM mats) {
   if (!L.live) return;
   if (a.cost) L.cold.count_ray(); // cost-probe pass (wave-uniform)
@@ -344,7 +344,7 @@ __device__ __forceinline__ void lane_shade(Lane& L, const KArgs& a, const HitSta
       else if (UV == UV_WINNER) winner_uv(recs, h.hit, L.ray, h.closest, rec, u, v);
       else { u = 0.0f; v = 0.0f; }
     };
-    cont = shade(mats, a.atlas, rec, uv, L.ray, L.att, L.rng, out);
+    cont = shade<MATS>(mats, a.atlas, rec, uv, L.ray, L.att, L.rng, out);
     if (cont && ++L.b >= a.depth) { // bounce loop exhausted: black (render.hpp:91)
       out = mk(0.0f, 0.0f, 0.0f);
       cont = false;
@@ -384,7 +384,10 @@ __device__ __forceinline__ void lane_prepare(Lane& L, const KArgs& a) {
 // nothing the walk needs can weigh on its 72-register budget).
 // TRIPOOL: the kernel carries the exact culling of long triangle runs (pt_device.hpp: tri_pool_scan); scalar-cache variant only
 // (such scenes are far beyond LDS), its own register budget.
-template <int UV, bool LDS, bool MLDS, bool COOP, bool CL = false, bool FAST = false, bool BADOUEL = false, bool GRID = true, bool TRIPOOL = false>
+// MATS: the material / texture kinds the scene can contain (pt_device.hpp: MATS_*): the headline family has instantiations for
+// "lambertian + lightsource over solid textures" that carry no metal / glass / isotropic / checker / image code.
+template <int UV, bool LDS, bool MLDS, bool COOP, bool CL = false, bool FAST = false, bool BADOUEL = false, bool GRID = true, bool TRIPOOL = false,
+          int MATS = MATS_ALL>
 __global__ __launch_bounds__(kBlock, TRIPOOL ? PT_MIN_WAVES_TRIPOOL : CL ? PT_MIN_WAVES_CL : COOP ? (UV ? PT_MIN_WAVES_COOP_IMG : PT_MIN_WAVES_COOP) : (UV ? PT_MIN_WAVES_IMG : PT_MIN_WAVES))
 void render_kernel(KArgs a) {
   constexpr bool IMG = UV == UV_TRACKED;
@@ -438,8 +441,8 @@ void render_kernel(KArgs a) {
       asm volatile("" ::"v"(h.closest), "v"(h.hit));
       PT_STAMP(t2);
 #endif
-      if constexpr (MLDS) lane_shade<UV, FAST>(L, a, h, (lds_f4p)smem, (lds_f4p)smem + a.blob_f4);
-      else lane_shade<UV, FAST>(L, a, h, (lds_f4p)smem, a.mats);
+      if constexpr (MLDS) lane_shade<UV, FAST, MATS>(L, a, h, (lds_f4p)smem, (lds_f4p)smem + a.blob_f4);
+      else lane_shade<UV, FAST, MATS>(L, a, h, (lds_f4p)smem, a.mats);
 #ifdef PT_STAMPS
       asm volatile("" ::"v"(L.att.x), "v"(L.ray.d.x));
       PT_STAMP(t3);
@@ -450,7 +453,7 @@ void render_kernel(KArgs a) {
       c.live = L.live;
       const bool fast = wave_all_regular(c, L.live);
       hit_world<IMG, BADOUEL, GRID, TRIPOOL>((cst_f4p)a.blob, (cst_f4p)a.blob, a.n_runs, c, fast, L.rng, h);
-      lane_shade<UV, FAST>(L, a, h, a.blob, a.mats);
+      lane_shade<UV, FAST, MATS>(L, a, h, a.blob, a.mats);
     }
   }
 #ifdef PT_STAMPS_WALK
@@ -874,6 +877,7 @@ struct PtScene {
   float traversal_cost = 0.0f; // estimated VALU instructions of one ray's scan of the list (sphere runs through their lists)
   int grid_spheres = 0;        // spheres that sit in a culling grid (the resident non-cooperative kernels walk it)
   int tri_pooled = 0;          // triangles that sit in a triangle pool (the TRIPOOL kernels query it)
+  bool mats_simple = false;    // every material is lambertian or lightsource over a solid texture (kernels compiled with MATS_LAMB_LIGHT_SOLID)
   size_t blob_bytes = 0;
   int num_cus = 256;
   mutable unsigned int* ws_cost = nullptr; // LPT workspace: per-tile ray counts of the probe pass
@@ -1017,6 +1021,11 @@ int pt_scene_create(const PtSceneDesc* desc, PtScene** out_scene) {
     }
   }
   s->grid_spheres = flat.grid_spheres;
+  s->mats_simple = desc->n_materials > 0 && std::getenv("PT_NO_MATSPEC") == nullptr; // PT_NO_MATSPEC: A/B knob (generic shading)
+  for (int i = 0; i < desc->n_materials && s->mats_simple; i++) {
+    const PtMaterial& m = desc->materials[i];
+    if ((m.kind != PT_MAT_LAMBERTIAN && m.kind != PT_MAT_LIGHTSOURCE) || desc->textures[m.texture].kind != PT_TEX_SOLID) s->mats_simple = false;
+  }
   s->tri_pooled = flat.has_badouel ? 0 : flat.tri_pooled; // (scenes with Badouel-strategy triangles keep the round-2 kernels)
   s->blob_bytes = flat.blob.size() * 16;
   s->mats_f4 = (int)flat.mats.size();
@@ -1209,6 +1218,13 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
     if (!resident) return launch(render_kernel_stream<UV>);
     if constexpr (UV == UV_NONE) { // no image texture and no sphere grid (the headline scene): kernels without the grid walk
       if (s->grid_spheres == 0 && !coop) {
+        if (s->mats_simple) { // lambertian + lightsource over solid textures: kernels without the other materials' code
+          constexpr int MS = MATS_LAMB_LIGHT_SOLID;
+          if (!lds) return launch(render_kernel<UV, false, false, false, false, false, false, false, false, MS>);
+          if (mlds && shmem <= kMaxLdsColdScene && !s->knobs.no_cold_lds) return launch(render_kernel<UV, true, true, false, true, false, false, false, false, MS>);
+          return mlds ? launch(render_kernel<UV, true, true, false, false, false, false, false, false, MS>)
+                      : launch(render_kernel<UV, true, false, false, false, false, false, false, false, MS>);
+        }
         if (!lds) return launch(render_kernel<UV, false, false, false, false, false, false, false>);
         if (mlds && shmem <= kMaxLdsColdScene && !s->knobs.no_cold_lds) return launch(render_kernel<UV, true, true, false, true, false, false, false>);
         return mlds ? launch(render_kernel<UV, true, true, false, false, false, false, false>)

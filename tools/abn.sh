@@ -2,7 +2,7 @@
 # Several builds side by side in ONE gpurun call:  tools/abn.sh "lib1 lib2 ..." scene spp shards [width height]
 # (libs = files under path_tracer_amd/, e.g. libpt_render.so libpt_var_k2.so); prints kernel ms of shard 0 of N
 for lib in $1; do
-  PT_RENDER_LIB=$PWD/path_tracer_amd/$lib python - "$2" "$3" "$4" "${5:-1920}" "${6:-1080}" "$lib" <<'PY'
+  PT_RENDER_LIB_ALLOW_OLDER=1 PT_RENDER_LIB=$PWD/path_tracer_amd/$lib python - "$2" "$3" "$4" "${5:-1920}" "${6:-1080}" "$lib" <<'PY'
 import sys
 sys.path.insert(0, '.')
 import torch
