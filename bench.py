@@ -61,6 +61,39 @@ OPS = dict(
 # not run, need nothing from oracle/; the N=1 cpu_baseline leg re-derives the figure live and reports that.
 ALGORITHMIC_OPS_PER_SAMPLE = {"cornell": 2062.7, "smoke": 39395.4, "triangles": 8220663.0}
 
+# The 496-hittable scene does NOT run the reference's algorithm as written: 476 of its 489 spheres sit in an exact culling grid
+#  and a ray tests the spheres of the cells it crosses instead of all of them.  Pricing the kernel against the
+# reference's 483 sphere tests per ray gave "fractions" above 1; the roofline of such a kernel is priced for the algorithm it
+# runs: everything but the gridded spheres as counted by the oracle, plus the grid walk as counted IN the kernel
+# (profiles/r03_smoke_walk_counters.json: diagnostic build, tools/stamps.py): cells visited x the ops of a DDA step, walks x the
+# ops of a walk's set-up, grid sphere tests priced like the oracle's sphere tests.
+GRID_WALK = {"smoke": dict(cells_per_sample=6.44, tests_per_sample=13.61, source="profiles/r03_smoke_walk_counters.json")}
+OPS_GRID = dict(step=19,    # min3 (2) + axis select (3) + index step (3) + bounds (3) + boundary update (3) + header decode (2) + limit (3)
+                setup=45)   # origin and reciprocal direction in cell units (9), slab clip (14), entry cell (12), first boundaries (9), sign selects (1)
+
+
+def ops_per_sample_culled(ctr: dict, n_spheres: int, grid_spheres: int, walk: dict) -> float:
+    """Algorithmic lane-ops per sample of the CULLED algorithm: ops_per_sample() with the sphere part replaced.  The oracle's
+    sphere counters cover all spheres; the kernel tests the (n_spheres - grid_spheres) listed ones for every ray and the
+    gridded ones per cell.  Sphere accepts are priced as counted (a hit is a hit in any order); every other sphere test — the
+    listed ones of every ray and the walk's — at the oracle's own mix of its two rejecting exits; moving-sphere extras in
+    proportion."""
+    n = ctr["samples"]
+    se = ctr["sphere_exit"]
+    brute_spheres = (se[0] * OPS["sphere_nodisc"] + se[1] * OPS["sphere_roots_rejected"] + se[2] * OPS["sphere_accept"]
+                     + ctr["sphere_moving"] * OPS["sphere_moving"])
+    rest = ops_per_sample(ctr) * n - brute_spheres
+    reject_price = (se[0] * OPS["sphere_nodisc"] + se[1] * OPS["sphere_roots_rejected"]) / max(1, se[0] + se[1])
+    moving_share = ctr["sphere_moving"] / max(1, sum(se))
+    tests = ctr["rays"] * (n_spheres - grid_spheres) + walk["tests_per_sample"] * n
+    spheres = (se[2] * OPS["sphere_accept"] + max(0.0, tests - se[2]) * reject_price + tests * moving_share * OPS["sphere_moving"])
+    walk_ops = walk["cells_per_sample"] * n * OPS_GRID["step"] + ctr["rays"] * OPS_GRID["setup"]
+    return (rest + spheres + walk_ops) / n
+
+
+# recorded like ALGORITHMIC_OPS_PER_SAMPLE (the N = 1 cpu_baseline leg re-derives it live): the culled algorithm's figure
+ALGORITHMIC_OPS_PER_SAMPLE_CULLED = {"smoke": 2116.7}
+
 
 def ops_per_sample(ctr: dict) -> float:
     """Algorithmic lane-ops per sample from the oracle's exit-point counters, priced per exit."""
@@ -264,6 +297,7 @@ def main() -> None:
         samples_per_step = W * H * SPP
         value = samples_per_step * args.steps / elapsed / 1e6
         ops = ALGORITHMIC_OPS_PER_SAMPLE[scene_name]
+        ops_culled = ALGORITHMIC_OPS_PER_SAMPLE_CULLED.get(scene_name) if not os.environ.get("PT_NO_GRID") else None
         cpu_line = None
         if world == 1 and not args.no_cpu_baseline:
             # --- cpu_baseline leg: the only place bench.py touches oracle/ (test infrastructure) ---------------
@@ -272,6 +306,12 @@ def main() -> None:
             cw, ch, cs = (480, 270, 4) if scene_name != "triangles" else (96, 54, 1)
             _, ctr = orc.render(packed, scenes.make_camera(cam_args, cw, ch).c, cw, ch, cs, DEPTH, counters=True)
             ops = ops_per_sample(ctr.as_dict())  # exit-point counters -> algorithmic ops per sample, live
+            if scene_name in GRID_WALK and not os.environ.get("PT_NO_GRID"):
+                import ctypes as C_
+                from path_tracer_amd import abi as abi_
+                st = (C_.c_int32 * 8)()
+                abi_.check(abi_.load_library().pt_debug_tri_pool(C_.byref(packed.desc), st), "pt_debug_tri_pool")
+                ops_culled = ops_per_sample_culled(ctr.as_dict(), sum(1 for k in packed.kinds() if k == abi_.PT_HIT_SPHERE), st[7], GRID_WALK[scene_name])
             # bounded sample of the same workload, sized for ~15 s of CPU work from a 1-spp probe
             bw, bh = (W, H) if scene_name != "triangles" else (240, 135)
             bcam = scenes.make_camera(cam_args, bw, bh)
@@ -313,6 +353,9 @@ def main() -> None:
         # the committed counters are those of the parity kernels with default flags: any other mode / flag set gets nulls
         pmc = pmc_traffic(scene_name, W, H, SPP) if (world == 1 and args.flags == 0) else None
         kernel_samples_per_s = samples_per_step / (kern_ms * 1e-3)  # whole job; each rank renders 1/world of it
+        ops_reference = ops
+        if ops_culled:  # a kernel that provably skips tests is priced for the algorithm it runs; the reference's figure rides beside
+            ops = ops_culled
         achieved = ops * kernel_samples_per_s / 1e12 / world  # per GPU
         headline = (scene_name, W1, H1, SPP) == ("cornell", 1920, 1080, 1024)
         at = "1080p 1024spp" if (W, H, SPP) == (1920, 1080, 1024) else f"{W}x{H} {SPP}spp"
@@ -331,11 +374,13 @@ def main() -> None:
                        "sharding": "whole frame" if world == 1 else f"8x8 tiles round-robin over {world} ranks + RCCL gather"},
             "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": round(PEAK_TLANEOPS, 1), "unit": "Tlaneop/s",
                          "frac": round(achieved / PEAK_TLANEOPS, 4),
-                         # `achieved` prices the REFERENCE's algorithm as written (every hittable tested by every ray); a
-                         # kernel that provably skips tests (the exact culling grid of sphere fields) does less
-                         # than that and can exceed 1 — its own instruction counters are in the PMC fields below
-                         "frac_note": ("exceeds 1: exact culling skips most of the reference's sphere tests; see executed_over_algorithmic"
-                                       if achieved / PEAK_TLANEOPS > 1 else None),
+                         # `achieved` prices the algorithm the kernel RUNS: the reference's as written, except where an exact
+                         # culling structure provably skips tests (sphere grid: ops_per_sample_culled); the reference's own
+                         # figure rides beside as algorithmic_ops_per_sample_reference
+                         "frac_note": ("exceeds 1: the kernel skips tests the pricing still counts" if achieved / PEAK_TLANEOPS > 1 else None),
+                         "priced_algorithm": ("culled: sphere grid (cells visited and grid tests counted in-kernel: " + GRID_WALK[scene_name]["source"] + ")"
+                                              if ops_culled else "the reference's algorithm as written"),
+                         "algorithmic_ops_per_sample_reference": round(ops_reference, 1),
                          "traffic": pmc[0] if pmc else None, "traffic_source": pmc[1] if pmc else None,
                          # north-star evidence: HBM is not the limiter, VALU issue is busy (PMC of the committed profile)
                          "hbm": {"achieved_gbs": round(pmc[0] / (kern_ms * 1e-3) / 1e9, 3), "peak_gbs": 8000.0,

@@ -325,7 +325,7 @@ int pt_debug_flatten(const PtSceneDesc* desc, float* blob_out, int64_t blob_cap_
 
 /* Host-only statistics of the triangle pool pt_scene_create() would build (no GPU needed): out[0] = triangles in pooled runs,
  * out[1] = entries of the always list, out[2..4] = triangles on the three cube-map band levels, out[5] = 1000 x mean grid cells
- * per triangle, out[6] = blob size in 16-byte records, out[7] = 0.  All zero when the scene gets no pool.                 */
+ * per triangle, out[6] = blob size in 16-byte records (always), out[7] = spheres that sit in a sphere culling grid (always).     */
 int pt_debug_tri_pool(const PtSceneDesc* desc, int32_t out[8]);
 
 /* What the scheduler decided for the LAST render of this scene (blocks until that render is done): out[0] = tiles sent

@@ -979,7 +979,7 @@ int pt_debug_tri_pool(const PtSceneDesc* desc, int32_t out[8]) {
   if (rc) return fail(rc, err);
   out[0] = flat.tri_pooled; out[1] = flat.tri_always;
   for (int k = 0; k < 3; k++) out[2 + k] = flat.tri_level_counts[k];
-  out[5] = (int32_t)(1000.0 * flat.tri_cells_per_triangle); out[6] = (int32_t)flat.blob.size(); out[7] = 0;
+  out[5] = (int32_t)(1000.0 * flat.tri_cells_per_triangle); out[6] = (int32_t)flat.blob.size(); out[7] = flat.grid_spheres;
   return PT_OK;
 }
 

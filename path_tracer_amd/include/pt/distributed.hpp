@@ -10,6 +10,8 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <atomic>
+#include <mutex>
 #include <thread>
 
 #include "../../../include/pt_dist.h"
@@ -63,15 +65,28 @@ inline void render_multi_gpu(const std::vector<int>& devices, int width, int hei
   if (ncclCommInitAll(comms.data(), n, devices.data()) != ncclSuccess) throw std::runtime_error("ncclCommInitAll failed");
   std::vector<std::string> errors((std::size_t)n);
   std::vector<std::thread> threads;
+  // A rank that fails before it reaches the gather (hipSetDevice, scene upload, an allocation, a rejected parameter) would
+  // leave its peers blocked inside the collective for ever: the failing thread aborts EVERY communicator, which ends the
+  // peers' pending collectives, so that all threads can be joined and the first error is rethrown.
+  std::atomic<bool> aborted{false};
+  std::mutex abort_mutex;
   for (int r = 0; r < n; r++)
     threads.emplace_back([&, r] {
       try {
         if (hipSetDevice(devices[(std::size_t)r]) != hipSuccess) throw std::runtime_error("hipSetDevice failed");
         render_sharded(comms[(std::size_t)r], r, n, width, height, samples, frame_buf, hittables, cam, depth, 0);
-      } catch (const std::exception& e) { errors[(std::size_t)r] = e.what(); }
+      } catch (const std::exception& e) {
+        errors[(std::size_t)r] = e.what();
+        std::lock_guard<std::mutex> g(abort_mutex);
+        if (!aborted.exchange(true))
+          for (auto c : comms) (void)ncclCommAbort(c);
+      }
     });
   for (auto& t : threads) t.join();
-  for (auto c : comms) (void)ncclCommDestroy(c);
+  if (!aborted.load())
+    for (auto c : comms) (void)ncclCommDestroy(c);
+  for (std::size_t r = 0; r < errors.size(); r++) // the rank that failed first names the cause; peers only report the abort
+    if (!errors[r].empty() && errors[r].find("pt_dist_render") == std::string::npos) throw std::runtime_error("render_multi_gpu: rank " + std::to_string(r) + ": " + errors[r]);
   for (auto& e : errors) if (!e.empty()) throw std::runtime_error("render_multi_gpu: " + e);
 }
 

@@ -134,3 +134,29 @@ def test_committed_final_summaries_are_unambiguous():
     for key in seen:
         got = bench.pmc_traffic(*key)
         assert got is not None and got[0] > 0
+
+
+def test_culled_algorithm_pricing_for_the_sphere_grid_scene(orc, lib):
+    """cfg1 / cfg3 / cfg4 run an exact culling grid: bench.py prices the roofline for the algorithm the kernel runs (the oracle's
+    counters for everything but the gridded spheres + the walk as counted in the kernel), so that `frac` stays below 1 and
+    means something; the reference's own figure rides beside.  The recorded figure agrees with a live derivation."""
+    import ctypes as C
+    from path_tracer_amd import abi
+    bench = load_bench()
+    packed, cam_args = scenes.build("smoke")
+    orc.set_math(True)
+    _, ctr = orc.render(packed, scenes.make_camera(cam_args, 240, 135).c, 240, 135, 2, 50, counters=True)
+    st = (C.c_int32 * 8)()
+    abi.check(lib.pt_debug_tri_pool(C.byref(packed.desc), st), "pt_debug_tri_pool")
+    n_spheres = sum(1 for k in packed.kinds() if k == abi.PT_HIT_SPHERE)
+    assert n_spheres == 489 and st[7] == 482  # 7 spheres stay in the lists: ground, the glowing ball, the five big ones
+    live = bench.ops_per_sample_culled(ctr.as_dict(), n_spheres, st[7], bench.GRID_WALK["smoke"])
+    assert abs(live / bench.ALGORITHMIC_OPS_PER_SAMPLE_CULLED["smoke"] - 1) < 0.08
+    assert live < 0.1 * bench.ALGORITHMIC_OPS_PER_SAMPLE["smoke"]       # the grid removes > 90 % of the reference's arithmetic
+    # at the measured ~4 700 Msamples/s that is 0.13 of the VALU peak — the number round 2 reported as "2.36"
+    assert live * 4.7e9 / 1e12 / bench.PEAK_TLANEOPS < 0.2
+    src = (ROOT / bench.GRID_WALK["smoke"]["source"])
+    if src.exists():  # the committed in-kernel counters the constants were read from
+        d = json.loads(src.read_text())
+        assert abs(d["per_sample"]["cells_visited"] / bench.GRID_WALK["smoke"]["cells_per_sample"] - 1) < 0.05
+        assert abs(d["per_sample"]["grid_sphere_tests"] / bench.GRID_WALK["smoke"]["tests_per_sample"] - 1) < 0.05

@@ -36,6 +36,15 @@ if WALK:
     print(f"  per walk: wave-steps {wsteps/max(walks,1):.2f}, lane-steps {lsteps/max(walks,1):.1f} (lanes stepping per wave-step {lsteps/max(wsteps,1):.1f}), "
           f"test trips {wtrips/max(walks,1):.2f}, lane sphere tests {ltests/max(walks,1):.1f} (lanes testing per trip {ltests/max(wtrips,1):.1f}), split phases {splits/max(walks,1):.3f}")
     print(f"  per sample: cells visited {lsteps/samples:.2f}, grid sphere tests {ltests/samples:.2f}")
+    if os.environ.get("PT_WALK_JSON"):  # the record bench.py's culled-algorithm pricing is built on (profiles/<tag>_walk_counters.json)
+        import json
+        json.dump({"scene": scene, "workload": f"{W}x{H}x{spp}", "shards": N, "note": "in-kernel counters of the sphere-grid walk, diagnostic build "
+                   "(make -C path_tracer_amd/csrc stamps EXTRA=-DPT_STAMPS_WALK), probe pass included in the wave counts, not in the per-sample figures' denominators",
+                   "per_sample": {"cells_visited": lsteps / samples, "grid_sphere_tests": ltests / samples, "walks_waves": walks / samples},
+                   "per_walk": {"wave_steps": wsteps / max(walks, 1), "test_trips": wtrips / max(walks, 1), "lanes_per_step": lsteps / max(wsteps, 1),
+                                "lanes_per_trip": ltests / max(wtrips, 1), "cycles": cyc / max(walks, 1)},
+                   "cycles_per_wave_iteration": {"prepare": prep / iters, "traversal": trav / iters, "shade": shade / iters},
+                   "walk_share_of_iteration": cyc / max(tot, 1)}, open(os.environ["PT_WALK_JSON"], "w"), indent=1)
 elif not os.environ.get("PT_STAMPS_POOL"):
     print(f"  gridded sphere runs scanned {out[4]:.3e}; full-list fallback in {out[5]/max(out[4],1):.4f} of them (far origin in {out[6]/max(out[4],1):.4f}), {out[7]/max(out[5],1):.1f} lanes at fault on average")
 if os.environ.get("PT_STAMPS_POOL"):
