@@ -138,6 +138,22 @@ def pmc_traffic(scene: str, w: int, h: int, spp: int, profiles_dir=None):
     return best
 
 
+def predicted_chain_floor_ms(scene: str, w: int, h: int, spp: int, n_gpus: int, profiles_dir=None):
+    """Kernel ms of shard 0 of `n_gpus` of this frame as measured on ONE GPU (tools/shard_table.py -> profiles/*_shard_table_*.json,
+    final-marked like the PMC summaries): the step time an N-GPU parity run cannot beat — a shard is bounded by its heaviest
+    pixel's sequential RNG chain, so strong scaling flattens where this figure stops falling."""
+    best, best_round = None, -1
+    for f in (Path(profiles_dir) if profiles_dir else ROOT / "profiles").glob("*_shard_table_*.json"):
+        try:
+            d = json.loads(f.read_text())
+        except Exception:  # noqa: BLE001
+            continue
+        if d.get("final") and d.get("scene") == scene and d.get("workload") == f"{w}x{h}x{spp}" and str(n_gpus) in d.get("parity", {}):
+            if int(d.get("round", 0)) > best_round:
+                best, best_round = (d["parity"][str(n_gpus)], f.name), int(d.get("round", 0))
+    return best
+
+
 def weak_frame(width: int, height: int, n_gpus: int):
     """Frame of an N-GPU weak-scaling step: N x the pixels of the 1-GPU frame, aspect kept (every rank gets one 1-GPU
     frame's worth of 8x8 tiles).  1920x1080 -> 2715x1527, 3840x2160, 5431x3055 for N = 2, 4, 8."""
@@ -397,6 +413,10 @@ def main() -> None:
                          "kernel_msamples_per_s_per_gpu": round(kernel_samples_per_s / world / 1e6, 2),
                          "hbm_algorithmic_bytes": W * H * 12 // world},
         }
+        if world > 1 and args.mode == "parity":  # why the strong-scaling curve flattens: the shard's own chain floor, measured on one GPU
+            floor = predicted_chain_floor_ms(scene_name, W1, H1, SPP, world)
+            line["predicted_chain_floor_ms"] = floor[0] if floor else None
+            line["predicted_chain_floor_source"] = floor[1] if floor else None
         if other:
             line[other["scaling"] + "_scaling"] = other
         if cpu_line:

@@ -266,8 +266,12 @@ __device__ __forceinline__ void lane_acquire(Lane& L, const KArgs& a) {
   L.need_new = true;
 }
 
-// One 12-byte store per finished pixel (render.hpp:105): global_store_dwordx3 needs dword alignment only.  Three scalar
-// dword stores made the write traffic 2.7x the algorithmic 12 B/pixel (partial-line writes; r02e_cornell_pmc_summary.json).
+// One 12-byte store per finished pixel (render.hpp:105): global_store_dwordx3 needs dword alignment only.
+// (HBM write traffic of a frame launch: 26.3 MB against the algorithmic 24.9 MB — profiles/r03_cornell_pmc_write.csv, the
+// 148 ms dispatch.  The "68 MB" of the round-2 summaries was the cost-probe launch's per-pixel atomics, picked up because the
+// summary took each counter's maximum over the two launches: tools/pmc_summary.py now reads the frame launch only.  Deferring
+// the stores until a wave's whole tile is done — eight lanes writing 96 contiguous bytes — was tried and changes nothing:
+// 26.26 MB.)
 struct __attribute__((packed, aligned(4))) Rgb12 { float r, g, b; };
 __device__ __forceinline__ void store_rgb(float* p, V3 c) { *(Rgb12*)p = Rgb12{c.x, c.y, c.z}; }
 

@@ -160,3 +160,16 @@ def test_culled_algorithm_pricing_for_the_sphere_grid_scene(orc, lib):
         d = json.loads(src.read_text())
         assert abs(d["per_sample"]["cells_visited"] / bench.GRID_WALK["smoke"]["cells_per_sample"] - 1) < 0.05
         assert abs(d["per_sample"]["grid_sphere_tests"] / bench.GRID_WALK["smoke"]["tests_per_sample"] - 1) < 0.05
+
+
+def test_predicted_chain_floor_is_read_from_final_shard_tables(tmp_path):
+    bench = load_bench()
+    (tmp_path / "r03_shard_table_cornell.json").write_text(json.dumps(
+        {"scene": "cornell", "workload": "1920x1080x1024", "final": True, "round": 3, "parity": {"1": 148.0, "8": 43.0}}))
+    (tmp_path / "r02_shard_table_cornell.json").write_text(json.dumps(
+        {"scene": "cornell", "workload": "1920x1080x1024", "final": True, "round": 2, "parity": {"8": 47.1}}))
+    (tmp_path / "r09_shard_table_cornell.json").write_text(json.dumps(
+        {"scene": "cornell", "workload": "1920x1080x1024", "round": 9, "parity": {"8": 1.0}}))  # not final: ignored
+    assert bench.predicted_chain_floor_ms("cornell", 1920, 1080, 1024, 8, tmp_path) == (43.0, "r03_shard_table_cornell.json")
+    assert bench.predicted_chain_floor_ms("cornell", 1920, 1080, 1024, 4, tmp_path) is None
+    assert bench.predicted_chain_floor_ms("smoke", 1920, 1080, 1024, 8, tmp_path) is None

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Copies what tools/profile_round.sh left in gpurun_out/<tag>/ into profiles/ (tracked):
-#   tools/collect_profiles.sh TAG SCENE W H SPP       e.g.  tools/collect_profiles.sh r02_smoke smoke 1920 1080 1024
+#   [PT_FINAL_ROUND=3] tools/collect_profiles.sh TAG SCENE W H SPP       e.g.  tools/collect_profiles.sh r02_smoke smoke 1920 1080 1024
+# PT_FINAL_ROUND marks the PMC summary as the round's final one for its workload (what bench.py's pmc_traffic selects)
 TAG=$1; SCENE=$2; W=$3; H=$4; SPP=$5
 SRC=gpurun_out/$TAG
 DST=profiles
@@ -12,5 +13,5 @@ for p in a b fetch write icache; do
   f=$(find $SRC/pmc_$p -name "*counter_collection.csv" 2>/dev/null | head -1)
   [ -n "$f" ] && (head -1 $f; grep -E "render_kernel" $f) > $DST/${TAG}_pmc_$p.csv
 done
-python tools/pmc_summary.py $TAG $SCENE $W $H $SPP $DST/${TAG}_pmc_a.csv $DST/${TAG}_pmc_b.csv $DST/${TAG}_pmc_fetch.csv $DST/${TAG}_pmc_write.csv > $DST/${TAG}_pmc_summary.json
+python tools/pmc_summary.py ${PT_FINAL_ROUND:+--final $PT_FINAL_ROUND} $TAG $SCENE $W $H $SPP $DST/${TAG}_pmc_a.csv $DST/${TAG}_pmc_b.csv $DST/${TAG}_pmc_fetch.csv $DST/${TAG}_pmc_write.csv > $DST/${TAG}_pmc_summary.json
 cat $DST/${TAG}_pmc_summary.json | python -c "import json,sys; d=json.load(sys.stdin); print(json.dumps(d['derived'], indent=1)); print(d['kernel'])"

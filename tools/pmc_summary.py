@@ -18,17 +18,24 @@ def main():
         final_round = int(sys.argv[2])
         del sys.argv[1:3]
     tag, scene, w, h, spp = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
-    # A render is two launches of the render kernel (a short cost-probe pass, then the frame): report the
-    # frame launch = the dispatch with the largest value, per counter.
-    disp = collections.defaultdict(lambda: collections.defaultdict(float))
+    # A render is two launches of the render kernel (a short cost-probe pass, then the frame).  The FRAME launch is the dispatch
+    # that runs longest; every counter is read from that dispatch of its own pass.  (Round 2 took each counter's maximum over
+    # the dispatches instead, which for WRITE_SIZE picked the probe pass — 66 MB of per-pixel cost atomics in 1.6 ms — and made
+    # the frame's write traffic look 2.7x its algorithmic 12 B/pixel; it is 1.06x.)
     meta = {}
+    per = {}
     for path in sys.argv[6:]:
-        for r in csv.DictReader(open(path)):
-            if "render_kernel" not in r["Kernel_Name"]:
-                continue
-            disp[r["Counter_Name"]][(path, r["Dispatch_Id"])] += float(r["Counter_Value"])
-            meta = {k: r[k] for k in ("Kernel_Name", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Grid_Size", "Workgroup_Size")}
-    per = {k: max(v.values()) for k, v in disp.items()}
+        rows = [r for r in csv.DictReader(open(path)) if "render_kernel" in r["Kernel_Name"]]
+        if not rows:
+            continue
+        dur = collections.defaultdict(float)
+        for r in rows:
+            dur[r["Dispatch_Id"]] = max(dur[r["Dispatch_Id"]], float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+        frame = max(dur, key=dur.get)
+        for r in rows:
+            if r["Dispatch_Id"] == frame:
+                per[r["Counter_Name"]] = per.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+                meta = {k: r[k] for k in ("Kernel_Name", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Grid_Size", "Workgroup_Size")}
     samples = w * h * spp
     out = {"tag": tag, "scene": scene, "workload": f"{w}x{h}x{spp}", "kernel": meta, "per_launch": per, "derived": {}}
     if final_round is not None:
