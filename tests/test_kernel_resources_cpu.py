@@ -39,10 +39,11 @@ def usage():
 
 
 def test_headline_kernels_fit_seven_waves_without_scratch(usage):
-    # render_kernel<UV_NONE, LDS, MLDS, COOP=false, CL, FAST=false, BADOUEL=false, GRID=false>: the instantiations scenes without a
-    # sphere grid (the headline Cornell-style scene) run; mangled ...render_kernelILi0ELb?ELb?ELb0ELb?ELb0ELb0ELb0E...
-    hot = {k: v for k, v in usage.items() if re.search(r"render_kernelILi0ELb[01]ELb[01]ELb0ELb[01]ELb0ELb0ELb0E", k)}
-    assert len(hot) == 4, sorted(usage)
+    # render_kernel<UV_NONE, LDS, MLDS, COOP=false, CL, FAST=false, BADOUEL=false, GRID=false, TRIPOOL=false, MATS>: the instantiations
+    # scenes without a sphere grid run — generic shading (MATS_ALL = 287) and the lambertian + light / solid-texture
+    # specialisation the headline Cornell-style scene takes (MATS = 9); mangled ...render_kernelILi0ELb?ELb?ELb0ELb?ELb0ELb0ELb0ELb0ELi<MATS>E...
+    hot = {k: v for k, v in usage.items() if re.search(r"render_kernelILi0ELb[01]ELb[01]ELb0ELb[01]ELb0ELb0ELb0ELb0ELi(9|287)E", k)}
+    assert len(hot) == 8, sorted(usage)
     for k, v in hot.items():
         # the kernel the headline config runs (cold lane state in LDS: CL = 1) has no scratch at all; the variants that keep
         # the cold state in registers park up to seven dwords around the slab pool (once per iteration, outside every loop)

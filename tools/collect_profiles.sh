@@ -6,11 +6,12 @@ TAG=$1; SCENE=$2; W=$3; H=$4; SPP=$5
 SRC=gpurun_out/$TAG
 DST=profiles
 cp $SRC/bench_n1.json $DST/${TAG}_bench_n1.json
-cp $(find $SRC/kt -name "*kernel_stats.csv" | head -1) $DST/${TAG}_kernel_stats.csv
-KT=$(find $SRC/kt -name "*kernel_trace.csv" | head -1)
+cp $(ls -t $(find $SRC/kt -name "*kernel_stats.csv") | head -1) $DST/${TAG}_kernel_stats.csv   # the newest run of this tag
+KT=$(ls -t $(find $SRC/kt -name "*kernel_trace.csv") | head -1)
 (head -1 $KT; grep -E "render_kernel|lpt_order" $KT | head -8) > $DST/${TAG}_kernel_trace_rows.csv
 for p in a b fetch write icache; do
-  f=$(find $SRC/pmc_$p -name "*counter_collection.csv" 2>/dev/null | head -1)
+  [ -d $SRC/pmc_$p ] || continue
+  f=$(ls -t $(find $SRC/pmc_$p -name "*counter_collection.csv" 2>/dev/null) 2>/dev/null | head -1)
   [ -n "$f" ] && (head -1 $f; grep -E "render_kernel" $f) > $DST/${TAG}_pmc_$p.csv
 done
 python tools/pmc_summary.py ${PT_FINAL_ROUND:+--final $PT_FINAL_ROUND} $TAG $SCENE $W $H $SPP $DST/${TAG}_pmc_a.csv $DST/${TAG}_pmc_b.csv $DST/${TAG}_pmc_fetch.csv $DST/${TAG}_pmc_write.csv > $DST/${TAG}_pmc_summary.json
