@@ -1046,8 +1046,20 @@ __device__ __forceinline__ void slab_pool(P blob, cst_f4p cblob, int pool_off, i
 #define PT_TRI_COUNT(i, v) do { } while (0)
 #endif
 
-__device__ __forceinline__ void tri_test_unordered(glb_f4p gblob, int o, const Ray& r, HitState& h) {
-  const f4 R0 = gblob[o], R1 = gblob[o + 1], R2 = gblob[o + 2];
+__device__ __forceinline__ unsigned int gdword(glb_f4p gblob, int base_f4, int i) { return ((const __attribute__((address_space(1))) unsigned int*)(gblob + base_f4))[i]; }
+
+// returns false when some live lane's ray is outside what the pool is exact for (irregular, or its origin beyond rlimit): the
+// caller then scans the whole run.
+// Memory shape.  This scan is bound by the LATENCY of its loads (a wave's loads are dependent and land in L2 / MALL: ~3 700
+// cycles each on the 100 k-triangle mesh: PMC), so everything is organised to put many independent loads in
+// flight per wait: every list a lane streams (a cell's candidates, a strip row's candidates) is CONTIGUOUS with the records
+// its filters need inline, and is consumed FOUR entries per trip (twelve loads issued together); the always list is loaded
+// 64 entries at a time, one per lane, and broadcast with v_readlane; survivors of the filters are parked in a per-lane LDS
+// stack and their exact tests run for the whole wave two triangles at a time (six loads together).
+constexpr int kTriPendCap = 16; // parked candidates per lane (flushed when some lane holds more than kTriPendCap - 4)
+__device__ __forceinline__ int* tri_pend_stack() { __shared__ int s[kTriPendCap * 256]; return s; }
+
+__device__ __forceinline__ void tri_test_loaded(f4 R0, f4 R1, f4 R2, int o, const Ray& r, HitState& h) {
   const TriEval e = tri_eval(R0, R1, R2, r);
   if (e.pass) {
     const float a_abs = __builtin_fabsf(e.a);
@@ -1066,13 +1078,6 @@ __device__ __forceinline__ void tri_test_unordered(glb_f4p gblob, int o, const R
   }
 }
 
-__device__ __forceinline__ unsigned int gdword(glb_f4p gblob, int base_f4, int i) { return ((const __attribute__((address_space(1))) unsigned int*)(gblob + base_f4))[i]; }
-
-// returns false when some live lane's ray is outside what the pool is exact for (irregular, or its origin beyond rlimit): the
-// caller then scans the whole run.
-// Memory shape: every list a lane streams (a cell's candidates, a strip row's candidates) is CONTIGUOUS and carries the
-// records its filters need inline, and the next entry is requested while the current one is tested; only the exact test of
-// the few survivors gathers (three records of the triangle itself), and those are parked and run for the whole wave at once.
 __device__ __forceinline__ bool tri_pool_scan(glb_f4p gblob, cst_f4p cblob, int hdr, int goff, const RayCtx& c, HitState& h) {
   const Ray& r = c.r;
   const f4 H0 = cblob[hdr], H1 = cblob[hdr + 1], H2 = cblob[hdr + 2], H3 = cblob[hdr + 3], H4 = cblob[hdr + 4], H5 = cblob[hdr + 5], H6 = cblob[hdr + 6];
@@ -1086,19 +1091,25 @@ __device__ __forceinline__ bool tri_pool_scan(glb_f4p gblob, cst_f4p cblob, int 
     const V3 x = cross(C - r.o, r.d);
     return dot(x, x) <= rad * rad * c.a * 1.00001f;
   };
-  // A lane whose candidate passes its filters parks the triangle; the exact test runs for the whole wave when some lane gets its
-  // second one (and at the end): once per ~10-50 trips instead of in nearly every one.
-  int pend = -1;
+  // parked candidates: a per-lane stack in LDS (slot s of this thread at pend[s * blockDim + thread])
+  int* const pend = tri_pend_stack() + threadIdx.x;
+  int np = 0;
   auto flush = [&]() {
     PT_TRI_COUNT(6, 1);
-    PT_TRI_COUNT(3, __builtin_popcountll(__builtin_amdgcn_ballot_w64(pend >= 0)));
-    if (pend >= 0) tri_test_unordered(gblob, goff + 3 * pend, r, h);
-    pend = -1;
+    for (int j = 0; __builtin_amdgcn_ballot_w64(j < np) != 0; j += 2) {
+      PT_TRI_COUNT(3, __builtin_popcountll(__builtin_amdgcn_ballot_w64(j < np)) + __builtin_popcountll(__builtin_amdgcn_ballot_w64(j + 1 < np)));
+      if (j < np) {
+        const bool two = j + 1 < np;
+        const int oa = goff + 3 * pend[j * 256], ob = goff + 3 * pend[(two ? j + 1 : j) * 256];
+        const f4 A0 = gblob[oa], A1 = gblob[oa + 1], A2 = gblob[oa + 2], B0 = gblob[ob], B1 = gblob[ob + 1], B2 = gblob[ob + 2];
+        tri_test_loaded(A0, A1, A2, oa, r, h);
+        if (two) tri_test_loaded(B0, B1, B2, ob, r, h);
+      }
+    }
+    np = 0;
   };
-  auto park = [&](bool pass, int i) {
-    if (__builtin_amdgcn_ballot_w64(pass && pend >= 0) != 0) flush();
-    pend = pass ? i : pend;
-  };
+  auto room = [&]() { if (__builtin_amdgcn_ballot_w64(np > kTriPendCap - 4) != 0) flush(); }; // before a chunk of four
+  auto park = [&](bool pass, int i) { if (pass) { pend[np * 256] = i; ++np; } };
   // ---- (1) the grid: cells of the segment [0, closest (1 + kappa)] -------------------------------------------------------------
   {
     const float inv = H0.w, cell = H1.w, kappa = H3.y;
@@ -1132,17 +1143,19 @@ __device__ __forceinline__ bool tri_pool_scan(glb_f4p gblob, cst_f4p cblob, int 
       const bool inside = ((unsigned)ix < (unsigned)nx) & ((unsigned)iy < (unsigned)ny) & ((unsigned)iz < (unsigned)nz);
       int n0 = 0, n1 = 0;
       if (active & inside) { const int ci = (iz * ny + iy) * nx + ix; n0 = (int)gdword(gblob, cell_first, ci); n1 = (int)gdword(gblob, cell_first, ci + 1); }
-      f4 B = f4{0, 0, 0, 0};
-      int bi = 0;
-      if (k0 < k1) { B = gblob[cell_ball + k0]; bi = (int)gdword(gblob, cell_cand, k0); }
-      for (int k = k0; __builtin_amdgcn_ballot_w64(k < k1) != 0; ++k) {
+      for (int k = k0; __builtin_amdgcn_ballot_w64(k < k1) != 0; k += 4) {
         PT_TRI_COUNT(4, 1);
+        room();
+        if (k < k1) { // four candidates: their (centroid, radius) records and indices, eight loads together
+          f4 B[4];
+          int bi[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) { B[j] = gblob[cell_ball + k + j]; bi[j] = (int)gdword(gblob, cell_cand, k + j); }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < 4; j++) park(k + j < k1 && near_line(xyz(B[j]), B[j].w), bi[j]); // the line within Rv + sigma' of the centroid
+        }
         PT_TRI_COUNT(1, __builtin_popcountll(__builtin_amdgcn_ballot_w64(k < k1)));
-        f4 Bn = f4{0, 0, 0, 0};
-        int bn = 0;
-        if (k + 1 < k1) { Bn = gblob[cell_ball + k + 1]; bn = (int)gdword(gblob, cell_cand, k + 1); }
-        park(k < k1 && near_line(xyz(B), B.w), bi); // within L (1 + 8.5 / (M - 1)) of the centroid (the radius rides in the record)
-        B = Bn; bi = bn;
       }
       // the walk ends where the next cell lies outside the grid or begins beyond the nearest hit so far (parked candidates
       // have not lowered `closest` yet: the walk only runs a little longer for it)
@@ -1202,32 +1215,55 @@ __device__ __forceinline__ bool tri_pool_scan(glb_f4p gblob, cst_f4p cblob, int 
       for (int rr = 0; rr < R; ++rr) {
         int n0 = 0, n1 = 0;
         if (rr + 1 < R) row_range(rr + 1, n0, n1); // in flight while this row's candidates are scanned
-        f4 G = f4{0, 0, 0, 0}, Bc = G;
-        int gi = 0;
-        if (k0 < k1) { G = gblob[tr + 2 * k0]; Bc = gblob[tr + 2 * k0 + 1]; gi = (int)gdword(gblob, tc, k0); }
-        for (int k = k0; __builtin_amdgcn_ballot_w64(k < k1) != 0; ++k) {
+        for (int k = k0; __builtin_amdgcn_ballot_w64(k < k1) != 0; k += 4) {
           PT_TRI_COUNT(5, 1);
+          room();
+          if (k < k1) { // four candidates: band records, centroid records, indices — twelve loads together
+            f4 G[4], Bc[4];
+            int gi[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) { G[j] = gblob[tr + 2 * (k + j)]; Bc[j] = gblob[tr + 2 * (k + j) + 1]; gi[j] = (int)gdword(gblob, tc, k + j); }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; j++) park(k + j < k1 && band_pass(G[j], Bc[j]), gi[j]);
+          }
           PT_TRI_COUNT(2, __builtin_popcountll(__builtin_amdgcn_ballot_w64(k < k1)));
-          f4 Gn = f4{0, 0, 0, 0}, Bn = Gn;
-          int gn = 0;
-          if (k + 1 < k1) { Gn = gblob[tr + 2 * k + 2]; Bn = gblob[tr + 2 * k + 3]; gn = (int)gdword(gblob, tc, k + 1); }
-          park(k < k1 && band_pass(G, Bc), gi);
-          G = Gn; Bc = Bn; gi = gn;
         }
         k0 = n0; k1 = n1;
       }
     }
   }
-  // (3) the always list: wave-uniform, its records through the scalar cache
+  // (3) the always list: 64 entries per load, one per lane (coalesced), broadcast lane by lane (v_readlane: the records become
+  // scalar operands of the band test); the next 64 are requested while these are tested
   const int n_always = as_i(H3.z);
-  for (int k = 0; k < n_always; ++k) {
-    const f4 G = cblob[acheap + 2 * k], Bc = cblob[acheap + 2 * k + 1];
-    const int i = (int)(((const __attribute__((address_space(4))) unsigned int*)(cblob + always_idx))[k]);
-    PT_TRI_COUNT(5, 1);
-    PT_TRI_COUNT(2, __builtin_popcountll(__builtin_amdgcn_ballot_w64(c.live)));
-    park(c.live && band_pass(G, Bc), i);
+  if (n_always > 0) {
+    const int lane = threadIdx.x & 63;
+    auto load_tile = [&](int base, f4& G, f4& Bc, int& gi) {
+      const int e = min(base + lane, n_always - 1); // (a tail lane repeats the last entry: never read back)
+      G = gblob[acheap + 2 * e]; Bc = gblob[acheap + 2 * e + 1]; gi = (int)gdword(gblob, always_idx, e);
+    };
+    f4 G, Bc;
+    int gi;
+    load_tile(0, G, Bc, gi);
+    for (int base = 0; base < n_always; base += 64) {
+      f4 Gn = G, Bn = Bc;
+      int gn = gi;
+      if (base + 64 < n_always) load_tile(base + 64, Gn, Bn, gn);
+      const int cnt = min(64, n_always - base);
+      for (int j = 0; j < cnt; ++j) {
+        if ((j & 3) == 0) room();
+        PT_TRI_COUNT(5, 1);
+        PT_TRI_COUNT(2, __builtin_popcountll(__builtin_amdgcn_ballot_w64(c.live)));
+        const f4 g = f4{as_f(__builtin_amdgcn_readlane(as_i(G.x), j)), as_f(__builtin_amdgcn_readlane(as_i(G.y), j)),
+                        as_f(__builtin_amdgcn_readlane(as_i(G.z), j)), as_f(__builtin_amdgcn_readlane(as_i(G.w), j))};
+        const f4 b = f4{as_f(__builtin_amdgcn_readlane(as_i(Bc.x), j)), as_f(__builtin_amdgcn_readlane(as_i(Bc.y), j)),
+                        as_f(__builtin_amdgcn_readlane(as_i(Bc.z), j)), as_f(__builtin_amdgcn_readlane(as_i(Bc.w), j))};
+        park(c.live && band_pass(g, b), __builtin_amdgcn_readlane(gi, j));
+      }
+      G = Gn; Bc = Bn; gi = gn;
+    }
   }
-  if (__builtin_amdgcn_ballot_w64(pend >= 0) != 0) flush();
+  if (__builtin_amdgcn_ballot_w64(np > 0) != 0) flush();
   return true;
 }
 

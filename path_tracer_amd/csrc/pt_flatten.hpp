@@ -283,18 +283,19 @@ inline void put_box(std::vector<F4>& b, const float* f, int32_t mat, int32_t hid
 //   H6 (ball_abs, kr_a, kr_b, ea)
 //   per level k, three F4: (R, triangles, pn_max, qn_max) (first, cand, inline band records of orientation 0) (... of orientation 1)
 inline int32_t put_tri_pool(std::vector<F4>& b, const TriPool& tp) {
-  auto put_u32 = [&](const std::vector<uint32_t>& v) { const int32_t at = (int32_t)b.size(); put_dwords(b, v.data(), v.size()); if (v.empty()) b.push_back({0, 0, 0, 0}); b.push_back({0, 0, 0, 0}); return at; };
+  // (every array is followed by spare entries: the scans load whole chunks of four without clamping)
+  auto put_u32 = [&](const std::vector<uint32_t>& v) { const int32_t at = (int32_t)b.size(); put_dwords(b, v.data(), v.size()); for (int k = 0; k < 3; k++) b.push_back({0, 0, 0, 0}); return at; };
   // records INLINE beside the candidate lists, in candidate order (a lane streams its cell's / its strip's candidates from
   // consecutive addresses instead of gathering one record per index): grid candidates carry (centroid, filter radius), band
   // candidates their band record (g, c).  Each array is followed by a spare entry (the scans request one ahead).
   auto put_inline = [&](const std::vector<uint32_t>& idx, auto rec_of) {
     const int32_t at = (int32_t)b.size();
     for (uint32_t i : idx) rec_of(i);
-    b.push_back({0, 0, 0, 0}); b.push_back({0, 0, 0, 0}); b.push_back({0, 0, 0, 0}); b.push_back({0, 0, 0, 0});
+    for (int k = 0; k < 10; k++) b.push_back({0, 0, 0, 0});
     return at;
   };
   // grid candidate: one F4 (centroid, L k_sigma + ball_abs); band candidate: two F4 (g, c) (centroid, L)
-  auto ball_rec = [&](uint32_t i) { b.push_back(F4{tp.ball[(size_t)i * 4], tp.ball[(size_t)i * 4 + 1], tp.ball[(size_t)i * 4 + 2], tp.ball[(size_t)i * 4 + 3] * tp.k_sigma + tp.ball_abs}); };
+  auto ball_rec = [&](uint32_t i) { b.push_back(F4{tp.ball[(size_t)i * 4], tp.ball[(size_t)i * 4 + 1], tp.ball[(size_t)i * 4 + 2], tp.grid_radius[(size_t)i]}); };
   auto band_rec = [&](uint32_t i) {
     b.push_back(F4{tp.cheap[(size_t)i * 4], tp.cheap[(size_t)i * 4 + 1], tp.cheap[(size_t)i * 4 + 2], tp.cheap[(size_t)i * 4 + 3]});
     b.push_back(F4{tp.ball[(size_t)i * 4], tp.ball[(size_t)i * 4 + 1], tp.ball[(size_t)i * 4 + 2], tp.ball[(size_t)i * 4 + 3]});

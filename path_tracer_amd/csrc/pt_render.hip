@@ -796,9 +796,10 @@ static int flatten_with_env(const PtSceneDesc* desc, ptf::Flat& flat, std::strin
   if (const char* e = std::getenv("PT_GRID_CELL")) tune.cell = (float)std::atof(e);
   const bool allow_grid = std::getenv("PT_NO_GRID") == nullptr;
   // PT_TRICULL=1: OPT-IN exact culling of long triangle runs (pt_tripool.hpp).  It is exact (the GPU suite runs it against the
-  // oracle's full scan, bit for bit) but on BASELINE config 5 — a random triangle soup — it is ~3x SLOWER than the SIMD-amortised
-  // full scan it replaces (per ray it must still look at ~3 000 band records and ~600 grid candidates, gathered
-  // per lane, where the full scan costs the equivalent of 1 560 tests per ray), so it is not the default; PT_NO_TRICULL wins.
+  // oracle's full scan, bit for bit) but on BASELINE config 5 — a random triangle soup — it is ~1.5x SLOWER than the SIMD-amortised
+  // full scan it replaces (per ray it must still look at ~2 700 band records, ~100 grid candidates and ~250 exact
+  // tests, gathered per lane from a 30 MB working set, where the full scan costs the equivalent of 1 560 tests per ray with no
+  // per-lane memory traffic at all), so it is not the default; PT_NO_TRICULL wins.
   // PT_TRI_M / PT_TRI_CELL / PT_TRI_MIN: the pool's barycentric slack 1/M, its grid cell (in median grown boxes), the shortest
   // run that gets one (pt_tripool.hpp: TriPoolTuning)
   const bool allow_tri = std::getenv("PT_TRICULL") != nullptr && std::getenv("PT_NO_TRICULL") == nullptr;

@@ -63,9 +63,9 @@
 namespace ptf {
 
 struct TriPoolTuning {
-  float M = 16.0f;      // PT_TRI_M: barycentric slack 1/M; the band width grows with M, the boxes' growth sigma' with 1/M
+  float M = 24.0f;      // PT_TRI_M (swept 12 ... 32 on cfg5: profiles/r03_tripool_sweep.log): barycentric slack 1/M; the band width grows with M, the boxes' growth sigma' with 1/M
   float Ma = 256.0f;    // relative slack of t: the walk runs to max (1 + 2.2 / (Ma - 1))
-  float cell = 1.5f;    // PT_TRI_CELL: grid cell edge in units of the median grown box extent
+  float cell = 0.8f;    // PT_TRI_CELL (swept 0.7 ... 1.5): grid cell edge in units of the median grown box extent
   int min_run = 256;    // PT_TRI_MIN: shorter triangle runs are scanned as before
 };
 
@@ -91,6 +91,7 @@ struct TriPool {
   std::vector<uint32_t> always;
   std::vector<float> cheap;         // 4 floats per triangle: g = N' / P, c = Q / P      band test: |d . g| < |d| (rho + c)
   std::vector<float> ball;          // 4 floats per triangle: centroid C, L = longest stored edge (every vertex is within L of C)
+  std::vector<float> grid_radius;   // per triangle: Rv + sigma' + ball_abs, Rv = the largest distance of a vertex from C (the grid filter's radius)
   float p_per_L = 0, k_sigma = 0, ball_abs = 0, kr_a = 0, kr_b = 0, ea = 0; // constants of the two distance filters (see build_tri_pool)
   // statistics for the tests / DESIGN
   double mean_cells_per_triangle = 0;
@@ -117,6 +118,8 @@ inline TriPool build_tri_pool(const PtHittable* h, int count, TriPoolTuning tune
   ext.reserve((size_t)count);
   tp.cheap.assign((size_t)count * 4, 0.0f);
   tp.ball.assign((size_t)count * 4, 0.0f);
+  std::vector<double> rv_of; // per LIVE triangle, in order
+  std::vector<int> live_index((size_t)count, -1);
   for (int i = 0; i < count; i++) {
     const float* f = h[i].f;
     // the edges as the flattener stores them (binary32 differences: triangle.hpp:65-66)
@@ -131,6 +134,7 @@ inline TriPool build_tri_pool(const PtHittable* h, int count, TriPoolTuning tune
     // a = e1 . (d x e2) is a sum of products of edge components: an edge pair whose cross product is exactly 0 in every
     // component the reference can form (both edges zero, or one zero) gives a = +-0 for every ray: |a| < 1e-7, never accepted
     if (!(L > 0.0) || l1 == 0.0 || l2 == 0.0) { dead[(size_t)i] = 1; continue; }
+    live_index[(size_t)i] = (int)rv_of.size();
     P[(size_t)i] = M * 17.5 * u * L * SAFE;
     Q[(size_t)i] = (Ma * 7.0 + 4.0) * u * l1 * l2 * SAFE + std::ldexp(1.0, -40);
     sig[(size_t)i] = 8.5 * L / (M - 1.0);
@@ -143,6 +147,16 @@ inline TriPool build_tri_pool(const PtHittable* h, int count, TriPoolTuning tune
     } else { pn[(size_t)i] = qn[(size_t)i] = INFINITY; }
     for (int k = 0; k < 3; k++) tp.ball[(size_t)i * 4 + k] = (float)(f[k] + (e1[k] + e2[k]) / 3.0); // centroid of v0, v0 + e1, v0 + e2
     tp.ball[(size_t)i * 4 + 3] = (float)(L * (1 + 2 * u));
+    {
+      double rv = 0;
+      const double cx[3] = {tp.ball[(size_t)i * 4], tp.ball[(size_t)i * 4 + 1], tp.ball[(size_t)i * 4 + 2]}; // the ROUNDED centroid the device uses
+      for (int v = 0; v < 3; v++) {
+        double d2 = 0;
+        for (int k = 0; k < 3; k++) { const double pv = (double)f[k] + (v == 1 ? e1[k] : v == 2 ? e2[k] : 0.0); d2 += (pv - cx[k]) * (pv - cx[k]); }
+        rv = std::max(rv, std::sqrt(d2));
+      }
+      rv_of.push_back(rv);
+    }
     double emax = 0;
     for (int k = 0; k < 3; k++) {
       const double lo = std::min({(double)f[k], (double)f[3 + k], (double)f[6 + k]}), hi = std::max({(double)f[k], (double)f[3 + k], (double)f[6 + k]});
@@ -216,6 +230,11 @@ inline TriPool build_tri_pool(const PtHittable* h, int count, TriPoolTuning tune
     if (!(rl > 0)) return tp;
     tp.rlimit2 = (float)(rl * rl * 0.99);
     tp.ball_abs = (float)(64 * u * (rl + R + 2 * std::sqrt(half_diag2)));
+    // (i) tightened: every point of the triangle is within Rv_i (its farthest vertex) of the centroid, so the line passes within
+    // Rv_i + sigma'_i of it
+    tp.grid_radius.assign((size_t)count, 0.0f);
+    for (int i = 0; i < count; i++)
+      if (!dead[(size_t)i]) tp.grid_radius[(size_t)i] = (float)((rv_of[(size_t)live_index[(size_t)i]] + sig[(size_t)i]) * (1 + 8 * u) + tp.ball_abs);
   }
   const double inv = (double)tp.inv_cell; // assign with the float value the device uses
   const size_t ncell = (size_t)tp.n[0] * tp.n[1] * tp.n[2];
