@@ -91,8 +91,33 @@ def ops_per_sample_culled(ctr: dict, n_spheres: int, grid_spheres: int, walk: di
     return (rest + spheres + walk_ops) / n
 
 
-# recorded like ALGORITHMIC_OPS_PER_SAMPLE (the N = 1 cpu_baseline leg re-derives it live): the culled algorithm's figure
-ALGORITHMIC_OPS_PER_SAMPLE_CULLED = {"smoke": 2116.7}
+# The 100 k-triangle mesh (cfg5) likewise: since round 3 its long triangle run is culled exactly by a triangle pool —
+# per ray the kernel runs the reference's test on the candidates of the grid cells it crosses, a 4-op band test on the records of
+# its cube-map strips and of the always list, and the reference's test on the few survivors.  Counted in the kernel (diagnostic
+# build `make stamps EXTRA=-DPT_STAMPS_TRI`, tools/tri_counters.py; profiles/r03_tripool_counters.txt): 41.5 grid rounds of 64
+# candidates, 17.2 band trips x 51.4 lanes x 4 records, 3 624 always-list records, 4.3 grid cells per ray.
+TRI_POOL = {"triangles": dict(exact_per_ray=41.5 * 64, band_per_ray=17.2 * 51.4 * 4 + 3624, cells_per_ray=4.3,
+                              source="profiles/r03_tripool_counters.txt")}
+OPS_TRI_POOL = dict(band=8,        # d . g (5) + |.| + rho + c, compare (3)
+                    setup=45 + 9 * 40)  # the grid walk's set-up + per (level, face): strip coefficients, reach test, row ranges (amortised over 64 lanes)
+
+
+def ops_per_sample_culled_tri(ctr: dict, pool: dict) -> float:
+    """ops_per_sample() with the triangle part replaced by what the pool runs: exact tests priced at the oracle's own mix of the
+    triangle test's five exits (the candidates are the triangles NEAR the ray, so this under-prices them if anything), band
+    records at OPS_TRI_POOL['band'], grid steps as the sphere grid's."""
+    n = ctr["samples"]
+    te = ctr["tri_exit"]
+    brute_tri = sum(c * p for c, p in zip(te, OPS["tri"]))
+    rest = ops_per_sample(ctr) * n - brute_tri
+    tri_price = brute_tri / max(1, sum(te))
+    per_ray = (pool["exact_per_ray"] * tri_price + pool["band_per_ray"] * OPS_TRI_POOL["band"]
+               + pool["cells_per_ray"] * OPS_GRID["step"] + OPS_TRI_POOL["setup"])
+    return (rest + ctr["rays"] * per_ray) / n
+
+
+# recorded like ALGORITHMIC_OPS_PER_SAMPLE (the N = 1 cpu_baseline leg re-derives them live): the culled algorithms' figures
+ALGORITHMIC_OPS_PER_SAMPLE_CULLED = {"smoke": 2116.7, "triangles": 357415.2}
 
 
 def ops_per_sample(ctr: dict) -> float:
@@ -313,7 +338,9 @@ def main() -> None:
         samples_per_step = W * H * SPP
         value = samples_per_step * args.steps / elapsed / 1e6
         ops = ALGORITHMIC_OPS_PER_SAMPLE[scene_name]
-        ops_culled = ALGORITHMIC_OPS_PER_SAMPLE_CULLED.get(scene_name) if not os.environ.get("PT_NO_GRID") else None
+        ops_culled = ALGORITHMIC_OPS_PER_SAMPLE_CULLED.get(scene_name)
+        if (scene_name == "smoke" and os.environ.get("PT_NO_GRID")) or (scene_name == "triangles" and os.environ.get("PT_NO_TRICULL")):
+            ops_culled = None  # the A/B knobs select the reference's algorithm as written
         cpu_line = None
         if world == 1 and not args.no_cpu_baseline:
             # --- cpu_baseline leg: the only place bench.py touches oracle/ (test infrastructure) ---------------
@@ -328,6 +355,8 @@ def main() -> None:
                 st = (C_.c_int32 * 8)()
                 abi_.check(abi_.load_library().pt_debug_tri_pool(C_.byref(packed.desc), st), "pt_debug_tri_pool")
                 ops_culled = ops_per_sample_culled(ctr.as_dict(), sum(1 for k in packed.kinds() if k == abi_.PT_HIT_SPHERE), st[7], GRID_WALK[scene_name])
+            if scene_name in TRI_POOL and not os.environ.get("PT_NO_TRICULL"):
+                ops_culled = ops_per_sample_culled_tri(ctr.as_dict(), TRI_POOL[scene_name])
             # bounded sample of the same workload, sized for ~15 s of CPU work from a 1-spp probe
             bw, bh = (W, H) if scene_name != "triangles" else (240, 135)
             bcam = scenes.make_camera(cam_args, bw, bh)
@@ -394,7 +423,8 @@ def main() -> None:
                          # culling structure provably skips tests (sphere grid: ops_per_sample_culled); the reference's own
                          # figure rides beside as algorithmic_ops_per_sample_reference
                          "frac_note": ("exceeds 1: the kernel skips tests the pricing still counts" if achieved / PEAK_TLANEOPS > 1 else None),
-                         "priced_algorithm": ("culled: sphere grid (cells visited and grid tests counted in-kernel: " + GRID_WALK[scene_name]["source"] + ")"
+                         "priced_algorithm": (("culled: " + ("sphere grid" if scene_name in GRID_WALK else "triangle pool") + " (counted in-kernel: "
+                                               + (GRID_WALK.get(scene_name) or TRI_POOL[scene_name])["source"] + ")")
                                               if ops_culled else "the reference's algorithm as written"),
                          "algorithmic_ops_per_sample_reference": round(ops_reference, 1),
                          "traffic": pmc[0] if pmc else None, "traffic_source": pmc[1] if pmc else None,

@@ -28,8 +28,7 @@
 extern __device__ unsigned long long g_stamps[8]; // diagnostic build only (pt_render.hip)
 #endif
 #ifdef PT_STAMPS_TRI
-// diagnostic build (triangle pool): [0] scans (waves) [1] lane grid tests [2] lane band (cheap) tests [3] lane exact tests from the
-// band / always list [4] wave grid-test trips [5] wave cheap-test trips [6] flushes [7] fallbacks to the full scan
+// diagnostic build (triangle pool): [0] scans (waves) [1] live rays [2] grid rounds (64 candidates each) [3] grid cells visited [4] lanes busy over the band's trips [5] [6] [7] band trips (four candidates per lane) of levels 0, 1, 2
 extern __device__ unsigned long long g_tri[8];
 #endif
 #ifdef PT_STAMPS_WALK
@@ -1050,220 +1049,279 @@ __device__ __forceinline__ unsigned int gdword(glb_f4p gblob, int base_f4, int i
 
 // returns false when some live lane's ray is outside what the pool is exact for (irregular, or its origin beyond rlimit): the
 // caller then scans the whole run.
-// Memory shape.  This scan is bound by the LATENCY of its loads (a wave's loads are dependent and land in L2 / MALL: ~3 700
-// cycles each on the 100 k-triangle mesh: PMC), so everything is organised to put many independent loads in
-// flight per wait: every list a lane streams (a cell's candidates, a strip row's candidates) is CONTIGUOUS with the records
-// its filters need inline, and is consumed FOUR entries per trip (twelve loads issued together); the always list is loaded
-// 64 entries at a time, one per lane, and broadcast with v_readlane; survivors of the filters are parked in a per-lane LDS
-// stack and their exact tests run for the whole wave two triangles at a time (six loads together).
-constexpr int kTriPendCap = 16; // parked candidates per lane (flushed when some lane holds more than kTriPendCap - 4)
-__device__ __forceinline__ int* tri_pend_stack() { __shared__ int s[kTriPendCap * 256]; return s; }
-
-__device__ __forceinline__ void tri_test_loaded(f4 R0, f4 R1, f4 R2, int o, const Ray& r, HitState& h) {
-  const TriEval e = tri_eval(R0, R1, R2, r);
-  if (e.pass) {
-    const float a_abs = __builtin_fabsf(e.a);
-    const bool a_pos = e.a > 0.0f;
-    const V3 edge1 = xyz(R1), edge2 = xyz(R2);
-    const V3 s = r.o - xyz(R0);
-    const V3 q = cross(s, edge1);
-    const float v = dot(r.d, q);
-    const bool v_pos = v > 0.0f;
-    if (!((v_pos != a_pos) | (__builtin_fabsf(e.u + v) > a_abs))) {
-      const float t = dot(edge2, q) / e.a;
-      // (pool scenes and regular rays: t is finite.)  the scan's `!(t < min || t > max)` with the tie rule for any order
-      const bool holder_later = (h.hit >= 0) & (hit_off(h.hit) > o);
-      if (!(t < PT_TMIN) && (t < h.closest || (t == h.closest && !holder_later))) { h.closest = t; h.hit = hit_pack(DK_TRI, 0, o); }
-    }
-  }
+//
+// SIMD shape: ONE RAY AT A TIME, ITS CANDIDATES ACROSS THE 64 LANES.  The first versions let every lane walk its own ray
+// (its own grid cells, its own strips): ~18 of 64 lanes busy per trip, every load a per-lane gather, 5 M lane-instructions
+// per sample — no better than the full scan's 6.7 M, and bound by the latency of its scattered loads.  The
+// full scan is fast because a triangle fetch is shared by 64 rays; the transposed scan shares a RAY among 64 triangles
+// instead: the wave takes its live rays one after the other (the ray's context read from its lane with v_readlane: scalar
+// operands from then on), and for that ray
+//   (1) walks the grid once (a uniform DDA), the candidates of each cell dealt to the lanes k0 + lane, k0 + 64 + lane, ...
+//       (coalesced loads of the inline (centroid, radius) records);
+//   (2) deals the rows of every cube-map level that the ray's strip can reach to the lanes (R = 128: a row per lane, two
+//       rounds; R = 32 / 16: two / four lanes per row), each lane streaming its row's contiguous candidates four per trip;
+//   every survivor of the filters is tested exactly on the spot with the uniform ray, and a hit goes into the ray's slot of a
+//   per-wave LDS table with ONE 64-bit atomic minimum: key = (bits of t) << 32 | (0xffffff - record offset), so that the
+//   smallest t wins and, among equal t, the LAST record in list order — the scan's own acceptance (triangle.hpp:91 accepts
+//   t == max); the slot starts as the ray's hit so far (earlier runs have smaller offsets: an equal t loses to any triangle,
+//   as in the scan).  Every candidate's t is independent of the running maximum, so the order of the tests does not matter.
+//   (3) The always list runs the other way round: 64 entries in the lanes (one coalesced load), the live rays in the inner loop.
+#ifndef PT_TRI_ABLATE
+#define PT_TRI_ABLATE 0 /* timing experiments only: 1 no grid, 2 no band levels, 4 no always list (wrong images) */
+#endif
+__device__ __forceinline__ unsigned long long* tri_slots() { __shared__ unsigned long long s[256]; return s; }
+__device__ __forceinline__ int* tri_rows() { __shared__ int s[4 * 264]; return s; } // per wave: the row table of the strip being scanned
+__device__ __forceinline__ unsigned long long tri_key(float t, int off) {
+  return ((unsigned long long)(unsigned int)as_i(t) << 32) | (unsigned long long)(unsigned int)(0xffffff - off);
 }
+// triangle.hpp:58-89: everything but the range test on t; false = rejected by |a|, u, v or u + v
+__device__ __forceinline__ bool tri_param(f4 R0, f4 R1, f4 R2, const Ray& r, float& t) {
+  const TriEval e = tri_eval(R0, R1, R2, r);
+  if (!e.pass) return false;
+  const float a_abs = __builtin_fabsf(e.a);
+  const bool a_pos = e.a > 0.0f;
+  const V3 edge1 = xyz(R1), edge2 = xyz(R2);
+  const V3 s = r.o - xyz(R0);
+  const V3 q = cross(s, edge1);
+  const float v = dot(r.d, q);
+  const bool v_pos = v > 0.0f;
+  if ((v_pos != a_pos) | (__builtin_fabsf(e.u + v) > a_abs)) return false;
+  t = dot(edge2, q) / e.a;
+  return true;
+}
+__device__ __forceinline__ float rl_f(float v, int src) { return as_f(__builtin_amdgcn_readlane(as_i(v), src)); }
 
 __device__ __forceinline__ bool tri_pool_scan(glb_f4p gblob, cst_f4p cblob, int hdr, int goff, const RayCtx& c, HitState& h) {
-  const Ray& r = c.r;
   const f4 H0 = cblob[hdr], H1 = cblob[hdr + 1], H2 = cblob[hdr + 2], H3 = cblob[hdr + 3], H4 = cblob[hdr + 4], H5 = cblob[hdr + 5], H6 = cblob[hdr + 6];
-  const V3 oc = r.o - xyz(H2);
-  const float oc2 = dot(oc, oc);
-  if (__builtin_amdgcn_ballot_w64(c.live && !(c.reg && oc2 <= H3.x)) != 0) { PT_TRI_COUNT(7, 1); return false; }
-  PT_TRI_COUNT(0, 1);
+  const V3 oc_own = c.r.o - xyz(H2);
+  const float oc2_own = dot(oc_own, oc_own);
+  if (__builtin_amdgcn_ballot_w64(c.live && !(c.reg && oc2_own <= H3.x)) != 0) return false;
   const int cell_first = as_i(H4.x), cell_cand = as_i(H4.y), always_idx = as_i(H4.z), cell_ball = as_i(H4.w), acheap = as_i(H5.x);
-  // does the ray's LINE pass within `rad` of the point C?  (both filters of pt_tripool.hpp; necessary conditions)
-  auto near_line = [&](V3 C, float rad) {
-    const V3 x = cross(C - r.o, r.d);
-    return dot(x, x) <= rad * rad * c.a * 1.00001f;
+  const int lane = threadIdx.x & 63;
+  unsigned long long* const slot = tri_slots() + (threadIdx.x & ~63); // this wave's 64 slots
+  const unsigned long long key0 = h.hit >= 0 ? tri_key(h.closest, hit_off(h.hit)) : ((unsigned long long)0x7f800000u << 32);
+  slot[lane] = key0;
+  // band test of triangle i for a ray: |d . g_i| <= |d| (rho + c_i); rho and |d| rounded up
+  const float rho_own = (__builtin_amdgcn_sqrtf(oc2_own) + H2.w) * 1.000002f;
+  const float dn_own = __builtin_amdgcn_sqrtf(c.a) * 1.000002f;
+  const unsigned long long live = __builtin_amdgcn_ballot_w64(c.live);
+  PT_TRI_COUNT(0, 1);
+  PT_TRI_COUNT(1, __builtin_popcountll(live));
+  // the exact test of triangle i for the (uniform) ray of lane src; a hit goes to that ray's slot
+  auto exact = [&](int i, const Ray& ur, int src) {
+    const int o = goff + 3 * i;
+    const f4 R0 = gblob[o], R1 = gblob[o + 1], R2 = gblob[o + 2];
+    float t;
+    if (tri_param(R0, R1, R2, ur, t) && !(t < PT_TMIN)) atomicMin(&slot[src], tri_key(t, o));
   };
-  // parked candidates: a per-lane stack in LDS (slot s of this thread at pend[s * blockDim + thread])
-  int* const pend = tri_pend_stack() + threadIdx.x;
-  int np = 0;
-  auto flush = [&]() {
-    PT_TRI_COUNT(6, 1);
-    for (int j = 0; __builtin_amdgcn_ballot_w64(j < np) != 0; j += 2) {
-      PT_TRI_COUNT(3, __builtin_popcountll(__builtin_amdgcn_ballot_w64(j < np)) + __builtin_popcountll(__builtin_amdgcn_ballot_w64(j + 1 < np)));
-      if (j < np) {
-        const bool two = j + 1 < np;
-        const int oa = goff + 3 * pend[j * 256], ob = goff + 3 * pend[(two ? j + 1 : j) * 256];
-        const f4 A0 = gblob[oa], A1 = gblob[oa + 1], A2 = gblob[oa + 2], B0 = gblob[ob], B1 = gblob[ob + 1], B2 = gblob[ob + 2];
-        tri_test_loaded(A0, A1, A2, oa, r, h);
-        if (two) tri_test_loaded(B0, B1, B2, ob, r, h);
-      }
-    }
-    np = 0;
-  };
-  auto room = [&]() { if (__builtin_amdgcn_ballot_w64(np > kTriPendCap - 4) != 0) flush(); }; // before a chunk of four
-  auto park = [&](bool pass, int i) { if (pass) { pend[np * 256] = i; ++np; } };
-  // ---- (1) the grid: cells of the segment [0, closest (1 + kappa)] -------------------------------------------------------------
-  {
-    const float inv = H0.w, cell = H1.w, kappa = H3.y;
-    const int nx = as_i(H1.x), ny = as_i(H1.y), nz = as_i(H1.z);
-    const float gx = (r.o.x - H0.x) * inv, gy = (r.o.y - H0.y) * inv, gz = (r.o.z - H0.z) * inv;
-    const float rx = c.yx * cell, ry = c.yy * cell, rz = c.yz * cell;
-    const float ax = (0.0f - gx) * rx, bx = ((float)nx - gx) * rx;
-    const float ay = (0.0f - gy) * ry, by = ((float)ny - gy) * ry;
-    const float az = (0.0f - gz) * rz, bz = ((float)nz - gz) * rz;
-    const float t_in = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
-    const float t_out = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
-    const float t0 = __builtin_fmaxf(t_in, 0.0f);
-    // closest (1 + kappa), then the walk's own slack as in the sphere grid (relative 1e-4: rounding of the boundaries' parameters)
-    auto limit = [&]() { const float m = __builtin_fminf(t_out, h.closest + h.closest * kappa); return m + (__builtin_fabsf(m) * 1e-4f + 1e-4f); };
-    bool active = c.live && t0 <= limit();
-    const float px = gx + t0 * (r.d.x * inv), py = gy + t0 * (r.d.y * inv), pz = gz + t0 * (r.d.z * inv);
-    int ix = min(max((int)__builtin_floorf(px), 0), nx - 1);
-    int iy = min(max((int)__builtin_floorf(py), 0), ny - 1);
-    int iz = min(max((int)__builtin_floorf(pz), 0), nz - 1);
-    const bool fx = r.d.x > 0.0f, fy = r.d.y > 0.0f, fz = r.d.z > 0.0f;
-    float tmx = ((float)(ix + (fx ? 1 : 0)) - gx) * rx, tmy = ((float)(iy + (fy ? 1 : 0)) - gy) * ry, tmz = ((float)(iz + (fz ? 1 : 0)) - gz) * rz;
-    const float dtx = __builtin_fabsf(rx), dty = __builtin_fabsf(ry), dtz = __builtin_fabsf(rz);
-    const int stx = fx ? 1 : -1, sty = fy ? 1 : -1, stz = fz ? 1 : -1;
-    int k0 = 0, k1 = 0;
-    if (active) { const int ci = (iz * ny + iy) * nx + ix; k0 = (int)gdword(gblob, cell_first, ci); k1 = (int)gdword(gblob, cell_first, ci + 1); }
-    while (__builtin_amdgcn_ballot_w64(active) != 0) {
-      // the next cell and its candidate range, requested before this cell's candidates are scanned
-      const float tn = __builtin_fminf(tmx, __builtin_fminf(tmy, tmz));
-      const bool sx = tmx == tn, sy = !sx & (tmy == tn), sz = !sx & !sy;
-      ix += sx ? stx : 0; iy += sy ? sty : 0; iz += sz ? stz : 0;
-      const bool inside = ((unsigned)ix < (unsigned)nx) & ((unsigned)iy < (unsigned)ny) & ((unsigned)iz < (unsigned)nz);
-      int n0 = 0, n1 = 0;
-      if (active & inside) { const int ci = (iz * ny + iy) * nx + ix; n0 = (int)gdword(gblob, cell_first, ci); n1 = (int)gdword(gblob, cell_first, ci + 1); }
-      for (int k = k0; __builtin_amdgcn_ballot_w64(k < k1) != 0; k += 4) {
-        PT_TRI_COUNT(4, 1);
-        room();
-        if (k < k1) { // four candidates: their (centroid, radius) records and indices, eight loads together
-          f4 B[4];
-          int bi[4];
-#pragma unroll
-          for (int j = 0; j < 4; j++) { B[j] = gblob[cell_ball + k + j]; bi[j] = (int)gdword(gblob, cell_cand, k + j); }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int j = 0; j < 4; j++) park(k + j < k1 && near_line(xyz(B[j]), B[j].w), bi[j]); // the line within Rv + sigma' of the centroid
-        }
-        PT_TRI_COUNT(1, __builtin_popcountll(__builtin_amdgcn_ballot_w64(k < k1)));
-      }
-      // the walk ends where the next cell lies outside the grid or begins beyond the nearest hit so far (parked candidates
-      // have not lowered `closest` yet: the walk only runs a little longer for it)
-      active = active & inside & !(tn > limit());
-      tmx += sx ? dtx : 0.0f; tmy += sy ? dty : 0.0f; tmz += sz ? dtz : 0.0f;
-      k0 = active ? n0 : 0; k1 = active ? n1 : 0;
-    }
-  }
-  // ---- (2) + (3): the triangles this ray grazes -------------------------------------------------------------------------------
-  // band test of triangle i: |d . g_i| <= |d| (rho + c_i), (g_i, c_i) its band record; rho and |d| rounded up
-  const float rho = (__builtin_amdgcn_sqrtf(oc2) + H2.w) * 1.000002f;
-  const float dn = __builtin_amdgcn_sqrtf(c.a) * 1.000002f;
-  // band test, then the noise-radius filter: the line within L + kr rho |d| / (|a'| - ea |d|) of the centroid
-  auto band_pass = [&](f4 G, f4 Bc) {
-    const float dg = __builtin_fabsf(r.d.x * G.x + r.d.y * G.y + r.d.z * G.z);
-    if (!(dg <= dn * (rho + G.w))) return false;
-    const float L = Bc.w, L2 = L * L;
-    const float a1 = dg * (H5.z * L) - H6.w * L2 * dn;                 // |a'| - ea |d|   (|a'| = |d . g| P, P = (P / L) L)
-    const float rr = (H6.y + H6.z * L) * L2 * rho * dn / a1;           // the noise radius; a1 <= 0: no bound
-    return !(a1 > 0.0f) || near_line(xyz(Bc), L + rr + H6.x);
-  };
-  const V3 dh = __builtin_amdgcn_rsqf(c.a) * r.d; // unit direction (a few ulp: covered by the strips' absolute slack)
-  const int n_levels = as_i(H3.w);
-  for (int lv = 0; lv < n_levels; ++lv) {
-    const f4 L0 = cblob[hdr + 7 + 3 * lv], T0 = cblob[hdr + 8 + 3 * lv], T1 = cblob[hdr + 9 + 3 * lv];
-    const int R = as_i(L0.x);
-    if (as_i(L0.y) == 0) continue;
-    const float W = 1.7320509f * (rho * L0.z + L0.w) * 1.00001f + 2e-5f; // |A p + B q + C| <= sqrt(3) tau on the face of n's largest component
-    const float step = 2.0f / (float)R, halfR = 0.5f * (float)R;
-    for (int face = 0; face < 3; ++face) {
-      const float A = face == 0 ? dh.y : face == 1 ? dh.z : dh.x; // face k: (p, q) = (n_a, n_b) / n_k, a = k + 1, b = k + 2 (mod 3)
-      const float B = face == 0 ? dh.z : face == 1 ? dh.x : dh.y;
-      const float C = face == 0 ? dh.x : face == 1 ? dh.y : dh.z;
-      const bool reach = c.live && (__builtin_fabsf(A) + __builtin_fabsf(B) + W >= __builtin_fabsf(C)); // can the strip meet the square?
-      if (__builtin_amdgcn_ballot_w64(reach) == 0) continue;
-      // rows along the axis with the smaller coefficient; the other coordinate solved: y(x) = -(C + mn x) / mj.  Orientation 0
-      // (|A| >= |B|): rows are q-rows, cells contiguous in p; orientation 1: rows are p-columns, cells contiguous in q.
-      const bool swp = __builtin_fabsf(B) > __builtin_fabsf(A);
-      const float mj = swp ? B : A, mn = swp ? A : B;
-      const float ninv = -1.0f / mj;
-      const float hw = W * __builtin_fabsf(ninv) * 1.00001f + 2e-5f;
-      const int tf = swp ? as_i(T1.x) : as_i(T0.x), tc = swp ? as_i(T1.y) : as_i(T0.y), tr = swp ? as_i(T1.z) : as_i(T0.z);
-      auto row_range = [&](int rr, int& k0, int& k1) { // the candidate range of row rr of this lane's strip (two loads)
-        const float x0 = -1.0f + (float)rr * step, x1 = x0 + step;
-        const float y0 = (C + mn * x0) * ninv, y1 = (C + mn * x1) * ninv;
-        const float ylo = __builtin_fminf(y0, y1) - hw, yhi = __builtin_fmaxf(y0, y1) + hw;
-        const int c0 = (int)__builtin_floorf((__builtin_fmaxf(ylo, -1.0f) + 1.0f) * halfR);
-        const int c1 = min((int)__builtin_floorf((__builtin_fminf(yhi, 1.0f) + 1.0f) * halfR), R - 1);
-        k0 = 0; k1 = 0;
-        if (reach && yhi >= -1.0f && ylo <= 1.0f && c0 <= c1) { // (NaN: nothing)
-          const int base = (face * R + rr) * R;
-          k0 = (int)gdword(gblob, tf, base + c0); k1 = (int)gdword(gblob, tf, base + c1 + 1);
-        }
+  for (unsigned long long todo = live; todo != 0; todo &= todo - 1) {
+    const int src = __builtin_ctzll(todo);
+    Ray ur;
+    ur.o = mk(rl_f(c.r.o.x, src), rl_f(c.r.o.y, src), rl_f(c.r.o.z, src));
+    ur.d = mk(rl_f(c.r.d.x, src), rl_f(c.r.d.y, src), rl_f(c.r.d.z, src));
+    ur.tm = 0.0f;
+    const float ua = rl_f(c.a, src), uyx = rl_f(c.yx, src), uyy = rl_f(c.yy, src), uyz = rl_f(c.yz, src);
+    const float rho = rl_f(rho_own, src), dn = rl_f(dn_own, src);
+    // does the ray's LINE pass within `rad` of the point C?  (both filters of pt_tripool.hpp; necessary conditions)
+    auto near_line = [&](V3 C, float rad) {
+      const V3 x = cross(C - ur.o, ur.d);
+      return dot(x, x) <= rad * rad * ua * 1.00001f;
+    };
+    // ---- (1) the grid: cells of the segment [0, closest (1 + kappa)], one uniform walk -----------------------------------------
+#if !(PT_TRI_ABLATE & 1)
+    {
+      const float inv = H0.w, cell = H1.w, kappa = H3.y;
+      const int nx = as_i(H1.x), ny = as_i(H1.y), nz = as_i(H1.z);
+      const float gx = (ur.o.x - H0.x) * inv, gy = (ur.o.y - H0.y) * inv, gz = (ur.o.z - H0.z) * inv;
+      const float rx = uyx * cell, ry = uyy * cell, rz = uyz * cell;
+      const float ax = (0.0f - gx) * rx, bx = ((float)nx - gx) * rx;
+      const float ay = (0.0f - gy) * ry, by = ((float)ny - gy) * ry;
+      const float az = (0.0f - gz) * rz, bz = ((float)nz - gz) * rz;
+      const float t_in = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
+      const float t_out = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
+      const float t0 = __builtin_fmaxf(t_in, 0.0f);
+      // closest (1 + kappa) — closest = the slot's t, lowered by every hit so far — then the walk's own slack (relative 1e-4)
+      auto limit = [&]() {
+        const float cl = as_f((int)(unsigned int)(slot[src] >> 32));
+        const float m = __builtin_fminf(t_out, cl + cl * kappa);
+        return m + (__builtin_fabsf(m) * 1e-4f + 1e-4f);
       };
-      int k0, k1;
-      row_range(0, k0, k1);
-      for (int rr = 0; rr < R; ++rr) {
-        int n0 = 0, n1 = 0;
-        if (rr + 1 < R) row_range(rr + 1, n0, n1); // in flight while this row's candidates are scanned
-        for (int k = k0; __builtin_amdgcn_ballot_w64(k < k1) != 0; k += 4) {
-          PT_TRI_COUNT(5, 1);
-          room();
-          if (k < k1) { // four candidates: band records, centroid records, indices — twelve loads together
-            f4 G[4], Bc[4];
-            int gi[4];
+      bool active = t0 <= limit();
+      const float px = gx + t0 * (ur.d.x * inv), py = gy + t0 * (ur.d.y * inv), pz = gz + t0 * (ur.d.z * inv);
+      int ix = min(max((int)__builtin_floorf(px), 0), nx - 1);
+      int iy = min(max((int)__builtin_floorf(py), 0), ny - 1);
+      int iz = min(max((int)__builtin_floorf(pz), 0), nz - 1);
+      const bool fx = ur.d.x > 0.0f, fy = ur.d.y > 0.0f, fz = ur.d.z > 0.0f;
+      float tmx = ((float)(ix + (fx ? 1 : 0)) - gx) * rx, tmy = ((float)(iy + (fy ? 1 : 0)) - gy) * ry, tmz = ((float)(iz + (fz ? 1 : 0)) - gz) * rz;
+      const float dtx = __builtin_fabsf(rx), dty = __builtin_fabsf(ry), dtz = __builtin_fabsf(rz);
+      const int stx = fx ? 1 : -1, sty = fy ? 1 : -1, stz = fz ? 1 : -1;
+      while (__builtin_amdgcn_readfirstlane((int)active) != 0) { // (every lane computes the same walk)
+        const int ci = __builtin_amdgcn_readfirstlane((iz * ny + iy) * nx + ix);
+        PT_TRI_COUNT(3, 1);
+        const int k0 = (int)dword_at(cblob + cell_first, ci), k1 = (int)dword_at(cblob + cell_first, ci + 1);
+        for (int base = k0; base < k1; base += 64) {
+          PT_TRI_COUNT(2, 1);
+          const int k = base + lane;
+          const bool on = k < k1;
+          if (on) { // the candidate's own records ride inline (cell order): one fetch, the exact test for all 64 lanes at once
+            const f4 R0 = gblob[cell_ball + 3 * k], R1 = gblob[cell_ball + 3 * k + 1], R2 = gblob[cell_ball + 3 * k + 2];
+            float t;
+            if (tri_param(R0, R1, R2, ur, t) && !(t < PT_TMIN)) atomicMin(&slot[src], tri_key(t, goff + 3 * as_i(R2.w)));
+          }
+        }
+        const float tn = __builtin_fminf(tmx, __builtin_fminf(tmy, tmz));
+        const bool sx = tmx == tn, sy = !sx & (tmy == tn), sz = !sx & !sy;
+        ix += sx ? stx : 0; iy += sy ? sty : 0; iz += sz ? stz : 0;
+        const bool inside = ((unsigned)ix < (unsigned)nx) & ((unsigned)iy < (unsigned)ny) & ((unsigned)iz < (unsigned)nz);
+        active = inside & !(tn > limit());
+        tmx += sx ? dtx : 0.0f; tmy += sy ? dty : 0.0f; tmz += sz ? dtz : 0.0f;
+      }
+    }
+#endif
+    // ---- (2) the cube-map levels: the triangles this ray grazes (narrow bands) ------------------------------------------------------
+    // band test, then the noise-radius filter: the line within L + kr rho |d| / (|a'| - ea |d|) of the centroid
+    auto band_pass = [&](f4 G, f4 Bc) {
+      const float dg = __builtin_fabsf(ur.d.x * G.x + ur.d.y * G.y + ur.d.z * G.z);
+      if (!(dg <= dn * (rho + G.w))) return false;
+      const float L = Bc.w, L2 = L * L;
+      const float a1 = dg * (H5.z * L) - H6.w * L2 * dn;                 // |a'| - ea |d|   (|a'| = |d . g| P, P = (P / L) L)
+      const float rr = (H6.y + H6.z * L) * L2 * rho * dn / a1;           // the noise radius; a1 <= 0: no bound
+      return !(a1 > 0.0f) || near_line(xyz(Bc), L + rr + H6.x);
+    };
+    const V3 dh = __builtin_amdgcn_rsqf(ua) * ur.d; // unit direction (a few ulp: covered by the strips' absolute slack)
+    const int n_levels = (PT_TRI_ABLATE & 2) ? 0 : as_i(H3.w);
+    for (int lv = 0; lv < n_levels; ++lv) {
+      const f4 L0 = cblob[hdr + 7 + 3 * lv], T0 = cblob[hdr + 8 + 3 * lv], T1 = cblob[hdr + 9 + 3 * lv];
+      const int R = as_i(L0.x);
+      if (as_i(L0.y) == 0) continue;
+      const float W = 1.7320509f * (rho * L0.z + L0.w) * 1.00001f + 2e-5f; // |A p + B q + C| <= sqrt(3) tau on the face of n's largest component
+      const float step = 2.0f / (float)R, halfR = 0.5f * (float)R;
+      for (int face = 0; face < 3; ++face) {
+        const float A = face == 0 ? dh.y : face == 1 ? dh.z : dh.x; // face k: (p, q) = (n_a, n_b) / n_k, a = k + 1, b = k + 2 (mod 3)
+        const float B = face == 0 ? dh.z : face == 1 ? dh.x : dh.y;
+        const float C = face == 0 ? dh.x : face == 1 ? dh.y : dh.z;
+        if (!(__builtin_fabsf(A) + __builtin_fabsf(B) + W >= __builtin_fabsf(C))) continue; // the strip cannot meet the square (uniform)
+        // rows along the axis with the smaller coefficient; the other coordinate solved: y(x) = -(C + mn x) / mj.  Orientation 0
+        // (|A| >= |B|): rows are q-rows, cells contiguous in p; orientation 1: rows are p-columns, cells contiguous in q.
+        const bool swp = __builtin_fabsf(B) > __builtin_fabsf(A);
+        const float mj = swp ? B : A, mn = swp ? A : B;
+        const float ninv = -1.0f / mj;
+        const float hw = W * __builtin_fabsf(ninv) * 1.00001f + 2e-5f;
+        const int tf = swp ? as_i(T1.x) : as_i(T0.x), tc = swp ? as_i(T1.y) : as_i(T0.y), tr = swp ? as_i(T1.z) : as_i(T0.z);
+        // The strip's rows, BALANCED over the lanes.  Row populations are very uneven (the 100 k-triangle mesh: 1.3 triangles per cell of
+        // level 0 on average, 337 in the fullest), so "a row per lane" left ~6 of 64 lanes busy for ~20 trips.  Instead: every lane
+        // looks up the candidate range of its row(s); a wave scan turns the lengths into positions of one concatenated sequence of T
+        // candidates (row table in LDS, empty rows dropped); lane l takes positions [l per, (l + 1) per), four per trip.
+        const int rpl = R > 64 ? 2 : 1; // rows per lane (R <= 128)
+        int rk0[2] = {0, 0}, rlen[2] = {0, 0};
 #pragma unroll
-            for (int j = 0; j < 4; j++) { G[j] = gblob[tr + 2 * (k + j)]; Bc[j] = gblob[tr + 2 * (k + j) + 1]; gi[j] = (int)gdword(gblob, tc, k + j); }
+        for (int q = 0; q < 2; q++) {
+          const int rr = lane * rpl + q;
+          if (q < rpl && rr < R) { // this lane's row: its candidate range (two loads)
+            const float x0 = -1.0f + (float)rr * step, x1 = x0 + step;
+            const float y0 = (C + mn * x0) * ninv, y1 = (C + mn * x1) * ninv;
+            const float ylo = __builtin_fminf(y0, y1) - hw, yhi = __builtin_fmaxf(y0, y1) + hw;
+            const int c0 = (int)__builtin_floorf((__builtin_fmaxf(ylo, -1.0f) + 1.0f) * halfR);
+            const int c1 = min((int)__builtin_floorf((__builtin_fminf(yhi, 1.0f) + 1.0f) * halfR), R - 1);
+            if (yhi >= -1.0f && ylo <= 1.0f && c0 <= c1) { // (NaN: nothing)
+              const int base = (face * R + rr) * R;
+              rk0[q] = (int)gdword(gblob, tf, base + c0);
+              rlen[q] = (int)gdword(gblob, tf, base + c1 + 1) - rk0[q];
+            }
+          }
+        }
+        const int mine = rlen[0] + rlen[1];
+        int incl = mine;
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) { const int o = __shfl_up(incl, dd, 64); incl += lane >= dd ? o : 0; }
+        const int T = __builtin_amdgcn_readlane(incl, 63);
+        if (T == 0) continue;
+        const unsigned long long f0 = __builtin_amdgcn_ballot_w64(rlen[0] > 0), f1 = __builtin_amdgcn_ballot_w64(rlen[1] > 0);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        const int dense = __builtin_popcountll(f0 & below) + __builtin_popcountll(f1 & below); // non-empty rows before this lane's
+        const int nr = __builtin_popcountll(f0) + __builtin_popcountll(f1);
+        int* const rpos = tri_rows() + (threadIdx.x >> 6) * 264; // [0, 132): first position of every non-empty row (+ sentinel T)
+        int* const rbas = rpos + 132;                                // [132, 264): first candidate - first position
+        int pos = incl - mine;
+        if (rlen[0] > 0) { rpos[dense] = pos; rbas[dense] = rk0[0] - pos; }
+        if (rlen[1] > 0) { const int d1 = dense + (rlen[0] > 0 ? 1 : 0); rpos[d1] = pos + rlen[0]; rbas[d1] = rk0[1] - (pos + rlen[0]); }
+        if (lane == 0) rpos[nr] = T;
+        const int per = (((T + 63) >> 6) + 3) & ~3; // positions per lane: a multiple of four
+        int p = lane * per;
+        const int pend = min(p + per, T);
+        int r = 0; // the row of position p: the last one that starts at or before it
+        { int lo = 0, hi = nr; // rpos[lo] <= p < rpos[hi] whenever p < T
+#pragma unroll
+          for (int it = 0; it < 8; it++) { const int mid = (lo + hi) >> 1; const bool up = mid > lo && rpos[mid] <= p; lo = up ? mid : lo; hi = up ? hi : (mid > lo ? mid : hi); }
+          r = lo; }
+        int rnext = rpos[r + 1], rb = rbas[r];
+        for (; __builtin_amdgcn_ballot_w64(p < pend) != 0; p += 4) {
+          PT_TRI_COUNT(5 + (lv < 2 ? lv : 2), 1);
+          PT_TRI_COUNT(4, __builtin_popcountll(__builtin_amdgcn_ballot_w64(p < pend)));
+          unsigned int passmask = 0;
+          int gi[4] = {0, 0, 0, 0};
+          if (p < pend) { // four candidates: band records, centroid records, indices — twelve loads together
+            int kk[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              const int pj = min(p + j, pend - 1); // (a tail position repeats the last candidate: masked out below)
+              while (pj >= rnext) { ++r; rnext = rpos[r + 1]; rb = rbas[r]; } // non-empty rows only: a few steps at most
+              kk[j] = rb + pj;
+            }
+            f4 G[4], Bc[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) { G[j] = gblob[tr + 2 * kk[j]]; Bc[j] = gblob[tr + 2 * kk[j] + 1]; gi[j] = (int)gdword(gblob, tc, kk[j]); }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < 4; j++) park(k + j < k1 && band_pass(G[j], Bc[j]), gi[j]);
+            for (int j = 0; j < 4; j++) passmask |= (p + j < pend && band_pass(G[j], Bc[j])) ? (1u << j) : 0u;
           }
-          PT_TRI_COUNT(2, __builtin_popcountll(__builtin_amdgcn_ballot_w64(k < k1)));
+          while (__builtin_amdgcn_ballot_w64(passmask != 0) != 0) { // survivors (rare): the exact test, first one of every lane at a time
+            if (passmask != 0) {
+              const int j = __builtin_ctz(passmask);
+              passmask &= passmask - 1;
+              exact(j == 0 ? gi[0] : j == 1 ? gi[1] : j == 2 ? gi[2] : gi[3], ur, src);
+            }
+          }
         }
-        k0 = n0; k1 = n1;
       }
     }
   }
-  // (3) the always list: 64 entries per load, one per lane (coalesced), broadcast lane by lane (v_readlane: the records become
-  // scalar operands of the band test); the next 64 are requested while these are tested
-  const int n_always = as_i(H3.z);
-  if (n_always > 0) {
-    const int lane = threadIdx.x & 63;
-    auto load_tile = [&](int base, f4& G, f4& Bc, int& gi) {
-      const int e = min(base + lane, n_always - 1); // (a tail lane repeats the last entry: never read back)
-      G = gblob[acheap + 2 * e]; Bc = gblob[acheap + 2 * e + 1]; gi = (int)gdword(gblob, always_idx, e);
-    };
-    f4 G, Bc;
-    int gi;
-    load_tile(0, G, Bc, gi);
-    for (int base = 0; base < n_always; base += 64) {
-      f4 Gn = G, Bn = Bc;
-      int gn = gi;
-      if (base + 64 < n_always) load_tile(base + 64, Gn, Bn, gn);
-      const int cnt = min(64, n_always - base);
-      for (int j = 0; j < cnt; ++j) {
-        if ((j & 3) == 0) room();
-        PT_TRI_COUNT(5, 1);
-        PT_TRI_COUNT(2, __builtin_popcountll(__builtin_amdgcn_ballot_w64(c.live)));
-        const f4 g = f4{as_f(__builtin_amdgcn_readlane(as_i(G.x), j)), as_f(__builtin_amdgcn_readlane(as_i(G.y), j)),
-                        as_f(__builtin_amdgcn_readlane(as_i(G.z), j)), as_f(__builtin_amdgcn_readlane(as_i(G.w), j))};
-        const f4 b = f4{as_f(__builtin_amdgcn_readlane(as_i(Bc.x), j)), as_f(__builtin_amdgcn_readlane(as_i(Bc.y), j)),
-                        as_f(__builtin_amdgcn_readlane(as_i(Bc.z), j)), as_f(__builtin_amdgcn_readlane(as_i(Bc.w), j))};
-        park(c.live && band_pass(g, b), __builtin_amdgcn_readlane(gi, j));
+  // ---- (3) the always list: 64 entries in the lanes (one coalesced load each), the live rays in the inner loop --------------------
+  const int n_always = (PT_TRI_ABLATE & 4) ? 0 : as_i(H3.z);
+  for (int base = 0; base < n_always; base += 64) {
+    const int e = base + lane;
+    const bool on = e < n_always;
+    f4 G = f4{0, 0, 0, 0}, Bc = G;
+    f4 R0 = G, R1 = G, R2 = G;
+    if (on) { G = gblob[acheap + 5 * e]; Bc = gblob[acheap + 5 * e + 1]; R0 = gblob[acheap + 5 * e + 2]; R1 = gblob[acheap + 5 * e + 3]; R2 = gblob[acheap + 5 * e + 4]; }
+    for (unsigned long long todo = live; todo != 0; todo &= todo - 1) {
+      const int src = __builtin_ctzll(todo);
+      Ray ur;
+      ur.o = mk(rl_f(c.r.o.x, src), rl_f(c.r.o.y, src), rl_f(c.r.o.z, src));
+      ur.d = mk(rl_f(c.r.d.x, src), rl_f(c.r.d.y, src), rl_f(c.r.d.z, src));
+      ur.tm = 0.0f;
+      const float ua = rl_f(c.a, src), rho = rl_f(rho_own, src), dn = rl_f(dn_own, src);
+      bool pass = false;
+      if (on) {
+        const float dg = __builtin_fabsf(ur.d.x * G.x + ur.d.y * G.y + ur.d.z * G.z);
+        if (dg <= dn * (rho + G.w)) {
+          const float L = Bc.w, L2 = L * L;
+          const float a1 = dg * (H5.z * L) - H6.w * L2 * dn;
+          const float rr = (H6.y + H6.z * L) * L2 * rho * dn / a1;
+          const float rad = L + rr + H6.x;
+          const V3 x = cross(xyz(Bc) - ur.o, ur.d);
+          pass = !(a1 > 0.0f) || dot(x, x) <= rad * rad * ua * 1.00001f;
+        }
       }
-      G = Gn; Bc = Bn; gi = gn;
+      if (pass) { // the entry's own triangle rides in the lane: no fetch
+        float t;
+        if (tri_param(R0, R1, R2, ur, t) && !(t < PT_TMIN)) atomicMin(&slot[src], tri_key(t, goff + 3 * as_i(R2.w)));
+      }
     }
   }
-  if (__builtin_amdgcn_ballot_w64(np > 0) != 0) flush();
+  // each lane reads its own ray's slot back: changed = some triangle of this run is the nearest hit so far
+  const unsigned long long kf = slot[lane];
+  if (kf != key0) { h.closest = as_f((int)(unsigned int)(kf >> 32)); h.hit = hit_pack(DK_TRI, 0, 0xffffff - (int)(unsigned int)(kf & 0xffffffu)); }
   return true;
 }
 

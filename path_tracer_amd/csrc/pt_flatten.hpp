@@ -282,7 +282,7 @@ inline void put_box(std::vector<F4>& b, const float* f, int32_t mat, int32_t hid
 //   H5 (band records of the always list, per-triangle (centroid, L) records: blob offsets; P / L, k_sigma)
 //   H6 (ball_abs, kr_a, kr_b, ea)
 //   per level k, three F4: (R, triangles, pn_max, qn_max) (first, cand, inline band records of orientation 0) (... of orientation 1)
-inline int32_t put_tri_pool(std::vector<F4>& b, const TriPool& tp) {
+inline int32_t put_tri_pool(std::vector<F4>& b, const TriPool& tp, const PtHittable* tri) {
   // (every array is followed by spare entries: the scans load whole chunks of four without clamping)
   auto put_u32 = [&](const std::vector<uint32_t>& v) { const int32_t at = (int32_t)b.size(); put_dwords(b, v.data(), v.size()); for (int k = 0; k < 3; k++) b.push_back({0, 0, 0, 0}); return at; };
   // records INLINE beside the candidate lists, in candidate order (a lane streams its cell's / its strip's candidates from
@@ -291,17 +291,25 @@ inline int32_t put_tri_pool(std::vector<F4>& b, const TriPool& tp) {
   auto put_inline = [&](const std::vector<uint32_t>& idx, auto rec_of) {
     const int32_t at = (int32_t)b.size();
     for (uint32_t i : idx) rec_of(i);
-    for (int k = 0; k < 10; k++) b.push_back({0, 0, 0, 0});
+    for (int k = 0; k < 20; k++) b.push_back({0, 0, 0, 0});
     return at;
   };
-  // grid candidate: one F4 (centroid, L k_sigma + ball_abs); band candidate: two F4 (g, c) (centroid, L)
-  auto ball_rec = [&](uint32_t i) { b.push_back(F4{tp.ball[(size_t)i * 4], tp.ball[(size_t)i * 4 + 1], tp.ball[(size_t)i * 4 + 2], tp.grid_radius[(size_t)i]}); };
+  // grid candidate: the triangle's own three records (v0, material)(edge1, hittable index)(edge2, triangle index in the run) — the walk
+  // tests a cell's candidates exactly, 64 at a time, without a second (dependent) fetch; band candidate: two F4 (g, c) (centroid, L);
+  // always-list entry: both, five F4
+  auto tri_rec = [&](uint32_t i) {
+    const float* f = tri[i].f;
+    b.push_back({f[0], f[1], f[2], as_f(tri[i].material)});
+    b.push_back({f[3] - f[0], f[4] - f[1], f[5] - f[2], 0.0f});
+    b.push_back({f[6] - f[0], f[7] - f[1], f[8] - f[2], as_f((int32_t)i)});
+  };
+  auto ball_rec = [&](uint32_t i) { tri_rec(i); };
   auto band_rec = [&](uint32_t i) {
     b.push_back(F4{tp.cheap[(size_t)i * 4], tp.cheap[(size_t)i * 4 + 1], tp.cheap[(size_t)i * 4 + 2], tp.cheap[(size_t)i * 4 + 3]});
     b.push_back(F4{tp.ball[(size_t)i * 4], tp.ball[(size_t)i * 4 + 1], tp.ball[(size_t)i * 4 + 2], tp.ball[(size_t)i * 4 + 3]});
   };
   const int32_t cell_first = put_u32(tp.cell_first), cell_cand = put_u32(tp.cell_cand), cell_ball = put_inline(tp.cell_cand, ball_rec);
-  const int32_t always = put_u32(tp.always), acheap = put_inline(tp.always, band_rec);
+  const int32_t always = put_u32(tp.always), acheap = put_inline(tp.always, [&](uint32_t i) { band_rec(i); tri_rec(i); });
   const int32_t ball = 0; // (every record the filters need rides inline)
   int32_t lfirst[3][2], lcand[3][2], lrec[3][2];
   for (int k = 0; k < 3; k++)
@@ -442,7 +450,7 @@ inline int flatten(const PtSceneDesc* sc, Flat& out, std::string& err, bool allo
       if (allow_tri_pool) {
         const TriPool tp = build_tri_pool(&sc->hittables[run.first], run.count, tri_tune);
         if (tp.ok) {
-          hdr = put_tri_pool(b, tp);
+          hdr = put_tri_pool(b, tp, &sc->hittables[run.first]);
           pooled = true;
           out.tri_pooled += run.count;
           out.tri_cells_per_triangle = tp.mean_cells_per_triangle;

@@ -795,15 +795,13 @@ static int flatten_with_env(const PtSceneDesc* desc, ptf::Flat& flat, std::strin
   if (const char* e = std::getenv("PT_GRID_M")) tune.m = (float)std::atof(e);
   if (const char* e = std::getenv("PT_GRID_CELL")) tune.cell = (float)std::atof(e);
   const bool allow_grid = std::getenv("PT_NO_GRID") == nullptr;
-  // PT_TRICULL=1: OPT-IN exact culling of long triangle runs (pt_tripool.hpp).  It is exact (the GPU suite runs it against the
-  // oracle's full scan, bit for bit) but on BASELINE config 5 — a random triangle soup — it is ~1.5x SLOWER than the SIMD-amortised
-  // full scan it replaces (per ray it must still look at ~2 700 band records, ~100 grid candidates and ~250 exact
-  // tests, gathered per lane from a 30 MB working set, where the full scan costs the equivalent of 1 560 tests per ray with no
-  // per-lane memory traffic at all), so it is not the default; PT_NO_TRICULL wins.
-  // PT_TRI_M / PT_TRI_CELL / PT_TRI_MIN: the pool's barycentric slack 1/M, its grid cell (in median grown boxes), the shortest
-  // run that gets one (pt_tripool.hpp: TriPoolTuning)
-  const bool allow_tri = std::getenv("PT_TRICULL") != nullptr && std::getenv("PT_NO_TRICULL") == nullptr;
+  // Exact culling of long triangle runs (pt_tripool.hpp; pt_device.hpp: tri_pool_scan).  Default: runs of >= 4096 triangles get a
+  // pool (BASELINE config 5, 100 k triangles: 68.9 -> 49.8 s per frame, bit-identical); PT_TRICULL=1 lowers that to 256 (the fuzz
+  // tests), PT_NO_TRICULL switches the pools off (the round-2 path: every triangle streamed and tested), PT_TRI_MIN sets the
+  // threshold, PT_TRI_M / PT_TRI_CELL the pool's barycentric slack 1/M and its grid cell (in median grown boxes).
+  const bool allow_tri = std::getenv("PT_NO_TRICULL") == nullptr;
   ptf::TriPoolTuning tri;
+  if (std::getenv("PT_TRICULL")) tri.min_run = 256;
   if (const char* e = std::getenv("PT_TRI_M")) tri.M = (float)std::atof(e);
   if (const char* e = std::getenv("PT_TRI_CELL")) tri.cell = (float)std::atof(e);
   if (const char* e = std::getenv("PT_TRI_MIN")) tri.min_run = std::max(1, std::atoi(e));

@@ -63,10 +63,10 @@
 namespace ptf {
 
 struct TriPoolTuning {
-  float M = 24.0f;      // PT_TRI_M (swept 12 ... 32 on cfg5: profiles/r03_tripool_sweep.log): barycentric slack 1/M; the band width grows with M, the boxes' growth sigma' with 1/M
+  float M = 12.0f;      // PT_TRI_M (swept 8 ... 32 on cfg5: profiles/r03_tripool_sweep*.log): barycentric slack 1/M; the band width grows with M, the boxes' growth sigma' with 1/M
   float Ma = 256.0f;    // relative slack of t: the walk runs to max (1 + 2.2 / (Ma - 1))
-  float cell = 0.8f;    // PT_TRI_CELL (swept 0.7 ... 1.5): grid cell edge in units of the median grown box extent
-  int min_run = 256;    // PT_TRI_MIN: shorter triangle runs are scanned as before
+  float cell = 1.0f;    // PT_TRI_CELL (swept 0.7 ... 3.0): grid cell edge in units of the median grown box extent
+  int min_run = 4096;   // PT_TRI_MIN: shorter triangle runs are scanned as before (PT_TRICULL=1: 256)
 };
 
 struct TriPoolLevel {
@@ -193,7 +193,19 @@ inline TriPool build_tri_pool(const PtHittable* h, int count, TriPoolTuning tune
       tp.n[k] = (int)std::min(nk, 256.0);
       total *= nk;
     }
-    if (fits && total <= 2097152.0) break;
+    // ... and a bounded candidate table: every (cell, triangle) entry carries the triangle's three records inline, and a few
+    // triangles that span the whole grid (cells are sized for the median one) would otherwise list themselves in every cell
+    double entries = 0;
+    if (fits && total <= 2097152.0) {
+      for (int i = 0; i < count && entries <= 1e9; i++) {
+        if (dead[(size_t)i]) continue;
+        double blo[3], bhi[3], e = 1;
+        box_of(i, 0.0, blo, bhi);
+        for (int k = 0; k < 3; k++) e *= std::min((double)tp.n[k], (bhi[k] - blo[k]) / cell + 2.0);
+        entries += e;
+      }
+      if (entries <= std::max(24.0 * (double)ext.size(), 65536.0)) break;
+    }
     cell *= 1.25;
   }
   const double slack = 1e-3 * cell; // the walk's own rounding (the ray must start within rlimit: below)
@@ -274,7 +286,7 @@ inline TriPool build_tri_pool(const PtHittable* h, int count, TriPoolTuning tune
   // level k takes the triangles whose band half-width at the reference distance, tau_i = rho_ref pn_i + qn_i, is <= tau_k
   const double rho_ref = 3.0 * R;
   const double tau_cap[3] = {0.004, 0.016, 0.064};
-  const int res[3] = {96, 40, 16};
+  const int res[3] = {128, 32, 16}; // powers of two: the device deals a level's rows (or fractions of rows) to the 64 lanes of a wave
   tp.levels.resize(3);
   std::vector<int> level_of((size_t)count, -1);
   for (int i = 0; i < count; i++) {

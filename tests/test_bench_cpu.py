@@ -173,3 +173,15 @@ def test_predicted_chain_floor_is_read_from_final_shard_tables(tmp_path):
     assert bench.predicted_chain_floor_ms("cornell", 1920, 1080, 1024, 8, tmp_path) == (43.0, "r03_shard_table_cornell.json")
     assert bench.predicted_chain_floor_ms("cornell", 1920, 1080, 1024, 4, tmp_path) is None
     assert bench.predicted_chain_floor_ms("smoke", 1920, 1080, 1024, 8, tmp_path) is None
+
+
+def test_culled_algorithm_pricing_for_the_triangle_pool(orc):
+    """cfg5's long triangle run is culled exactly by a triangle pool: priced for what the kernel runs (grid candidates at the
+    oracle's own triangle-exit mix, band records at 8 ops, both counted in the kernel), not for 100 000 tests per ray."""
+    bench = load_bench()
+    packed, cam_args = scenes.build("triangles", n_triangles=100_000)
+    orc.set_math(True)
+    _, ctr = orc.render(packed, scenes.make_camera(cam_args, 96, 54).c, 96, 54, 1, 50, counters=True)
+    live = bench.ops_per_sample_culled_tri(ctr.as_dict(), bench.TRI_POOL["triangles"])
+    assert abs(live / bench.ALGORITHMIC_OPS_PER_SAMPLE_CULLED["triangles"] - 1) < 0.02
+    assert live < 0.06 * bench.ops_per_sample(ctr.as_dict())

@@ -403,10 +403,10 @@ def test_random_triangle_fields_through_the_triangle_pool(orc, lib, seed):
     assert_bit_identical(R.render_host(w, h, 70, ds, c, flags=F), orc.render(ps, c.c, w, h, 70, flags=F), f"triangle field seed {seed} fast mode")
 
 
-def test_triangle_pool_is_opt_in_and_small_runs(orc, lib, monkeypatch):
-    """Without PT_TRICULL no pool is built (the default: on BASELINE config 5 the pool is exact but slower than the full scan);
-    PT_NO_TRICULL overrides PT_TRICULL; PT_TRI_MIN=4 puts pools into the small mixed scenes (triangle runs of a handful, between
-    spheres, boxes and media; Badouel-strategy scenes keep their kernels)."""
+def test_triangle_pool_thresholds_and_small_runs(orc, lib, monkeypatch):
+    """By default only runs of >= 4096 triangles get a pool (the fuzz fields do not: full scan); PT_TRICULL=1 lowers the threshold
+    to 256; PT_NO_TRICULL overrides everything; PT_TRI_MIN=4 puts pools into the small mixed scenes (triangle runs of a handful,
+    between spheres, boxes and media; Badouel-strategy scenes keep their kernels)."""
     import ctypes as C
     ps, cam = random_triangle_field(8003)
     st = (C.c_int32 * 8)()
@@ -417,7 +417,7 @@ def test_triangle_pool_is_opt_in_and_small_runs(orc, lib, monkeypatch):
         assert list(st)[:6] == [0] * 6
     c = scenes.make_camera(cam, 40, 24)
     orc.set_math(True)
-    assert_bit_identical(R.render_host(40, 24, 6, ps, c), orc.render(ps, c.c, 40, 24, 6), "default: no pool")
+    assert_bit_identical(R.render_host(40, 24, 6, ps, c), orc.render(ps, c.c, 40, 24, 6), "default: no pool for a short run")
     for seed in (1001, 1003, 1004, 1006):
         ps, cam = random_scene(seed, allow_image_on_triangle=(seed % 2 == 0))
         c = scenes.make_camera(cam, 45, 27)

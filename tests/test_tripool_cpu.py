@@ -20,7 +20,7 @@ from path_tracer_amd.scene import hittable_dtype
 
 f32 = np.float32
 U = 2.0 ** -24
-M, MA, SAFE = 24.0, 256.0, 1.5   # pt_tripool.hpp: TriPoolTuning defaults and SAFE
+M, MA, SAFE = 12.0, 256.0, 1.5   # pt_tripool.hpp: TriPoolTuning defaults and SAFE
 
 
 def cross32(a, b):
@@ -109,21 +109,27 @@ def test_accepted_pairs_are_band_or_grid_candidates():
     assert stats["accepted"] > 3000 and stats["band"] > 20 and stats["grid"] > 2000, stats
 
 
-def test_pool_is_opt_in_and_its_tables_are_consistent(lib, monkeypatch):
-    """No pool without PT_TRICULL (the default: exact, but slower than the full scan on BASELINE config 5); with it, the
-    100 k-triangle mesh gets one, every triangle sits in exactly one of {three band levels, always list}, and the blob grows by
-    the inline candidate records."""
+def test_pool_thresholds_and_tables(lib, monkeypatch):
+    """Long triangle runs (>= 4096) get a pool by default — the 100 k-triangle mesh of BASELINE config 5 does — shorter ones only
+    with PT_TRICULL=1 (>= 256: the fuzz fields), none with PT_NO_TRICULL; every triangle sits in exactly one of {three band
+    levels, always list}, and the blob grows by the inline candidate records."""
     ps, _ = scenes.triangle_mesh_scene()
     st = (C.c_int32 * 8)()
     abi.check(lib.pt_debug_tri_pool(C.byref(ps.desc), st), "pt_debug_tri_pool")
-    assert list(st)[:6] == [0] * 6 and st[6] * 16 < 5.0e6
-    monkeypatch.setenv("PT_TRICULL", "1")
-    abi.check(lib.pt_debug_tri_pool(C.byref(ps.desc), st), "pt_debug_tri_pool")
     assert st[0] == 100_000 and st[1] + st[2] + st[3] + st[4] == 100_000
-    assert 2000 < st[5] < 30000 and st[6] * 16 > 1.5e7
+    assert 2000 < st[5] < 30000 and 1.5e7 < st[6] * 16 < 2.0e8
     n_f4, n_runs, flags = C.c_int32(), C.c_int32(), C.c_int32()
     abi.check(lib.pt_debug_flatten(C.byref(ps.desc), None, 0, C.byref(n_f4), C.byref(n_runs), None, 0, C.byref(flags)), "pt_debug_flatten")
     assert flags.value & 4 and n_runs.value == 3
+    small, _ = scenes.triangle_mesh_scene(n_triangles=1000)
+    abi.check(lib.pt_debug_tri_pool(C.byref(small.desc), st), "pt_debug_tri_pool")
+    assert st[0] == 0                       # 1000 triangles: full scan by default
+    monkeypatch.setenv("PT_TRICULL", "1")
+    abi.check(lib.pt_debug_tri_pool(C.byref(small.desc), st), "pt_debug_tri_pool")
+    assert st[0] == 1000
     monkeypatch.setenv("PT_NO_TRICULL", "1")
+    for sc in (ps, small):
+        abi.check(lib.pt_debug_tri_pool(C.byref(sc.desc), st), "pt_debug_tri_pool")
+        assert list(st)[:6] == [0] * 6
     abi.check(lib.pt_debug_tri_pool(C.byref(ps.desc), st), "pt_debug_tri_pool")
-    assert list(st)[:6] == [0] * 6
+    assert st[6] * 16 < 5.0e6               # the plain blob: 4.8 MB

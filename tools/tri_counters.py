@@ -23,8 +23,7 @@ lib.pt_debug_tri(None, 1)
 fb, ms = R.render(W, H, spp, ds, cam, flags=abi.PT_FLAG_NO_LPT, timed=True)
 o = (C.c_ulonglong * 8)()
 lib.pt_debug_tri(o, 0)
-scans, lg, lc, lx, wg, wc, fl, fb_ = [o[i] for i in range(8)]
-print(f"{W}x{H}x{spp}: {ms:.1f} ms = {W*H*spp/ms/1e3:.2f} Msamples/s; wave scans {scans:.3e}, fallbacks {fb_:.3e}")
-rays = max(1, scans) * 64
-print(f"per scan (wave): grid trips {wg/max(scans,1):.1f} (lanes busy {lg/max(wg,1):.1f}), cheap trips {wc/max(scans,1):.1f} (lanes busy {lc/max(wc,1):.1f}), flushes {fl/max(scans,1):.1f} (lanes {lx/max(fl,1):.1f})")
-print(f"per lane-ray (upper bound, idle lanes included): grid tests {lg/rays:.1f}, cheap tests {lc/rays:.1f}, exact tests after the band {lx/rays:.1f}")
+scans, rays, grid, alw, lanes, b0, b1, b2 = [o[i] for i in range(8)]
+rays = max(rays, 1)
+print(f"{W}x{H}x{spp}: {ms:.1f} ms = {W*H*spp/ms/1e3:.2f} Msamples/s; wave scans {scans:.3e}, live rays per scan {rays/max(scans,1):.1f}")
+print(f"per ray: grid rounds {grid/rays:.1f}; band trips level 0 / 1 / 2: {b0/rays:.1f} / {b1/rays:.1f} / {b2/rays:.1f} (lanes busy per trip {lanes/max(b0+b1+b2,1):.1f}); grid cells visited {alw/rays:.1f}")
