@@ -29,7 +29,7 @@ extern __device__ unsigned long long g_stamps[8]; // diagnostic build only (pt_r
 #endif
 #ifdef PT_STAMPS_TRI
 // diagnostic build (triangle pool): [0] scans (waves) [1] live rays [2] grid rounds (64 candidates each) [3] grid cells visited [4] lanes busy over the band's trips [5] [6] [7] band trips (four candidates per lane) of levels 0, 1, 2
-extern __device__ unsigned long long g_tri[8];
+extern __device__ unsigned long long g_tri[12];
 #endif
 #ifdef PT_STAMPS_WALK
 // diagnostic build: per-workgroup counters of the sphere-grid walk in LDS (cheap ds_add; global atomics per step distort the
@@ -1044,6 +1044,9 @@ __device__ __forceinline__ void slab_pool(P blob, cst_f4p cblob, int pool_off, i
 #else
 #define PT_TRI_COUNT(i, v) do { } while (0)
 #endif
+// bits set in a 4-bit per-lane mask, summed over the wave (diagnostic counters only)
+#define PT_TRI_WAVE_BITS(m) (__builtin_popcountll(__builtin_amdgcn_ballot_w64(((m) & 1u) != 0)) + __builtin_popcountll(__builtin_amdgcn_ballot_w64(((m) & 2u) != 0)) + \
+                             __builtin_popcountll(__builtin_amdgcn_ballot_w64(((m) & 4u) != 0)) + __builtin_popcountll(__builtin_amdgcn_ballot_w64(((m) & 8u) != 0)))
 
 __device__ __forceinline__ unsigned int gdword(glb_f4p gblob, int base_f4, int i) { return ((const __attribute__((address_space(1))) unsigned int*)(gblob + base_f4))[i]; }
 
@@ -1093,10 +1096,12 @@ __device__ __forceinline__ float rl_f(float v, int src) { return as_f(__builtin_
 
 __device__ __forceinline__ bool tri_pool_scan(glb_f4p gblob, cst_f4p cblob, int hdr, int goff, const RayCtx& c, HitState& h) {
   const f4 H0 = cblob[hdr], H1 = cblob[hdr + 1], H2 = cblob[hdr + 2], H3 = cblob[hdr + 3], H4 = cblob[hdr + 4], H5 = cblob[hdr + 5], H6 = cblob[hdr + 6];
+  const f4 H7 = cblob[hdr + 7], H8 = cblob[hdr + 8], H9 = cblob[hdr + 9]; // the quantisation of the compressed filter records (pt_tripool.hpp)
+  const int cell_n = as_i(H9.z);
   const V3 oc_own = c.r.o - xyz(H2);
   const float oc2_own = dot(oc_own, oc_own);
   if (__builtin_amdgcn_ballot_w64(c.live && !(c.reg && oc2_own <= H3.x)) != 0) return false;
-  const int cell_first = as_i(H4.x), cell_cand = as_i(H4.y), always_idx = as_i(H4.z), cell_ball = as_i(H4.w), acheap = as_i(H5.x);
+  const int cell_first = as_i(H4.x), cell_cand = as_i(H4.y), tri_sorted = as_i(H4.z), cell_q = as_i(H4.w), acheap = as_i(H5.x);
   const int lane = threadIdx.x & 63;
   unsigned long long* const slot = tri_slots() + (threadIdx.x & ~63); // this wave's 64 slots
   const unsigned long long key0 = h.hit >= 0 ? tri_key(h.closest, hit_off(h.hit)) : ((unsigned long long)0x7f800000u << 32);
@@ -1159,14 +1164,49 @@ __device__ __forceinline__ bool tri_pool_scan(glb_f4p gblob, cst_f4p cblob, int 
         const int ci = __builtin_amdgcn_readfirstlane((iz * ny + iy) * nx + ix);
         PT_TRI_COUNT(3, 1);
         const int k0 = (int)dword_at(cblob + cell_first, ci), k1 = (int)dword_at(cblob + cell_first, ci + 1);
-        for (int base = k0; base < k1; base += 64) {
+        for (int base = k0; base < k1; base += 256) { // four candidates per lane and trip: k = base + 64 j + lane
           PT_TRI_COUNT(2, 1);
-          const int k = base + lane;
-          const bool on = k < k1;
-          if (on) { // the candidate's own records ride inline (cell order): one fetch, the exact test for all 64 lanes at once
-            const f4 R0 = gblob[cell_ball + 3 * k], R1 = gblob[cell_ball + 3 * k + 1], R2 = gblob[cell_ball + 3 * k + 2];
-            float t;
-            if (tri_param(R0, R1, R2, ur, t) && !(t < PT_TMIN)) atomicMin(&slot[src], tri_key(t, goff + 3 * as_i(R2.w)));
+          unsigned int q0[4], q1[4], n0[4], n1[4];
+          int gi[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) { // (the arrays carry 256 spare entries: no clamping)
+            const int k = base + 64 * j + lane;
+            q0[j] = gdword(gblob, cell_q, 2 * k); q1[j] = gdword(gblob, cell_q, 2 * k + 1); gi[j] = (int)gdword(gblob, cell_cand, k);
+            n0[j] = gdword(gblob, cell_n, 2 * k); n1[j] = gdword(gblob, cell_n, 2 * k + 1);
+          }
+          // filter (i) of pt_tripool.hpp on the compressed records: the walked SEGMENT [0, lim] passes within the radius of the
+          // centroid — the line within it, and the centroid's projection neither more than it behind the origin nor beyond lim —
+          // for the TIGHT radius, or for the LOOSE one if the pair also passes the band test at Mg ("compressed records")
+          const float cl = as_f((int)(unsigned int)(slot[src] >> 32));
+          const float lim_ua = (cl + cl * kappa) * ua * 1.00001f;
+          unsigned int passmask = 0;
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const V3 C = mk(H7.x + (float)(q0[j] & 0xffffu) * H8.x, H7.y + (float)(q0[j] >> 16) * H8.y, H7.z + (float)(q1[j] & 0xffffu) * H8.z);
+            const float rad = as_f((int)(q1[j] & 0xffff0000u)), radl = rad * H9.x;
+            const V3 oc = C - ur.o;
+            const float m = dot(oc, ur.d);
+            const V3 x = cross(oc, ur.d);
+            const float xx = dot(x, x), sm = 1.001f * rad * dn, sml = 1.001f * radl * dn;
+            const bool in_t = (xx <= rad * rad * ua * 1.00001f) & (m >= -sm) & (m <= lim_ua + sm);
+            const bool in_l = (xx <= radl * radl * ua * 1.00001f) & (m >= -sml) & (m <= lim_ua + sml);
+            const float nx = (float)((int)(n0[j] << 16) >> 16), ny = (float)((int)n0[j] >> 16), nz = (float)((int)(n1[j] << 16) >> 16);
+            const float pne = as_f((int)(n1[j] & 0xffff0000u));
+            const float dq = __builtin_fabsf(ur.d.x * nx + ur.d.y * ny + ur.d.z * nz) * 3.0518509e-5f;
+            const bool mid = dq <= dn * (H9.y * pne * (rho + H5.y * (2.0f * rad)) + H8.w) * 1.00001f;
+            const bool pass = (base + 64 * j + lane < k1) & (in_t | (in_l & mid));
+            passmask |= pass ? (1u << j) : 0u;
+          }
+          PT_TRI_COUNT(8, PT_TRI_WAVE_BITS(passmask));
+          while (__builtin_amdgcn_ballot_w64(passmask != 0) != 0) { // survivors: the reference's test on the triangle's own records
+            if (passmask != 0) {
+              const int j = __builtin_ctz(passmask);
+              passmask &= passmask - 1;
+              const int o = tri_sorted + 3 * (j == 0 ? gi[0] : j == 1 ? gi[1] : j == 2 ? gi[2] : gi[3]); // the Morton-ordered copy
+              const f4 R0 = gblob[o], R1 = gblob[o + 1], R2 = gblob[o + 2];
+              float t;
+              if (tri_param(R0, R1, R2, ur, t) && !(t < PT_TMIN)) atomicMin(&slot[src], tri_key(t, goff + 3 * as_i(R2.w)));
+            }
           }
         }
         const float tn = __builtin_fminf(tmx, __builtin_fminf(tmy, tmz));
@@ -1180,18 +1220,25 @@ __device__ __forceinline__ bool tri_pool_scan(glb_f4p gblob, cst_f4p cblob, int 
 #endif
     // ---- (2) the cube-map levels: the triangles this ray grazes (narrow bands) ------------------------------------------------------
     // band test, then the noise-radius filter: the line within L + kr rho |d| / (|a'| - ea |d|) of the centroid
-    auto band_pass = [&](f4 G, f4 Bc) {
-      const float dg = __builtin_fabsf(ur.d.x * G.x + ur.d.y * G.y + ur.d.z * G.z);
-      if (!(dg <= dn * (rho + G.w))) return false;
-      const float L = Bc.w, L2 = L * L;
-      const float a1 = dg * (H5.z * L) - H6.w * L2 * dn;                 // |a'| - ea |d|   (|a'| = |d . g| P, P = (P / L) L)
-      const float rr = (H6.y + H6.z * L) * L2 * rho * dn / a1;           // the noise radius; a1 <= 0: no bound
-      return !(a1 > 0.0f) || near_line(xyz(Bc), L + rr + H6.x);
+    // on the 16-byte compressed record (pt_tripool.hpp "compressed records"; every quantity rounded to the safe side)
+    auto band_pass = [&](f4 Q) {
+      const unsigned int w0 = (unsigned int)as_i(Q.x), w1 = (unsigned int)as_i(Q.y), w2 = (unsigned int)as_i(Q.z), w3 = (unsigned int)as_i(Q.w);
+      const float nx = (float)((int)(w0 << 16) >> 16), ny = (float)((int)w0 >> 16), nz = (float)((int)(w1 << 16) >> 16);
+      const float pn = as_f((int)(w1 & 0xffff0000u)), L = as_f((int)(w3 & 0xffff0000u));
+      const float dq = __builtin_fabsf(ur.d.x * nx + ur.d.y * ny + ur.d.z * nz) * 3.0518509e-5f; // |d . n~|, n~ = (nx, ny, nz) / 32767
+      const float rL = __builtin_amdgcn_rcpf(L) * 1.00001f;
+      if (!(dq <= dn * (pn * (rho + H5.y * L + H5.w * rL) + H8.w) * 1.00001f)) return false;
+      const float L2 = L * L;
+      const float nlow = 0.98f * H5.z * L * __builtin_amdgcn_rcpf(pn);          // <= |N|
+      const float a1 = (dq - dn * H8.w) * nlow - H6.w * L2 * dn;                 // <= |a'| - ea |d|
+      const float rr = (H6.y + H6.z * L) * L2 * rho * dn * __builtin_amdgcn_rcpf(a1) * 1.001f; // >= the noise radius; a1 <= 0: no bound
+      const V3 C = mk(H7.x + (float)(w2 & 0xffffu) * H8.x, H7.y + (float)(w2 >> 16) * H8.y, H7.z + (float)(w3 & 0xffffu) * H8.z);
+      return !(a1 > 0.0f) || near_line(C, L + rr + H6.x + H7.w);
     };
     const V3 dh = __builtin_amdgcn_rsqf(ua) * ur.d; // unit direction (a few ulp: covered by the strips' absolute slack)
     const int n_levels = (PT_TRI_ABLATE & 2) ? 0 : as_i(H3.w);
     for (int lv = 0; lv < n_levels; ++lv) {
-      const f4 L0 = cblob[hdr + 7 + 3 * lv], T0 = cblob[hdr + 8 + 3 * lv], T1 = cblob[hdr + 9 + 3 * lv];
+      const f4 L0 = cblob[hdr + 10 + 3 * lv], T0 = cblob[hdr + 11 + 3 * lv], T1 = cblob[hdr + 12 + 3 * lv];
       const int R = as_i(L0.x);
       if (as_i(L0.y) == 0) continue;
       const float W = 1.7320509f * (rho * L0.z + L0.w) * 1.00001f + 2e-5f; // |A p + B q + C| <= sqrt(3) tau on the face of n's largest component
@@ -1259,27 +1306,27 @@ __device__ __forceinline__ bool tri_pool_scan(glb_f4p gblob, cst_f4p cblob, int 
           PT_TRI_COUNT(5 + (lv < 2 ? lv : 2), 1);
           PT_TRI_COUNT(4, __builtin_popcountll(__builtin_amdgcn_ballot_w64(p < pend)));
           unsigned int passmask = 0;
-          int gi[4] = {0, 0, 0, 0};
-          if (p < pend) { // four candidates: band records, centroid records, indices — twelve loads together
-            int kk[4];
+          int kk[4] = {0, 0, 0, 0};
+          if (p < pend) { // four candidates: their 16-byte records, four loads together
 #pragma unroll
             for (int j = 0; j < 4; j++) {
               const int pj = min(p + j, pend - 1); // (a tail position repeats the last candidate: masked out below)
               while (pj >= rnext) { ++r; rnext = rpos[r + 1]; rb = rbas[r]; } // non-empty rows only: a few steps at most
               kk[j] = rb + pj;
             }
-            f4 G[4], Bc[4];
+            f4 Q[4];
 #pragma unroll
-            for (int j = 0; j < 4; j++) { G[j] = gblob[tr + 2 * kk[j]]; Bc[j] = gblob[tr + 2 * kk[j] + 1]; gi[j] = (int)gdword(gblob, tc, kk[j]); }
+            for (int j = 0; j < 4; j++) Q[j] = gblob[tr + kk[j]];
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < 4; j++) passmask |= (p + j < pend && band_pass(G[j], Bc[j])) ? (1u << j) : 0u;
+            for (int j = 0; j < 4; j++) passmask |= (p + j < pend && band_pass(Q[j])) ? (1u << j) : 0u;
           }
+          PT_TRI_COUNT(9, PT_TRI_WAVE_BITS(passmask));
           while (__builtin_amdgcn_ballot_w64(passmask != 0) != 0) { // survivors (rare): the exact test, first one of every lane at a time
             if (passmask != 0) {
               const int j = __builtin_ctz(passmask);
               passmask &= passmask - 1;
-              exact(j == 0 ? gi[0] : j == 1 ? gi[1] : j == 2 ? gi[2] : gi[3], ur, src);
+              exact((int)gdword(gblob, tc, j == 0 ? kk[0] : j == 1 ? kk[1] : j == 2 ? kk[2] : kk[3]), ur, src);
             }
           }
         }

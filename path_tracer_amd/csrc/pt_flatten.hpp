@@ -276,55 +276,93 @@ inline void put_box(std::vector<F4>& b, const float* f, int32_t mat, int32_t hid
 
 // box_cull: 0 = no slab pools, 1 = where the cost model says they pay, 2 = every stretch of >= 2 rects / boxes (tests)
 // In front of a triangle run's records: ONE aux F4 = (1 if the run has a triangle pool else 0, header offset, 0, 0), and for a
-// pooled run, before it, the pool's tables and its 11-F4 header (pt_device.hpp: tri_pool_scan reads them):
+// pooled run, before it, the pool's tables and its header (pt_device.hpp: tri_pool_scan reads them):
 //   H0 (grid origin xyz, 1 / cell)   H1 (nx, ny, nz, cell)   H2 (centre xyz, R)   H3 (rlimit^2, kappa, n_always, n_levels)
-//   H4 (cell_first, cell_cand, always index list, the grid candidates' inline (centroid, filter radius) records: blob offsets)
-//   H5 (band records of the always list, per-triangle (centroid, L) records: blob offsets; P / L, k_sigma)
-//   H6 (ball_abs, kr_a, kr_b, ea)
+//   H4 (cell_first, cell_cand (positions in the Morton-ordered copy), that copy of the run's records, the grid candidates' inline
+//       8-byte filter records: blob offsets)
+//   H5 (always-list entries: blob offset; KQ; P / L; KT)          H6 (ball_abs, kr_a, kr_b, ea)
+//   H7 (centroid quantisation origin xyz, eps_c)                   H8 (centroid quantisation step xyz, eps_n)
+//   H9 (loose / tight grid radius, Mg / M, the grid candidates' inline 8-byte (normal, pn) records: blob offset)
 //   per level k, three F4: (R, triangles, pn_max, qn_max) (first, cand, inline band records of orientation 0) (... of orientation 1)
 inline int32_t put_tri_pool(std::vector<F4>& b, const TriPool& tp, const PtHittable* tri) {
   // (every array is followed by spare entries: the scans load whole chunks of four without clamping)
   auto put_u32 = [&](const std::vector<uint32_t>& v) { const int32_t at = (int32_t)b.size(); put_dwords(b, v.data(), v.size()); for (int k = 0; k < 3; k++) b.push_back({0, 0, 0, 0}); return at; };
-  // records INLINE beside the candidate lists, in candidate order (a lane streams its cell's / its strip's candidates from
-  // consecutive addresses instead of gathering one record per index): grid candidates carry (centroid, filter radius), band
-  // candidates their band record (g, c).  Each array is followed by a spare entry (the scans request one ahead).
+  // COMPRESSED filter records inline beside the candidate lists, in candidate order (a wave streams a cell's / a strip's
+  // candidates from consecutive addresses): grid candidates 8 bytes (quantised centroid, bfloat16 filter radius), band candidates
+  // 16 bytes (quantised unit normal, pn, centroid, L) — pt_tripool.hpp "compressed records"; only the survivors of the filters
+  // fetch the triangle's own records (by index, from the run).  Always-list entries stay exact: band record (g, c), (centroid, L),
+  // and the triangle's three records (v0, material)(edge1, hittable index)(edge2, triangle index in the run), five F4.
   auto put_inline = [&](const std::vector<uint32_t>& idx, auto rec_of) {
     const int32_t at = (int32_t)b.size();
     for (uint32_t i : idx) rec_of(i);
     for (int k = 0; k < 20; k++) b.push_back({0, 0, 0, 0});
     return at;
   };
-  // grid candidate: the triangle's own three records (v0, material)(edge1, hittable index)(edge2, triangle index in the run) — the walk
-  // tests a cell's candidates exactly, 64 at a time, without a second (dependent) fetch; band candidate: two F4 (g, c) (centroid, L);
-  // always-list entry: both, five F4
+  auto put_q = [&](const std::vector<uint32_t>& idx, const std::vector<uint32_t>& q, int per, int spare_f4) {
+    const int32_t at = (int32_t)b.size();
+    std::vector<uint32_t> v;
+    v.reserve(idx.size() * (size_t)per);
+    for (uint32_t i : idx) for (int k = 0; k < per; k++) v.push_back(q[(size_t)i * per + k]);
+    put_dwords(b, v.data(), v.size());
+    for (int k = 0; k < spare_f4; k++) b.push_back({0, 0, 0, 0});
+    return at;
+  };
   auto tri_rec = [&](uint32_t i) {
     const float* f = tri[i].f;
     b.push_back({f[0], f[1], f[2], as_f(tri[i].material)});
     b.push_back({f[3] - f[0], f[4] - f[1], f[5] - f[2], 0.0f});
     b.push_back({f[6] - f[0], f[7] - f[1], f[8] - f[2], as_f((int32_t)i)});
   };
-  auto ball_rec = [&](uint32_t i) { tri_rec(i); };
   auto band_rec = [&](uint32_t i) {
     b.push_back(F4{tp.cheap[(size_t)i * 4], tp.cheap[(size_t)i * 4 + 1], tp.cheap[(size_t)i * 4 + 2], tp.cheap[(size_t)i * 4 + 3]});
     b.push_back(F4{tp.ball[(size_t)i * 4], tp.ball[(size_t)i * 4 + 1], tp.ball[(size_t)i * 4 + 2], tp.ball[(size_t)i * 4 + 3]});
   };
-  const int32_t cell_first = put_u32(tp.cell_first), cell_cand = put_u32(tp.cell_cand), cell_ball = put_inline(tp.cell_cand, ball_rec);
+  // The survivors of the grid filter gather their triangle's records, and a cell's survivors are neighbours in space: a copy of the
+  // run's records in MORTON order of the centroids (R2.w = the triangle's index in the run, for the tie rule) turns those gathers
+  // into reads of a few nearby lines; a cell's candidates are listed by position in that copy, ascending.
+  const size_t ntri = tp.grid_q.size() / 2;
+  std::vector<uint32_t> order(ntri), pos_of(ntri);
+  {
+    auto spread = [](uint32_t v) { uint64_t x = v & 0xffffu; x = (x | (x << 32)) & 0x1f00000000ffffull; x = (x | (x << 16)) & 0x1f0000ff0000ffull;
+                                   x = (x | (x << 8)) & 0x100f00f00f00f00full; x = (x | (x << 4)) & 0x10c30c30c30c30c3ull; return (x | (x << 2)) & 0x1249249249249249ull; };
+    std::vector<uint64_t> code(ntri);
+    for (size_t i = 0; i < ntri; i++) {
+      const uint32_t a = tp.grid_q[2 * i], c = tp.grid_q[2 * i + 1];
+      code[i] = spread(a & 0xffffu) | (spread(a >> 16) << 1) | (spread(c & 0xffffu) << 2);
+      order[i] = (uint32_t)i;
+    }
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return code[x] < code[y]; });
+    for (size_t p = 0; p < ntri; p++) pos_of[order[p]] = (uint32_t)p;
+  }
+  const int32_t tri_sorted = put_inline(order, tri_rec);
+  std::vector<uint32_t> cell_sorted(tp.cell_cand), cell_pos(tp.cell_cand.size());
+  for (size_t c = 0; c + 1 < tp.cell_first.size(); c++)
+    std::sort(cell_sorted.begin() + tp.cell_first[c], cell_sorted.begin() + tp.cell_first[c + 1], [&](uint32_t x, uint32_t y) { return pos_of[x] < pos_of[y]; });
+  for (size_t k = 0; k < cell_sorted.size(); k++) cell_pos[k] = pos_of[cell_sorted[k]];
+  // (the grid scan reads up to 256 entries past a cell's last candidate: spare entries behind both arrays)
+  const int32_t cell_first = put_u32(tp.cell_first);
+  const int32_t cell_cand = (int32_t)b.size();
+  put_dwords(b, cell_pos.data(), cell_pos.size());
+  for (int k = 0; k < 68; k++) b.push_back({0, 0, 0, 0});
+  const int32_t cell_q = put_q(cell_sorted, tp.grid_q, 2, 132), cell_n = put_q(cell_sorted, tp.grid_n, 2, 132);
   const int32_t always = put_u32(tp.always), acheap = put_inline(tp.always, [&](uint32_t i) { band_rec(i); tri_rec(i); });
-  const int32_t ball = 0; // (every record the filters need rides inline)
   int32_t lfirst[3][2], lcand[3][2], lrec[3][2];
   for (int k = 0; k < 3; k++)
     for (int o = 0; o < 2; o++) {
       lfirst[k][o] = put_u32(tp.levels[(size_t)k].first[o]); lcand[k][o] = put_u32(tp.levels[(size_t)k].cand[o]);
-      lrec[k][o] = put_inline(tp.levels[(size_t)k].cand[o], band_rec);
+      lrec[k][o] = put_q(tp.levels[(size_t)k].cand[o], tp.band_q, 4, 20);
     }
   const int32_t hdr = (int32_t)b.size();
   b.push_back({tp.origin[0], tp.origin[1], tp.origin[2], tp.inv_cell});
   b.push_back({as_f(tp.n[0]), as_f(tp.n[1]), as_f(tp.n[2]), tp.cell});
   b.push_back({tp.centre[0], tp.centre[1], tp.centre[2], tp.R});
   b.push_back({tp.rlimit2, tp.kappa, as_f((int32_t)tp.always.size()), as_f(3)});
-  b.push_back({as_f(cell_first), as_f(cell_cand), as_f(always), as_f(cell_ball)});
-  b.push_back({as_f(acheap), as_f(ball), tp.p_per_L, tp.k_sigma});
+  b.push_back({as_f(cell_first), as_f(cell_cand), as_f(tri_sorted), as_f(cell_q)});
+  b.push_back({as_f(acheap), tp.kq, tp.p_per_L, tp.kt});
   b.push_back({tp.ball_abs, tp.kr_a, tp.kr_b, tp.ea});
+  b.push_back({tp.cq_lo[0], tp.cq_lo[1], tp.cq_lo[2], tp.eps_c});
+  b.push_back({tp.cq_step[0], tp.cq_step[1], tp.cq_step[2], tp.eps_n});
+  b.push_back({tp.k_loose, tp.m_scale, as_f(cell_n), 0});
   for (int k = 0; k < 3; k++) {
     const TriPoolLevel& L = tp.levels[(size_t)k];
     b.push_back({as_f(L.R), as_f((int32_t)L.cand[0].size()), L.pn_max, L.qn_max});

@@ -35,7 +35,7 @@ __device__ unsigned long long g_stamps[8];
 __device__ unsigned long long g_walk[8];
 #endif
 #ifdef PT_STAMPS_TRI
-__device__ unsigned long long g_tri[8];
+__device__ unsigned long long g_tri[12];
 #endif
 
 using namespace ptd;
@@ -803,6 +803,7 @@ static int flatten_with_env(const PtSceneDesc* desc, ptf::Flat& flat, std::strin
   ptf::TriPoolTuning tri;
   if (std::getenv("PT_TRICULL")) tri.min_run = 256;
   if (const char* e = std::getenv("PT_TRI_M")) tri.M = (float)std::atof(e);
+  if (const char* e = std::getenv("PT_TRI_MG")) tri.Mg = (float)std::atof(e);
   if (const char* e = std::getenv("PT_TRI_CELL")) tri.cell = (float)std::atof(e);
   if (const char* e = std::getenv("PT_TRI_MIN")) tri.min_run = std::max(1, std::atoi(e));
   int rc = ptf::flatten(desc, flat, err, allow_grid, box_cull, tune, allow_tri, tri);
@@ -1401,8 +1402,8 @@ int pt_debug_stamps(unsigned long long* out8, int reset) { // diagnostic build o
 }
 #ifdef PT_STAMPS_TRI
 int pt_debug_tri(unsigned long long* out8, int reset) { // -DPT_STAMPS_TRI: counters of the triangle pool (pt_device.hpp: PT_TRI_COUNT)
-  if (out8) PT_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_tri), 8 * sizeof(unsigned long long)));
-  if (reset) { unsigned long long z[8] = {0}; PT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_tri), z, sizeof z)); }
+  if (out8) PT_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_tri), 12 * sizeof(unsigned long long)));
+  if (reset) { unsigned long long z[12] = {0}; PT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_tri), z, sizeof z)); }
   return PT_OK;
 }
 #endif

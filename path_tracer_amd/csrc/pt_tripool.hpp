@@ -64,6 +64,7 @@ namespace ptf {
 
 struct TriPoolTuning {
   float M = 12.0f;      // PT_TRI_M (swept 8 ... 32 on cfg5: profiles/r03_tripool_sweep*.log): barycentric slack 1/M; the band width grows with M, the boxes' growth sigma' with 1/M
+  float Mg = 96.0f;     // PT_TRI_MG: the grid's TIGHT slack (pairs with |a^| >= thr(Mg) are found within sigma'(Mg) of the triangle; the others of the grid's share, thr(M) <= |a^| < thr(Mg), pass a band test at Mg: see "compressed records")
   float Ma = 256.0f;    // relative slack of t: the walk runs to max (1 + 2.2 / (Ma - 1))
   float cell = 1.0f;    // PT_TRI_CELL (swept 0.7 ... 3.0): grid cell edge in units of the median grown box extent
   int min_run = 4096;   // PT_TRI_MIN: shorter triangle runs are scanned as before (PT_TRICULL=1: 256)
@@ -93,6 +94,12 @@ struct TriPool {
   std::vector<float> ball;          // 4 floats per triangle: centroid C, L = longest stored edge (every vertex is within L of C)
   std::vector<float> grid_radius;   // per triangle: Rv + sigma' + ball_abs, Rv = the largest distance of a vertex from C (the grid filter's radius)
   float p_per_L = 0, k_sigma = 0, ball_abs = 0, kr_a = 0, kr_b = 0, ea = 0; // constants of the two distance filters (see build_tri_pool)
+  // COMPRESSED filter records (what the device streams: the filters are necessary conditions, so any relaxation of them is
+  // still exact — see "compressed records" in build_tri_pool): per triangle 2 dwords for the grid, 4 for the band
+  float cq_lo[3] = {0, 0, 0}, cq_step[3] = {0, 0, 0}, eps_c = 0, eps_n = 0, kq = 0, kt = 0, k_loose = 0, m_scale = 0;
+  std::vector<uint32_t> grid_q; // (cq.x | cq.y << 16) (cq.z | bf16(tight radius) << 16)
+  std::vector<uint32_t> grid_n; // (nq.x | nq.y << 16) (nq.z | bf16(pn_eff) << 16)
+  std::vector<uint32_t> band_q; // (nq.x | nq.y << 16) (nq.z | bf16(pn) << 16) (cq.x | cq.y << 16) (cq.z | bf16(L) << 16)
   // statistics for the tests / DESIGN
   double mean_cells_per_triangle = 0;
 };
@@ -324,6 +331,95 @@ inline TriPool build_tri_pool(const PtHittable* h, int count, TriPoolTuning tune
       std::vector<uint32_t> cu(L.first[orient].begin(), L.first[orient].end() - 1);
       for (int i = 0; i < count; i++) if (level_of[(size_t)i] == lv) L.cand[orient][cu[map_cell(i, orient)]++] = (uint32_t)i;
     }
+  }
+  // ---- compressed records --------------------------------------------------------------------------------------------------
+  // The scan is bound by the bytes it streams, and both filters are NECESSARY conditions of an acceptance: any
+  // relaxation keeps the pool exact.  So the device reads them from quantised records, every quantity rounded to the safe side:
+  //   centroid  C~ = cq_lo + k cq_step, k a 16-bit integer per axis; |C~ - C| <= eps_c (measured below on the device's own
+  //             binary32 decode) is added to every radius;
+  //   radius / L / pn  as bfloat16 rounded UP (relative 2^-7);
+  //   unit normal  n~ = (kx, ky, kz) / 32767, |n~ - N/|N|| <= eps_n (measured): |d . n~| <= |d . N|/|N| + |d| eps_n.
+  // The GRID's filter has two radii.  The bound of the header holds for any M >= 8: a pair with |a^| >= thr(Mg) (Mg = 96 >> M) has
+  // its P' within sigma'(Mg) = (6/Mg + 6/Ma + 1.2/(Mg-1)) L of the triangle — the TIGHT radius Rv + sigma'(Mg), stored per candidate;
+  // the rest of the grid's share, thr(M) <= |a^| < thr(Mg), lies within the LOOSE radius Rv + sigma'(M) <= tight (1 + 2 (8.5/(M-1) -
+  // sigma'(Mg)/L)) (every edge is <= 2 Rv), and satisfies the band test at Mg:  |d . N/|N|| < |d| (rho pn Mg/M + qn)  — evaluated on
+  // n~ with pn_eff = pn (1 + KT / (L R)) >= pn + (the 2^-40 term of qn) / rho  (rho >= R) and L <= 2 tight.  A candidate is tested
+  // exactly when  within(tight) or (within(loose) and band(Mg)).  The cells list a triangle by its box grown by sigma'(M), as before.
+  // Band test in normalised form: |d . N'| <= |d| (rho P + Q) <=> |d . N/|N|| <= |d| (rho pn + qn), pn = P/|N|, qn = Q/|N|, and
+  // with 1/|N| = pn / (kP L):  qn = pn (kQ l1 l2 / (kP L) + 2^-40 / (kP L)) <= pn (KQ L + KT / L)   (l1 l2 <= L^2) — so the
+  // record needs pn and L only.  The noise radius needs |a'| = |d . N'| >= (|d . n~| - |d| eps_n) |N| and |N| >= 0.98 kP L~/pn~.
+  {
+    double clo[3] = {1e300, 1e300, 1e300}, chi[3] = {-1e300, -1e300, -1e300};
+    for (int i = 0; i < count; i++) {
+      if (dead[(size_t)i]) continue;
+      for (int k = 0; k < 3; k++) { clo[k] = std::min(clo[k], (double)tp.ball[(size_t)i * 4 + k]); chi[k] = std::max(chi[k], (double)tp.ball[(size_t)i * 4 + k]); }
+    }
+    for (int k = 0; k < 3; k++) { tp.cq_lo[k] = (float)clo[k]; tp.cq_step[k] = (float)((chi[k] - clo[k]) / 65535.0); }
+    auto bf16_up = [](float x) -> uint32_t { // smallest bfloat16 >= x (x >= 0, finite)
+      uint32_t b;
+      std::memcpy(&b, &x, 4);
+      if (b & 0xffffu) b += 0x10000u;
+      return b >> 16;
+    };
+    auto bf16_val = [](uint32_t h) { const uint32_t b = h << 16; float f; std::memcpy(&f, &b, 4); return f; };
+    std::vector<uint32_t> cq((size_t)count * 3, 0);
+    double dev_c = 0, dev_n = 0;
+    for (int i = 0; i < count; i++) {
+      if (dead[(size_t)i]) continue;
+      double d2 = 0;
+      for (int k = 0; k < 3; k++) {
+        const double C = tp.ball[(size_t)i * 4 + k];
+        long q = tp.cq_step[k] > 0 ? std::lrint((C - (double)tp.cq_lo[k]) / (double)tp.cq_step[k]) : 0;
+        q = std::max(0l, std::min(65535l, q));
+        cq[(size_t)i * 3 + k] = (uint32_t)q;
+        const float prod = (float)q * tp.cq_step[k]; // the device's decode, operation by operation (no contraction)
+        const float dec = tp.cq_lo[k] + prod;
+        d2 += ((double)dec - C) * ((double)dec - C);
+      }
+      dev_c = std::max(dev_c, std::sqrt(d2));
+    }
+    tp.eps_c = (float)(dev_c * (1 + 1e-6) + 1e-37);
+    tp.kq = (float)((Ma * 7.0 + 4.0) / (M * 17.5) * 1.001);
+    tp.kt = (float)(std::ldexp(1.0, -40) / (M * 17.5 * u * SAFE) * 1.02);
+    const double Mg = std::max(M, (double)tune.Mg);
+    const double sig_g = (6.0 / Mg + 6.0 / Ma + 1.2 / (Mg - 1.0)) * (1 + 8 * u); // sigma'(Mg) / L
+    tp.k_loose = (float)((1.0 + 2.0 * std::max(0.0, 8.5 / (M - 1.0) - sig_g)) * (1 + 1e-6));
+    tp.m_scale = (float)(Mg / M * (1 + 1e-6));
+    tp.grid_q.assign((size_t)count * 2, 0);
+    tp.grid_n.assign((size_t)count * 2, 0);
+    tp.band_q.assign((size_t)count * 4, 0);
+    std::vector<double> nq_dev((size_t)count, 0.0);
+    for (int i = 0; i < count; i++) {
+      if (dead[(size_t)i]) continue;
+      const uint32_t* c3 = &cq[(size_t)i * 3];
+      const double Ld = tp.ball[(size_t)i * 4 + 3];
+      const float rg = (float)((rv_of[(size_t)live_index[(size_t)i]] + sig_g * Ld) * (1 + 8 * u) + tp.ball_abs + tp.eps_c);
+      tp.grid_q[(size_t)i * 2] = c3[0] | (c3[1] << 16);
+      tp.grid_q[(size_t)i * 2 + 1] = c3[2] | (bf16_up(rg * (1 + 2e-7f)) << 16);
+      tp.grid_n[(size_t)i * 2 + 1] = 0x7f7fu << 16; // (|N| = 0: no direction — the band test at Mg always passes)
+      if (!(pn[(size_t)i] < 1e30)) continue; // (|N| = 0: always list, exact records)
+      int32_t nq[3];
+      double d2 = 0;
+      for (int k = 0; k < 3; k++) {
+        nq[k] = (int32_t)std::lrint(nrm[(size_t)i * 3 + k] * 32767.0);
+        d2 += (nq[k] / 32767.0 - nrm[(size_t)i * 3 + k]) * (nq[k] / 32767.0 - nrm[(size_t)i * 3 + k]);
+      }
+      dev_n = std::max(dev_n, std::sqrt(d2));
+      const uint32_t pnh = bf16_up((float)(pn[(size_t)i] * (1 + 1e-6))), Lh = bf16_up(tp.ball[(size_t)i * 4 + 3]);
+      {
+        const double pe = pn[(size_t)i] * (1.0 + (double)tp.kt / (Ld * std::max(R, 1e-30))) * (1 + 1e-6);
+        tp.grid_n[(size_t)i * 2] = ((uint32_t)nq[0] & 0xffffu) | ((uint32_t)nq[1] << 16);
+        tp.grid_n[(size_t)i * 2 + 1] = ((uint32_t)nq[2] & 0xffffu) | ((pe < 3e38 ? bf16_up((float)pe) : 0x7f7fu) << 16);
+      }
+      tp.band_q[(size_t)i * 4] = ((uint32_t)nq[0] & 0xffffu) | ((uint32_t)nq[1] << 16);
+      tp.band_q[(size_t)i * 4 + 1] = ((uint32_t)nq[2] & 0xffffu) | (pnh << 16);
+      tp.band_q[(size_t)i * 4 + 2] = c3[0] | (c3[1] << 16);
+      tp.band_q[(size_t)i * 4 + 3] = c3[2] | (Lh << 16);
+      // the closed form really bounds this triangle's qn (and pn~, L~ are finite): otherwise no pool
+      const double pnv = bf16_val(pnh), Lv = bf16_val(Lh);
+      if (!(pnv < 1e30 && Lv < 1e30 && qn[(size_t)i] * (1 + 8 * u) <= pnv * ((double)tp.kq * Lv + (double)tp.kt / Lv))) return tp;
+    }
+    tp.eps_n = (float)(dev_n * (1 + 1e-6) + 3e-6); // + the binary32 rounding of d . (kx, ky, kz) / 32767 and of N'/|N'| against N/|N|
   }
   tp.ok = true;
   return tp;

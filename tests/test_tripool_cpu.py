@@ -21,6 +21,7 @@ from path_tracer_amd.scene import hittable_dtype
 f32 = np.float32
 U = 2.0 ** -24
 M, MA, SAFE = 12.0, 256.0, 1.5   # pt_tripool.hpp: TriPoolTuning defaults and SAFE
+MG = 96.0                        # the grid's tight slack (TriPoolTuning::Mg)
 
 
 def cross32(a, b):
@@ -46,15 +47,18 @@ def test_accepted_pairs_are_band_or_grid_candidates():
     P = M * 17.5 * U * L * SAFE
     Q = (MA * 7 + 4) * U * l1 * l2 * SAFE + 2.0 ** -40
     sig = 8.5 * L / (M - 1)
+    Pg = MG * 17.5 * U * L * SAFE                       # the grid's TIGHT radius: pairs with |a^| >= thr(MG)
+    sig_g = (6 / MG + 6 / MA + 1.2 / (MG - 1)) * L
     centre = v0d.mean(0)
     R = np.linalg.norm(v0d - centre, axis=1).max()
     lo = np.minimum(np.minimum(v0d, v0d + e1d), v0d + e2d)
     hi = np.maximum(np.maximum(v0d, v0d + e1d), v0d + e2d)
     cen = v0d + (e1d + e2d) / 3
+    rv = np.max(np.stack([np.linalg.norm(v0d - cen, axis=1), np.linalg.norm(v0d + e1d - cen, axis=1), np.linalg.norm(v0d + e2d - cen, axis=1)]), axis=0)
     Np = Nd.astype(f32).astype(np.float64)
     kr = 6 * SAFE * U * L * L * (17.5 + 7 * L / R)
     rng = np.random.default_rng(5)
-    stats = dict(accepted=0, band=0, grid=0)
+    stats = dict(accepted=0, band=0, grid=0, tight=0, loose=0)
 
     def check(o, d):
         o, d = o.astype(f32), d.astype(f32)
@@ -91,6 +95,17 @@ def test_accepted_pairs_are_band_or_grid_candidates():
             assert np.max(np.maximum(np.maximum(lo[i] - Pp, Pp - hi[i]), 0)) <= sig[i], ("grown box", i)
             assert abs(float(t[i]) - th) <= 2.2 / (MA - 1) * abs(th) + 1.2 * L[i] / ((M - 1) * dn) + 1e-12, ("t", i)
             assert dist_line <= L[i] * (1 + 8.5 / (M - 1)), ("grid ball filter", i)
+            # the two-radius filter of the compressed grid records: not grazing at MG -> the walked point P' within Rv + sigma'(MG)
+            # of the centroid (tight); otherwise the pair passes the band test at MG by definition, and P' is within Rv + sigma'(M)
+            # <= (Rv + sigma'(MG)) (1 + 2 (8.5 / (M - 1) - sigma'(MG) / L)) (loose: every edge is <= 2 Rv)
+            assert L[i] <= 2 * rv[i] * (1 + 1e-12)
+            if ap[i] >= dn * (rho * Pg[i] + Q[i]):
+                stats["tight"] += 1
+                assert np.max(np.maximum(np.maximum(lo[i] - Pp, Pp - hi[i]), 0)) <= sig_g[i], ("tight box", i)
+                assert np.linalg.norm(Pp - cen[i]) <= rv[i] + sig_g[i], ("tight ball", i)
+            else:
+                stats["loose"] += 1
+                assert np.linalg.norm(Pp - cen[i]) <= (rv[i] + sig_g[i]) * (1 + 2 * (8.5 / (M - 1) - sig_g[i] / L[i])), ("loose ball", i)
 
     for _ in range(60):
         o = rng.uniform([-3, 0, -3], [3, 3, 3])
@@ -106,7 +121,7 @@ def test_accepted_pairs_are_band_or_grid_candidates():
         d = (np.cos(ang) * t1 + np.sin(ang) * t2 + nh * 10 ** rng.uniform(-8, -2) * rng.choice([-1, 1])) * rng.uniform(0.3, 2)
         target = v0d[i] + rng.uniform(-0.2, 1.2) * e1d[i] + rng.uniform(-0.2, 1.2) * e2d[i] + rng.normal(size=3) * 10 ** rng.uniform(-7, -3)
         check(target - d / np.linalg.norm(d) * rng.uniform(0.01, 12), d)
-    assert stats["accepted"] > 3000 and stats["band"] > 20 and stats["grid"] > 2000, stats
+    assert stats["accepted"] > 3000 and stats["band"] > 20 and stats["grid"] > 2000 and stats["tight"] > 1500 and stats["loose"] > 50, stats
 
 
 def test_pool_thresholds_and_tables(lib, monkeypatch):
@@ -133,3 +148,91 @@ def test_pool_thresholds_and_tables(lib, monkeypatch):
         assert list(st)[:6] == [0] * 6
     abi.check(lib.pt_debug_tri_pool(C.byref(ps.desc), st), "pt_debug_tri_pool")
     assert st[6] * 16 < 5.0e6               # the plain blob: 4.8 MB
+
+
+def test_compressed_filter_records_round_to_the_safe_side(lib, monkeypatch):
+    """The device streams QUANTISED filter records (pt_tripool.hpp "compressed records").  Parse them back out of the flattened
+    blob of a 3000-triangle field and check every one against the triangle it stands for: centroid within eps_c, unit normal within
+    eps_n, tight radius >= Rv + sigma'(MG) L, pn_eff >= pn (1 + KT / (L R)), band pn >= pn, L >= L, and the closed form
+    pn (KQ L + KT / L) >= qn; the Morton-ordered copy is a permutation of the run's records that remembers each triangle's index."""
+    monkeypatch.setenv("PT_TRICULL", "1")
+    ps, _ = scenes.triangle_mesh_scene(n_triangles=3000, seed=77)
+    n_f4, n_runs, flags = C.c_int32(), C.c_int32(), C.c_int32()
+    abi.check(lib.pt_debug_flatten(C.byref(ps.desc), None, 0, C.byref(n_f4), C.byref(n_runs), None, 0, C.byref(flags)), "pt_debug_flatten")
+    blob = np.zeros((n_f4.value, 4), f32)
+    FP = C.POINTER(C.c_float)
+    abi.check(lib.pt_debug_flatten(C.byref(ps.desc), blob.ctypes.data_as(FP), len(blob), C.byref(n_f4), C.byref(n_runs), None, 0, C.byref(flags)), "pt_debug_flatten")
+    assert flags.value & 4
+    bi = blob.view(np.int32)
+    bu = blob.view(np.uint32).reshape(-1)
+    runs = bi[:n_runs.value]
+    tri = [r for r in runs if r[0] == 2][0]
+    first, count = int(tri[1]), int(tri[2])
+    assert bi[first - 1][0] == 1
+    hdr = int(bi[first - 1][1])
+    H = blob[hdr:hdr + 10]
+    Hi = bi[hdr:hdr + 10]
+    cell_first, cell_cand, tri_sorted, cell_q = [int(x) for x in Hi[4]]
+    kq, p_per_L, kt = float(H[5][1]), float(H[5][2]), float(H[5][3])
+    cq_lo, eps_c = H[7][:3].astype(np.float64), float(H[7][3])
+    cq_step, eps_n = H[8][:3].astype(np.float64), float(H[8][3])
+    k_loose, m_scale, cell_n = float(H[9][0]), float(H[9][1]), int(Hi[9][2])
+    assert abs(m_scale - MG / M) < 1e-3 and 2.0 < k_loose < 2.5
+    nx, ny, nz = [int(x) for x in Hi[1][:3]]
+    ncell = nx * ny * nz
+    cf = bu[4 * cell_first: 4 * cell_first + ncell + 1].astype(np.int64)
+    total = int(cf[-1])
+    pos = bu[4 * cell_cand: 4 * cell_cand + total].astype(np.int64)
+    gq = bu[4 * cell_q: 4 * cell_q + 2 * total].reshape(-1, 2)
+    gn = bu[4 * cell_n: 4 * cell_n + 2 * total].reshape(-1, 2)
+    srt = blob[tri_sorted: tri_sorted + 3 * count].reshape(count, 3, 4)
+    orig = srt[:, 2, 3].view(np.int32).astype(np.int64)
+    assert sorted(orig.tolist()) == list(range(count))                      # a permutation ...
+    recs = blob[first: first + 3 * count].reshape(count, 3, 4)
+    assert np.array_equal(srt[:, :, :3], recs[orig][:, :, :3])               # ... of the run's own records (v0, edge1, edge2)
+    for c in range(ncell):
+        assert np.all(np.diff(pos[cf[c]:cf[c + 1]]) > 0)                      # a cell's candidates ascend in the Morton copy
+    # the triangles, in float64
+    v0 = recs[:, 0, :3].astype(np.float64); e1 = recs[:, 1, :3].astype(np.float64); e2 = recs[:, 2, :3].astype(np.float64)
+    N = np.cross(e1, e2); nN = np.linalg.norm(N, axis=1)
+    l1, l2 = np.linalg.norm(e1, axis=1), np.linalg.norm(e2, axis=1)
+    L = np.maximum(l1, l2)
+    cen = (v0 + (e1 + e2) / 3).astype(f32).astype(np.float64)                # the rounded centroid the host measures from
+    rv = np.max(np.stack([np.linalg.norm(v0 - cen, axis=1), np.linalg.norm(v0 + e1 - cen, axis=1), np.linalg.norm(v0 + e2 - cen, axis=1)]), axis=0)
+    centre = H[2][:3].astype(np.float64); R = float(H[2][3])
+    pn = M * 17.5 * U * SAFE * L / nN
+    qn = ((MA * 7 + 4) * U * l1 * l2 * SAFE + 2.0 ** -40) / nN
+    sig_g = (6 / MG + 6 / MA + 1.2 / (MG - 1)) * L
+    bf = lambda hi16: (hi16.astype(np.uint32) << 16).view(f32).astype(np.float64)
+    s16 = lambda v: ((v.astype(np.int64) & 0xffff) ^ 0x8000) - 0x8000
+    t = orig[pos]                                                            # the triangle of every grid entry
+    lo32, st32 = H[7][:3].astype(f32), H[8][:3].astype(f32)
+    dec = lambda kx, ky, kz: np.stack([(lo32[a] + (k.astype(f32) * st32[a]).astype(f32)).astype(f32) for a, k in enumerate((kx, ky, kz))], -1).astype(np.float64)  # the device's binary32 decode
+    C_dec = dec(gq[:, 0] & 0xffff, gq[:, 0] >> 16, gq[:, 1] & 0xffff)
+    dev = np.linalg.norm(C_dec - cen[t], axis=1)
+    assert np.all(dev <= eps_c * (1 + 1e-6) + 1e-12), (dev.max(), eps_c, int(np.argmax(dev)), cq_step)
+    assert np.all(bf(gq[:, 1] >> 16) >= rv[t] + sig_g[t] + eps_c)
+    n_dec = np.stack([s16(gn[:, 0]), s16(gn[:, 0] >> 16), s16(gn[:, 1])], -1) / 32767.0
+    assert np.all(np.linalg.norm(n_dec - N[t] / nN[t][:, None], axis=1) <= eps_n)
+    assert np.all(bf(gn[:, 1] >> 16) >= pn[t] * (1 + kt / (L[t] * R)))
+    # band records of the three levels (both orientations)
+    n_band = 0
+    for lv in range(3):
+        T = bi[hdr + 10 + 3 * lv: hdr + 13 + 3 * lv]
+        Rl = int(T[0][0])
+        for o in (1, 2):
+            tf, tc, tr = [int(x) for x in T[o][:3]]
+            nc = 3 * Rl * Rl
+            fr = bu[4 * tf: 4 * tf + nc + 1].astype(np.int64)
+            k = int(fr[-1])
+            idx = bu[4 * tc: 4 * tc + k].astype(np.int64)
+            q = bu[4 * tr: 4 * tr + 4 * k].reshape(-1, 4)
+            nd = np.stack([s16(q[:, 0]), s16(q[:, 0] >> 16), s16(q[:, 1])], -1) / 32767.0
+            assert np.all(np.linalg.norm(nd - N[idx] / nN[idx][:, None], axis=1) <= eps_n)
+            pq, Lq = bf(q[:, 1] >> 16), bf(q[:, 3] >> 16)
+            assert np.all(pq >= pn[idx]) and np.all(pq <= pn[idx] * 1.01) and np.all(Lq >= L[idx]) and np.all(Lq <= L[idx] * 1.01)
+            assert np.all(pq * (kq * Lq + kt / Lq) >= qn[idx])
+            Cd = dec(q[:, 2] & 0xffff, q[:, 2] >> 16, q[:, 3] & 0xffff)
+            assert np.all(np.linalg.norm(Cd - cen[idx], axis=1) <= eps_c * (1 + 1e-6) + 1e-12)
+            n_band += k
+    assert total > 3000 and n_band > 3000

@@ -21,9 +21,10 @@ print("pool: triangles", st[0], "always", st[1], "levels", list(st)[2:5], "cells
 R.render(W, H, 1, ds, cam, flags=abi.PT_FLAG_NO_LPT); torch.cuda.synchronize()
 lib.pt_debug_tri(None, 1)
 fb, ms = R.render(W, H, spp, ds, cam, flags=abi.PT_FLAG_NO_LPT, timed=True)
-o = (C.c_ulonglong * 8)()
+o = (C.c_ulonglong * 12)()
 lib.pt_debug_tri(o, 0)
 scans, rays, grid, alw, lanes, b0, b1, b2 = [o[i] for i in range(8)]
 rays = max(rays, 1)
 print(f"{W}x{H}x{spp}: {ms:.1f} ms = {W*H*spp/ms/1e3:.2f} Msamples/s; wave scans {scans:.3e}, live rays per scan {rays/max(scans,1):.1f}")
+print(f"per ray: grid survivors (exact tests) {o[8]/rays:.1f}; band survivors {o[9]/rays:.1f}")
 print(f"per ray: grid rounds {grid/rays:.1f}; band trips level 0 / 1 / 2: {b0/rays:.1f} / {b1/rays:.1f} / {b2/rays:.1f} (lanes busy per trip {lanes/max(b0+b1+b2,1):.1f}); grid cells visited {alw/rays:.1f}")
