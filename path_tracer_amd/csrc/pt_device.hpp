@@ -1073,6 +1073,7 @@ __device__ __forceinline__ unsigned int gdword(glb_f4p gblob, int base_f4, int i
 #define PT_TRI_ABLATE 0 /* timing experiments only: 1 no grid, 2 no band levels, 4 no always list (wrong images) */
 #endif
 __device__ __forceinline__ unsigned long long* tri_slots() { __shared__ unsigned long long s[256]; return s; }
+__device__ __forceinline__ int* tri_queue() { __shared__ int s[4 * 384]; return s; } // per wave: survivors of the filters waiting for the exact test
 __device__ __forceinline__ int* tri_rows() { __shared__ int s[4 * 264]; return s; } // per wave: the row table of the strip being scanned
 __device__ __forceinline__ unsigned long long tri_key(float t, int off) {
   return ((unsigned long long)(unsigned int)as_i(t) << 32) | (unsigned long long)(unsigned int)(0xffffff - off);
@@ -1112,12 +1113,33 @@ __device__ __forceinline__ bool tri_pool_scan(glb_f4p gblob, cst_f4p cblob, int 
   const unsigned long long live = __builtin_amdgcn_ballot_w64(c.live);
   PT_TRI_COUNT(0, 1);
   PT_TRI_COUNT(1, __builtin_popcountll(live));
-  // the exact test of triangle i for the (uniform) ray of lane src; a hit goes to that ray's slot
-  auto exact = [&](int i, const Ray& ur, int src) {
-    const int o = goff + 3 * i;
-    const f4 R0 = gblob[o], R1 = gblob[o + 1], R2 = gblob[o + 2];
-    float t;
-    if (tri_param(R0, R1, R2, ur, t) && !(t < PT_TMIN)) atomicMin(&slot[src], tri_key(t, o));
+  // Survivors of the filters do not run the exact test on the spot (a few lanes busy per trip, each with its own gather): they
+  // are QUEUED per wave in LDS — entry >= 0: the triangle's position in the Morton-ordered copy; entry < 0: ~(dword index in
+  // the blob of that position: a band candidate, whose index is not loaded before it is needed) — and tested 64 at a time.
+  int* const tq = tri_queue() + (threadIdx.x >> 6) * 384;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  int qn = 0; // entries queued (uniform)
+  auto push = [&](bool p, int e) {
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(p);
+    if (p) tq[qn + __builtin_popcountll(m & below)] = e;
+    qn += __builtin_popcountll(m);
+  };
+  // the reference's test for the top min(64, qn) entries and the (uniform) ray of lane src; a hit goes to that ray's slot
+  auto drain = [&](int keep, const Ray& ur, int src) {
+    __builtin_amdgcn_wave_barrier();
+    while (qn > keep) {
+      const int n = min(qn, 64);
+      if (lane < n) {
+        const int e = tq[qn - n + lane];
+        const int pos = e >= 0 ? e : (int)gdword(gblob, 0, ~e);
+        const int o = tri_sorted + 3 * pos;
+        const f4 R0 = gblob[o], R1 = gblob[o + 1], R2 = gblob[o + 2];
+        float t;
+        if (tri_param(R0, R1, R2, ur, t) && !(t < PT_TMIN)) atomicMin(&slot[src], tri_key(t, goff + 3 * as_i(R2.w)));
+      }
+      qn -= n;
+    }
+    __builtin_amdgcn_wave_barrier();
   };
   for (unsigned long long todo = live; todo != 0; todo &= todo - 1) {
     const int src = __builtin_ctzll(todo);
@@ -1198,17 +1220,11 @@ __device__ __forceinline__ bool tri_pool_scan(glb_f4p gblob, cst_f4p cblob, int 
             passmask |= pass ? (1u << j) : 0u;
           }
           PT_TRI_COUNT(8, PT_TRI_WAVE_BITS(passmask));
-          while (__builtin_amdgcn_ballot_w64(passmask != 0) != 0) { // survivors: the reference's test on the triangle's own records
-            if (passmask != 0) {
-              const int j = __builtin_ctz(passmask);
-              passmask &= passmask - 1;
-              const int o = tri_sorted + 3 * (j == 0 ? gi[0] : j == 1 ? gi[1] : j == 2 ? gi[2] : gi[3]); // the Morton-ordered copy
-              const f4 R0 = gblob[o], R1 = gblob[o + 1], R2 = gblob[o + 2];
-              float t;
-              if (tri_param(R0, R1, R2, ur, t) && !(t < PT_TMIN)) atomicMin(&slot[src], tri_key(t, goff + 3 * as_i(R2.w)));
-            }
-          }
+#pragma unroll
+          for (int j = 0; j < 4; j++) push((passmask >> j) & 1u, gi[j]);
+          drain(63, ur, src); // whole batches of 64
         }
+        drain(0, ur, src); // the rest before the walk looks at the limit again
         const float tn = __builtin_fminf(tmx, __builtin_fminf(tmy, tmz));
         const bool sx = tmx == tn, sy = !sx & (tmy == tn), sz = !sx & !sy;
         ix += sx ? stx : 0; iy += sy ? sty : 0; iz += sz ? stz : 0;
@@ -1284,7 +1300,6 @@ __device__ __forceinline__ bool tri_pool_scan(glb_f4p gblob, cst_f4p cblob, int 
         const int T = __builtin_amdgcn_readlane(incl, 63);
         if (T == 0) continue;
         const unsigned long long f0 = __builtin_amdgcn_ballot_w64(rlen[0] > 0), f1 = __builtin_amdgcn_ballot_w64(rlen[1] > 0);
-        const unsigned long long below = (1ull << lane) - 1ull;
         const int dense = __builtin_popcountll(f0 & below) + __builtin_popcountll(f1 & below); // non-empty rows before this lane's
         const int nr = __builtin_popcountll(f0) + __builtin_popcountll(f1);
         int* const rpos = tri_rows() + (threadIdx.x >> 6) * 264; // [0, 132): first position of every non-empty row (+ sentinel T)
@@ -1293,24 +1308,24 @@ __device__ __forceinline__ bool tri_pool_scan(glb_f4p gblob, cst_f4p cblob, int 
         if (rlen[0] > 0) { rpos[dense] = pos; rbas[dense] = rk0[0] - pos; }
         if (rlen[1] > 0) { const int d1 = dense + (rlen[0] > 0 ? 1 : 0); rpos[d1] = pos + rlen[0]; rbas[d1] = rk0[1] - (pos + rlen[0]); }
         if (lane == 0) rpos[nr] = T;
-        const int per = (((T + 63) >> 6) + 3) & ~3; // positions per lane: a multiple of four
-        int p = lane * per;
-        const int pend = min(p + per, T);
-        int r = 0; // the row of position p: the last one that starts at or before it
-        { int lo = 0, hi = nr; // rpos[lo] <= p < rpos[hi] whenever p < T
-#pragma unroll
-          for (int it = 0; it < 8; it++) { const int mid = (lo + hi) >> 1; const bool up = mid > lo && rpos[mid] <= p; lo = up ? mid : lo; hi = up ? hi : (mid > lo ? mid : hi); }
-          r = lo; }
-        int rnext = rpos[r + 1], rb = rbas[r];
-        for (; __builtin_amdgcn_ballot_w64(p < pend) != 0; p += 4) {
+        // 256 positions per trip; a GROUP OF FOUR LANES reads sixteen consecutive candidates (load j: positions 4 j ... 4 j + 3 of the
+        // sixteen, one 64-byte line per group) — a load instruction touches 16 lines, not 64 (lane-private chunks did: DESIGN.md §3)
+        for (int base = 0; base < T; base += 256) {
           PT_TRI_COUNT(5 + (lv < 2 ? lv : 2), 1);
-          PT_TRI_COUNT(4, __builtin_popcountll(__builtin_amdgcn_ballot_w64(p < pend)));
+          const int p = base + ((lane >> 2) << 4) + (lane & 3);
+          PT_TRI_COUNT(4, __builtin_popcountll(__builtin_amdgcn_ballot_w64(p < T)));
           unsigned int passmask = 0;
           int kk[4] = {0, 0, 0, 0};
-          if (p < pend) { // four candidates: their 16-byte records, four loads together
+          if (p < T) {
+            int r; // the row of position p: the last one that starts at or before it
+            { int lo = 0, hi = nr; // rpos[lo] <= p < rpos[hi]
+#pragma unroll
+              for (int it = 0; it < 8; it++) { const int mid = (lo + hi) >> 1; const bool up = mid > lo && rpos[mid] <= p; lo = up ? mid : lo; hi = up ? hi : (mid > lo ? mid : hi); }
+              r = lo; }
+            int rnext = rpos[r + 1], rb = rbas[r];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-              const int pj = min(p + j, pend - 1); // (a tail position repeats the last candidate: masked out below)
+              const int pj = min(p + 4 * j, T - 1); // (a tail position repeats the last candidate: masked out below)
               while (pj >= rnext) { ++r; rnext = rpos[r + 1]; rb = rbas[r]; } // non-empty rows only: a few steps at most
               kk[j] = rb + pj;
             }
@@ -1319,19 +1334,16 @@ __device__ __forceinline__ bool tri_pool_scan(glb_f4p gblob, cst_f4p cblob, int 
             for (int j = 0; j < 4; j++) Q[j] = gblob[tr + kk[j]];
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < 4; j++) passmask |= (p + j < pend && band_pass(Q[j])) ? (1u << j) : 0u;
+            for (int j = 0; j < 4; j++) passmask |= (p + 4 * j < T && band_pass(Q[j])) ? (1u << j) : 0u;
           }
           PT_TRI_COUNT(9, PT_TRI_WAVE_BITS(passmask));
-          while (__builtin_amdgcn_ballot_w64(passmask != 0) != 0) { // survivors (rare): the exact test, first one of every lane at a time
-            if (passmask != 0) {
-              const int j = __builtin_ctz(passmask);
-              passmask &= passmask - 1;
-              exact((int)gdword(gblob, tc, j == 0 ? kk[0] : j == 1 ? kk[1] : j == 2 ? kk[2] : kk[3]), ur, src);
-            }
-          }
+#pragma unroll
+          for (int j = 0; j < 4; j++) push((passmask >> j) & 1u, ~(4 * tc + kk[j]));
+          drain(63, ur, src);
         }
       }
     }
+    drain(0, ur, src);
   }
   // ---- (3) the always list: 64 entries in the lanes (one coalesced load each), the live rays in the inner loop --------------------
   const int n_always = (PT_TRI_ABLATE & 4) ? 0 : as_i(H3.z);
@@ -1340,7 +1352,7 @@ __device__ __forceinline__ bool tri_pool_scan(glb_f4p gblob, cst_f4p cblob, int 
     const bool on = e < n_always;
     f4 G = f4{0, 0, 0, 0}, Bc = G;
     f4 R0 = G, R1 = G, R2 = G;
-    if (on) { G = gblob[acheap + 5 * e]; Bc = gblob[acheap + 5 * e + 1]; R0 = gblob[acheap + 5 * e + 2]; R1 = gblob[acheap + 5 * e + 3]; R2 = gblob[acheap + 5 * e + 4]; }
+    if (on) { const int as = as_i(H9.w); G = gblob[acheap + e]; Bc = gblob[acheap + as + e]; R0 = gblob[acheap + 2 * as + e]; R1 = gblob[acheap + 3 * as + e]; R2 = gblob[acheap + 4 * as + e]; }
     for (unsigned long long todo = live; todo != 0; todo &= todo - 1) {
       const int src = __builtin_ctzll(todo);
       Ray ur;

@@ -282,7 +282,8 @@ inline void put_box(std::vector<F4>& b, const float* f, int32_t mat, int32_t hid
 //       8-byte filter records: blob offsets)
 //   H5 (always-list entries: blob offset; KQ; P / L; KT)          H6 (ball_abs, kr_a, kr_b, ea)
 //   H7 (centroid quantisation origin xyz, eps_c)                   H8 (centroid quantisation step xyz, eps_n)
-//   H9 (loose / tight grid radius, Mg / M, the grid candidates' inline 8-byte (normal, pn) records: blob offset)
+//   H9 (loose / tight grid radius, Mg / M, the grid candidates' inline 8-byte (normal, pn) records: blob offset, stride of the
+//       always list's five arrays)
 //   per level k, three F4: (R, triangles, pn_max, qn_max) (first, cand, inline band records of orientation 0) (... of orientation 1)
 inline int32_t put_tri_pool(std::vector<F4>& b, const TriPool& tp, const PtHittable* tri) {
   // (every array is followed by spare entries: the scans load whole chunks of four without clamping)
@@ -345,11 +346,31 @@ inline int32_t put_tri_pool(std::vector<F4>& b, const TriPool& tp, const PtHitta
   put_dwords(b, cell_pos.data(), cell_pos.size());
   for (int k = 0; k < 68; k++) b.push_back({0, 0, 0, 0});
   const int32_t cell_q = put_q(cell_sorted, tp.grid_q, 2, 132), cell_n = put_q(cell_sorted, tp.grid_n, 2, 132);
-  const int32_t always = put_u32(tp.always), acheap = put_inline(tp.always, [&](uint32_t i) { band_rec(i); tri_rec(i); });
+  // always-list entries, structure of arrays: five arrays of n_always (+ spare) F4 — (g, c) (centroid, L) (v0, material) (edge1, -)
+  // (edge2, triangle index) — so that the 64 lanes of a tile read consecutive records of each
+  const int32_t always = put_u32(tp.always);
+  const int32_t astride = (int32_t)tp.always.size() + 4;
+  const int32_t acheap = (int32_t)b.size();
+  for (int part = 0; part < 5; part++) {
+    for (uint32_t i : tp.always) {
+      const float* f = tri[i].f;
+      switch (part) {
+        case 0: b.push_back(F4{tp.cheap[(size_t)i * 4], tp.cheap[(size_t)i * 4 + 1], tp.cheap[(size_t)i * 4 + 2], tp.cheap[(size_t)i * 4 + 3]}); break;
+        case 1: b.push_back(F4{tp.ball[(size_t)i * 4], tp.ball[(size_t)i * 4 + 1], tp.ball[(size_t)i * 4 + 2], tp.ball[(size_t)i * 4 + 3]}); break;
+        case 2: b.push_back({f[0], f[1], f[2], as_f(tri[i].material)}); break;
+        case 3: b.push_back({f[3] - f[0], f[4] - f[1], f[5] - f[2], 0.0f}); break;
+        default: b.push_back({f[6] - f[0], f[7] - f[1], f[8] - f[2], as_f((int32_t)i)}); break;
+      }
+    }
+    for (int k = 0; k < 4; k++) b.push_back({0, 0, 0, 0});
+  }
   int32_t lfirst[3][2], lcand[3][2], lrec[3][2];
   for (int k = 0; k < 3; k++)
     for (int o = 0; o < 2; o++) {
-      lfirst[k][o] = put_u32(tp.levels[(size_t)k].first[o]); lcand[k][o] = put_u32(tp.levels[(size_t)k].cand[o]);
+      lfirst[k][o] = put_u32(tp.levels[(size_t)k].first[o]);
+      std::vector<uint32_t> lpos(tp.levels[(size_t)k].cand[o]); // (positions in the Morton-ordered copy, like the grid's)
+      for (uint32_t& v : lpos) v = pos_of[v];
+      lcand[k][o] = put_u32(lpos);
       lrec[k][o] = put_q(tp.levels[(size_t)k].cand[o], tp.band_q, 4, 20);
     }
   const int32_t hdr = (int32_t)b.size();
@@ -362,7 +383,7 @@ inline int32_t put_tri_pool(std::vector<F4>& b, const TriPool& tp, const PtHitta
   b.push_back({tp.ball_abs, tp.kr_a, tp.kr_b, tp.ea});
   b.push_back({tp.cq_lo[0], tp.cq_lo[1], tp.cq_lo[2], tp.eps_c});
   b.push_back({tp.cq_step[0], tp.cq_step[1], tp.cq_step[2], tp.eps_n});
-  b.push_back({tp.k_loose, tp.m_scale, as_f(cell_n), 0});
+  b.push_back({tp.k_loose, tp.m_scale, as_f(cell_n), as_f(astride)});
   for (int k = 0; k < 3; k++) {
     const TriPoolLevel& L = tp.levels[(size_t)k];
     b.push_back({as_f(L.R), as_f((int32_t)L.cand[0].size()), L.pn_max, L.qn_max});

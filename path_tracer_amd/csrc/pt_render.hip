@@ -58,7 +58,7 @@ namespace {
 #define PT_MIN_WAVES_COOP 5 /* cooperative kernels: 93 VGPRs, no scratch (7 waves: 72 VGPRs + 76 B/lane of spills in the loop) */
 #endif
 #ifndef PT_MIN_WAVES_TRIPOOL
-#define PT_MIN_WAVES_TRIPOOL 4 /* triangle-pool kernels (per-lane walks + parked candidates): 128 VGPRs */
+#define PT_MIN_WAVES_TRIPOOL 3 /* triangle-pool kernels: the bound only keeps the allocator from spilling — they take ~122 VGPRs and run 4 waves per SIMD; 5, 6, 8 waves (96, 80, 64 VGPRs, 36-188 bytes of scratch) measured slower */
 #endif
 #ifndef PT_MIN_WAVES_COOP_IMG
 #define PT_MIN_WAVES_COOP_IMG 5 /* 96 VGPRs + 60 B/lane of spills; spill-free needs 116 VGPRs = 4 waves: 496-hittable scene -9 % (A/B) */
@@ -804,6 +804,7 @@ static int flatten_with_env(const PtSceneDesc* desc, ptf::Flat& flat, std::strin
   if (std::getenv("PT_TRICULL")) tri.min_run = 256;
   if (const char* e = std::getenv("PT_TRI_M")) tri.M = (float)std::atof(e);
   if (const char* e = std::getenv("PT_TRI_MG")) tri.Mg = (float)std::atof(e);
+  if (const char* e = std::getenv("PT_TRI_RES")) std::sscanf(e, "%d,%d,%d", &tri.res[0], &tri.res[1], &tri.res[2]);
   if (const char* e = std::getenv("PT_TRI_CELL")) tri.cell = (float)std::atof(e);
   if (const char* e = std::getenv("PT_TRI_MIN")) tri.min_run = std::max(1, std::atoi(e));
   int rc = ptf::flatten(desc, flat, err, allow_grid, box_cull, tune, allow_tri, tri);

@@ -67,6 +67,7 @@ struct TriPoolTuning {
   float Mg = 96.0f;     // PT_TRI_MG: the grid's TIGHT slack (pairs with |a^| >= thr(Mg) are found within sigma'(Mg) of the triangle; the others of the grid's share, thr(M) <= |a^| < thr(Mg), pass a band test at Mg: see "compressed records")
   float Ma = 256.0f;    // relative slack of t: the walk runs to max (1 + 2.2 / (Ma - 1))
   float cell = 1.0f;    // PT_TRI_CELL (swept 0.7 ... 3.0): grid cell edge in units of the median grown box extent
+  int res[3] = {128, 32, 16}; // PT_TRI_RES=a,b,c: cube-map resolution of the three band levels (powers of two <= 128: the device deals a level's rows to the 64 lanes)
   int min_run = 4096;   // PT_TRI_MIN: shorter triangle runs are scanned as before (PT_TRICULL=1: 256)
 };
 
@@ -293,7 +294,8 @@ inline TriPool build_tri_pool(const PtHittable* h, int count, TriPoolTuning tune
   // level k takes the triangles whose band half-width at the reference distance, tau_i = rho_ref pn_i + qn_i, is <= tau_k
   const double rho_ref = 3.0 * R;
   const double tau_cap[3] = {0.004, 0.016, 0.064};
-  const int res[3] = {128, 32, 16}; // powers of two: the device deals a level's rows (or fractions of rows) to the 64 lanes of a wave
+  int res[3];
+  for (int k = 0; k < 3; k++) { res[k] = 16; while (res[k] < tune.res[k] && res[k] < 128) res[k] *= 2; } // powers of two in [16, 128]
   tp.levels.resize(3);
   std::vector<int> level_of((size_t)count, -1);
   for (int i = 0; i < count; i++) {

@@ -225,7 +225,7 @@ def test_compressed_filter_records_round_to_the_safe_side(lib, monkeypatch):
             nc = 3 * Rl * Rl
             fr = bu[4 * tf: 4 * tf + nc + 1].astype(np.int64)
             k = int(fr[-1])
-            idx = bu[4 * tc: 4 * tc + k].astype(np.int64)
+            idx = orig[bu[4 * tc: 4 * tc + k].astype(np.int64)]     # (listed by position in the Morton copy, like the grid's)
             q = bu[4 * tr: 4 * tr + 4 * k].reshape(-1, 4)
             nd = np.stack([s16(q[:, 0]), s16(q[:, 0] >> 16), s16(q[:, 1])], -1) / 32767.0
             assert np.all(np.linalg.norm(nd - N[idx] / nN[idx][:, None], axis=1) <= eps_n)
