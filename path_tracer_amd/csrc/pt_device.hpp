@@ -1038,7 +1038,7 @@ __device__ __forceinline__ void slab_pool(P blob, cst_f4p cblob, int pool_off, i
 // half below) with the scan's acceptance spelled out for any order: min <= t <= closest, and an equal t replaces the
 // holder unless the holder is a LATER record (triangle.hpp:91 accepts t == max: the last in list order wins; records keep
 // list order in the blob).  Re-testing a triangle is therefore a no-op, and a triangle found by two sources is harmless.
-// All table reads are per-lane global loads (each lane walks its own ray): this path belongs to scenes far beyond LDS.
+// The tables live in global memory (tens of MB: this path belongs to scenes far beyond LDS).
 #ifdef PT_STAMPS_TRI
 #define PT_TRI_COUNT(i, v) do { const unsigned long long v_ = (unsigned long long)(v); if ((threadIdx.x & 63) == 0) atomicAdd(&g_tri[i], v_); } while (0)
 #else
@@ -1060,10 +1060,12 @@ __device__ __forceinline__ unsigned int gdword(glb_f4p gblob, int base_f4, int i
 // instead: the wave takes its live rays one after the other (the ray's context read from its lane with v_readlane: scalar
 // operands from then on), and for that ray
 //   (1) walks the grid once (a uniform DDA), the candidates of each cell dealt to the lanes k0 + lane, k0 + 64 + lane, ...
-//       (coalesced loads of the inline (centroid, radius) records);
-//   (2) deals the rows of every cube-map level that the ray's strip can reach to the lanes (R = 128: a row per lane, two
-//       rounds; R = 32 / 16: two / four lanes per row), each lane streaming its row's contiguous candidates four per trip;
-//   every survivor of the filters is tested exactly on the spot with the uniform ray, and a hit goes into the ray's slot of a
+//       (coalesced loads of the inline COMPRESSED filter records: 8 + 8 bytes per candidate);
+//   (2) looks up the rows of every cube-map level that the ray's strip can reach, one or two per lane, concatenates their
+//       candidate ranges (a wave scan + an LDS row table) and splits that sequence evenly: 256 candidates per trip, groups of
+//       four lanes on consecutive 16-byte compressed records;
+//   the survivors of the filters are queued in LDS and run the reference's test 64 at a time with the uniform ray, on their
+//   triangle's records in a Morton-ordered copy of the run; a hit goes into the ray's slot of a
 //   per-wave LDS table with ONE 64-bit atomic minimum: key = (bits of t) << 32 | (0xffffff - record offset), so that the
 //   smallest t wins and, among equal t, the LAST record in list order — the scan's own acceptance (triangle.hpp:91 accepts
 //   t == max); the slot starts as the ray's hit so far (earlier runs have smaller offsets: an equal t loses to any triangle,

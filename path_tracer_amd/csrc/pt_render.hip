@@ -58,7 +58,7 @@ namespace {
 #define PT_MIN_WAVES_COOP 5 /* cooperative kernels: 93 VGPRs, no scratch (7 waves: 72 VGPRs + 76 B/lane of spills in the loop) */
 #endif
 #ifndef PT_MIN_WAVES_TRIPOOL
-#define PT_MIN_WAVES_TRIPOOL 3 /* triangle-pool kernels: the bound only keeps the allocator from spilling — they take ~122 VGPRs and run 4 waves per SIMD; 5, 6, 8 waves (96, 80, 64 VGPRs, 36-188 bytes of scratch) measured slower */
+#define PT_MIN_WAVES_TRIPOOL 3 /* triangle-pool kernels: the bound only keeps the allocator from spilling — without image textures they take ~122 VGPRs and run 4 waves per SIMD (the image-texture variants are held to 4 explicitly); 5, 6, 8 waves (96, 80, 64 VGPRs, 36-188 bytes of scratch) measured slower */
 #endif
 #ifndef PT_MIN_WAVES_COOP_IMG
 #define PT_MIN_WAVES_COOP_IMG 5 /* 96 VGPRs + 60 B/lane of spills; spill-free needs 116 VGPRs = 4 waves: 496-hittable scene -9 % (A/B) */
@@ -392,7 +392,7 @@ __device__ __forceinline__ void lane_prepare(Lane& L, const KArgs& a) {
 // "lambertian + lightsource over solid textures" that carry no metal / glass / isotropic / checker / image code.
 template <int UV, bool LDS, bool MLDS, bool COOP, bool CL = false, bool FAST = false, bool BADOUEL = false, bool GRID = true, bool TRIPOOL = false,
           int MATS = MATS_ALL>
-__global__ __launch_bounds__(kBlock, TRIPOOL ? PT_MIN_WAVES_TRIPOOL : CL ? PT_MIN_WAVES_CL : COOP ? (UV ? PT_MIN_WAVES_COOP_IMG : PT_MIN_WAVES_COOP) : (UV ? PT_MIN_WAVES_IMG : PT_MIN_WAVES))
+__global__ __launch_bounds__(kBlock, TRIPOOL ? (UV ? 4 : PT_MIN_WAVES_TRIPOOL) : CL ? PT_MIN_WAVES_CL : COOP ? (UV ? PT_MIN_WAVES_COOP_IMG : PT_MIN_WAVES_COOP) : (UV ? PT_MIN_WAVES_IMG : PT_MIN_WAVES))
 void render_kernel(KArgs a) {
   constexpr bool IMG = UV == UV_TRACKED;
   typedef LaneT<CL> Lane;

@@ -1,6 +1,6 @@
 """Soak run of the path-ray check (tests/path_rays.py) over many fuzz scenes: box fields, sphere fields, the random mixed
 scenes with a slab pool forced into every stretch of rects / boxes, with and without image textures on triangles / media,
-and (round 3) triangle fields through the opt-in triangle pool (PT_TRICULL=1).
+and (round 3) triangle fields through the triangle pool (PT_TRICULL=1: from 256 triangles).
 Needs a GPU and the oracle (a test tool, like tests/).   python tools/soak_path_rays.py [scenes-per-kind-multiplier] [rays] [kinds, e.g. triangle]"""
 import os, sys
 from pathlib import Path

@@ -1,4 +1,4 @@
-"""ONE render of the 100 k-triangle mesh through the opt-in triangle pool (the program to put behind `rocprofv3 --pmc ... --`):
+"""ONE render of the 100 k-triangle mesh through the triangle pool (the program to put behind `rocprofv3 --pmc ... --`):
     PT_TRICULL=1 python tools/tri_once.py [W H SPP]"""
 import os, sys
 os.environ.setdefault("PT_TRICULL", "1")
