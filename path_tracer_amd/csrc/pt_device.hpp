@@ -1074,8 +1074,10 @@ __device__ __forceinline__ unsigned int gdword(glb_f4p gblob, int base_f4, int i
 #ifndef PT_TRI_ABLATE
 #define PT_TRI_ABLATE 0 /* timing experiments only: 1 no grid, 2 no band levels, 4 no always list (wrong images) */
 #endif
+typedef short short2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned long long* tri_slots() { __shared__ unsigned long long s[256]; return s; }
 __device__ __forceinline__ int* tri_queue() { __shared__ int s[4 * 384]; return s; } // per wave: survivors of the filters waiting for the exact test
+__device__ __forceinline__ int* tri_bqueue() { __shared__ int s[4 * 768]; return s; } // per wave: band candidates past the integer band test, (record, index) pairs
 __device__ __forceinline__ int* tri_rows() { __shared__ int s[4 * 264]; return s; } // per wave: the row table of the strip being scanned
 __device__ __forceinline__ unsigned long long tri_key(float t, int off) {
   return ((unsigned long long)(unsigned int)as_i(t) << 32) | (unsigned long long)(unsigned int)(0xffffff - off);
@@ -1187,6 +1189,8 @@ __device__ __forceinline__ bool tri_pool_scan(glb_f4p gblob, cst_f4p cblob, int 
       while (__builtin_amdgcn_readfirstlane((int)active) != 0) { // (every lane computes the same walk)
         const int ci = __builtin_amdgcn_readfirstlane((iz * ny + iy) * nx + ix);
         PT_TRI_COUNT(3, 1);
+        // (requesting the NEXT cell's range here, before this cell's candidates are processed, measured 12 % slower: scalar loads and
+        // LDS share a counter, so the first LDS wait of the processing waits for the prefetch as well)
         const int k0 = (int)dword_at(cblob + cell_first, ci), k1 = (int)dword_at(cblob + cell_first, ci + 1);
         for (int base = k0; base < k1; base += 256) { // four candidates per lane and trip: k = base + 64 j + lane
           PT_TRI_COUNT(2, 1);
@@ -1200,7 +1204,9 @@ __device__ __forceinline__ bool tri_pool_scan(glb_f4p gblob, cst_f4p cblob, int 
           }
           // filter (i) of pt_tripool.hpp on the compressed records: the walked SEGMENT [0, lim] passes within the radius of the
           // centroid — the line within it, and the centroid's projection neither more than it behind the origin nor beyond lim —
-          // for the TIGHT radius, or for the LOOSE one if the pair also passes the band test at Mg ("compressed records")
+          // for the TIGHT radius, or for the LOOSE one if the pair also passes the band test at Mg ("compressed records").
+          // (A second stage for the loose-only candidates — queue them, band test 64 at a time — removes 3 % of the instructions
+          // and costs 10 % in time: one more dependent LDS -> gather -> LDS stage per round.  Measured, not kept.)
           const float cl = as_f((int)(unsigned int)(slot[src] >> 32));
           const float lim_ua = (cl + cl * kappa) * ua * 1.00001f;
           unsigned int passmask = 0;
@@ -1254,6 +1260,50 @@ __device__ __forceinline__ bool tri_pool_scan(glb_f4p gblob, cst_f4p cblob, int 
       return !(a1 > 0.0f) || near_line(C, L + rr + H6.x + H7.w);
     };
     const V3 dh = __builtin_amdgcn_rsqf(ua) * ur.d; // unit direction (a few ulp: covered by the strips' absolute slack)
+    // Two stages.  Stage 1, on every enumerated candidate: the band test alone, in INTEGERS — the record's normal is three 16-bit
+    // integers k / 32767, the ray's unit direction is rounded to the same grid once per ray, and two v_dot2_i32_i16 give
+    // S = kn . kd exactly (|S| <= 32767^2 (1 + 1e-4): no overflow); |d^ . n^| <= |S| / 32767^2 + eps_n + eps_d with
+    // eps_d = sqrt(3) / (2 * 32767) + 1e-6 (the rounding of the direction and of rsq), so the test below passes whenever the band
+    // test of pt_tripool.hpp does.  Its survivors (about a quarter) are queued and run the full filter 64 at a time (stage 2).
+    const int kdx = (int)__builtin_rintf(dh.x * 32767.0f), kdy = (int)__builtin_rintf(dh.y * 32767.0f), kdz = (int)__builtin_rintf(dh.z * 32767.0f);
+    short2_t dxy, dz0;
+    { const unsigned int a = ((unsigned int)kdx & 0xffffu) | ((unsigned int)kdy << 16), b = (unsigned int)kdz & 0xffffu; __builtin_memcpy(&dxy, &a, 4); __builtin_memcpy(&dz0, &b, 4); }
+    const float e1s = H8.w + 2.75e-5f;
+    auto band_stage1 = [&](f4 Q) {
+      const unsigned int w0 = (unsigned int)as_i(Q.x), w1 = (unsigned int)as_i(Q.y), w3 = (unsigned int)as_i(Q.w);
+      short2_t nxy, nzp;
+      __builtin_memcpy(&nxy, &w0, 4); __builtin_memcpy(&nzp, &w1, 4); // (nzp's high half is pn's bits: multiplied by dz0's zero)
+      const int S = __builtin_amdgcn_sdot2(nzp, dz0, __builtin_amdgcn_sdot2(nxy, dxy, 0, false), false);
+      const float sa = (float)(S < 0 ? -S : S);
+      const float pn = as_f((int)(w1 & 0xffff0000u)), L = as_f((int)(w3 & 0xffff0000u));
+      const float rL = __builtin_amdgcn_rcpf(L) * 1.00001f;
+      return sa <= (pn * (rho + H5.y * L + H5.w * rL) + e1s) * 1.0737e9f; // 32767^2 (1 + 2e-5)
+    };
+    int* const bq = tri_bqueue() + (threadIdx.x >> 6) * 768;
+    int bn = 0;
+    auto bpush = [&](bool p, int e0, int e1) {
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(p);
+      if (p) { const int at = 2 * (bn + __builtin_popcountll(m & below)); bq[at] = e0; bq[at + 1] = e1; }
+      bn += __builtin_popcountll(m);
+    };
+    auto drain_band = [&](int keep) {
+      __builtin_amdgcn_wave_barrier();
+      while (bn > keep) {
+        const int n = min(bn, 64);
+        bool pass = false;
+        int e1 = 0;
+        if (lane < n) { // (the candidate's position in the Morton copy is fetched beside its record: no dependent gather in the exact stage)
+          const int at = 2 * (bn - n + lane);
+          e1 = (int)gdword(gblob, 0, ~bq[at + 1]);
+          pass = band_pass(gblob[bq[at]]);
+        }
+        bn -= n;
+        PT_TRI_COUNT(9, __builtin_popcountll(__builtin_amdgcn_ballot_w64(pass)));
+        push(pass, e1);
+        drain(63, ur, src);
+      }
+      __builtin_amdgcn_wave_barrier();
+    };
     const int n_levels = (PT_TRI_ABLATE & 2) ? 0 : as_i(H3.w);
     for (int lv = 0; lv < n_levels; ++lv) {
       const f4 L0 = cblob[hdr + 10 + 3 * lv], T0 = cblob[hdr + 11 + 3 * lv], T1 = cblob[hdr + 12 + 3 * lv];
@@ -1313,7 +1363,7 @@ __device__ __forceinline__ bool tri_pool_scan(glb_f4p gblob, cst_f4p cblob, int 
         // 256 positions per trip; a GROUP OF FOUR LANES reads sixteen consecutive candidates (load j: positions 4 j ... 4 j + 3 of the
         // sixteen, one 64-byte line per group) — a load instruction touches 16 lines, not 64 (lane-private chunks did: DESIGN.md §3)
         for (int base = 0; base < T; base += 256) {
-          PT_TRI_COUNT(5 + (lv < 2 ? lv : 2), 1);
+          PT_TRI_COUNT(5 + (lv < 1 ? lv : 1), 1);
           const int p = base + ((lane >> 2) << 4) + (lane & 3);
           PT_TRI_COUNT(4, __builtin_popcountll(__builtin_amdgcn_ballot_w64(p < T)));
           unsigned int passmask = 0;
@@ -1336,50 +1386,102 @@ __device__ __forceinline__ bool tri_pool_scan(glb_f4p gblob, cst_f4p cblob, int 
             for (int j = 0; j < 4; j++) Q[j] = gblob[tr + kk[j]];
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < 4; j++) passmask |= (p + 4 * j < T && band_pass(Q[j])) ? (1u << j) : 0u;
+            for (int j = 0; j < 4; j++) passmask |= (p + 4 * j < T && band_stage1(Q[j])) ? (1u << j) : 0u;
           }
-          PT_TRI_COUNT(9, PT_TRI_WAVE_BITS(passmask));
+          PT_TRI_COUNT(10, PT_TRI_WAVE_BITS(passmask));
 #pragma unroll
-          for (int j = 0; j < 4; j++) push((passmask >> j) & 1u, ~(4 * tc + kk[j]));
-          drain(63, ur, src);
+          for (int j = 0; j < 4; j++) bpush((passmask >> j) & 1u, tr + kk[j], ~(4 * tc + kk[j]));
+          drain_band(63);
         }
       }
     }
+    drain_band(0);
     drain(0, ur, src);
   }
-  // ---- (3) the always list: 64 entries in the lanes (one coalesced load each), the live rays in the inner loop --------------------
+  // ---- (3) the always list: 64 entries in the lanes (one coalesced load), the live rays in the inner loop ---------------------------
+  // The inner loop runs the band test only; (ray, entry) PAIRS that pass are queued (the band queue's storage is idle now) and take
+  // the noise-radius filter 64 pairs at a time, every lane with the context of ITS pair's ray (ds_bpermute); the pairs that pass
+  // that are queued again (the survivor queue's storage) and run the reference's test 64 at a time.  Slivers pass the band test for
+  // a large share of the rays, and ~29 pairs per ray reach the exact test: testing them where they arise kept the wave at a few
+  // lanes for most of the loop.
   const int n_always = (PT_TRI_ABLATE & 4) ? 0 : as_i(H3.z);
+  const int astr = as_i(H9.w);
+  int* const aq = tri_bqueue() + (threadIdx.x >> 6) * 768; // pairs (lane of the ray, entry) past the band test
+  int an = 0, xn = 0;                                       // (tq: pairs past the noise radius)
+  auto pair_push = [&](int* q, int& n, bool p, int s2, int e) {
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(p);
+    if (p) { const int at = 2 * (n + __builtin_popcountll(m & below)); q[at] = s2; q[at + 1] = e; }
+    n += __builtin_popcountll(m);
+  };
+  auto ray_of = [&](int s2, Ray& r2) { // the ray of lane s2, in every lane its own s2
+    r2.o = mk(__shfl(c.r.o.x, s2, 64), __shfl(c.r.o.y, s2, 64), __shfl(c.r.o.z, s2, 64));
+    r2.d = mk(__shfl(c.r.d.x, s2, 64), __shfl(c.r.d.y, s2, 64), __shfl(c.r.d.z, s2, 64));
+    r2.tm = 0.0f;
+  };
+  auto exact_pairs = [&](int keep) {
+    __builtin_amdgcn_wave_barrier();
+    while (xn > keep) {
+      const int n = min(xn, 64);
+      const bool on = lane < n;
+      const int at = 2 * (xn - n + (on ? lane : 0));
+      const int s2 = tq[at], e = tq[at + 1];
+      Ray r2;
+      ray_of(s2, r2);
+      if (on) { // (the entry's triangle: a gather from the always list's arrays)
+        const f4 R0 = gblob[acheap + 2 * astr + e], R1 = gblob[acheap + 3 * astr + e], R2 = gblob[acheap + 4 * astr + e];
+        float t;
+        if (tri_param(R0, R1, R2, r2, t) && !(t < PT_TMIN)) atomicMin(&slot[s2], tri_key(t, goff + 3 * as_i(R2.w)));
+      }
+      xn -= n;
+    }
+    __builtin_amdgcn_wave_barrier();
+  };
+  auto filter_pairs = [&](int keep) {
+    __builtin_amdgcn_wave_barrier();
+    while (an > keep) {
+      const int n = min(an, 64);
+      const bool on = lane < n;
+      const int at = 2 * (an - n + (on ? lane : 0));
+      const int s2 = aq[at], e = aq[at + 1];
+      Ray r2;
+      ray_of(s2, r2);
+      const float ua = __shfl(c.a, s2, 64), rho = __shfl(rho_own, s2, 64), dn = __shfl(dn_own, s2, 64);
+      bool pass = false;
+      if (on) {
+        const f4 G = gblob[acheap + e], Bc = gblob[acheap + astr + e];
+        const float dg = __builtin_fabsf(r2.d.x * G.x + r2.d.y * G.y + r2.d.z * G.z);
+        const float L = Bc.w, L2 = L * L;
+        const float a1 = dg * (H5.z * L) - H6.w * L2 * dn;
+        const float rr = (H6.y + H6.z * L) * L2 * rho * dn / a1;
+        const float rad = L + rr + H6.x;
+        const V3 x = cross(xyz(Bc) - r2.o, r2.d);
+        pass = !(a1 > 0.0f) || dot(x, x) <= rad * rad * ua * 1.00001f;
+      }
+      an -= n;
+      PT_TRI_COUNT(11, __builtin_popcountll(__builtin_amdgcn_ballot_w64(pass)));
+      pair_push(tq, xn, pass, s2, e);
+      exact_pairs(63);
+    }
+    __builtin_amdgcn_wave_barrier();
+  };
   for (int base = 0; base < n_always; base += 64) {
     const int e = base + lane;
     const bool on = e < n_always;
-    f4 G = f4{0, 0, 0, 0}, Bc = G;
-    f4 R0 = G, R1 = G, R2 = G;
-    if (on) { const int as = as_i(H9.w); G = gblob[acheap + e]; Bc = gblob[acheap + as + e]; R0 = gblob[acheap + 2 * as + e]; R1 = gblob[acheap + 3 * as + e]; R2 = gblob[acheap + 4 * as + e]; }
+    f4 G = f4{0, 0, 0, 0};
+    if (on) G = gblob[acheap + e];
     for (unsigned long long todo = live; todo != 0; todo &= todo - 1) {
       const int src = __builtin_ctzll(todo);
-      Ray ur;
-      ur.o = mk(rl_f(c.r.o.x, src), rl_f(c.r.o.y, src), rl_f(c.r.o.z, src));
-      ur.d = mk(rl_f(c.r.d.x, src), rl_f(c.r.d.y, src), rl_f(c.r.d.z, src));
-      ur.tm = 0.0f;
-      const float ua = rl_f(c.a, src), rho = rl_f(rho_own, src), dn = rl_f(dn_own, src);
-      bool pass = false;
-      if (on) {
-        const float dg = __builtin_fabsf(ur.d.x * G.x + ur.d.y * G.y + ur.d.z * G.z);
-        if (dg <= dn * (rho + G.w)) {
-          const float L = Bc.w, L2 = L * L;
-          const float a1 = dg * (H5.z * L) - H6.w * L2 * dn;
-          const float rr = (H6.y + H6.z * L) * L2 * rho * dn / a1;
-          const float rad = L + rr + H6.x;
-          const V3 x = cross(xyz(Bc) - ur.o, ur.d);
-          pass = !(a1 > 0.0f) || dot(x, x) <= rad * rad * ua * 1.00001f;
-        }
-      }
-      if (pass) { // the entry's own triangle rides in the lane: no fetch
-        float t;
-        if (tri_param(R0, R1, R2, ur, t) && !(t < PT_TMIN)) atomicMin(&slot[src], tri_key(t, goff + 3 * as_i(R2.w)));
-      }
+      const float dx = rl_f(c.r.d.x, src), dy = rl_f(c.r.d.y, src), dz = rl_f(c.r.d.z, src);
+      const float rho = rl_f(rho_own, src), dn = rl_f(dn_own, src);
+      const float dg = __builtin_fabsf(dx * G.x + dy * G.y + dz * G.z);
+      const bool p1 = on & (dg <= dn * (rho + G.w));
+      PT_TRI_COUNT(7, __builtin_popcountll(__builtin_amdgcn_ballot_w64(p1)));
+      pair_push(aq, an, p1, src, e);
+      filter_pairs(63);
     }
   }
+  filter_pairs(0);
+  exact_pairs(0);
   // each lane reads its own ray's slot back: changed = some triangle of this run is the nearest hit so far
   const unsigned long long kf = slot[lane];
   if (kf != key0) { h.closest = as_f((int)(unsigned int)(kf >> 32)); h.hit = hit_pack(DK_TRI, 0, 0xffffff - (int)(unsigned int)(kf & 0xffffffu)); }

@@ -26,5 +26,6 @@ lib.pt_debug_tri(o, 0)
 scans, rays, grid, alw, lanes, b0, b1, b2 = [o[i] for i in range(8)]
 rays = max(rays, 1)
 print(f"{W}x{H}x{spp}: {ms:.1f} ms = {W*H*spp/ms/1e3:.2f} Msamples/s; wave scans {scans:.3e}, live rays per scan {rays/max(scans,1):.1f}")
-print(f"per ray: grid survivors (exact tests) {o[8]/rays:.1f}; band survivors {o[9]/rays:.1f}")
-print(f"per ray: grid rounds {grid/rays:.1f}; band trips level 0 / 1 / 2: {b0/rays:.1f} / {b1/rays:.1f} / {b2/rays:.1f} (lanes busy per trip {lanes/max(b0+b1+b2,1):.1f}); grid cells visited {alw/rays:.1f}")
+print(f"per ray: grid survivors (exact tests) {o[8]/rays:.1f}; band: past the integer band test {o[10]/rays:.1f}, survivors (exact tests) {o[9]/rays:.1f}")
+print(f"per ray: always list: pairs past the band test {o[7]/rays:.1f}, exact tests {o[11]/rays:.1f} (band trips of levels 1 and 2 are counted together)")
+print(f"per ray: grid rounds {grid/rays:.1f}; band trips level 0 / levels 1 + 2: {b0/rays:.1f} / {b1/rays:.1f} (lanes busy per trip {lanes/max(b0+b1,1):.1f}); grid cells visited {alw/rays:.1f}")
