@@ -96,10 +96,11 @@ def ops_per_sample_culled(ctr: dict, n_spheres: int, grid_spheres: int, walk: di
 # its cube-map strips and of the always list, and the reference's test on the few survivors.  Counted in the kernel (diagnostic
 # build `make stamps EXTRA=-DPT_STAMPS_TRI`, tools/tri_counters.py; profiles/r03_tripool_counters.txt): 41.5 grid rounds of 64
 # candidates, 17.2 band trips x 51.4 lanes x 4 records, 3 624 always-list records, 4.3 grid cells per ray.
-TRI_POOL = {"triangles": dict(exact_per_ray=399.9 + 25.3, grid_filter_per_ray=41.5 * 64, band_per_ray=17.2 * 51.8 * 4 + 3624, cells_per_ray=4.3,
-                              source="profiles/r03_tripool_counters.txt")}
+TRI_POOL = {"triangles": dict(exact_per_ray=399.9 + 25.3 + 29.2, grid_filter_per_ray=41.5 * 64, band_per_ray=17.2 * 51.8 * 4 + 3624,
+                              noise_per_ray=566.1 + 743.9, cells_per_ray=4.3, source="profiles/r03_tripool_counters.txt")}
 OPS_TRI_POOL = dict(band=8,        # d . g (5) + |.| + rho + c, compare (3)
                     grid_filter=20,  # C - o (3), cross (9), |.|^2 (5), radius^2 |d|^2 + compare (3): the tight line test of a grid candidate
+                    noise=33,      # the noise-radius filter of a pair past the band test: |a'| - ea |d| (4), radius (10), line test (19)
                     setup=45 + 9 * 40)  # the grid walk's set-up + per (level, face): strip coefficients, reach test, row ranges (amortised over 64 lanes)
 
 
@@ -113,13 +114,13 @@ def ops_per_sample_culled_tri(ctr: dict, pool: dict) -> float:
     rest = ops_per_sample(ctr) * n - brute_tri
     tri_price = brute_tri / max(1, sum(te))
     per_ray = (pool["exact_per_ray"] * tri_price + pool["band_per_ray"] * OPS_TRI_POOL["band"]
-               + pool.get("grid_filter_per_ray", 0.0) * OPS_TRI_POOL["grid_filter"]
+               + pool.get("grid_filter_per_ray", 0.0) * OPS_TRI_POOL["grid_filter"] + pool.get("noise_per_ray", 0.0) * OPS_TRI_POOL["noise"]
                + pool["cells_per_ray"] * OPS_GRID["step"] + OPS_TRI_POOL["setup"])
     return (rest + ctr["rays"] * per_ray) / n
 
 
 # recorded like ALGORITHMIC_OPS_PER_SAMPLE (the N = 1 cpu_baseline leg re-derives them live): the culled algorithms' figures
-ALGORITHMIC_OPS_PER_SAMPLE_CULLED = {"smoke": 2116.7, "triangles": 302169.2}
+ALGORITHMIC_OPS_PER_SAMPLE_CULLED = {"smoke": 2116.7, "triangles": 408416.6}
 
 
 def ops_per_sample(ctr: dict) -> float:

@@ -177,7 +177,7 @@ def test_predicted_chain_floor_is_read_from_final_shard_tables(tmp_path):
 
 def test_culled_algorithm_pricing_for_the_triangle_pool(orc):
     """cfg5's long triangle run is culled exactly by a triangle pool: priced for what the kernel runs (the survivors of its filters at
-    the oracle's own triangle-exit mix, grid candidates' line test at 20 ops, band records at 8 ops, all counted in the kernel), not for 100 000 tests per ray."""
+    the oracle's own triangle-exit mix, grid candidates' line test at 20 ops, band records at 8 ops, the noise-radius filter of the pairs past the band test at 33 ops, all counted in the kernel), not for 100 000 tests per ray."""
     bench = load_bench()
     packed, cam_args = scenes.build("triangles", n_triangles=100_000)
     orc.set_math(True)
