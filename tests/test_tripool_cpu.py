@@ -236,3 +236,39 @@ def test_compressed_filter_records_round_to_the_safe_side(lib, monkeypatch):
             assert np.all(np.linalg.norm(Cd - cen[idx], axis=1) <= eps_c * (1 + 1e-6) + 1e-12)
             n_band += k
     assert total > 3000 and n_band > 3000
+
+
+def test_integer_band_test_is_conservative():
+    """Stage 1 of the band filter (pt_device.hpp: band_stage1) evaluates |d^ . n^| in integers: n^ and the ray's unit direction are
+    rounded to k / 32767 per component and S = kn . kd is exact (two v_dot2_i32_i16).  Whenever the real band condition
+    |d^ . n^| <= thr holds, the device's comparison  |S| <= (thr + eps_n + eps_d) * 32767^2 (1 + 2e-5)  must hold — emulated here in
+    binary32 for random and for barely-inside pairs, with thr across the range of the three levels; and |S| stays below 2^31."""
+    rng = np.random.default_rng(11)
+    n_pairs = 400_000
+    n = rng.normal(size=(n_pairs, 3)); n /= np.linalg.norm(n, axis=1)[:, None]
+    # directions close to the band's edge: d = cos(a) t + sin(a) n with sin(a) = thr (1 - tiny) and thr log-uniform in [1e-5, 0.3]
+    thr = 10 ** rng.uniform(-5, np.log10(0.3), n_pairs)
+    t = np.cross(n, rng.normal(size=(n_pairs, 3))); t /= np.linalg.norm(t, axis=1)[:, None]
+    inside = rng.uniform(0, 1, n_pairs) ** 0.05                      # mostly within a few per cent of the edge, on the inside
+    sa = thr * inside * rng.choice([-1.0, 1.0], n_pairs)
+    d = t * np.sqrt(1 - sa * sa)[:, None] + n * sa[:, None]
+    assert np.all(np.abs(np.einsum("ij,ij->i", d, n)) <= thr * (1 + 1e-12))
+    scale = 10 ** rng.uniform(-3, 3, n_pairs)                        # the ray's direction is not normalised
+    d32 = (d * scale[:, None]).astype(f32)
+    ua = dot32(d32, d32)
+    dh = ((f32(1.0) / np.sqrt(ua)).astype(f32)[:, None] * d32).astype(f32)   # rsq(ua) * d: within a few ulp of the unit vector
+    kd = np.rint(dh * f32(32767.0)).astype(np.int64)
+    kn = np.rint(n * 32767.0).astype(np.int64)
+    assert np.abs(kd).max() <= 32767 and np.abs(kn).max() <= 32767
+    S = np.einsum("ij,ij->i", kn, kd)
+    assert np.abs(S).max() < 2 ** 31 and np.abs(kn[:, :2] * kd[:, :2]).sum(1).max() < 2 ** 31
+    eps_n = np.sqrt(3) * 0.5 / 32767 * (1 + 1e-6) + 3e-6              # what build_tri_pool measures, at its worst
+    e1s = f32(eps_n) + f32(2.75e-5)
+    lhs = np.abs(S).astype(f32)
+    rhs = ((thr.astype(f32) + e1s).astype(f32) * f32(1.0737e9)).astype(f32)
+    assert np.all(lhs <= rhs), int(np.argmax(lhs - rhs))
+    # and it is a filter: of random pairs against a band of 1e-3 it rejects all but the ones near the band
+    kd2 = rng.permutation(kd)
+    S2 = np.abs(np.einsum("ij,ij->i", kn, kd2)).astype(f32)
+    keep = S2 <= ((f32(1e-3) + e1s) * f32(1.0737e9)).astype(f32)
+    assert keep.mean() < 0.002
