@@ -1076,7 +1076,11 @@ __device__ __forceinline__ unsigned int gdword(glb_f4p gblob, int base_f4, int i
 #endif
 typedef short short2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned long long* tri_slots() { __shared__ unsigned long long s[256]; return s; }
-__device__ __forceinline__ int* tri_queue() { __shared__ int s[4 * 384]; return s; } // per wave: survivors of the filters waiting for the exact test
+#ifndef PT_TRI_GRID_PER_LANE
+#define PT_TRI_GRID_PER_LANE 4 /* grid candidates per lane and trip; 8 (one trip per cell, 159 VGPRs = three waves per SIMD) measured 4 % slower */
+#endif
+#define PT_TRI_QUEUE (64 + 64 * (PT_TRI_GRID_PER_LANE > 4 ? PT_TRI_GRID_PER_LANE : 5))
+__device__ __forceinline__ int* tri_queue() { __shared__ int s[4 * PT_TRI_QUEUE]; return s; } // per wave: survivors of the filters waiting for the exact test
 __device__ __forceinline__ int* tri_bqueue() { __shared__ int s[4 * 768]; return s; } // per wave: band candidates past the integer band test, (record, index) pairs
 __device__ __forceinline__ int* tri_rows() { __shared__ int s[4 * 264]; return s; } // per wave: the row table of the strip being scanned
 __device__ __forceinline__ unsigned long long tri_key(float t, int off) {
@@ -1120,7 +1124,7 @@ __device__ __forceinline__ bool tri_pool_scan(glb_f4p gblob, cst_f4p cblob, int 
   // Survivors of the filters do not run the exact test on the spot (a few lanes busy per trip, each with its own gather): they
   // are QUEUED per wave in LDS — entry >= 0: the triangle's position in the Morton-ordered copy; entry < 0: ~(dword index in
   // the blob of that position: a band candidate, whose index is not loaded before it is needed) — and tested 64 at a time.
-  int* const tq = tri_queue() + (threadIdx.x >> 6) * 384;
+  int* const tq = tri_queue() + (threadIdx.x >> 6) * PT_TRI_QUEUE;
   const unsigned long long below = (1ull << lane) - 1ull;
   int qn = 0; // entries queued (uniform)
   auto push = [&](bool p, int e) {
@@ -1192,12 +1196,12 @@ __device__ __forceinline__ bool tri_pool_scan(glb_f4p gblob, cst_f4p cblob, int 
         // (requesting the NEXT cell's range here, before this cell's candidates are processed, measured 12 % slower: scalar loads and
         // LDS share a counter, so the first LDS wait of the processing waits for the prefetch as well)
         const int k0 = (int)dword_at(cblob + cell_first, ci), k1 = (int)dword_at(cblob + cell_first, ci + 1);
-        for (int base = k0; base < k1; base += 256) { // four candidates per lane and trip: k = base + 64 j + lane
+        for (int base = k0; base < k1; base += 64 * PT_TRI_GRID_PER_LANE) { // PT_TRI_GRID_PER_LANE candidates per lane and trip: k = base + 64 j + lane
           PT_TRI_COUNT(2, 1);
-          unsigned int q0[4], q1[4], n0[4], n1[4];
-          int gi[4];
+          unsigned int q0[PT_TRI_GRID_PER_LANE], q1[PT_TRI_GRID_PER_LANE], n0[PT_TRI_GRID_PER_LANE], n1[PT_TRI_GRID_PER_LANE];
+          int gi[PT_TRI_GRID_PER_LANE];
 #pragma unroll
-          for (int j = 0; j < 4; j++) { // (the arrays carry 256 spare entries: no clamping)
+          for (int j = 0; j < PT_TRI_GRID_PER_LANE; j++) { // (the arrays carry 256 spare entries: no clamping)
             const int k = base + 64 * j + lane;
             q0[j] = gdword(gblob, cell_q, 2 * k); q1[j] = gdword(gblob, cell_q, 2 * k + 1); gi[j] = (int)gdword(gblob, cell_cand, k);
             n0[j] = gdword(gblob, cell_n, 2 * k); n1[j] = gdword(gblob, cell_n, 2 * k + 1);
@@ -1211,7 +1215,7 @@ __device__ __forceinline__ bool tri_pool_scan(glb_f4p gblob, cst_f4p cblob, int 
           const float lim_ua = (cl + cl * kappa) * ua * 1.00001f;
           unsigned int passmask = 0;
 #pragma unroll
-          for (int j = 0; j < 4; j++) {
+          for (int j = 0; j < PT_TRI_GRID_PER_LANE; j++) {
             const V3 C = mk(H7.x + (float)(q0[j] & 0xffffu) * H8.x, H7.y + (float)(q0[j] >> 16) * H8.y, H7.z + (float)(q1[j] & 0xffffu) * H8.z);
             const float rad = as_f((int)(q1[j] & 0xffff0000u)), radl = rad * H9.x;
             const V3 oc = C - ur.o;
@@ -1229,7 +1233,7 @@ __device__ __forceinline__ bool tri_pool_scan(glb_f4p gblob, cst_f4p cblob, int 
           }
           PT_TRI_COUNT(8, PT_TRI_WAVE_BITS(passmask));
 #pragma unroll
-          for (int j = 0; j < 4; j++) push((passmask >> j) & 1u, gi[j]);
+          for (int j = 0; j < PT_TRI_GRID_PER_LANE; j++) push((passmask >> j) & 1u, gi[j]);
           drain(63, ur, src); // whole batches of 64
         }
         drain(0, ur, src); // the rest before the walk looks at the limit again

@@ -340,12 +340,12 @@ inline int32_t put_tri_pool(std::vector<F4>& b, const TriPool& tp, const PtHitta
   for (size_t c = 0; c + 1 < tp.cell_first.size(); c++)
     std::sort(cell_sorted.begin() + tp.cell_first[c], cell_sorted.begin() + tp.cell_first[c + 1], [&](uint32_t x, uint32_t y) { return pos_of[x] < pos_of[y]; });
   for (size_t k = 0; k < cell_sorted.size(); k++) cell_pos[k] = pos_of[cell_sorted[k]];
-  // (the grid scan reads up to 256 entries past a cell's last candidate: spare entries behind both arrays)
+  // (the grid scan reads up to 512 entries past a cell's last candidate: spare entries behind the arrays)
   const int32_t cell_first = put_u32(tp.cell_first);
   const int32_t cell_cand = (int32_t)b.size();
   put_dwords(b, cell_pos.data(), cell_pos.size());
-  for (int k = 0; k < 68; k++) b.push_back({0, 0, 0, 0});
-  const int32_t cell_q = put_q(cell_sorted, tp.grid_q, 2, 132), cell_n = put_q(cell_sorted, tp.grid_n, 2, 132);
+  for (int k = 0; k < 132; k++) b.push_back({0, 0, 0, 0});
+  const int32_t cell_q = put_q(cell_sorted, tp.grid_q, 2, 260), cell_n = put_q(cell_sorted, tp.grid_n, 2, 260);
   // always-list entries, structure of arrays: five arrays of n_always (+ spare) F4 — (g, c) (centroid, L) (v0, material) (edge1, -)
   // (edge2, triangle index) — so that the 64 lanes of a tile read consecutive records of each
   const int32_t always = put_u32(tp.always);

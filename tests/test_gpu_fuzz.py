@@ -29,7 +29,8 @@ def forced_pools():
 
 @contextlib.contextmanager
 def tri_pools(**knobs):
-    """PT_TRICULL=1 (+ PT_TRI_* knobs) while scenes are created: the opt-in exact culling of long triangle runs."""
+    """PT_TRICULL=1 (+ PT_TRI_* knobs) while scenes are created: the exact culling of long triangle runs, from 256 triangles on
+    (the default threshold is 4096)."""
     env = {"PT_TRICULL": "1", **{k: str(v) for k, v in knobs.items()}}
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
@@ -489,6 +490,6 @@ def test_path_rays_on_the_baseline_scenes(orc, lib, name, n, gens):
     ps, cam = scenes.build(name, **({"n_triangles": 100_000} if name == "triangles" else {}))
     w, h = (192, 108) if name == "cornell" else (200, 112)
     c = scenes.make_camera(cam, w, h)
-    with tri_pools() if name == "triangles" else contextlib.nullcontext():  # the 100 k-triangle mesh through its (opt-in) triangle pool
+    with tri_pools() if name == "triangles" else contextlib.nullcontext():  # the 100 k-triangle mesh through its triangle pool
         checked, bad = follow_paths(lib, orc, ps, c.c, w, h, n, gens, 7)
     assert checked >= 1.5 * n and not bad, f"{len(bad)} of {checked} rays differ: " + " | ".join(bad[:3])
