@@ -918,6 +918,8 @@ __device__ __forceinline__ bool slab_chunk_pass(P xrecs, P slrecs, cst_f4p srecs
     asm("v_med3_u32 %0, %1, %0, %2" : "+v"(k2) : "v"(k1), "v"(kk));
     asm("v_min_u32_e32 %0, %0, %1" : "+v"(k1) : "v"(kk));
   };
+  // (four entries per trip of this scalar loop — two s_load_dwordx16 in flight — measured 2.3 % SLOWER on the headline scene, 150.2
+  // against 146.9 ms, three alternating runs each: profiles/r03_ab_slab_unroll4.log)
   for (int j = 0; j < cn; j += 2) {
     const f16v e = pairs[j >> 1];
     entry(e[0], e[1], e[2], e[4], e[5], e[6], j);
