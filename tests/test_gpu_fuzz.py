@@ -296,15 +296,18 @@ def test_random_box_fields_through_the_slab_culling(orc, lib, seed):
     assert_bit_identical(R.render_host(w, h, 70, ps, c, flags=F), orc.render(ps, c.c, w, h, 70, flags=F), f"box field seed {seed} fast mode")
 
 
-def random_triangle_field(seed: int):
+def random_triangle_field(seed: int, images: int = 0):
     """Long runs of Moller-Trumbore triangles for the exact triangle pool (csrc/pt_tripool.hpp; pt_device.hpp: tri_pool_scan),
     with what it has to get right varied at random: small random triangles, SLIVERS (edges nearly parallel: wide grazing
     bands, the always list), degenerate triangles (repeated vertices, collinear vertices), exact duplicates and coplanar
     re-orderings (equal-t ties: the later one wins), meshes with shared edges and vertices (rays through edges), triangles in
     the coordinate planes seen by cameras that look along those planes (every primary ray grazes them), huge and tiny
     scales, off-origin centres, a second triangle run behind another kind, and cameras inside, near, far and beyond the
-    pool's rlimit (fallback to the full scan)."""
+    pool's rlimit (fallback to the full scan).  images = 1: an image-textured sphere beside the field (the pool kernels that carry
+    the winner's u, v); images = 2: image-textured triangles as well (u, v of every accepted triangle)."""
     rng = np.random.default_rng(seed)
+    atlas = TextureAtlas() if images else None
+    img = image_texture.from_array(rng.integers(0, 256, (11, 19, 3), dtype=np.uint8), 1.5, atlas) if images else None
 
     def color():
         return tuple(float(x) for x in rng.random(3))
@@ -319,7 +322,11 @@ def random_triangle_field(seed: int):
     size = scale * float(rng.choice([0.03, 0.1, 0.3]))   # typical edge
     n = int(rng.integers(300, 2500))
     mats = [material() for _ in range(12)]
+    if images >= 2:
+        mats[0] = mats[5] = lambertian_material(img)
     hs = [sphere(tuple(centre + [0, -1000 * scale - 0.5 * scale, 0]), 1000 * scale, lambertian_material(checker_texture((0.2, 0.3, 0.1), (0.9, 0.9, 0.9))))]
+    if images:
+        hs.append(sphere(tuple(centre + [0.2 * scale, 0.1 * scale, -0.1 * scale]), 0.15 * scale, lambertian_material(img)))
     first = len(hs)
 
     def P():
@@ -381,7 +388,28 @@ def random_triangle_field(seed: int):
     cam = dict(look_from=tuple(float(x) for x in frm), look_at=tuple(float(x) for x in at), vup=(0, 1, 0),
                vfov=float(70.0 if dist < scale else min(70.0, 2 * np.degrees(np.arctan(0.7 * scale / dist)) + 5.0)),
                aperture=0.0, focus_dist=float(max(dist, 0.1 * scale)), time0=0.0, time1=1.0)
-    return pack(hs), cam
+    return (pack(hs, atlas) if images else pack(hs)), cam
+
+
+@pytest.mark.parametrize("seed,images", [(8100, 1), (8101, 2), (8102, 2), (8104, 1), (8107, 2)])
+def test_triangle_pool_with_image_textures(orc, lib, seed, images):
+    """The triangle-pool kernels that carry texture coordinates: an image on a sphere beside the field (UV of the winner) and on
+    triangles of the field itself (u, v of the accepted triangle: the pool's winner is known only when the scan is over)."""
+    import ctypes as C
+    ps, cam = random_triangle_field(seed, images)
+    st = (C.c_int32 * 8)()
+    w, h, spp = 40, 24, 8
+    c = scenes.make_camera(cam, w, h)
+    orc.set_math(True)
+    ref = orc.render(ps, c.c, w, h, spp)
+    with tri_pools():
+        abi.check(lib.pt_debug_tri_pool(C.byref(ps.desc), st), "pt_debug_tri_pool")
+        assert st[0] >= 300
+        ds = R.DeviceScene(ps)
+    for name, flags in (("pool", 0), ("full scan (stream)", abi.PT_FLAG_FORCE_STREAM)):
+        assert_bit_identical(R.render_host(w, h, spp, ds, c, flags=flags), ref, f"textured triangle field seed {seed} images {images} {name}")
+    F = abi.PT_FLAG_FAST_RNG
+    assert_bit_identical(R.render_host(w, h, 70, ds, c, flags=F), orc.render(ps, c.c, w, h, 70, flags=F), f"textured triangle field seed {seed} fast mode")
 
 
 @pytest.mark.parametrize("seed", range(14))
