@@ -93,6 +93,8 @@ struct KArgs {
   const int* order;    // non-NULL: queue position -> local tile, heaviest first
   const int* n_split;  // non-NULL (COOP kernels): [0] how many leading tiles of `order` go through the wide phase, [1] log2 G
   int tile_granular;   // PT_FLAG_TILE_GRANULAR
+  int scatter_p;       // > 0 (triangle-pool kernels): queue positions are dealt to tiles in runs of 2^scatter_log pixels with this stride (lane_acquire)
+  int scatter_log;
   int n_hittables;
   int coop_prefix;     // >= 0: cooperative traversal allowed, list splittable up to this hittable; -1: disabled
   int fast_ok; // every rect/box coordinate finite and <= 2^60: rays may use the shared-reciprocal division
@@ -243,10 +245,27 @@ __device__ __forceinline__ void lane_acquire(Lane& L, const KArgs& a) {
   if (i >= (unsigned int)k.n_local_pixels) { L.retired = true; return; }
   // fast mode: the queue hands out (tile, chunk) units, a tile's chunks back to back
   unsigned int unit = i >> 6;
+  int in_tile = (int)(i & 63);
+  {
+    // Triangle-pool kernels: a wave takes its live rays ONE AT A TIME, so its time is the SUM over its lanes' pixels, and 64 pixels of
+    // one heavy tile in one wave are a chain 64 times as long as the heaviest pixel's (a shard of 1/8 of the 100 k-triangle frame took
+    // 3.3 s of the whole frame's 3.8 s).  So consecutive queue positions are dealt in runs of 2^scatter_log pixels (default: single
+    // pixels) to tiles that lie scatter_p apart in the (cost-sorted) order: a wave's 64 pixels come from 64 tiles spread evenly over the
+    // cost distribution — every wave gets a stratified sample of the frame's work — and a tile's pixels go to 64 different waves.
+    // 1080p x 32 spp: whole frame 3.78 -> 3.12 s, shard 0/8 3.29 -> 0.53 s (runs of 2 / 4 / 8 / 16 pixels: 0.59 / 0.65 / 0.82 / 1.22 s).
+    // A bijection of [0, 64 nt): run c = i >> g -> (position c mod nt, run-in-tile (c / nt) mod (64 >> g)), position -> position *
+    // scatter_p mod nt with gcd(scatter_p, nt) = 1.  Which pixel a lane renders changes nothing in the image: a pixel's seed is its id.
+    if (k.scatter_p > 0) {
+      const unsigned int g = (unsigned int)k.scatter_log, nt = (unsigned int)k.n_local_pixels >> 6, c = i >> g;
+      const unsigned int pos = c % nt, row = (c / nt) & ((64u >> g) - 1u);
+      unit = (unsigned int)(((unsigned long long)pos * (unsigned int)k.scatter_p) % nt);
+      in_tile = (int)((row << g) + (i & ((1u << g) - 1u)));
+    }
+  }
   int chunk = 0;
-  if constexpr (FAST) { chunk = (int)(unit % (unsigned int)k.fast_chunks); unit /= (unsigned int)k.fast_chunks; }
+  if constexpr (FAST) { chunk = (int)(unit % (unsigned int)k.fast_chunks); unit /= (unsigned int)k.fast_chunks; } // (fast mode: nt counts (tile, chunk) units)
   // queue position -> local tile: identity, or the cost-sorted order of the probe pass (heaviest tiles first)
-  const int l = k.order ? k.order[unit] : (int)unit, in_tile = (int)(i & 63);
+  const int l = k.order ? k.order[unit] : (int)unit;
   const long long g = (long long)l * k.shard_count + k.shard_index; // global tile (pt_render.h: round-robin shards)
   const int tx = (int)(g % k.tiles_x), ty = (int)(g / k.tiles_x);
   const int x = tx * PT_TILE + (in_tile & 7), y = ty * PT_TILE + (in_tile >> 3);
@@ -838,7 +857,13 @@ struct EnvKnobs {
   int lpt_max = -1, probe_spp_max = 16; // PT_LPT_MAX / PT_PROBE_SPP_MAX: order tiles by their heaviest pixel; probe depth cap
   int grid_min_tiles = kGridMinTiles;    // PT_GRID_MIN_TILES: frames (shards) of fewer tiles keep the cooperative kernels and the lists
   float model_fixed = 2400.0f, model_chain = 2400.0f; // PT_MODEL_FIXED / PT_MODEL_CHAIN: constants of the makespan model (lpt_order_kernel)
+  int scatter_log = 0;     // PT_SCATTER_LOG: log2 of the pixels of one tile that a wave takes together (0: every lane a pixel of another tile)
+  bool lpt_with_scatter = false; // PT_LPT_SCATTER: the cost probe + heaviest-first order also for scattered (triangle-pool) renders
+  bool no_scatter = false; // PT_NO_SCATTER: triangle-pool kernels hand out whole tiles' pixels to a wave again (lane_acquire)
   EnvKnobs() {
+    no_scatter = std::getenv("PT_NO_SCATTER") != nullptr;
+    lpt_with_scatter = std::getenv("PT_LPT_SCATTER") != nullptr;
+    if (const char* e = std::getenv("PT_SCATTER_LOG")) scatter_log = std::min(5, std::max(0, std::atoi(e)));
     if (const char* e = std::getenv("PT_BLOCKS_PER_CU")) blocks_per_cu = std::max(1, std::atoi(e));
     no_cold_lds = std::getenv("PT_NO_COLD_LDS") != nullptr;
     if (const char* e = std::getenv("PT_WIDE_LOGG")) wide_logG = std::min(6, std::max(1, std::atoi(e)));
@@ -1157,6 +1182,18 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
   // streaming kernel (a workgroup waits for its slowest lane); either can be forced
   // (the triangle-pool kernels' iterations are long and per-lane: single pixels, like the streaming kernel)
   a.tile_granular = (p->flags & PT_FLAG_TILE_GRANULAR) ? 1 : (p->flags & PT_FLAG_PIXEL_GRANULAR) ? 0 : ((resident && !tri_pool) ? 1 : 0);
+  a.scatter_p = 0; a.scatter_log = 0;
+  auto set_scatter = [&]() { // (after a.n_local_pixels is final: fast mode multiplies it by the chunks per pixel)
+    if (!(tri_pool && !a.tile_granular && !s->knobs.no_scatter)) return;
+    const unsigned int nt = (unsigned int)a.n_local_pixels >> 6;
+    a.scatter_log = s->knobs.scatter_log;
+    const unsigned int per_wave = 64u >> a.scatter_log; // tiles a wave's 64 pixels come from
+    unsigned int P = nt / per_wave > 1 ? nt / per_wave : 1;
+    auto gcd = [](unsigned int x, unsigned int y) { while (y) { const unsigned int t = x % y; x = y; y = t; } return x; };
+    while (gcd(P, nt) != 1) ++P;
+    a.scatter_p = (int)P;
+  };
+  set_scatter();
   a.cost = nullptr;
   a.cost_max = 0;
   a.order = nullptr;
@@ -1255,7 +1292,10 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
   // pixel's, from a deeper probe: 496-hittable scene +3-6 % (same box), Cornell-style -0.8 % (kept on the sum).
   const bool cost_by_max = s->knobs.lpt_max >= 0 ? s->knobs.lpt_max != 0 : use_grid;
   if (cost_by_max) probe_spp = std::min(std::max(probe_spp, p->samples / 64), s->knobs.probe_spp_max);
-  if (probe_spp >= 1 && local_tiles >= 64 && !(p->flags & PT_FLAG_NO_LPT)) {
+  // (the triangle-pool kernels deal every wave a stratified sample of the frame's tiles — lane_acquire, scatter_p — which balances the
+  // waves without knowing the costs: the probe only costs there, 1080p x 32 spp 3.12 -> 2.95 s without it; PT_LPT_SCATTER=1 keeps it)
+  const bool probe_pays = !(a.scatter_p > 0) || s->knobs.lpt_with_scatter;
+  if (probe_spp >= 1 && local_tiles >= 64 && !(p->flags & PT_FLAG_NO_LPT) && probe_pays) {
     if (int rc = reserve_tiles(s, local_tiles)) return rc; // first render at a new size only (or never: pt_scene_reserve)
     PT_HIP(hipMemsetAsync(s->ws_cost, 0, (size_t)local_tiles * sizeof(unsigned int), st));
     KArgs main_args = a;
@@ -1296,6 +1336,7 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
     a.fast_stride = (long long)plane;
     a.fb = s->ws_partial;
     a.n_local_pixels = local_tiles * PT_TILE_PIXELS * chunks;
+    set_scatter();
     a.n_split = nullptr;
     launch_units = (long long)local_tiles * chunks;
     s->last_had_wide_phase = false;

@@ -412,6 +412,29 @@ def test_triangle_pool_with_image_textures(orc, lib, seed, images):
     assert_bit_identical(R.render_host(w, h, 70, ds, c, flags=F), orc.render(ps, c.c, w, h, 70, flags=F), f"textured triangle field seed {seed} fast mode")
 
 
+@pytest.mark.parametrize("size", [(100, 37), (64, 64), (257, 9)])
+def test_triangle_pool_scattered_pixels_cover_the_frame(orc, lib, size, monkeypatch):
+    """The triangle-pool kernels deal consecutive queue positions to DIFFERENT tiles (pt_render.hip: lane_acquire, scatter_p): every
+    pixel of a frame with padding tiles must still be rendered exactly once — whole frames and three shards, bit for bit, for
+    single pixels (the default), runs of 4 and of 8 pixels, and with the scattering off."""
+    ps, cam = random_triangle_field(8003)
+    w, h = size
+    c = scenes.make_camera(cam, w, h)
+    orc.set_math(True)
+    ref = orc.render(ps, c.c, w, h, 3)
+    for knob in (None, "2", "3", "off"):
+        if knob == "off":
+            monkeypatch.setenv("PT_NO_SCATTER", "1")
+        elif knob is not None:
+            monkeypatch.setenv("PT_SCATTER_LOG", knob)
+        with tri_pools():
+            ds = R.DeviceScene(ps)
+        assert_bit_identical(R.render_host(w, h, 3, ds, c), ref, f"{w}x{h} scatter {knob}")
+        for k in range(3):
+            assert_bit_identical(R.render_host(w, h, 3, ds, c, shard_index=k, shard_count=3),
+                                 orc.render(ps, c.c, w, h, 3, shard_index=k, shard_count=3), f"{w}x{h} scatter {knob}, shard {k}/3")
+
+
 @pytest.mark.parametrize("seed", range(14))
 def test_random_triangle_fields_through_the_triangle_pool(orc, lib, seed):
     ps, cam = random_triangle_field(8000 + seed)
