@@ -59,7 +59,7 @@ OPS = dict(
 # Algorithmic lane-ops per sample of the standard scenes at depth 50: oracle exit-point counters (a 480x270x4 render;
 # 96x54x1 for the mesh) priced with OPS above.  Recorded so that ranks of an N>1 job, where the cpu_baseline leg does
 # not run, need nothing from oracle/; the N=1 cpu_baseline leg re-derives the figure live and reports that.
-ALGORITHMIC_OPS_PER_SAMPLE = {"cornell": 2062.7, "smoke": 39395.4, "triangles": 8220663.0}
+ALGORITHMIC_OPS_PER_SAMPLE = {"cornell": 2062.7, "smoke": 39395.4, "triangles": 402477.1}
 
 # The 496-hittable scene does NOT run the reference's algorithm as written: 476 of its 489 spheres sit in an exact culling grid
 #  and a ray tests the spheres of the cells it crosses instead of all of them.  Pricing the kernel against the
@@ -96,8 +96,8 @@ def ops_per_sample_culled(ctr: dict, n_spheres: int, grid_spheres: int, walk: di
 # its cube-map strips and of the always list, and the reference's test on the few survivors.  Counted in the kernel (diagnostic
 # build `make stamps EXTRA=-DPT_STAMPS_TRI`, tools/tri_counters.py; profiles/r03_tripool_counters.txt): 41.5 grid rounds of 64
 # candidates, 17.2 band trips x 51.4 lanes x 4 records, 3 624 always-list records, 4.3 grid cells per ray.
-TRI_POOL = {"triangles": dict(exact_per_ray=399.9 + 25.3 + 29.2, grid_filter_per_ray=41.5 * 64, band_per_ray=17.2 * 51.8 * 4 + 3624,
-                              noise_per_ray=566.1 + 743.9, cells_per_ray=4.3, source="profiles/r03_tripool_counters.txt")}
+TRI_POOL = {"triangles": dict(exact_per_ray=396.5 + 25.7 + 29.4, grid_filter_per_ray=41.5 * 64, band_per_ray=15.1 * 50.0 * 4 + 3624,
+                              noise_per_ray=594.5 + 774.8, cells_per_ray=5.2, source="profiles/r03_tripool_counters.txt")}
 OPS_TRI_POOL = dict(band=8,        # d . g (5) + |.| + rho + c, compare (3)
                     grid_filter=20,  # C - o (3), cross (9), |.|^2 (5), radius^2 |d|^2 + compare (3): the tight line test of a grid candidate
                     noise=33,      # the noise-radius filter of a pair past the band test: |a'| - ea |d| (4), radius (10), line test (19)
@@ -120,7 +120,7 @@ def ops_per_sample_culled_tri(ctr: dict, pool: dict) -> float:
 
 
 # recorded like ALGORITHMIC_OPS_PER_SAMPLE (the N = 1 cpu_baseline leg re-derives them live): the culled algorithms' figures
-ALGORITHMIC_OPS_PER_SAMPLE_CULLED = {"smoke": 2116.7, "triangles": 408416.6}
+ALGORITHMIC_OPS_PER_SAMPLE_CULLED = {"smoke": 2116.7, "triangles": 402477.1}
 
 
 def ops_per_sample(ctr: dict) -> float:

@@ -58,7 +58,7 @@ namespace {
 #define PT_MIN_WAVES_COOP 5 /* cooperative kernels: 93 VGPRs, no scratch (7 waves: 72 VGPRs + 76 B/lane of spills in the loop) */
 #endif
 #ifndef PT_MIN_WAVES_TRIPOOL
-#define PT_MIN_WAVES_TRIPOOL 3 /* triangle-pool kernels: the bound only keeps the allocator from spilling — without image textures they take ~122 VGPRs and run 4 waves per SIMD (the image-texture variants are held to 4 explicitly); 5, 6, 8 waves (96, 80, 64 VGPRs, 36-188 bytes of scratch) measured slower */
+#define PT_MIN_WAVES_TRIPOOL 6 /* triangle-pool kernels without image textures: 80 VGPRs + 116 bytes of scratch, six waves per SIMD (what 25 KB of LDS per workgroup allows).  With whole tiles per wave the frame time was the heaviest wave's chain and 4 waves (122 VGPRs, no scratch) measured best; with the stratified deal (lane_acquire) it is throughput: 1080p x 32 spp 2.89 s at 4 waves, 2.65 at 5, 2.51 at 6 (the image-texture variants are held to 4) */
 #endif
 #ifndef PT_MIN_WAVES_COOP_IMG
 #define PT_MIN_WAVES_COOP_IMG 5 /* 96 VGPRs + 60 B/lane of spills; spill-free needs 116 VGPRs = 4 waves: 496-hittable scene -9 % (A/B) */

@@ -66,8 +66,8 @@ struct TriPoolTuning {
   float M = 12.0f;      // PT_TRI_M (swept 8 ... 32 on cfg5: profiles/r03_tripool_sweep*.log): barycentric slack 1/M; the band width grows with M, the boxes' growth sigma' with 1/M
   float Mg = 96.0f;     // PT_TRI_MG: the grid's TIGHT slack (pairs with |a^| >= thr(Mg) are found within sigma'(Mg) of the triangle; the others of the grid's share, thr(M) <= |a^| < thr(Mg), pass a band test at Mg: see "compressed records")
   float Ma = 256.0f;    // relative slack of t: the walk runs to max (1 + 2.2 / (Ma - 1))
-  float cell = 1.0f;    // PT_TRI_CELL (swept 0.7 ... 3.0): grid cell edge in units of the median grown box extent
-  int res[3] = {128, 32, 16}; // PT_TRI_RES=a,b,c: cube-map resolution of the three band levels (powers of two <= 128: the device deals a level's rows to the 64 lanes)
+  float cell = 0.7f;    // PT_TRI_CELL (swept 0.35 ... 3.0; 0.5 / 0.7 / 1.0 / 1.4: 2.51 / 2.50 / 2.53 / 2.56 s at 1080p x 32 spp): grid cell edge in units of the median grown box extent
+  int res[3] = {128, 64, 32}; // PT_TRI_RES=a,b,c (128,32,16 / 128,64,32 / 128,128,64: 2.53 / 2.41 / 2.40 s at 1080p x 32 spp): cube-map resolution of the three band levels (powers of two <= 128: the device deals a level's rows to the 64 lanes)
   int min_run = 4096;   // PT_TRI_MIN: shorter triangle runs are scanned as before (PT_TRICULL=1: 256)
 };
 
