@@ -1083,7 +1083,8 @@ __device__ __forceinline__ unsigned long long* tri_slots() { __shared__ unsigned
 #endif
 #define PT_TRI_QUEUE (64 + 64 * (PT_TRI_GRID_PER_LANE > 4 ? PT_TRI_GRID_PER_LANE : 5))
 __device__ __forceinline__ int* tri_queue() { __shared__ int s[4 * PT_TRI_QUEUE]; return s; } // per wave: survivors of the filters waiting for the exact test
-__device__ __forceinline__ int* tri_bqueue() { __shared__ int s[4 * 768]; return s; } // per wave: band candidates past the integer band test, (record, index) pairs
+#define PT_TRI_BQUEUE 640
+__device__ __forceinline__ int* tri_bqueue() { __shared__ int s[4 * PT_TRI_BQUEUE]; return s; } // per wave (2 x (63 + 256) ints are needed): band candidates past the integer band test, (record, index) pairs
 __device__ __forceinline__ int* tri_rows() { __shared__ int s[4 * 264]; return s; } // per wave: the row table of the strip being scanned
 __device__ __forceinline__ unsigned long long tri_key(float t, int off) {
   return ((unsigned long long)(unsigned int)as_i(t) << 32) | (unsigned long long)(unsigned int)(0xffffff - off);
@@ -1285,7 +1286,7 @@ __device__ __forceinline__ bool tri_pool_scan(glb_f4p gblob, cst_f4p cblob, int 
       const float rL = __builtin_amdgcn_rcpf(L) * 1.00001f;
       return sa <= (pn * (rho + H5.y * L + H5.w * rL) + e1s) * 1.0737e9f; // 32767^2 (1 + 2e-5)
     };
-    int* const bq = tri_bqueue() + (threadIdx.x >> 6) * 768;
+    int* const bq = tri_bqueue() + (threadIdx.x >> 6) * PT_TRI_BQUEUE;
     int bn = 0;
     auto bpush = [&](bool p, int e0, int e1) {
       const unsigned long long m = __builtin_amdgcn_ballot_w64(p);
@@ -1414,7 +1415,7 @@ __device__ __forceinline__ bool tri_pool_scan(glb_f4p gblob, cst_f4p cblob, int 
   // lanes for most of the loop.
   const int n_always = (PT_TRI_ABLATE & 4) ? 0 : as_i(H3.z);
   const int astr = as_i(H9.w);
-  int* const aq = tri_bqueue() + (threadIdx.x >> 6) * 768; // pairs (lane of the ray, entry) past the band test
+  int* const aq = tri_bqueue() + (threadIdx.x >> 6) * PT_TRI_BQUEUE; // pairs (lane of the ray, entry) past the band test
   int an = 0, xn = 0;                                       // (tq: pairs past the noise radius)
   auto pair_push = [&](int* q, int& n, bool p, int s2, int e) {
     const unsigned long long m = __builtin_amdgcn_ballot_w64(p);
