@@ -1212,8 +1212,8 @@ __device__ __forceinline__ bool tri_pool_scan(glb_f4p gblob, cst_f4p cblob, int 
           // filter (i) of pt_tripool.hpp on the compressed records: the walked SEGMENT [0, lim] passes within the radius of the
           // centroid — the line within it, and the centroid's projection neither more than it behind the origin nor beyond lim —
           // for the TIGHT radius, or for the LOOSE one if the pair also passes the band test at Mg ("compressed records").
-          // (A second stage for the loose-only candidates — queue them, band test 64 at a time — removes 3 % of the instructions
-          // and costs 10 % in time: one more dependent LDS -> gather -> LDS stage per round.  Measured, not kept.)
+          // (A second stage for the loose-only candidates — queue them, band test 64 at a time — removes 3 % of the instructions; it
+          // cost 10 % while the frame time was the heaviest wave's chain and is neutral, 2.314 against 2.315 s, now.  Not kept.)
           const float cl = as_f((int)(unsigned int)(slot[src] >> 32));
           const float lim_ua = (cl + cl * kappa) * ua * 1.00001f;
           unsigned int passmask = 0;
