@@ -58,7 +58,7 @@ namespace {
 #define PT_MIN_WAVES_COOP 5 /* cooperative kernels: 93 VGPRs, no scratch (7 waves: 72 VGPRs + 76 B/lane of spills in the loop) */
 #endif
 #ifndef PT_MIN_WAVES_TRIPOOL
-#define PT_MIN_WAVES_TRIPOOL 7 /* triangle-pool kernels without image textures: 72 VGPRs + 144 bytes of scratch, seven waves per SIMD (what 22.1 KB of LDS per workgroup allow).  With whole tiles per wave the frame time was the heaviest wave's chain and 4 waves (122 VGPRs, no scratch) measured best; with the stratified deal (lane_acquire) it is throughput: 1080p x 32 spp 2.89 s at 4 waves, 2.65 at 5, 2.51 at 6, and 2.37 -> 2.32 from 6 to 7 at the final table settings (the image-texture variants are held to 4) */
+#define PT_MIN_WAVES_TRIPOOL 7 /* triangle-pool kernels: 72 VGPRs + 144 bytes of scratch (208 with image textures), seven waves per SIMD (what 22.1 KB of LDS per workgroup allow).  With whole tiles per wave the frame time was the heaviest wave's chain and 4 waves (122 VGPRs, no scratch) measured best; with the stratified deal (lane_acquire) it is throughput: 1080p x 32 spp 2.89 s at 4 waves, 2.65 at 5, 2.51 at 6, and 2.37 -> 2.32 from 6 to 7 at the final table settings; the image-texture variants (tools/tri_textured.py, 1080p x 16 spp) 1.41 s at 4 waves, 1.20 at 6, 1.17 at 7 */
 #endif
 #ifndef PT_MIN_WAVES_COOP_IMG
 #define PT_MIN_WAVES_COOP_IMG 5 /* 96 VGPRs + 60 B/lane of spills; spill-free needs 116 VGPRs = 4 waves: 496-hittable scene -9 % (A/B) */
@@ -411,7 +411,7 @@ __device__ __forceinline__ void lane_prepare(Lane& L, const KArgs& a) {
 // "lambertian + lightsource over solid textures" that carry no metal / glass / isotropic / checker / image code.
 template <int UV, bool LDS, bool MLDS, bool COOP, bool CL = false, bool FAST = false, bool BADOUEL = false, bool GRID = true, bool TRIPOOL = false,
           int MATS = MATS_ALL>
-__global__ __launch_bounds__(kBlock, TRIPOOL ? (UV ? 4 : PT_MIN_WAVES_TRIPOOL) : CL ? PT_MIN_WAVES_CL : COOP ? (UV ? PT_MIN_WAVES_COOP_IMG : PT_MIN_WAVES_COOP) : (UV ? PT_MIN_WAVES_IMG : PT_MIN_WAVES))
+__global__ __launch_bounds__(kBlock, TRIPOOL ? PT_MIN_WAVES_TRIPOOL : CL ? PT_MIN_WAVES_CL : COOP ? (UV ? PT_MIN_WAVES_COOP_IMG : PT_MIN_WAVES_COOP) : (UV ? PT_MIN_WAVES_IMG : PT_MIN_WAVES))
 void render_kernel(KArgs a) {
   constexpr bool IMG = UV == UV_TRACKED;
   typedef LaneT<CL> Lane;

@@ -55,17 +55,15 @@ def test_headline_kernels_fit_seven_waves_without_scratch(usage):
 def test_grid_walk_and_triangle_pool_kernels(usage):
     """The image-texture kernel cfg1 / cfg3 / cfg4 run (UV_WINNER, LDS, sphere-grid walk) holds 5 waves per SIMD — what the
     scene's 31 KB LDS image allows anyway — without scratch; the triangle-pool kernels (TRIPOOL = true: one ray at a time across the
-    wave over global tables) hold 7 without image textures, 4 with."""
+    wave over global tables) hold 7."""
     k1 = [v for k, v in usage.items() if re.search(r"render_kernelILi1ELb1ELb0ELb0ELb0ELb0ELb0ELb1ELb0E", k)]
     assert len(k1) == 1 and k1[0]["Occupancy [waves/SIMD]"] >= 5 and k1[0]["ScratchSize [bytes/lane]"] == 0, k1
     pool = {k: v for k, v in usage.items() if re.search(r"render_kernelILi[012]ELb0ELb0ELb0ELb0ELb[01]ELb0ELb1ELb1E", k)}
     assert len(pool) == 6, sorted(usage)
     for k, v in pool.items():
-        if "ILi0E" in k:   # no image textures (cfg5's kernels): SEVEN waves — with the stratified deal of pixels the pool is a throughput kernel,
-            # and seven waves at 72 VGPRs + ~36 dwords of scratch measured 20 % faster than four at 122 VGPRs without any (pt_render.hip)
-            assert v["Occupancy [waves/SIMD]"] >= 7 and v["ScratchSize [bytes/lane]"] <= 160, (k, v)
-        else:
-            assert v["Occupancy [waves/SIMD]"] >= 4 and v["ScratchSize [bytes/lane]"] <= 64, (k, v)
+        # SEVEN waves — with the stratified deal of pixels the pool is a throughput kernel, and seven waves at 72 VGPRs + 36-52 dwords of
+        # scratch measured 20 % faster than four at 122-128 VGPRs with (almost) none, with and without image textures (pt_render.hip)
+        assert v["Occupancy [waves/SIMD]"] >= 7 and v["ScratchSize [bytes/lane]"] <= (160 if "ILi0E" in k else 224), (k, v)
 
 
 def test_streaming_and_cooperative_kernels_without_image_textures(usage):
