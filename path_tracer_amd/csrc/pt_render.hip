@@ -95,6 +95,7 @@ struct KArgs {
   int tile_granular;   // PT_FLAG_TILE_GRANULAR
   int scatter_p;       // > 0 (triangle-pool kernels): queue positions are dealt to tiles in runs of 2^scatter_log pixels with this stride (lane_acquire)
   int scatter_log;
+  int lanes_cap;       // < 64 (triangle-pool kernels, fewer pixels than lanes): only the first lanes_cap lanes of a wave take pixels (lane_acquire)
   int n_hittables;
   int coop_prefix;     // >= 0: cooperative traversal allowed, list splittable up to this hittable; -1: disabled
   int fast_ok; // every rect/box coordinate finite and <= 2^60: rays may use the shared-reciprocal division
@@ -207,6 +208,9 @@ __host__ __device__ __forceinline__ uint32_t fast_seed(uint32_t pixel, uint32_t 
 // between lanes.  A wave leaves the phase when that queue is empty and its last wide pixel is done.
 template <bool FAST = false, typename Lane>
 __device__ __forceinline__ void lane_acquire(Lane& L, const KArgs& a) {
+  // (triangle-pool kernels: a wave's time is the sum over its lanes — when a launch has fewer pixels than lanes, every wave takes
+  // its share, lanes_cap pixels, instead of the first waves taking 64 each and the rest none)
+  if (a.lanes_cap < 64 && (int)(threadIdx.x & 63) >= a.lanes_cap) L.retired = true;
   const bool want = !L.live && !L.retired;
   const unsigned long long mask = __builtin_amdgcn_ballot_w64(want);
   if (mask == 0) return;
@@ -1235,7 +1239,14 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
     PT_HIP(hipMemsetAsync(a.queue, 0, 2 * sizeof(unsigned int), st));
     // one wave per tile is enough, except in the wide phase, where a split tile keeps G waves busy (how many tiles are
     // split is decided on the device, so such a launch simply fills the chip; surplus waves find the queues empty and exit)
-    const long long wanted = a.n_split ? (long long)resident_blocks : (launch_units + kWavesPerBlock - 1) / kWavesPerBlock;
+    long long wanted = a.n_split ? (long long)resident_blocks : (launch_units + kWavesPerBlock - 1) / kWavesPerBlock;
+    a.lanes_cap = 64;
+    if (a.scatter_p > 0) { // triangle-pool kernels: fill the chip and share the pixels out evenly (lane_acquire)
+      wanted = std::min<long long>(resident_blocks, ((long long)a.n_local_pixels + kBlock - 1) / kBlock * 64); // (at least one pixel per wave)
+      wanted = std::max<long long>(wanted, 1);
+      const long long waves = std::min<long long>(wanted, resident_blocks) * kWavesPerBlock;
+      a.lanes_cap = (int)std::min<long long>(64, std::max<long long>(1, ((long long)a.n_local_pixels + waves - 1) / waves));
+    }
     n_waves_resident = (int)std::min<long long>(wanted, resident_blocks) * kWavesPerBlock;
     dim3 grid((unsigned int)std::min<long long>(wanted, resident_blocks)), block(kBlock);
     hipLaunchKernelGGL(kernel, grid, block, shmem, st, a);
