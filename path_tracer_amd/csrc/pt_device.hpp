@@ -770,10 +770,149 @@ __device__ __forceinline__ void sphere_grid_walk(P recs, P cells, P cand, f4 g0,
   }
 }
 
+// ---- the walk, round 4: the wave still steps its walks together, but the candidates go through an LDS queue and are tested 64 PAIRS at a time
+// What the counters of the walk above say (496-hittable scene, profiles/r03_smoke_walk_counters.json, r04_walk_*): per wave and walk 6.4
+// wave-steps and 17.7 test trips for 127 lane-cells and 268 lane-tests — a test trip runs at 15 of 64 lanes, and whenever ONE of them has a
+// positive discriminant (a third of the trips) the whole wave walks through the root block: a correctly rounded square root and two
+// IEEE divisions, ~75 issue slots.  Instruction counts, from the ISA and SQ_INSTS_*: a wave-step ~48, a trip ~45 + 75 x 0.35.
+// Round 4 first tried per-lane cursors (a lane pushes up to two candidates of its cell per round or steps to its next cell, one ballot per
+// round): 9.6 rounds of ~125 slots + 4.9 batches — bit-exact, 58 of 64 lanes per batch, and NOT fewer instructions than the walk above
+// (SQ_INSTS_VALU + SALU + LDS per sample 196 -> 201): the bookkeeping of a round costs what the divergence did.  This version keeps the cheap
+// part of the old shape — the wave-synchronous DDA step and the loop to the largest candidate count — but a trip of that loop only QUEUES
+// (lane << 16 | sphere index | moving << 15) per candidate (a 16-bit read, a 32-bit write, the position from the trip's ballot + mbcnt:
+// ~17 slots), and whenever 64 pairs are queued the wave tests them together: each lane fetches its pair's ray from the owner lane
+// (ds_bpermute) and the sphere's record, evaluates the reference's test (sphere.hpp:59-93) and, for a root in range, lowers the owner's
+// slot of a per-wave LDS table with ONE 64-bit atomic minimum on (bits of t) << 32 | record offset: the smallest t wins and, among equal t,
+// the FIRST sphere in list order (sphere.hpp:77 needs t < max) — the tie rule of sphere_finish_unordered; the slot starts as the ray's hit
+// so far with ITS record offset, so an equal t replaces it iff the holder is a later record (an earlier run's hit, or a big sphere of this
+// run listed before the candidate, stays).  A candidate's t does not depend on the running maximum (first root if > min, else second root
+// if > min: the second root is never smaller than the first, so a first root that fails `t < max` takes the second down with it), hence
+// any order and any batching of the tests gives the scan's result.  A lane reads its slot back before a step looks at the limit: the walk
+// still ends where the next cell begins beyond the nearest hit so far — later than with immediate tests when pairs are still queued, never
+// earlier, and a later end only adds candidates.  Exactness of the culling itself is unchanged (pt_flatten.hpp: build_sphere_grid).
+// (the triangle pool's per-wave LDS arrays — tri_pool_scan below — declared here because kernels that carry both lend them to this walk)
+__device__ __forceinline__ unsigned long long* tri_slots() { __shared__ unsigned long long s[256]; return s; }
+#ifndef PT_TRI_GRID_PER_LANE
+#define PT_TRI_GRID_PER_LANE 4 /* grid candidates per lane and trip; 8 (one trip per cell, 159 VGPRs = three waves per SIMD) measured 4 % slower */
+#endif
+#define PT_TRI_QUEUE (64 + 64 * (PT_TRI_GRID_PER_LANE > 4 ? PT_TRI_GRID_PER_LANE : 5))
+__device__ __forceinline__ int* tri_queue() { __shared__ int s[4 * PT_TRI_QUEUE]; return s; } // per wave: survivors of the filters waiting for the exact test
+#ifndef PT_MAX_WAVES_PER_BLOCK
+#define PT_MAX_WAVES_PER_BLOCK 5
+#endif
+#define PT_SQ_CAP 128 /* 63 left over + one trip's pushes */
+__device__ __forceinline__ unsigned int* sphere_queue() { __shared__ unsigned int s[PT_MAX_WAVES_PER_BLOCK * PT_SQ_CAP]; return s; }
+__device__ __forceinline__ unsigned long long* sphere_slots() { __shared__ unsigned long long s[PT_MAX_WAVES_PER_BLOCK * 64]; return s; }
+
+// slot / q: this wave's 64 slots and its queue of PT_SQ_CAP entries (kernels with a triangle pool lend the pool's arrays: the two scans
+// never overlap)
+template <typename P, typename AcceptAt>
+__device__ __forceinline__ void sphere_grid_walk_queued(P recs, P cells, P cand, f4 g0, f4 g1, float frac, bool moves, int goff, const RayCtx& c,
+                                                        HitState& h, unsigned long long* const slot, unsigned int* const q, AcceptAt accept_at) {
+  const Ray& r = c.r;
+  const int lane = threadIdx.x & 63;
+  const float inv = g0.w, cell = g1.w;
+  const int nx = as_i(g1.x), ny = as_i(g1.y), nz = as_i(g1.z);
+  const float gx = (r.o.x - g0.x) * inv, gy = (r.o.y - g0.y) * inv, gz = (r.o.z - g0.z) * inv; // origin in cell units
+  const float rx = c.yx * cell, ry = c.yy * cell, rz = c.yz * cell;                           // 1 / (direction in cell units)
+  // slab clip of the line against the grid box [0, n]
+  const float ax = (0.0f - gx) * rx, bx = ((float)nx - gx) * rx;
+  const float ay = (0.0f - gy) * ry, by = ((float)ny - gy) * ry;
+  const float az = (0.0f - gz) * rz, bz = ((float)nz - gz) * rz;
+  const float t_in = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
+  const float t_out = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
+  const float t0 = __builtin_fmaxf(t_in, 0.0f);
+  float closest = h.closest; // the slot's t as last read back
+  auto limit = [&]() { const float m = __builtin_fminf(t_out, closest); return m + (__builtin_fabsf(m) * 1e-4f + 1e-4f); };
+  bool active = c.live && t0 <= limit();
+  // entry cell
+  const float px = gx + t0 * (r.d.x * inv), py = gy + t0 * (r.d.y * inv), pz = gz + t0 * (r.d.z * inv);
+  int ix = min(max((int)__builtin_floorf(px), 0), nx - 1);
+  int iy = min(max((int)__builtin_floorf(py), 0), ny - 1);
+  int iz = min(max((int)__builtin_floorf(pz), 0), nz - 1);
+  const bool fx = r.d.x > 0.0f, fy = r.d.y > 0.0f, fz = r.d.z > 0.0f; // walking towards larger indices?
+  float tmx = ((float)(ix + (fx ? 1 : 0)) - gx) * rx; // ray parameter at the next cell boundary, per axis
+  float tmy = ((float)(iy + (fy ? 1 : 0)) - gy) * ry;
+  float tmz = ((float)(iz + (fz ? 1 : 0)) - gz) * rz;
+  const float dtx = __builtin_fabsf(rx), dty = __builtin_fabsf(ry), dtz = __builtin_fabsf(rz);
+  const int stx = fx ? 1 : -1, sty = fy ? 1 : -1, stz = fz ? 1 : -1;
+  const unsigned long long key0 = ((unsigned long long)(unsigned int)as_i(h.closest) << 32) | (unsigned long long)(unsigned int)(h.hit >= 0 ? hit_off(h.hit) : 0);
+  slot[lane] = key0;
+  unsigned int hdr = 0;
+  if (active) hdr = dword_at(cells, (iz * ny + iy) * nx + ix);
+  int qn = 0;         // pairs queued (wave-uniform)
+  bool stale = false; // (wave-uniform) a batch ran since `closest` was last read back
+  // 64 pairs (the top of the queue) through the reference's test
+  auto test_batch = [&]() {
+    __builtin_amdgcn_wave_barrier();
+    const int n = min(qn, 64);
+    const bool on = lane < n;
+    const unsigned int e = q[qn - n + (on ? lane : 0)];
+    const int src = (int)(e >> 16);
+    PT_WALK_COUNT(6, 1);
+    PT_WALK_COUNT(5, n);
+    // the pair's ray, from its owner's registers
+    const V3 o = mk(__shfl(r.o.x, src, 64), __shfl(r.o.y, src, 64), __shfl(r.o.z, src, 64));
+    const V3 d = mk(__shfl(r.d.x, src, 64), __shfl(r.d.y, src, 64), __shfl(r.d.z, src, 64));
+    const float a = __shfl(c.a, src, 64);
+    float fr = 0.0f;
+    if (moves) fr = __shfl(frac, src, 64); // (wave-uniform: the run has moving spheres)
+    const int so = (int)(e & 0x7fffu) * SZ_SPHERE;
+    const f4 R0 = recs[so];
+    V3 center = xyz(R0);
+    if (moves) { if (e & 0x8000u) center = center + fr * xyz(recs[so + 2]); } // moving: sphere.hpp:54-55
+    const V3 oc = o - center;
+    const float b = dot(oc, d);
+    const float cc = dot(oc, oc) - __builtin_fabsf(R0.w);
+    const float disc = b * b - a * cc;
+    if (on && disc > 0) {
+      const float sq = sqrt_rn(disc);
+      float t = (-b - sq) / a;
+      if (!(t > PT_TMIN)) t = (-b + sq) / a;
+      if (t > PT_TMIN) atomicMin(&slot[src], ((unsigned long long)(unsigned int)as_i(t) << 32) | (unsigned long long)(unsigned int)(goff + so));
+    }
+    qn -= n;
+    stale = true;
+    __builtin_amdgcn_wave_barrier();
+  };
+  while (__builtin_amdgcn_ballot_w64(active) != 0) {
+    PT_WALK_COUNT(2, 1);
+    PT_WALK_COUNT(4, __builtin_popcountll(__builtin_amdgcn_ballot_w64(active)));
+    // the next cell (the axis whose boundary comes first; branch-free) and its header, requested BEFORE this cell's candidates are queued
+    const float tn = __builtin_fminf(tmx, __builtin_fminf(tmy, tmz));
+    const bool sx = tmx == tn, sy = !sx & (tmy == tn), sz = !sx & !sy;
+    const int jx = ix + (sx ? stx : 0), jy = iy + (sy ? sty : 0), jz = iz + (sz ? stz : 0);
+    const bool inside = ((unsigned)jx < (unsigned)nx) & ((unsigned)jy < (unsigned)ny) & ((unsigned)jz < (unsigned)nz);
+    unsigned int hdr_next = 0;
+    if (active & inside) hdr_next = dword_at(cells, (jz * ny + jy) * nx + jx);
+    const int count = (int)(hdr & 255u), first = (int)(hdr >> 8);
+    for (int k = 0;; ++k) {
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(k < count);
+      if (m == 0) break;
+      if (k < count) {
+        const unsigned int e = ushort_at(cand, first + k); // sphere index in the run | moving << 15
+        const int at = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+        q[at] = ((unsigned int)lane << 16) | e;
+      }
+      qn += __builtin_popcountll(m);
+      if (qn >= 64) test_batch();
+    }
+    if (stale) { closest = as_f((int)(unsigned int)(slot[lane] >> 32)); stale = false; }
+    // step: the walk ends where the next cell lies outside the grid or begins beyond the nearest hit so far
+    active = active & inside & !(tn > limit());
+    ix = jx; iy = jy; iz = jz;
+    tmx += sx ? dtx : 0.0f; tmy += sy ? dty : 0.0f; tmz += sz ? dtz : 0.0f;
+    hdr = active ? hdr_next : 0u;
+  }
+  if (qn > 0) test_batch();
+  const unsigned long long kf = slot[lane];
+  if (kf != key0) accept_at((int)(unsigned int)(kf & 0xffffffffull) - goff)(as_f((int)(unsigned int)(kf >> 32)));
+}
+
 // The whole run (recs = its first record, at blob offset goff).
 // GRID = false: the kernel does not carry the grid walk (the streaming kernel: its register budget belongs to the triangle
 // loop); a run with a grid is then scanned through its full lists.
-template <int K, bool GRID, typename P, typename AcceptAt>
+template <int K, bool GRID, bool TRIPOOL, typename P, typename AcceptAt>
 __device__ __forceinline__ void sphere_scan(P recs, cst_f4p cblob, int n, int goff, const RayCtx& c, HitState& h, AcceptAt accept_at) {
   const f4 aux = cblob[goff - 1];
   const int flags = as_i(aux.w), ns = as_i(aux.z), nm = n - ns;
@@ -832,7 +971,19 @@ __device__ __forceinline__ void sphere_scan(P recs, cst_f4p cblob, int n, int go
   const unsigned long long walk_t0 = __builtin_amdgcn_s_memtime();
   __builtin_amdgcn_sched_barrier(0);
 #endif
+#ifdef PT_WALK_OLD
   if constexpr (GRID) { if (walk) sphere_grid_walk(recs, recs + w_cell, recs + w_cand, wg0, wg1, frac, goff, c, h, accept_at); }
+#else
+  if constexpr (GRID) {
+    if (walk) {
+      unsigned long long* slot;
+      unsigned int* q;
+      if constexpr (TRIPOOL) { slot = tri_slots() + (threadIdx.x & ~63); q = (unsigned int*)(tri_queue() + (threadIdx.x >> 6) * PT_TRI_QUEUE); }
+      else { slot = sphere_slots() + (threadIdx.x & ~63); q = sphere_queue() + (threadIdx.x >> 6) * PT_SQ_CAP; }
+      sphere_grid_walk_queued(recs, recs + w_cell, recs + w_cand, wg0, wg1, frac, (flags & 2) != 0, goff, c, h, slot, q, accept_at);
+    }
+  }
+#endif
 #ifdef PT_STAMPS_WALK
   asm volatile("" ::"v"(h.closest), "v"(h.hit));
   __builtin_amdgcn_sched_barrier(0);
@@ -1077,12 +1228,6 @@ __device__ __forceinline__ unsigned int gdword(glb_f4p gblob, int base_f4, int i
 #define PT_TRI_ABLATE 0 /* timing experiments only: 1 no grid, 2 no band levels, 4 no always list (wrong images) */
 #endif
 typedef short short2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned long long* tri_slots() { __shared__ unsigned long long s[256]; return s; }
-#ifndef PT_TRI_GRID_PER_LANE
-#define PT_TRI_GRID_PER_LANE 4 /* grid candidates per lane and trip; 8 (one trip per cell, 159 VGPRs = three waves per SIMD) measured 4 % slower */
-#endif
-#define PT_TRI_QUEUE (64 + 64 * (PT_TRI_GRID_PER_LANE > 4 ? PT_TRI_GRID_PER_LANE : 5))
-__device__ __forceinline__ int* tri_queue() { __shared__ int s[4 * PT_TRI_QUEUE]; return s; } // per wave: survivors of the filters waiting for the exact test
 #define PT_TRI_BQUEUE 640
 __device__ __forceinline__ int* tri_bqueue() { __shared__ int s[4 * PT_TRI_BQUEUE]; return s; } // per wave (2 x (63 + 256) ints are needed): band candidates past the integer band test, (record, index) pairs
 __device__ __forceinline__ int* tri_rows() { __shared__ int s[4 * 264]; return s; } // per wave: the row table of the strip being scanned
@@ -1519,7 +1664,7 @@ __device__ __forceinline__ void hit_records(P recs, cst_f4p cblob, int kind, int
     };
     // (a run of one or two spheres — a lone ball between other kinds — is tested in place: the list machinery would cost it
     // two dependent scalar loads before the first record is even requested)
-    if (WHOLE && n > 2) sphere_scan<(TRIP >= 2 ? 4 : 2), GRID>(recs, cblob, n, goff, c, h, accept_at);
+    if (WHOLE && n > 2) sphere_scan<(TRIP >= 2 ? 4 : 2), GRID, TRIPOOL>(recs, cblob, n, goff, c, h, accept_at);
     else {
       TimeFrac tf = time_frac_none();
       for (int i = 0; i < n; ++i, off += SZ_SPHERE) sphere_roots(recs, off, c, PT_TMIN, h.closest, true, tf, accept_at(off));

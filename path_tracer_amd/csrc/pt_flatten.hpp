@@ -506,7 +506,13 @@ inline int flatten(const PtSceneDesc* sc, Flat& out, std::string& err, bool allo
     if (run.kind == DK_TRI) { // (Badouel-strategy runs have no pool: one parity-completeness loop)
       int32_t hdr = 0;
       bool pooled = false;
-      if (allow_tri_pool) {
+      // The pool's tables ride in the blob, whose record offsets are 24 bits (hit ids, tri_key): ~17 F4 per triangle (grid lists +
+      // inline filter records + the Morton-ordered copy + the band levels) beside the 3 F4 of the records themselves.  A run whose
+      // tables would push the blob past 2^24 F4 (~830 k triangles) is flattened WITHOUT a pool — the streaming full scan, as before
+      // round 3 — instead of building gigabytes of tables only to fail with PT_ERR_TOO_LARGE; pt_scene_create's retry covers what this
+      // estimate misses.
+      const bool pool_fits = (double)b.size() + 20.0 * (double)run.count < (double)(1u << 24);
+      if (allow_tri_pool && pool_fits) {
         const TriPool tp = build_tri_pool(&sc->hittables[run.first], run.count, tri_tune);
         if (tp.ok) {
           hdr = put_tri_pool(b, tp, &sc->hittables[run.first]);

@@ -67,6 +67,10 @@ namespace {
 enum { UV_NONE = 0, UV_WINNER = 1, UV_TRACKED = 2 };
 constexpr int kBlock = 256;                 // 4 wavefronts = 4 tiles per workgroup
 constexpr int kWavesPerBlock = kBlock / 64;
+#ifndef PT_GRID_BLOCK
+#define PT_GRID_BLOCK 320
+#endif
+constexpr int kGridBlock = PT_GRID_BLOCK;   // workgroup size of the LDS-resident kernels that walk a sphere grid (render_kernel: BLOCK)
 constexpr size_t kMaxLdsBlob = 64 * 1024;   // blob staged in LDS when it fits
 constexpr size_t kMaxLdsWithMaterials = 16 * 1024; // stage the material table too when records + materials are this small
 constexpr size_t kMaxLdsColdScene = 10 * 1024;    // records + materials this small: the 8-wave kernel with LDS-resident cold lane state
@@ -413,17 +417,23 @@ __device__ __forceinline__ void lane_prepare(Lane& L, const KArgs& a) {
 // (such scenes are far beyond LDS), its own register budget.
 // MATS: the material / texture kinds the scene can contain (pt_device.hpp: MATS_*): the headline family has instantiations for
 // "lambertian + lightsource over solid textures" that carry no metal / glass / isotropic / checker / image code.
+// BLOCK: threads per workgroup.  The loop has no barrier, so the workgroup size only decides how many waves share one LDS image of the scene:
+// the 496-hittable scene's 31 KB image + the queued walk's per-wave LDS (1 KB) fit four workgroups per CU, i.e. four waves per SIMD at 256
+// threads and five at 320 (kGridBlock).
 template <int UV, bool LDS, bool MLDS, bool COOP, bool CL = false, bool FAST = false, bool BADOUEL = false, bool GRID = true, bool TRIPOOL = false,
-          int MATS = MATS_ALL>
-__global__ __launch_bounds__(kBlock, TRIPOOL ? PT_MIN_WAVES_TRIPOOL : CL ? PT_MIN_WAVES_CL : COOP ? (UV ? PT_MIN_WAVES_COOP_IMG : PT_MIN_WAVES_COOP) : (UV ? PT_MIN_WAVES_IMG : PT_MIN_WAVES))
+          int MATS = MATS_ALL, int BLOCK = kBlock>
+__global__ __launch_bounds__(BLOCK, TRIPOOL ? PT_MIN_WAVES_TRIPOOL : CL ? PT_MIN_WAVES_CL : COOP ? (UV ? PT_MIN_WAVES_COOP_IMG : PT_MIN_WAVES_COOP) : (UV ? PT_MIN_WAVES_IMG : PT_MIN_WAVES))
 void render_kernel(KArgs a) {
   constexpr bool IMG = UV == UV_TRACKED;
   typedef LaneT<CL> Lane;
+  static_assert(!CL || BLOCK == kBlock, "the LDS-resident cold lane state is laid out for kBlock threads");
+  static_assert(BLOCK % 64 == 0 && BLOCK / 64 <= PT_MAX_WAVES_PER_BLOCK, "per-wave LDS arrays are sized for PT_MAX_WAVES_PER_BLOCK waves");
+  static_assert(!TRIPOOL || BLOCK == kBlock, "the triangle pool's per-wave LDS arrays are sized for kBlock threads");
   __shared__ float cold_slots[CL ? kColdSlots * kBlock : 1];
   extern __shared__ f4 smem[];
   if (LDS) {
     const int n = a.blob_f4 + (MLDS ? a.mats_f4 : 0); // a.mats == a.blob + a.blob_f4 (one device buffer)
-    for (int i = threadIdx.x; i < n; i += kBlock) smem[i] = a.blob[i];
+    for (int i = threadIdx.x; i < n; i += BLOCK) smem[i] = a.blob[i];
     __syncthreads();
   }
 #ifdef PT_STAMPS_WALK
@@ -822,7 +832,9 @@ static int flatten_with_env(const PtSceneDesc* desc, ptf::Flat& flat, std::strin
   // pool (BASELINE config 5, 100 k triangles: 68.9 -> 49.8 s per frame, bit-identical); PT_TRICULL=1 lowers that to 256 (the fuzz
   // tests), PT_NO_TRICULL switches the pools off (the round-2 path: every triangle streamed and tested), PT_TRI_MIN sets the
   // threshold, PT_TRI_M / PT_TRI_CELL the pool's barycentric slack 1/M and its grid cell (in median grown boxes).
-  const bool allow_tri = std::getenv("PT_NO_TRICULL") == nullptr;
+  bool allow_tri = std::getenv("PT_NO_TRICULL") == nullptr;
+  for (int i = 0; desc && desc->hittables && i < desc->n_hittables && allow_tri; i++) // scenes with Badouel-strategy triangles render through the
+    if (desc->hittables[i].kind == PT_HIT_TRIANGLE && desc->hittables[i].strategy == PT_TRI_BADOUEL) allow_tri = false; // round-2 kernels: no dead tables
   ptf::TriPoolTuning tri;
   if (std::getenv("PT_TRICULL")) tri.min_run = 256;
   if (const char* e = std::getenv("PT_TRI_M")) tri.M = (float)std::atof(e);
@@ -831,6 +843,10 @@ static int flatten_with_env(const PtSceneDesc* desc, ptf::Flat& flat, std::strin
   if (const char* e = std::getenv("PT_TRI_CELL")) tri.cell = (float)std::atof(e);
   if (const char* e = std::getenv("PT_TRI_MIN")) tri.min_run = std::max(1, std::atoi(e));
   int rc = ptf::flatten(desc, flat, err, allow_grid, box_cull, tune, allow_tri, tri);
+  if (rc == PT_ERR_TOO_LARGE && allow_tri) { // the pool's tables overflowed the 24-bit record offsets: the scene without a pool may still fit
+    std::string err2;
+    if (ptf::flatten(desc, flat, err2, allow_grid, box_cull, tune, false, tri) == PT_OK) rc = PT_OK;
+  }
   if (rc) return rc;
   if (flat.grid_spheres > 0 && flat.blob.size() * 16 > kMaxLdsBlob) {
     ptf::Flat plain;
@@ -863,9 +879,11 @@ struct EnvKnobs {
   float model_fixed = 2400.0f, model_chain = 2400.0f; // PT_MODEL_FIXED / PT_MODEL_CHAIN: constants of the makespan model (lpt_order_kernel)
   int scatter_log = 0;     // PT_SCATTER_LOG: log2 of the pixels of one tile that a wave takes together (0: every lane a pixel of another tile)
   bool lpt_with_scatter = false; // PT_LPT_SCATTER: the cost probe + heaviest-first order also for scattered (triangle-pool) renders
+  int grid_block = kGridBlock; // PT_GRID_BLOCK=256: the grid kernels at the common workgroup size (A/B)
   bool no_scatter = false; // PT_NO_SCATTER: triangle-pool kernels hand out whole tiles' pixels to a wave again (lane_acquire)
   EnvKnobs() {
     no_scatter = std::getenv("PT_NO_SCATTER") != nullptr;
+    if (const char* e = std::getenv("PT_GRID_BLOCK")) grid_block = std::atoi(e) == kBlock ? kBlock : kGridBlock;
     lpt_with_scatter = std::getenv("PT_LPT_SCATTER") != nullptr;
     if (const char* e = std::getenv("PT_SCATTER_LOG")) scatter_log = std::min(5, std::max(0, std::atoi(e)));
     if (const char* e = std::getenv("PT_BLOCKS_PER_CU")) blocks_per_cu = std::max(1, std::atoi(e));
@@ -1219,12 +1237,13 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
   const bool use_grid = s->grid_spheres > 0 && resident /* the streaming kernel scans the full lists */ && local_tiles >= s->knobs.grid_min_tiles && !(p->flags & PT_FLAG_FORCE_COOP);
   const bool coop = lds && a.coop_prefix >= 0 && !use_grid && (s->traversal_cost >= kCoopMinTraversal || (p->flags & PT_FLAG_FORCE_COOP));
   // Persistent grid: no more workgroups than the chip holds at once; lanes pull pixels from the queue.
-  auto launch = [&](auto kernel) -> int {
+  auto launch = [&](auto kernel, int block_threads = kBlock) -> int {
+    const int waves_per_block = block_threads / 64;
     int per_cu = 0;
     auto cached = s->occupancy.find((const void*)kernel);
     if (cached != s->occupancy.end()) per_cu = cached->second;
     else {
-      PT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, shmem));
+      PT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block_threads, shmem));
       s->occupancy[(const void*)kernel] = per_cu;
     }
     if (s->knobs.blocks_per_cu) per_cu = std::min(per_cu, s->knobs.blocks_per_cu); // tuning knob
@@ -1239,16 +1258,16 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
     PT_HIP(hipMemsetAsync(a.queue, 0, 2 * sizeof(unsigned int), st));
     // one wave per tile is enough, except in the wide phase, where a split tile keeps G waves busy (how many tiles are
     // split is decided on the device, so such a launch simply fills the chip; surplus waves find the queues empty and exit)
-    long long wanted = a.n_split ? (long long)resident_blocks : (launch_units + kWavesPerBlock - 1) / kWavesPerBlock;
+    long long wanted = a.n_split ? (long long)resident_blocks : (launch_units + waves_per_block - 1) / waves_per_block;
     a.lanes_cap = 64;
     if (a.scatter_p > 0) { // triangle-pool kernels: fill the chip and share the pixels out evenly (lane_acquire)
-      wanted = std::min<long long>(resident_blocks, ((long long)a.n_local_pixels + kBlock - 1) / kBlock * 64); // (at least one pixel per wave)
+      wanted = std::min<long long>(resident_blocks, ((long long)a.n_local_pixels + block_threads - 1) / block_threads * 64); // (at least one pixel per wave)
       wanted = std::max<long long>(wanted, 1);
-      const long long waves = std::min<long long>(wanted, resident_blocks) * kWavesPerBlock;
+      const long long waves = std::min<long long>(wanted, resident_blocks) * waves_per_block;
       a.lanes_cap = (int)std::min<long long>(64, std::max<long long>(1, ((long long)a.n_local_pixels + waves - 1) / waves));
     }
-    n_waves_resident = (int)std::min<long long>(wanted, resident_blocks) * kWavesPerBlock;
-    dim3 grid((unsigned int)std::min<long long>(wanted, resident_blocks)), block(kBlock);
+    n_waves_resident = (int)std::min<long long>(wanted, resident_blocks) * waves_per_block;
+    dim3 grid((unsigned int)std::min<long long>(wanted, resident_blocks)), block((unsigned int)block_threads);
     hipLaunchKernelGGL(kernel, grid, block, shmem, st, a);
     PT_HIP(hipGetLastError());
     PT_HIP(hipEventRecord(s->ring_done[slot], st));
@@ -1288,6 +1307,10 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
     if (coop) return mlds ? launch(render_kernel<UV, true, true, true>) : launch(render_kernel<UV, true, false, true>);
     if constexpr (UV == UV_NONE) { // small scene: cold lane state in LDS (7 workgroups x (scene + 8 KB) per CU)
       if (mlds && shmem <= kMaxLdsColdScene && !s->knobs.no_cold_lds) return launch(render_kernel<UV, true, true, false, true>);
+    }
+    if (use_grid && s->knobs.grid_block != kBlock) { // the queued grid walk: five waves share one LDS image of the scene (render_kernel: BLOCK)
+      return mlds ? launch(render_kernel<UV, true, true, false, false, false, false, true, false, MATS_ALL, kGridBlock>, kGridBlock)
+                  : launch(render_kernel<UV, true, false, false, false, false, false, true, false, MATS_ALL, kGridBlock>, kGridBlock);
     }
     return mlds ? launch(render_kernel<UV, true, true, false>) : launch(render_kernel<UV, true, false, false>);
   };
