@@ -790,6 +790,12 @@ __device__ __forceinline__ void sphere_grid_walk(P recs, P cells, P cand, f4 g0,
 // any order and any batching of the tests gives the scan's result.  A lane reads its slot back before a step looks at the limit: the walk
 // still ends where the next cell begins beyond the nearest hit so far — later than with immediate tests when pairs are still queued, never
 // earlier, and a later end only adds candidates.  Exactness of the culling itself is unchanged (pt_flatten.hpp: build_sphere_grid).
+// Measured on the 496-hittable scene at 1080p x 1024 spp (profiles/r04_walk_*): 450 -> 436 ms, VALU wave-instructions per sample 131.8 ->
+// 115.2 (SALU 60.8 -> 65.3, LDS 3.8 -> 6.5), lane utilisation 0.515 -> 0.59, 4.8 batches at 58 of 64 lanes instead of 17.7 trips at 15.
+// Two follow-ups measured and NOT kept: the roots of a batch deferred until a lane finds a second positive discriminant or the walk ends
+// (the root block then runs 1-2 times per walk instead of 4, but hits no longer end walks early: 438 -> 476 ms), and the same deferral for
+// the listed big spheres (a first pass notes positive discriminants per lane, a second runs the roots per lane: VALU per sample 115 ->
+// 129, 436 -> 447 ms — with 7 listed spheres the per-lane gather + recomputation costs more than the ~4 shared root blocks it replaces).
 // (the triangle pool's per-wave LDS arrays — tri_pool_scan below — declared here because kernels that carry both lend them to this walk)
 __device__ __forceinline__ unsigned long long* tri_slots() { __shared__ unsigned long long s[256]; return s; }
 #ifndef PT_TRI_GRID_PER_LANE
@@ -871,8 +877,8 @@ __device__ __forceinline__ void sphere_grid_walk_queued(P recs, P cells, P cand,
       if (!(t > PT_TMIN)) t = (-b + sq) / a;
       if (t > PT_TMIN) atomicMin(&slot[src], ((unsigned long long)(unsigned int)as_i(t) << 32) | (unsigned long long)(unsigned int)(goff + so));
     }
-    qn -= n;
     stale = true;
+    qn -= n;
     __builtin_amdgcn_wave_barrier();
   };
   while (__builtin_amdgcn_ballot_w64(active) != 0) {

@@ -68,7 +68,7 @@ enum { UV_NONE = 0, UV_WINNER = 1, UV_TRACKED = 2 };
 constexpr int kBlock = 256;                 // 4 wavefronts = 4 tiles per workgroup
 constexpr int kWavesPerBlock = kBlock / 64;
 #ifndef PT_GRID_BLOCK
-#define PT_GRID_BLOCK 320
+#define PT_GRID_BLOCK 256
 #endif
 constexpr int kGridBlock = PT_GRID_BLOCK;   // workgroup size of the LDS-resident kernels that walk a sphere grid (render_kernel: BLOCK)
 constexpr size_t kMaxLdsBlob = 64 * 1024;   // blob staged in LDS when it fits

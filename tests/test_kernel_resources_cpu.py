@@ -57,7 +57,10 @@ def test_grid_walk_and_triangle_pool_kernels(usage):
     scene's 31 KB LDS image allows anyway — without scratch; the triangle-pool kernels (TRIPOOL = true: one ray at a time across the
     wave over global tables) hold 7."""
     k1 = [v for k, v in usage.items() if re.search(r"render_kernelILi1ELb1ELb0ELb0ELb0ELb0ELb0ELb1ELb0E", k)]
-    assert len(k1) == 1 and k1[0]["Occupancy [waves/SIMD]"] >= 5 and k1[0]["ScratchSize [bytes/lane]"] == 0, k1
+    # round 4: the queued walk (64 (ray, sphere) pairs per batch) keeps five more values live across a batch: 20 bytes of scratch at the
+    # 96-register budget, stored before and reloaded after the walk — none inside its loops (A/B against 128 registers and no scratch:
+    # equal, profiles/r04_walk_ab.txt)
+    assert len(k1) == 1 and k1[0]["Occupancy [waves/SIMD]"] >= 5 and k1[0]["ScratchSize [bytes/lane]"] <= 24, k1
     pool = {k: v for k, v in usage.items() if re.search(r"render_kernelILi[012]ELb0ELb0ELb0ELb0ELb[01]ELb0ELb1ELb1E", k)}
     assert len(pool) == 6, sorted(usage)
     for k, v in pool.items():
