@@ -59,7 +59,7 @@ OPS = dict(
 # Algorithmic lane-ops per sample of the standard scenes at depth 50: oracle exit-point counters (a 480x270x4 render;
 # 96x54x1 for the mesh) priced with OPS above.  Recorded so that ranks of an N>1 job, where the cpu_baseline leg does
 # not run, need nothing from oracle/; the N=1 cpu_baseline leg re-derives the figure live and reports that.
-ALGORITHMIC_OPS_PER_SAMPLE = {"cornell": 2062.7, "smoke": 39395.4, "triangles": 402477.1}
+ALGORITHMIC_OPS_PER_SAMPLE = {"cornell": 2062.7, "smoke": 39395.4, "triangles": 8220663.0}  # the REFERENCE's algorithm as written (never the culled figures below)
 
 # The 496-hittable scene does NOT run the reference's algorithm as written: 476 of its 489 spheres sit in an exact culling grid
 #  and a ray tests the spheres of the cells it crosses instead of all of them.  Pricing the kernel against the
@@ -67,7 +67,30 @@ ALGORITHMIC_OPS_PER_SAMPLE = {"cornell": 2062.7, "smoke": 39395.4, "triangles": 
 # runs: everything but the gridded spheres as counted by the oracle, plus the grid walk as counted IN the kernel
 # (profiles/r03_smoke_walk_counters.json: diagnostic build, tools/stamps.py): cells visited x the ops of a DDA step, walks x the
 # ops of a walk's set-up, grid sphere tests priced like the oracle's sphere tests.
-GRID_WALK = {"smoke": dict(cells_per_sample=6.44, tests_per_sample=13.61, source="profiles/r03_smoke_walk_counters.json")}
+def counted_in_kernel(kind: str, scene: str, profiles_dir=None):
+    """The in-kernel counters a culled algorithm is priced with — `kind` "walk" (sphere grid: profiles/*_walk_counters.json, written
+    by tools/stamps.py with PT_WALK_JSON) or "tripool" (triangle pool: profiles/*_tripool_counters.json, tools/tri_counters.py with
+    PT_TRI_JSON) — selected like the PMC summaries: only records marked `"final": true`, the highest `"round"` wins.  Returns the
+    record with its file name under "source", or None (the kernel is then priced as the reference's algorithm as written)."""
+    best, best_round = None, -1
+    for f in (Path(profiles_dir) if profiles_dir else ROOT / "profiles").glob(f"*_{kind}_counters.json"):
+        try:
+            d = json.loads(f.read_text())
+        except Exception:  # noqa: BLE001
+            continue
+        if d.get("final") and d.get("scene") == scene and int(d.get("round", 0)) > best_round:
+            best, best_round = dict(d, source=f"profiles/{f.name}"), int(d.get("round", 0))
+    return best
+
+
+def grid_walk_counters(scene: str, profiles_dir=None):
+    d = counted_in_kernel("walk", scene, profiles_dir)
+    if not d:
+        return None
+    return dict(cells_per_sample=d["per_sample"]["cells_visited"], tests_per_sample=d["per_sample"]["grid_sphere_tests"], source=d["source"])
+
+
+GRID_WALK = {"smoke": grid_walk_counters("smoke")}
 OPS_GRID = dict(step=19,    # min3 (2) + axis select (3) + index step (3) + bounds (3) + boundary update (3) + header decode (2) + limit (3)
                 setup=45)   # origin and reciprocal direction in cell units (9), slab clip (14), entry cell (12), first boundaries (9), sign selects (1)
 
@@ -96,8 +119,16 @@ def ops_per_sample_culled(ctr: dict, n_spheres: int, grid_spheres: int, walk: di
 # its cube-map strips and of the always list, and the reference's test on the few survivors.  Counted in the kernel (diagnostic
 # build `make stamps EXTRA=-DPT_STAMPS_TRI`, tools/tri_counters.py; profiles/r03_tripool_counters.txt): 41.5 grid rounds of 64
 # candidates, 17.2 band trips x 51.4 lanes x 4 records, 3 624 always-list records, 4.3 grid cells per ray.
-TRI_POOL = {"triangles": dict(exact_per_ray=396.5 + 25.7 + 29.4, grid_filter_per_ray=41.5 * 64, band_per_ray=15.1 * 50.0 * 4 + 3624,
-                              noise_per_ray=594.5 + 774.8, cells_per_ray=5.2, source="profiles/r03_tripool_counters.txt")}
+def tri_pool_counters(scene: str, profiles_dir=None):
+    d = counted_in_kernel("tripool", scene, profiles_dir)
+    if not d:
+        return None
+    r = d["per_ray"]
+    return dict(exact_per_ray=r["exact_tests"], grid_filter_per_ray=r["grid_filter_tests"], band_per_ray=r["band_tests"] + r["always_tests"],
+                noise_per_ray=r["noise_radius_tests"], cells_per_ray=r["grid_cells"], source=d["source"])
+
+
+TRI_POOL = {"triangles": tri_pool_counters("triangles")}
 OPS_TRI_POOL = dict(band=8,        # d . g (5) + |.| + rho + c, compare (3)
                     grid_filter=20,  # C - o (3), cross (9), |.|^2 (5), radius^2 |d|^2 + compare (3): the tight line test of a grid candidate
                     noise=33,      # the noise-radius filter of a pair past the band test: |a'| - ea |d| (4), radius (10), line test (19)
@@ -297,6 +328,7 @@ def main() -> None:
         """`warmup` untimed + exactly `steps` timed steps of the W x H frame; returns (seconds, kernel ms, last frame)."""
         cam = scenes.make_camera(cam_args, W, H)
         kernel_ms = []
+        exchange = []  # (start, end) events around gather + un-interleave of every step (torch's current stream waits for the collective)
         fb = None
         # launch workspaces sized before the timed region, so that no timed step allocates (also with --warmup 0)
         ds.reserve(W, H, SPP, DEPTH, rank if dist_path else 0, world if dist_path else 1, args.flags)
@@ -308,11 +340,17 @@ def main() -> None:
                 return fb
             local, ms = R.render(W, H, SPP, ds, cam, DEPTH, flags=args.flags, shard_index=rank, shard_count=world, timed=True)
             kernel_ms.append(ms)
-            return R.gather_frame(local, W, H)  # one RCCL gather of the float tiles to rank 0 + un-interleave
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = R.gather_frame(local, W, H)  # one RCCL gather of the float tiles to rank 0 + un-interleave
+            e1.record()
+            exchange.append((e0, e1))
+            return out
 
         for _ in range(warmup):
             step()
         kernel_ms.clear()
+        exchange.clear()
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -320,19 +358,27 @@ def main() -> None:
         barrier()
         elapsed = time.perf_counter() - t0
         kern = sum(kernel_ms) / max(1, len(kernel_ms))
+        detail = None
         if dist_path:
+            xch = sum(a.elapsed_time(b) for a, b in exchange) / max(1, len(exchange))  # ms per step on this rank
+            mine = torch.tensor([kern, xch], dtype=torch.float64, device="cuda")
+            every = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(every, mine)  # every rank's own figures: the slowest rank sets the step, the others show the balance
+            detail = {"kernel_ms_per_rank": [round(float(t[0]), 3) for t in every],
+                      "gather_unshard_ms_per_rank": [round(float(t[1]), 3) for t in every],
+                      "gather_unshard_ms_root": round(float(every[0][1]), 3)}
             t = torch.tensor([elapsed, kern], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)  # the slowest rank's clock
             elapsed, kern = float(t[0]), float(t[1])
-        return elapsed, kern, fb, cam
+        return elapsed, kern, fb, cam, detail
 
     Ww, Hw = weak_frame(W1, H1, world)
     W, H = (Ww, Hw) if (world > 1 and args.scaling == "weak") else (W1, H1)
-    elapsed, kern_ms, fb, cam = measure(W, H, args.steps, args.warmup)
+    elapsed, kern_ms, fb, cam, dist_detail = measure(W, H, args.steps, args.warmup)
     other = None
     if world > 1:  # the other scaling mode, reported beside the headline (same steps / warmup)
         Wo, Ho = (W1, H1) if args.scaling == "weak" else (Ww, Hw)
-        eo, ko, _, _ = measure(Wo, Ho, args.steps, args.warmup)
+        eo, ko, _, _, _ = measure(Wo, Ho, args.steps, args.warmup)
         other = {"scaling": "strong" if args.scaling == "weak" else "weak", "frame": f"{Wo}x{Ho}",
                  "value": round(Wo * Ho * SPP * args.steps / eo / 1e6, 2), "unit": "Msamples/s",
                  "ms_per_step": round(eo / args.steps * 1e3, 3), "kernel_ms": round(ko, 3)}
@@ -352,13 +398,13 @@ def main() -> None:
             cw, ch, cs = (480, 270, 4) if scene_name != "triangles" else (96, 54, 1)
             _, ctr = orc.render(packed, scenes.make_camera(cam_args, cw, ch).c, cw, ch, cs, DEPTH, counters=True)
             ops = ops_per_sample(ctr.as_dict())  # exit-point counters -> algorithmic ops per sample, live
-            if scene_name in GRID_WALK and not os.environ.get("PT_NO_GRID"):
+            if GRID_WALK.get(scene_name) and not os.environ.get("PT_NO_GRID"):
                 import ctypes as C_
                 from path_tracer_amd import abi as abi_
                 st = (C_.c_int32 * 8)()
                 abi_.check(abi_.load_library().pt_debug_tri_pool(C_.byref(packed.desc), st), "pt_debug_tri_pool")
                 ops_culled = ops_per_sample_culled(ctr.as_dict(), sum(1 for k in packed.kinds() if k == abi_.PT_HIT_SPHERE), st[7], GRID_WALK[scene_name])
-            if scene_name in TRI_POOL and not os.environ.get("PT_NO_TRICULL"):
+            if TRI_POOL.get(scene_name) and not os.environ.get("PT_NO_TRICULL"):
                 ops_culled = ops_per_sample_culled_tri(ctr.as_dict(), TRI_POOL[scene_name])
             # bounded sample of the same workload, sized for ~15 s of CPU work from a 1-spp probe
             bw, bh = (W, H) if scene_name != "triangles" else (240, 135)
@@ -405,6 +451,18 @@ def main() -> None:
         if ops_culled:  # a kernel that provably skips tests is priced for the algorithm it runs; the reference's figure rides beside
             ops = ops_culled
         achieved = ops * kernel_samples_per_s / 1e12 / world  # per GPU
+        # algorithmic HBM bytes of one launch: the frame written once (12 B per pixel of this rank's share) + the scene read once
+        # (the flattened blob with its culling tables, the material table, the texture atlas)
+        import ctypes as C_
+        from path_tracer_amd import abi as abi_
+        st_ = (C_.c_int32 * 8)()
+        abi_.check(abi_.load_library().pt_debug_tri_pool(C_.byref(packed.desc), st_), "pt_debug_tri_pool")
+        scene_bytes = int(st_[6]) * 16 + int(packed.desc.n_materials) * 64 + int(packed.desc.atlas_bytes)
+        algorithmic_bytes = W * H * 12 // world + scene_bytes
+        valu_frac = achieved / PEAK_TLANEOPS
+        # memory leg: bytes that went past L2 (FETCH_SIZE + WRITE_SIZE of the committed PMC passes of this workload) / kernel time / 8 TB/s
+        mem_frac = (pmc[0] / (kern_ms * 1e-3) / 8e12) if pmc else None
+        bound = "hbm" if (mem_frac is not None and mem_frac > valu_frac) else "valu"
         headline = (scene_name, W1, H1, SPP) == ("cornell", 1920, 1080, 1024)
         at = "1080p 1024spp" if (W, H, SPP) == (1920, 1080, 1024) else f"{W}x{H} {SPP}spp"
         scaling = args.scaling  # (at N = 1 both modes coincide; the label stays the one the N > 1 lines of the same sweep carry)
@@ -420,20 +478,26 @@ def main() -> None:
                        "baseline_config": args.config, "hittables": packed.n_hittables, "mode": args.mode,
                        "frame_at_1_gpu": f"{W1}x{H1}",
                        "sharding": "whole frame" if world == 1 else f"8x8 tiles round-robin over {world} ranks + RCCL gather"},
-            "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": round(PEAK_TLANEOPS, 1), "unit": "Tlaneop/s",
-                         "frac": round(achieved / PEAK_TLANEOPS, 4),
+            # `bound`: the larger of the VALU fraction (algorithmic lane-ops / s over the issue peak) and the memory fraction (bytes past
+            # L2 per second over 8 TB/s).  achieved / peak / unit / frac describe THAT leg; the other one rides in "valu" / "hbm".
+            "roofline": {"bound": bound,
+                         "achieved": round(achieved, 3) if bound == "valu" else round(pmc[0] / (kern_ms * 1e-3) / 1e9, 1),
+                         "peak": round(PEAK_TLANEOPS, 1) if bound == "valu" else 8000.0,
+                         "unit": "Tlaneop/s" if bound == "valu" else "GB/s",
+                         "frac": round(valu_frac if bound == "valu" else mem_frac, 4),
+                         "valu": {"achieved_tlaneops": round(achieved, 3), "peak_tlaneops": round(PEAK_TLANEOPS, 1), "frac": round(valu_frac, 4)},
                          # `achieved` prices the algorithm the kernel RUNS: the reference's as written, except where an exact
                          # culling structure provably skips tests (sphere grid: ops_per_sample_culled); the reference's own
                          # figure rides beside as algorithmic_ops_per_sample_reference
                          "frac_note": ("exceeds 1: the kernel skips tests the pricing still counts" if achieved / PEAK_TLANEOPS > 1 else None),
-                         "priced_algorithm": (("culled: " + ("sphere grid" if scene_name in GRID_WALK else "triangle pool") + " (counted in-kernel: "
-                                               + (GRID_WALK.get(scene_name) or TRI_POOL[scene_name])["source"] + ")")
+                         "priced_algorithm": (("culled: " + ("sphere grid" if GRID_WALK.get(scene_name) else "triangle pool") + " (counted in-kernel: "
+                                               + (GRID_WALK.get(scene_name) or TRI_POOL.get(scene_name) or {"source": "recorded figure"})["source"] + ")")
                                               if ops_culled else "the reference's algorithm as written"),
                          "algorithmic_ops_per_sample_reference": round(ops_reference, 1),
                          "traffic": pmc[0] if pmc else None, "traffic_source": pmc[1] if pmc else None,
                          # north-star evidence: HBM is not the limiter, VALU issue is busy (PMC of the committed profile)
                          "hbm": {"achieved_gbs": round(pmc[0] / (kern_ms * 1e-3) / 1e9, 3), "peak_gbs": 8000.0,
-                                 "frac": round(pmc[0] / (kern_ms * 1e-3) / 8e12, 6)} if pmc else None,
+                                 "frac": round(mem_frac, 6), "traffic_over_algorithmic": round(pmc[0] / algorithmic_bytes, 2)} if pmc else None,
                          "valu_issue_occupancy_pmc": round(pmc[2].get("valu_issue_occupancy", 0.0), 3) if pmc else None,
                          "valu_lane_utilisation_pmc": round(pmc[2].get("valu_lane_utilisation", 0.0), 3) if pmc else None,
                          "issue_slot_occupancy_pmc": round(pmc[2]["issue_slot_occupancy"], 3) if pmc and "issue_slot_occupancy" in pmc[2] else None,
@@ -444,12 +508,19 @@ def main() -> None:
                          "kernel": "render_kernel", "kernel_ms": round(kern_ms, 3),
                          "algorithmic_ops_per_sample": round(ops, 1),
                          "kernel_msamples_per_s_per_gpu": round(kernel_samples_per_s / world / 1e6, 2),
-                         "hbm_algorithmic_bytes": W * H * 12 // world},
+                         "hbm_algorithmic_bytes": algorithmic_bytes, "hbm_algorithmic_bytes_scene": scene_bytes},
         }
-        if world > 1 and args.mode == "parity":  # why the strong-scaling curve flattens: the shard's own chain floor, measured on one GPU
-            floor = predicted_chain_floor_ms(scene_name, W1, H1, SPP, world)
-            line["predicted_chain_floor_ms"] = floor[0] if floor else None
-            line["predicted_chain_floor_source"] = floor[1] if floor else None
+        if dist_path:
+            # the N > 1 line explains itself: every rank's kernel time, the exchange step on its own, what the collective layer reports,
+            # and (parity mode) the shard's own chain floor as measured on ONE GPU — where strong scaling must flatten
+            line["distributed"] = dict(dist_detail or {}, backend=dist.get_backend(), world_size=dist.get_world_size(),
+                                       rccl_version=".".join(str(v) for v in torch.cuda.nccl.version()),
+                                       exchange="one ncclGather of float tiles to rank 0 + device un-interleave (pt_unshard_tiles)",
+                                       bytes_gathered_per_rank=int(((W + 7) // 8) * ((H + 7) // 8) + world - 1) // world * 64 * 12)
+            if args.mode == "parity":
+                floor = predicted_chain_floor_ms(scene_name, W1, H1, SPP, world)
+                line["predicted_chain_floor_ms"] = floor[0] if floor else None
+                line["predicted_chain_floor_source"] = floor[1] if floor else None
         if other:
             line[other["scaling"] + "_scaling"] = other
         if cpu_line:

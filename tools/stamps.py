@@ -38,7 +38,8 @@ if WALK:
     print(f"  per sample: cells visited {lsteps/samples:.2f}, grid sphere tests {ltests/samples:.2f}")
     if os.environ.get("PT_WALK_JSON"):  # the record bench.py's culled-algorithm pricing is built on (profiles/<tag>_walk_counters.json)
         import json
-        json.dump({"scene": scene, "workload": f"{W}x{H}x{spp}", "shards": N, "note": "in-kernel counters of the sphere-grid walk, diagnostic build "
+        final = {"final": True, "round": int(os.environ["PT_FINAL_ROUND"])} if os.environ.get("PT_FINAL_ROUND") else {}  # what bench.py selects
+        json.dump({**final, "scene": scene, "workload": f"{W}x{H}x{spp}", "shards": N, "note": "in-kernel counters of the sphere-grid walk, diagnostic build "
                    "(make -C path_tracer_amd/csrc stamps EXTRA=-DPT_STAMPS_WALK), probe pass included in the wave counts, not in the per-sample figures' denominators",
                    "per_sample": {"cells_visited": lsteps / samples, "grid_sphere_tests": ltests / samples, "walks_waves": walks / samples},
                    "per_walk": {"wave_steps": wsteps / max(walks, 1), "test_trips": wtrips / max(walks, 1), "lanes_per_step": lsteps / max(wsteps, 1),

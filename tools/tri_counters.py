@@ -29,3 +29,14 @@ print(f"{W}x{H}x{spp}: {ms:.1f} ms = {W*H*spp/ms/1e3:.2f} Msamples/s; wave scans
 print(f"per ray: grid survivors (exact tests) {o[8]/rays:.1f}; band: past the integer band test {o[10]/rays:.1f}, survivors (exact tests) {o[9]/rays:.1f}")
 print(f"per ray: always list: pairs past the band test {o[7]/rays:.1f}, exact tests {o[11]/rays:.1f} (band trips of levels 1 and 2 are counted together)")
 print(f"per ray: grid rounds {grid/rays:.1f}; band trips level 0 / levels 1 + 2: {b0/rays:.1f} / {b1/rays:.1f} (lanes busy per trip {lanes/max(b0+b1,1):.1f}); grid cells visited {alw/rays:.1f}")
+
+if os.environ.get("PT_TRI_JSON"):  # the record bench.py prices the culled algorithm with (profiles/<tag>_tripool_counters.json)
+    import json
+    final = {"final": True, "round": int(os.environ["PT_FINAL_ROUND"])} if os.environ.get("PT_FINAL_ROUND") else {}
+    lanes_per_trip = lanes / max(b0 + b1, 1)
+    json.dump({**final, "scene": "triangles", "workload": f"{W}x{H}x{spp}",
+               "note": "in-kernel counters of the triangle pool, diagnostic build (make -C path_tracer_amd/csrc stamps EXTRA=-DPT_STAMPS_TRI), tools/tri_counters.py",
+               "per_ray": {"exact_tests": (o[8] + o[9] + o[11]) / rays, "grid_filter_tests": grid / rays * 64 * 4, "band_tests": (b0 + b1) / rays * lanes_per_trip * 4,
+                           "always_tests": float(st[1]), "noise_radius_tests": (o[10] + o[7]) / rays, "grid_cells": alw / rays},
+               "pool": {"triangles": st[0], "always": st[1], "levels": list(st)[2:5], "blob_bytes": st[6] * 16}},
+              open(os.environ["PT_TRI_JSON"], "w"), indent=1)
