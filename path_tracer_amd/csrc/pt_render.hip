@@ -1014,11 +1014,11 @@ int pt_debug_flatten(const PtSceneDesc* desc, float* blob_out, int64_t blob_cap_
   if (flags_out) *flags_out = (flat.has_image ? 1 : 0) | (flat.has_medium ? 2 : 0) | (flat.tri_pooled ? 4 : 0);
   if (blob_out) {
     if (blob_cap_f4 < (int64_t)flat.blob.size()) return fail(PT_ERR_INVALID_ARG, "blob buffer too small");
-    std::memcpy(blob_out, flat.blob.data(), flat.blob.size() * 16);
+    if (!flat.blob.empty()) std::memcpy(blob_out, flat.blob.data(), flat.blob.size() * 16);
   }
   if (mats_out) {
     if (mats_cap_f4 < (int64_t)flat.mats.size()) return fail(PT_ERR_INVALID_ARG, "material buffer too small");
-    std::memcpy(mats_out, flat.mats.data(), flat.mats.size() * 16);
+    if (!flat.mats.empty()) std::memcpy(mats_out, flat.mats.data(), flat.mats.size() * 16);
   }
   return PT_OK;
 }

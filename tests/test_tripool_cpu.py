@@ -150,6 +150,18 @@ def test_pool_thresholds_and_tables(lib, monkeypatch):
     assert st[6] * 16 < 5.0e6               # the plain blob: 4.8 MB
 
 
+def test_meshes_too_large_for_a_pool_fall_back_to_the_plain_blob(lib):
+    """the pool's tables ride in the blob (~17 records of 16 bytes per triangle beside the triangle's own 3) and
+    record offsets are 24 bits, so a mesh of a million triangles — which flattens to 50 MB without a pool and rendered fine before
+    round 3 — must not fail with PT_ERR_TOO_LARGE because the pool is on by default: it is flattened WITHOUT a pool."""
+    ps, _ = scenes.triangle_mesh_scene(n_triangles=1_050_000)
+    st = (C.c_int32 * 8)()
+    abi.check(lib.pt_debug_tri_pool(C.byref(ps.desc), st), "pt_debug_tri_pool")
+    assert st[0] == 0                                           # no pool
+    assert 1_050_000 * 3 < st[6] < 1_050_000 * 3 + 64           # the plain blob: three records per triangle + headers
+    assert st[6] < (1 << 24)
+
+
 def test_compressed_filter_records_round_to_the_safe_side(lib, monkeypatch):
     """The device streams QUANTISED filter records (pt_tripool.hpp "compressed records").  Parse them back out of the flattened
     blob of a 3000-triangle field and check every one against the triangle it stands for: centroid within eps_c, unit normal within
