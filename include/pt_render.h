@@ -228,6 +228,50 @@ int pt_camera_init(PtCamera* cam, const float look_from[3], const float look_at[
 int pt_scene_create(const PtSceneDesc* desc, PtScene** out_scene);
 void pt_scene_destroy(PtScene* scene);
 
+/* ---- tuning --------------------------------------------------------------------------------------------------------------
+ * PERFORMANCE-ONLY knobs: every setting gives the same image bit for bit (tests/test_abi_cpu.py, the GPU parity suite runs
+ * several of them); they choose which exact culling structures pt_scene_create builds and how launches are scheduled.  A
+ * zero-initialised struct with struct_size set (pt_tuning_init) is the library's defaults.  pt_scene_create(desc, out) is
+ * pt_scene_create_tuned(desc, NULL, out): the defaults with the PT_* environment variables applied on top — the override
+ * channel of tools/ and of A/B runs (tools/README.md lists them).  A caller that passes a PtTuning gets EXACTLY that: the
+ * environment is not consulted.  Fields (0 = default unless said otherwise):
+ *   sphere_grid        -1: no culling grid for runs of small spheres (PT_NO_GRID)
+ *   grid_margin/cell   the grid's margin in median radii / cell edge in (median radius + margin) (PT_GRID_M, PT_GRID_CELL; 0.5, 3.0)
+ *   slab_pools         -1: no slab pools for rect / box stretches (PT_NO_BOXCULL); 1: a pool for every stretch of >= 2
+ *                      (PT_POOL_ALWAYS: also where the cost model says it does not pay)
+ *   tri_pool           -1: no triangle pool (PT_NO_TRICULL)
+ *   tri_min_run        shortest triangle run that gets a pool (PT_TRI_MIN; 4096; PT_TRICULL=1 means 256)
+ *   tri_M, tri_Mg, tri_cell, tri_res[3]   the pool's slack 1/M, tight slack 1/Mg, grid cell, cube-map resolutions
+ *                      (PT_TRI_M, PT_TRI_MG, PT_TRI_CELL, PT_TRI_RES; 12, 96, 0.7, {128, 64, 32})
+ *   generic_materials  1: no material-specialised kernels (PT_NO_MATSPEC)
+ *   blocks_per_cu      cap on resident workgroups per CU (PT_BLOCKS_PER_CU)
+ *   cold_state         -1: the cold lane state stays in registers (PT_NO_COLD_LDS)
+ *   wide_log2_group    forced log2 group size of the cooperative kernels' wide phase (PT_WIDE_LOGG; 0: the model picks)
+ *   split_tiles_mode / split_tiles   mode 1: `split_tiles` tiles go through the wide phase (< 0: all) (PT_SPLIT_TILES)
+ *   lpt_by_max         1 / -1: order tiles by their heaviest pixel / by their ray count (PT_LPT_MAX; 0: by kernel family)
+ *   probe_spp_max      depth cap of the cost probe (PT_PROBE_SPP_MAX; 16)
+ *   grid_min_tiles     frames (shards) of fewer tiles keep the cooperative kernels and the lists (PT_GRID_MIN_TILES; 0)
+ *   model_fixed/chain  constants of the makespan model (PT_MODEL_FIXED, PT_MODEL_CHAIN; 2400, 2400)
+ *   scatter_log        triangle-pool kernels: log2 of the pixels of one tile a wave takes together (PT_SCATTER_LOG; 0)
+ *   scatter_mode       -1: whole tiles per wave (PT_NO_SCATTER); 1: with the cost probe (PT_LPT_SCATTER)                  */
+typedef struct PtTuning {
+  int32_t struct_size; /* sizeof(PtTuning) of the caller's header */
+  int32_t sphere_grid;
+  float grid_margin, grid_cell;
+  int32_t slab_pools;
+  int32_t tri_pool, tri_min_run;
+  float tri_M, tri_Mg, tri_cell;
+  int32_t tri_res[3];
+  int32_t generic_materials;
+  int32_t blocks_per_cu, cold_state, wide_log2_group, split_tiles_mode, split_tiles, lpt_by_max, probe_spp_max, grid_min_tiles;
+  float model_fixed, model_chain;
+  int32_t scatter_log, scatter_mode;
+  int32_t reserved[8];
+} PtTuning;
+void pt_tuning_init(PtTuning* t);     /* zero + struct_size: the library's defaults                                          */
+void pt_tuning_from_env(PtTuning* t); /* the defaults with the PT_* environment applied: what pt_scene_create(desc, out) uses */
+int pt_scene_create_tuned(const PtSceneDesc* desc, const PtTuning* tuning, PtScene** out_scene);
+
 /* Number of floats the caller must provide to pt_render for these params:
  * shard_count==1: height*width*3 laid out [y][x][rgb], y=0 = bottom scan-line
  * (render.hpp:105, main.cpp:41).  shard_count>1: pt_shard_tiles()*64*3 laid
@@ -322,6 +366,9 @@ int pt_debug_camera_rays(const PtCamera* cam, int32_t width, int32_t height,
  * carries a triangle pool (exact culling tables for long runs of Moller-Trumbore triangles; csrc/pt_tripool.hpp).        */
 int pt_debug_flatten(const PtSceneDesc* desc, float* blob_out, int64_t blob_cap_f4, int32_t* n_blob_f4,
                      int32_t* n_runs, float* mats_out, int64_t mats_cap_f4, int32_t* flags_out);
+/* the same for an explicit PtTuning (NULL: defaults + environment, i.e. pt_debug_flatten) */
+int pt_debug_flatten_tuned(const PtSceneDesc* desc, const PtTuning* tuning, float* blob_out, int64_t blob_cap_f4, int32_t* n_blob_f4,
+                           int32_t* n_runs, float* mats_out, int64_t mats_cap_f4, int32_t* flags_out);
 
 /* Host-only statistics of the triangle pool pt_scene_create() would build (no GPU needed): out[0] = triangles in pooled runs,
  * out[1] = entries of the always list, out[2..4] = triangles on the three cube-map band levels, out[5] = 1000 x mean grid cells

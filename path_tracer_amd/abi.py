@@ -80,6 +80,30 @@ class PtRenderParams(C.Structure):
                 ("reserved", C.c_int32)]
 
 
+class PtTuning(C.Structure):
+    """include/pt_render.h PtTuning: performance-only knobs (same image under all of them).  Zero = the library's default."""
+    _fields_ = [("struct_size", C.c_int32), ("sphere_grid", C.c_int32), ("grid_margin", C.c_float), ("grid_cell", C.c_float),
+                ("slab_pools", C.c_int32), ("tri_pool", C.c_int32), ("tri_min_run", C.c_int32),
+                ("tri_M", C.c_float), ("tri_Mg", C.c_float), ("tri_cell", C.c_float), ("tri_res", C.c_int32 * 3),
+                ("generic_materials", C.c_int32), ("blocks_per_cu", C.c_int32), ("cold_state", C.c_int32),
+                ("wide_log2_group", C.c_int32), ("split_tiles_mode", C.c_int32), ("split_tiles", C.c_int32),
+                ("lpt_by_max", C.c_int32), ("probe_spp_max", C.c_int32), ("grid_min_tiles", C.c_int32),
+                ("model_fixed", C.c_float), ("model_chain", C.c_float), ("scatter_log", C.c_int32), ("scatter_mode", C.c_int32),
+                ("reserved", C.c_int32 * 8)]
+
+
+def tuning(**fields) -> "PtTuning":
+    """A PtTuning with the library's defaults (pt_tuning_init) and the given fields set."""
+    t = PtTuning()
+    load_library().pt_tuning_init(C.byref(t))
+    for k, v in fields.items():
+        if k == "tri_res":
+            t.tri_res[:] = list(v)
+        else:
+            setattr(t, k, v)
+    return t
+
+
 class PtBounceIn(C.Structure):
     _fields_ = [("origin", C.c_float * 3), ("dir", C.c_float * 3), ("time", C.c_float),
                 ("rng_state", C.c_uint32), ("attenuation", C.c_float * 3)]
@@ -110,6 +134,11 @@ SIGNATURES = {
     "pt_camera_init": (C.c_int, [C.POINTER(PtCamera), _FP, _FP, _FP, C.c_float, C.c_float, C.c_float, C.c_float,
                                  C.c_float, C.c_float]),
     "pt_scene_create": (C.c_int, [C.POINTER(PtSceneDesc), C.POINTER(_SCENE_P)]),
+    "pt_scene_create_tuned": (C.c_int, [C.POINTER(PtSceneDesc), C.POINTER(PtTuning), C.POINTER(_SCENE_P)]),
+    "pt_tuning_init": (None, [C.POINTER(PtTuning)]),
+    "pt_tuning_from_env": (None, [C.POINTER(PtTuning)]),
+    "pt_debug_flatten_tuned": (C.c_int, [C.POINTER(PtSceneDesc), C.POINTER(PtTuning), _FP, C.c_int64, C.POINTER(C.c_int32),
+                                         C.POINTER(C.c_int32), _FP, C.c_int64, C.POINTER(C.c_int32)]),
     "pt_scene_destroy": (None, [_SCENE_P]),
     "pt_scene_reserve": (C.c_int, [_SCENE_P, C.POINTER(PtRenderParams)]),
     "pt_fast_seed": (C.c_uint32, [C.c_uint32, C.c_uint32]),

@@ -815,33 +815,71 @@ __global__ void tonemap_kernel(const float* __restrict__ fb, uint8_t* __restrict
 
 thread_local std::string g_last_error;
 
+// ---- tuning: include/pt_render.h PtTuning.  Resolved ONCE per scene (pt_scene_create / pt_debug_flatten), never on the launch path.
+// A NULL PtTuning means the library's defaults with the PT_* environment variables applied on top (the override channel of tools/ and of
+// A/B runs); an explicit struct is taken as it is and the environment is not consulted.
+static void tuning_defaults(PtTuning& t) {
+  std::memset(&t, 0, sizeof t);
+  t.struct_size = (int32_t)sizeof(PtTuning);
+}
+static void tuning_env(PtTuning& t) {
+  tuning_defaults(t);
+  auto has = [](const char* n) { return std::getenv(n) != nullptr; };
+  if (has("PT_NO_GRID")) t.sphere_grid = -1;
+  if (const char* e = std::getenv("PT_GRID_M")) t.grid_margin = (float)std::atof(e);
+  if (const char* e = std::getenv("PT_GRID_CELL")) t.grid_cell = (float)std::atof(e);
+  t.slab_pools = has("PT_NO_BOXCULL") ? -1 : has("PT_POOL_ALWAYS") ? 1 : 0;
+  if (has("PT_NO_TRICULL")) t.tri_pool = -1;
+  if (has("PT_TRICULL")) t.tri_min_run = 256;
+  if (const char* e = std::getenv("PT_TRI_M")) t.tri_M = (float)std::atof(e);
+  if (const char* e = std::getenv("PT_TRI_MG")) t.tri_Mg = (float)std::atof(e);
+  if (const char* e = std::getenv("PT_TRI_RES")) std::sscanf(e, "%d,%d,%d", &t.tri_res[0], &t.tri_res[1], &t.tri_res[2]);
+  if (const char* e = std::getenv("PT_TRI_CELL")) t.tri_cell = (float)std::atof(e);
+  if (const char* e = std::getenv("PT_TRI_MIN")) t.tri_min_run = std::max(1, std::atoi(e));
+  if (has("PT_NO_MATSPEC")) t.generic_materials = 1;
+  if (const char* e = std::getenv("PT_BLOCKS_PER_CU")) t.blocks_per_cu = std::max(1, std::atoi(e));
+  if (has("PT_NO_COLD_LDS")) t.cold_state = -1;
+  if (const char* e = std::getenv("PT_WIDE_LOGG")) t.wide_log2_group = std::min(6, std::max(1, std::atoi(e)));
+  if (const char* e = std::getenv("PT_SPLIT_TILES")) { t.split_tiles_mode = 1; t.split_tiles = std::atoi(e); }
+  if (const char* e = std::getenv("PT_LPT_MAX")) t.lpt_by_max = std::atoi(e) != 0 ? 1 : -1;
+  if (const char* e = std::getenv("PT_PROBE_SPP_MAX")) t.probe_spp_max = std::max(1, std::atoi(e));
+  if (const char* e = std::getenv("PT_GRID_MIN_TILES")) t.grid_min_tiles = std::max(0, std::atoi(e));
+  if (const char* e = std::getenv("PT_MODEL_FIXED")) t.model_fixed = (float)std::atof(e);
+  if (const char* e = std::getenv("PT_MODEL_CHAIN")) t.model_chain = (float)std::atof(e);
+  if (const char* e = std::getenv("PT_SCATTER_LOG")) t.scatter_log = std::min(5, std::max(0, std::atoi(e)));
+  t.scatter_mode = has("PT_NO_SCATTER") ? -1 : has("PT_LPT_SCATTER") ? 1 : 0;
+}
+// the caller's struct (possibly from an older header: struct_size bytes are valid) or, for NULL, defaults + environment
+static int resolve_tuning(const PtTuning* user, PtTuning& t, std::string& err) {
+  if (!user) { tuning_env(t); return PT_OK; }
+  if (user->struct_size < 8 || user->struct_size > (int32_t)sizeof(PtTuning)) { err = "PtTuning.struct_size is not a size this library knows (use pt_tuning_init)"; return PT_ERR_INVALID_ARG; }
+  tuning_defaults(t);
+  std::memcpy(&t, user, (size_t)user->struct_size);
+  t.struct_size = (int32_t)sizeof(PtTuning);
+  return PT_OK;
+}
+
 // The flattening pt_scene_create uploads (pt_debug_flatten shows the same blob).
-// PT_NO_GRID / PT_NO_BOXCULL: A/B knobs (brute-force sphere runs / straight-line rect and box runs); PT_POOL_ALWAYS: a slab
-// pool for every stretch of two or more rects / boxes, also where it does not pay (the tests' way to put the pools into
-// small mixed scenes); PT_GRID_M / PT_GRID_CELL: the sphere grid's margin and cell size (tools/grid_sweep.sh).
 // LDS budget: the culling grid's tables ride in the blob, and only the LDS-resident kernels walk the grid.  A scene whose
 // blob exceeds kMaxLdsBlob WITH its grid but fits WITHOUT it (e.g. 1 200 small spheres: 101 KB against 62 KB) is flattened
 // without the grid, so that it keeps the resident kernels instead of falling to the streaming kernel with dead tables.
-static int flatten_with_env(const PtSceneDesc* desc, ptf::Flat& flat, std::string& err) {
-  const int box_cull = std::getenv("PT_NO_BOXCULL") ? 0 : std::getenv("PT_POOL_ALWAYS") ? 2 : 1;
+static int flatten_tuned(const PtSceneDesc* desc, const PtTuning& t, ptf::Flat& flat, std::string& err) {
+  const int box_cull = t.slab_pools < 0 ? 0 : t.slab_pools > 0 ? 2 : 1;
   ptf::GridTuning tune;
-  if (const char* e = std::getenv("PT_GRID_M")) tune.m = (float)std::atof(e);
-  if (const char* e = std::getenv("PT_GRID_CELL")) tune.cell = (float)std::atof(e);
-  const bool allow_grid = std::getenv("PT_NO_GRID") == nullptr;
+  if (t.grid_margin > 0.0f) tune.m = t.grid_margin;
+  if (t.grid_cell > 0.0f) tune.cell = t.grid_cell;
+  const bool allow_grid = t.sphere_grid >= 0;
   // Exact culling of long triangle runs (pt_tripool.hpp; pt_device.hpp: tri_pool_scan).  Default: runs of >= 4096 triangles get a
-  // pool (BASELINE config 5, 100 k triangles: 68.9 -> 49.8 s per frame, bit-identical); PT_TRICULL=1 lowers that to 256 (the fuzz
-  // tests), PT_NO_TRICULL switches the pools off (the round-2 path: every triangle streamed and tested), PT_TRI_MIN sets the
-  // threshold, PT_TRI_M / PT_TRI_CELL the pool's barycentric slack 1/M and its grid cell (in median grown boxes).
-  bool allow_tri = std::getenv("PT_NO_TRICULL") == nullptr;
+  // pool (BASELINE config 5, 100 k triangles: 68.9 -> 18.6 s per frame, bit-identical).
+  bool allow_tri = t.tri_pool >= 0;
   for (int i = 0; desc && desc->hittables && i < desc->n_hittables && allow_tri; i++) // scenes with Badouel-strategy triangles render through the
     if (desc->hittables[i].kind == PT_HIT_TRIANGLE && desc->hittables[i].strategy == PT_TRI_BADOUEL) allow_tri = false; // round-2 kernels: no dead tables
   ptf::TriPoolTuning tri;
-  if (std::getenv("PT_TRICULL")) tri.min_run = 256;
-  if (const char* e = std::getenv("PT_TRI_M")) tri.M = (float)std::atof(e);
-  if (const char* e = std::getenv("PT_TRI_MG")) tri.Mg = (float)std::atof(e);
-  if (const char* e = std::getenv("PT_TRI_RES")) std::sscanf(e, "%d,%d,%d", &tri.res[0], &tri.res[1], &tri.res[2]);
-  if (const char* e = std::getenv("PT_TRI_CELL")) tri.cell = (float)std::atof(e);
-  if (const char* e = std::getenv("PT_TRI_MIN")) tri.min_run = std::max(1, std::atoi(e));
+  if (t.tri_min_run > 0) tri.min_run = t.tri_min_run;
+  if (t.tri_M > 0.0f) tri.M = t.tri_M;
+  if (t.tri_Mg > 0.0f) tri.Mg = t.tri_Mg;
+  if (t.tri_res[0] > 0 && t.tri_res[1] > 0 && t.tri_res[2] > 0) { tri.res[0] = t.tri_res[0]; tri.res[1] = t.tri_res[1]; tri.res[2] = t.tri_res[2]; }
+  if (t.tri_cell > 0.0f) tri.cell = t.tri_cell;
   int rc = ptf::flatten(desc, flat, err, allow_grid, box_cull, tune, allow_tri, tri);
   if (rc == PT_ERR_TOO_LARGE && allow_tri) { // the pool's tables overflowed the 24-bit record offsets: the scene without a pool may still fit
     std::string err2;
@@ -867,34 +905,35 @@ int fail(int code, const std::string& msg) {
     if (e_ != hipSuccess) return fail(PT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
   } while (0)
 
-// Tuning knobs (environment), read once per scene in pt_scene_create — never on the launch path.
-struct EnvKnobs {
-  int blocks_per_cu = 0;   // PT_BLOCKS_PER_CU: cap on resident workgroups per CU (0 = none)
-  bool no_cold_lds = false; // PT_NO_COLD_LDS
-  int wide_logG = 0;       // PT_WIDE_LOGG: forced log2 group size of the wide phase (0 = the model picks)
+// The launch-side knobs of a scene's PtTuning, resolved once in pt_scene_create — never on the launch path.
+struct Knobs {
+  int blocks_per_cu = 0;   // cap on resident workgroups per CU (0 = none)
+  bool no_cold_lds = false;
+  int wide_logG = 0;       // forced log2 group size of the wide phase (0 = the model picks)
   bool has_split_tiles = false;
-  int split_tiles = 0;     // PT_SPLIT_TILES: fixed number of tiles through the wide phase (< 0: all)
-  int lpt_max = -1, probe_spp_max = 16; // PT_LPT_MAX / PT_PROBE_SPP_MAX: order tiles by their heaviest pixel; probe depth cap
-  int grid_min_tiles = kGridMinTiles;    // PT_GRID_MIN_TILES: frames (shards) of fewer tiles keep the cooperative kernels and the lists
-  float model_fixed = 2400.0f, model_chain = 2400.0f; // PT_MODEL_FIXED / PT_MODEL_CHAIN: constants of the makespan model (lpt_order_kernel)
-  int scatter_log = 0;     // PT_SCATTER_LOG: log2 of the pixels of one tile that a wave takes together (0: every lane a pixel of another tile)
-  bool lpt_with_scatter = false; // PT_LPT_SCATTER: the cost probe + heaviest-first order also for scattered (triangle-pool) renders
-  int grid_block = kGridBlock; // PT_GRID_BLOCK=256: the grid kernels at the common workgroup size (A/B)
-  bool no_scatter = false; // PT_NO_SCATTER: triangle-pool kernels hand out whole tiles' pixels to a wave again (lane_acquire)
-  EnvKnobs() {
-    no_scatter = std::getenv("PT_NO_SCATTER") != nullptr;
-    if (const char* e = std::getenv("PT_GRID_BLOCK")) grid_block = std::atoi(e) == kBlock ? kBlock : kGridBlock;
-    lpt_with_scatter = std::getenv("PT_LPT_SCATTER") != nullptr;
-    if (const char* e = std::getenv("PT_SCATTER_LOG")) scatter_log = std::min(5, std::max(0, std::atoi(e)));
-    if (const char* e = std::getenv("PT_BLOCKS_PER_CU")) blocks_per_cu = std::max(1, std::atoi(e));
-    no_cold_lds = std::getenv("PT_NO_COLD_LDS") != nullptr;
-    if (const char* e = std::getenv("PT_WIDE_LOGG")) wide_logG = std::min(6, std::max(1, std::atoi(e)));
-    if (const char* e = std::getenv("PT_SPLIT_TILES")) { has_split_tiles = true; split_tiles = std::atoi(e); }
-    if (const char* e = std::getenv("PT_LPT_MAX")) lpt_max = std::atoi(e);
-    if (const char* e = std::getenv("PT_GRID_MIN_TILES")) grid_min_tiles = std::max(0, std::atoi(e));
-    if (const char* e = std::getenv("PT_PROBE_SPP_MAX")) probe_spp_max = std::max(1, std::atoi(e));
-    if (const char* e = std::getenv("PT_MODEL_FIXED")) model_fixed = (float)std::atof(e);
-    if (const char* e = std::getenv("PT_MODEL_CHAIN")) model_chain = (float)std::atof(e);
+  int split_tiles = 0;     // fixed number of tiles through the wide phase (< 0: all)
+  int lpt_max = -1, probe_spp_max = 16; // order tiles by their heaviest pixel (-1: by kernel family); probe depth cap
+  int grid_min_tiles = kGridMinTiles;    // frames (shards) of fewer tiles keep the cooperative kernels and the lists
+  float model_fixed = 2400.0f, model_chain = 2400.0f; // constants of the makespan model (lpt_order_kernel)
+  int scatter_log = 0;     // log2 of the pixels of one tile that a wave takes together (0: every lane a pixel of another tile)
+  bool lpt_with_scatter = false; // the cost probe + heaviest-first order also for scattered (triangle-pool) renders
+  int grid_block = kGridBlock; // PT_GRID_BLOCK (build-time experiment: workgroup size of the grid kernels)
+  bool no_scatter = false; // triangle-pool kernels hand out whole tiles' pixels to a wave again (lane_acquire)
+  bool generic_materials = false;
+  Knobs() {}
+  explicit Knobs(const PtTuning& t) {
+    blocks_per_cu = std::max(0, t.blocks_per_cu);
+    no_cold_lds = t.cold_state < 0;
+    wide_logG = std::min(6, std::max(0, t.wide_log2_group));
+    has_split_tiles = t.split_tiles_mode == 1; split_tiles = t.split_tiles;
+    lpt_max = t.lpt_by_max > 0 ? 1 : t.lpt_by_max < 0 ? 0 : -1;
+    if (t.probe_spp_max > 0) probe_spp_max = t.probe_spp_max;
+    if (t.grid_min_tiles > 0) grid_min_tiles = t.grid_min_tiles;
+    if (t.model_fixed > 0.0f) model_fixed = t.model_fixed;
+    if (t.model_chain > 0.0f) model_chain = t.model_chain;
+    scatter_log = std::min(5, std::max(0, t.scatter_log));
+    no_scatter = t.scatter_mode < 0; lpt_with_scatter = t.scatter_mode > 0;
+    generic_materials = t.generic_materials != 0;
   }
 };
 
@@ -949,7 +988,7 @@ struct PtScene {
   // streams create one PtScene per stream (path_tracer_amd/render.py keys its cache by (device, stream)).
   mutable std::mutex sched;
   mutable std::map<const void*, int> occupancy; // resident workgroups per CU, per kernel variant (queried once)
-  EnvKnobs knobs;                               // environment tuning knobs as they were when the scene was created
+  Knobs knobs;                                  // the scene's PtTuning (launch side), as resolved when the scene was created
 };
 
 extern "C" {
@@ -1003,11 +1042,22 @@ int pt_camera_init(PtCamera* cam, const float look_from[3], const float look_at[
 }
 
 // Host-only view of the flattening (no GPU needed): blob_out/mats_out may be NULL to query sizes.
+void pt_tuning_init(PtTuning* t) { if (t) tuning_defaults(*t); }
+void pt_tuning_from_env(PtTuning* t) { if (t) tuning_env(*t); }
+
 int pt_debug_flatten(const PtSceneDesc* desc, float* blob_out, int64_t blob_cap_f4, int32_t* n_blob_f4,
                      int32_t* n_runs, float* mats_out, int64_t mats_cap_f4, int32_t* flags_out) {
+  return pt_debug_flatten_tuned(desc, nullptr, blob_out, blob_cap_f4, n_blob_f4, n_runs, mats_out, mats_cap_f4, flags_out);
+}
+
+int pt_debug_flatten_tuned(const PtSceneDesc* desc, const PtTuning* tuning, float* blob_out, int64_t blob_cap_f4, int32_t* n_blob_f4,
+                           int32_t* n_runs, float* mats_out, int64_t mats_cap_f4, int32_t* flags_out) {
   ptf::Flat flat;
   std::string err;
-  int rc = flatten_with_env(desc, flat, err); // the blob pt_scene_create would upload, knobs and LDS budget included
+  PtTuning t;
+  int rc = resolve_tuning(tuning, t, err);
+  if (rc) return fail(rc, err);
+  rc = flatten_tuned(desc, t, flat, err); // the blob pt_scene_create would upload, knobs and LDS budget included
   if (rc) return fail(rc, err);
   if (n_blob_f4) *n_blob_f4 = (int32_t)flat.blob.size();
   if (n_runs) *n_runs = flat.n_runs;
@@ -1027,7 +1077,9 @@ int pt_debug_tri_pool(const PtSceneDesc* desc, int32_t out[8]) {
   if (!out) return fail(PT_ERR_INVALID_ARG, "pt_debug_tri_pool: NULL argument");
   ptf::Flat flat;
   std::string err;
-  int rc = flatten_with_env(desc, flat, err);
+  PtTuning t;
+  tuning_env(t);
+  int rc = flatten_tuned(desc, t, flat, err);
   if (rc) return fail(rc, err);
   out[0] = flat.tri_pooled; out[1] = flat.tri_always;
   for (int k = 0; k < 3; k++) out[2 + k] = flat.tri_level_counts[k];
@@ -1035,16 +1087,22 @@ int pt_debug_tri_pool(const PtSceneDesc* desc, int32_t out[8]) {
   return PT_OK;
 }
 
-int pt_scene_create(const PtSceneDesc* desc, PtScene** out_scene) {
+int pt_scene_create(const PtSceneDesc* desc, PtScene** out_scene) { return pt_scene_create_tuned(desc, nullptr, out_scene); }
+
+int pt_scene_create_tuned(const PtSceneDesc* desc, const PtTuning* tuning, PtScene** out_scene) {
   if (!out_scene) return fail(PT_ERR_INVALID_ARG, "pt_scene_create: out_scene is NULL");
   *out_scene = nullptr;
   ptf::Flat flat;
   std::string err;
-  int rc = flatten_with_env(desc, flat, err);
+  PtTuning tun;
+  int rc = resolve_tuning(tuning, tun, err);
+  if (rc) return fail(rc, err);
+  rc = flatten_tuned(desc, tun, flat, err);
   if (rc) return fail(rc, err);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(PT_ERR_NO_DEVICE, "no HIP device visible");
   PtScene* s = new PtScene();
+  s->knobs = Knobs(tun);
   auto cleanup = [&]() { pt_scene_destroy(s); };
   hipError_t e;
 #define PT_TRY(expr) if ((e = (expr)) != hipSuccess) { cleanup(); return fail(PT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e)); }
@@ -1073,7 +1131,7 @@ int pt_scene_create(const PtSceneDesc* desc, PtScene** out_scene) {
     }
   }
   s->grid_spheres = flat.grid_spheres;
-  s->mats_simple = desc->n_materials > 0 && std::getenv("PT_NO_MATSPEC") == nullptr; // PT_NO_MATSPEC: A/B knob (generic shading)
+  s->mats_simple = desc->n_materials > 0 && !s->knobs.generic_materials; // PtTuning.generic_materials: A/B knob (generic shading)
   for (int i = 0; i < desc->n_materials && s->mats_simple; i++) {
     const PtMaterial& m = desc->materials[i];
     if ((m.kind != PT_MAT_LAMBERTIAN && m.kind != PT_MAT_LIGHTSOURCE) || desc->textures[m.texture].kind != PT_TEX_SOLID) s->mats_simple = false;

@@ -22,11 +22,16 @@ class DeviceScene:
     """The flattened, HBM-resident scene (pt_scene_create).  Replaces the sycl::buffer wrapping of the
     hittable vector and image_texture::freeze() (render.hpp:146-148); may be reused across renders."""
 
-    def __init__(self, scene: PackedScene):
+    def __init__(self, scene: PackedScene, tuning: "abi.PtTuning | None" = None):
+        """tuning: an abi.PtTuning (performance-only knobs, include/pt_render.h; abi.tuning(sphere_grid=-1, ...)); None = the
+        library's defaults with the PT_* environment applied."""
         self.lib = abi.load_library()
         self.handle = C.c_void_p()
         self._packed = scene  # keep the host tables alive
-        abi.check(self.lib.pt_scene_create(C.byref(scene.desc), C.byref(self.handle)), "pt_scene_create")
+        if tuning is None:
+            abi.check(self.lib.pt_scene_create(C.byref(scene.desc), C.byref(self.handle)), "pt_scene_create")
+        else:
+            abi.check(self.lib.pt_scene_create_tuned(C.byref(scene.desc), C.byref(tuning), C.byref(self.handle)), "pt_scene_create_tuned")
 
     def reserve(self, width, height, samples, depth=50, shard_index=0, shard_count=1, flags=0) -> None:
         """pt_scene_reserve: allocate the launch workspaces for these parameters now, so that render() never allocates."""

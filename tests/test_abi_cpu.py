@@ -350,3 +350,65 @@ def test_scene_fixture_roundtrip(tmp_path, orc):
         orc.set_math(True)
         a, b = orc.render(ps, c.c, 16, 12, 2), orc.render(ps2, c.c, 16, 12, 2)
         assert a.tobytes() == b.tobytes()
+
+
+def _blob(lib, ps, tuning=None):
+    n, r, fl = C.c_int32(), C.c_int32(), C.c_int32()
+    t = C.byref(tuning) if tuning is not None else None
+    abi.check(lib.pt_debug_flatten_tuned(C.byref(ps.desc), t, None, 0, C.byref(n), C.byref(r), None, 0, C.byref(fl)), "pt_debug_flatten_tuned")
+    blob = np.zeros(n.value * 4, np.float32)
+    abi.check(lib.pt_debug_flatten_tuned(C.byref(ps.desc), t, blob.ctypes.data_as(C.POINTER(C.c_float)), n.value, C.byref(n), C.byref(r),
+                                         None, 0, C.byref(fl)), "pt_debug_flatten_tuned")
+    return blob.tobytes(), fl.value
+
+
+def test_tuning_struct_and_environment_give_identical_blobs(lib, monkeypatch):
+    """what pt_scene_create builds no longer depends on the caller's environment only — a C-ABI caller sets the
+    grid / pool thresholds through PtTuning; the PT_* variables stay as the override channel of tools/ (a NULL PtTuning = defaults +
+    environment).  Every knob: the struct and the variable flatten to the same bytes, and an explicit struct ignores the environment."""
+    body = re.sub(r"/\*.*?\*/", "", HEADER.read_text(), flags=re.S)
+    body = body[body.index("typedef struct PtTuning {") + len("typedef struct PtTuning {"):body.index("} PtTuning;")]
+    dwords, names = 0, []
+    for decl in filter(None, (d.strip() for d in body.split(";"))):  # "int32_t a, b[3]" -> every field is a 4-byte scalar or an array of them
+        for item in decl.split(None, 1)[1].split(","):
+            m = re.fullmatch(r"\s*(\w+)(?:\[(\d+)\])?\s*", item)
+            names.append(m.group(1)); dwords += int(m.group(2) or 1)
+    assert C.sizeof(abi.PtTuning) == 4 * dwords and names == [f[0] for f in abi.PtTuning._fields_]  # header and abi.py agree field for field
+    t0 = abi.tuning()
+    assert t0.struct_size == C.sizeof(abi.PtTuning)
+    smoke, _ = scenes.build("smoke")
+    tri, _ = scenes.triangle_mesh_scene(n_triangles=3000)
+    mixed, _ = S.ALL["mixed"]()
+    base = {id(s): _blob(lib, s) for s in (smoke, tri, mixed)}
+    assert _blob(lib, smoke, t0) == base[id(smoke)] and _blob(lib, tri, t0) == base[id(tri)]
+    cases = [  # (environment, the same as PtTuning fields, scene)
+        ({"PT_NO_GRID": "1"}, dict(sphere_grid=-1), smoke),
+        ({"PT_GRID_M": "0.75", "PT_GRID_CELL": "3.43"}, dict(grid_margin=0.75, grid_cell=3.43), smoke),
+        ({"PT_TRICULL": "1"}, dict(tri_min_run=256), tri),
+        ({"PT_TRI_MIN": "1000", "PT_TRI_M": "20", "PT_TRI_MG": "48", "PT_TRI_CELL": "1.0", "PT_TRI_RES": "64,32,16"},
+         dict(tri_min_run=1000, tri_M=20.0, tri_Mg=48.0, tri_cell=1.0, tri_res=(64, 32, 16)), tri),
+        ({"PT_TRICULL": "1", "PT_NO_TRICULL": "1"}, dict(tri_min_run=256, tri_pool=-1), tri),
+        ({"PT_POOL_ALWAYS": "1"}, dict(slab_pools=1), mixed),
+        ({"PT_NO_BOXCULL": "1"}, dict(slab_pools=-1), scenes.build("cornell")[0]),
+    ]
+    for env, fields, ps in cases:
+        with monkeypatch.context() as m:
+            for k, v in env.items():
+                m.setenv(k, v)
+            from_env = _blob(lib, ps)
+            te = abi.PtTuning()
+            lib.pt_tuning_from_env(C.byref(te))
+            assert _blob(lib, ps, te) == from_env, env
+            assert _blob(lib, ps, t0) == _blob(lib, ps, abi.tuning()), env  # an explicit struct: the environment is not consulted
+        from_struct = _blob(lib, ps, abi.tuning(**fields))
+        assert from_struct == from_env, (env, fields)
+        if ps in (smoke, tri):
+            assert from_struct != base[id(ps)] or "PT_NO_TRICULL" in env, (env, "the knob changed nothing")
+    # an unknown struct_size is an error code, a shorter (older) struct is accepted
+    bad = abi.tuning(); bad.struct_size = 4
+    n = C.c_int32()
+    assert lib.pt_debug_flatten_tuned(C.byref(smoke.desc), C.byref(bad), None, 0, C.byref(n), None, None, 0, None) == abi.PT_ERR_INVALID_ARG
+    old = abi.tuning(sphere_grid=-1); old.struct_size = 16
+    with monkeypatch.context() as m:
+        m.setenv("PT_NO_GRID", "1")
+        assert _blob(lib, smoke, old) == _blob(lib, smoke)
