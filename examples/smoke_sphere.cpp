@@ -1,15 +1,15 @@
 // examples/smoke_sphere.cpp — the reference's src/main.cpp:61-197 rewritten against the C++20 facade: same scene literal
 // (the RNG calls inside one expression are evaluated left to right here; the reference leaves that order to the
-// compiler, main.cpp:83,87,92), same camera, same output stage (gamma 2, clamp, x256, rows flipped), PPM instead of
-// PNG (main.cpp:17-31; stb is not a dependency).  The two image textures are loaded like main.cpp:133,145 does, through
-// image_texture::image_texture_factory, from <images_dir>/Xilinx.ppm and <images_dir>/SYCL.ppm (default "../images" as in
-// the reference; `python -m path_tracer_amd --export-textures DIR` writes the decoded reference images there); a file
-// that cannot be loaded gets the reference's treatment — a message on stderr and the fallback texel.  images_dir
-// "procedural" selects small generated stand-ins instead.
+// compiler, main.cpp:83,87,92), same camera, same output stage (gamma 2, clamp, x256, rows flipped) into out.png (main.cpp:33-59)
+// or, for any other file name, a binary PPM (main.cpp:17-31).  stb is not a dependency: pt/image_io.hpp decodes and writes.  The two
+// image textures are loaded like main.cpp:133,145 does, through image_texture::image_texture_factory, from <images_dir>/Xilinx.jpg and
+// <images_dir>/SYCL.png (default "../images" as in the reference; a directory holding the decoded-pixel exports Xilinx.ppm / SYCL.ppm
+// of `python -m path_tracer_amd --export-textures DIR` works too); a file that cannot be loaded gets the reference's treatment — a
+// message on stderr and the fallback texel.  images_dir "procedural" selects small generated stand-ins instead.
 //
 //   g++ -std=c++20 -O2 -ffp-contract=off -Ipath_tracer_amd/include examples/smoke_sphere.cpp -Lpath_tracer_amd -lpt_render \
 //       -Wl,-rpath,$PWD/path_tracer_amd -Wl,-rpath,/opt/rocm/lib -o sycl-rt-mi355x
-//   ./sycl-rt-mi355x [width height samples out.ppm [tables.bin|- [images_dir]]]
+//   ./sycl-rt-mi355x [width height samples out.png|out.ppm [tables.bin|- [images_dir]]]
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -50,10 +50,18 @@ static std::vector<uint8_t> procedural_image(int w, int h, int seed) {
 int main(int argc, char** argv) {
   const int width = argc > 1 ? std::atoi(argv[1]) : 800, height = argc > 2 ? std::atoi(argv[2]) : 480; // CMakeLists.txt:44-54
   const int samples = argc > 3 ? std::atoi(argv[3]) : 100;                                            // main.cpp:186
-  const char* out = argc > 4 ? argv[4] : "out.ppm";
+  const char* out = argc > 4 ? argv[4] : "out.png"; // main.cpp:57
   const std::string images_dir = argc > 6 ? argv[6] : "../images";
   const bool procedural = images_dir == "procedural";
 
+  // the reference's own files (main.cpp:133,145: "../images/Xilinx.jpg", "../images/SYCL.png"), decoded by pt/image_io.hpp; a directory
+  // that only holds the decoded-pixel exports (`python -m path_tracer_amd --export-textures DIR`: Xilinx.ppm, SYCL.ppm) works too
+  auto image_file = [&](const char* name, const char* exported) {
+    const std::string a = images_dir + "/" + name, b = images_dir + "/" + exported;
+    if (std::FILE* f = std::fopen(a.c_str(), "rb")) { std::fclose(f); return a; }
+    if (std::FILE* f = std::fopen(b.c_str(), "rb")) { std::fclose(f); return b; }
+    return a; // neither: the factory reports the reference's file name and falls back to texel 0
+  };
   std::vector<hittable_t> hittables;
   texture_t t = checker_texture(color{0.2f, 0.3f, 0.1f}, color{0.9f, 0.9f, 0.9f});
   hittables.emplace_back(sphere(point{0, -1000, 0}, 1000, lambertian_material(t)));
@@ -90,14 +98,14 @@ int main(int argc, char** argv) {
   hittables.emplace_back(triangle(point{6.0f, 0.0f, 0.80f}, point{6.25f, 0.50f, 1.05f}, point{6.0f, 0.0f, 1.30f}, lambertian_material(color(0.0f, 0.0f, 1))));
   hittables.emplace_back(sphere(point{4, 1, 0}, 0.2f, lightsource_material(color(10, 0, 10))));
   if (procedural) { auto xil = procedural_image(256, 128, 0); t = image_texture::from_rgb8(xil.data(), 256, 128); }
-  else t = image_texture::image_texture_factory((images_dir + "/Xilinx.ppm").c_str()); // main.cpp:133
+  else t = image_texture::image_texture_factory(image_file("Xilinx.jpg", "Xilinx.ppm").c_str()); // main.cpp:133
   hittables.emplace_back(xy_rect(2, 4, 0, 1, -1, lambertian_material(t)));
   hittables.emplace_back(sphere(point{4, 1, 2.25f}, 1, lambertian_material(t)));
   hittables.emplace_back(sphere(point{0, 1, 0}, 1, dielectric_material(1.5f, color{1.0f, 0.5f, 0.5f})));
   hittables.emplace_back(sphere(point{-4, 1, 0}, 1, lambertian_material(color(0.4f, 0.2f, 0.1f))));
   hittables.emplace_back(sphere(point{0, 1, -2.25f}, 1, metal_material(color(0.7f, 0.6f, 0.5f), 0.0f)));
   if (procedural) { auto syc = procedural_image(320, 140, 1); t = image_texture::from_rgb8(syc.data(), 320, 140, 5); }
-  else t = image_texture::image_texture_factory((images_dir + "/SYCL.ppm").c_str(), 5); // main.cpp:145
+  else t = image_texture::image_texture_factory(image_file("SYCL.png", "SYCL.ppm").c_str(), 5); // main.cpp:145
   hittables.emplace_back(sphere{point{-60, 3, 5}, 4, lambertian_material{t}});
   hittables.emplace_back(box{point{6.5f, 0, -1.5f}, point{7.0f, 3.0f, -1.0f}, metal_material{color{0.7f, 0.6f, 0.5f}, 0.25f}});
   sphere smoke_sphere = sphere{point{5, 1, 3.5f}, 1, lambertian_material{color{0.75f, 0.75f, 0.75f}}};
@@ -131,9 +139,10 @@ int main(int argc, char** argv) {
   }
   double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 
-  // dump_image_ppm main.cpp:17-31 (binary P6 instead of text P3)
-  std::ofstream f(out, std::ios::binary);
-  f << "P6\n" << width << " " << height << "\n255\n";
+  // the output stage of main.cpp:33-59 (sqrt gamma, clamp to [0, 0.999], x 256, rows flipped), then save_image_png (a file name ending in
+  // .png: pt/image_io.hpp's writer in place of stbi_write_png) or dump_image_ppm (main.cpp:17-31; binary P6 instead of text P3)
+  std::vector<uint8_t> pixels;
+  pixels.reserve((size_t)width * height * 3);
   for (int y = height - 1; y >= 0; y--)
     for (int x = 0; x < width; x++) {
       const color& c = fb[(size_t)y * width + x];
@@ -141,9 +150,17 @@ int main(int argc, char** argv) {
         float s = std::sqrt(c.v[k]);
         float cl = std::clamp(s, 0.0f, 0.999f);
         float v = 256 * cl;
-        f.put((char)(uint8_t)(v == v ? (int)v : 0));
+        pixels.push_back((uint8_t)(v == v ? (int)v : 0));
       }
     }
+  const std::string out_name = out;
+  if (out_name.size() >= 4 && out_name.compare(out_name.size() - 4, 4, ".png") == 0) {
+    if (!image_io::write_png(out, pixels.data(), (size_t)width, (size_t)height)) { std::fprintf(stderr, "cannot write %s\n", out); return 1; }
+  } else {
+    std::ofstream f(out, std::ios::binary);
+    f << "P6\n" << width << " " << height << "\n255\n";
+    f.write((const char*)pixels.data(), (std::streamsize)pixels.size());
+  }
   std::printf("%zu hittables, %dx%dx%d spp in %.3f s (scene upload + render + copy back) -> %s\n", hittables.size(), width,
               height, samples, sec, out);
   return 0;

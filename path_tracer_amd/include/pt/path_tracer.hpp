@@ -34,6 +34,7 @@
 #include <vector>
 
 #include "../../../include/pt_render.h"
+#include "image_io.hpp"
 
 namespace pt {
 
@@ -99,57 +100,27 @@ struct image_texture {
     atlas.data.insert(atlas.data.end(), rgb, rgb + width * height * 3);
     return t;
   }
-  // texture.hpp:97-117: load an image file and append its texels to the atlas.  stb_image is not a dependency of this
-  // host, so the decoder is the one format that needs none — binary PPM ("P6", maxval 255, rows top-down; `convert
-  // x.jpg x.ppm`, PIL, or path_tracer_amd.scenes.export_reference_textures write it).  Everything else keeps the
-  // reference's failure semantics (texture.hpp:106-111): a message on stderr and the 1x1 texture at offset 0, i.e. the
-  // {0,0,1} fallback texel the atlas starts with; never an exception.
+  // texture.hpp:97-117: load an image file and append its texels to the atlas.  stb_image is not a dependency of this host: PNG,
+  // baseline JPEG and binary PPM are decoded by pt/image_io.hpp (the reference's own images/Xilinx.jpg and images/SYCL.png load as
+  // main.cpp:133,145 load them; the decoded texels are the ones the Python host's loader produces — image_io.hpp says which
+  // decoder choices that pins).  Everything else keeps the reference's failure semantics (texture.hpp:106-111): a message on
+  // stderr and the 1x1 texture at offset 0, i.e. the {0,0,1} fallback texel the atlas starts with; never an exception.
   static image_texture image_texture_factory(const char* file_name, float cyclic_frequency = 1.f,
                                              texture_atlas& atlas = default_atlas()) {
-    std::vector<uint8_t> rgb;
-    std::size_t w = 0, h = 0;
-    const char* reason = read_ppm(file_name, rgb, w, h);
+    image_io::Image img;
+    const char* reason = image_io::load_rgb8(file_name, img);
     if (reason) {
       std::cerr << "ERROR: Could not load texture image file '" << (file_name ? file_name : "(null)") << "'.\n" << reason << std::endl;
       image_texture t;
       t.cyclic_frequency = cyclic_frequency; // texture.hpp:116: w = h = 1, offset 0, the caller's frequency
       return t;
     }
-    return from_rgb8(rgb.data(), w, h, cyclic_frequency, atlas);
+    return from_rgb8(img.rgb.data(), img.width, img.height, cyclic_frequency, atlas);
   }
   std::size_t width{1}, height{1}, offset{0};
   float cyclic_frequency{1.f};
   auto key() const { return std::tie(width, height, offset, cyclic_frequency); }
 
- private:
-  // returns nullptr on success, else the failure reason (the role of stbi_failure_reason())
-  static const char* read_ppm(const char* path, std::vector<uint8_t>& rgb, std::size_t& w, std::size_t& h) {
-    if (!path) return "no file name";
-    std::FILE* f = std::fopen(path, "rb");
-    if (!f) return "can't fopen";
-    struct closer { std::FILE* f; ~closer() { std::fclose(f); } } guard{f};
-    auto token = [&](unsigned long& out) { // header integers, '#' comments allowed between them
-      int c = std::fgetc(f);
-      for (;;) {
-        while (c == ' ' || c == '\t' || c == '\n' || c == '\r') c = std::fgetc(f);
-        if (c != '#') break;
-        while (c != '\n' && c != EOF) c = std::fgetc(f);
-      }
-      if (c < '0' || c > '9') return false;
-      out = 0;
-      while (c >= '0' && c <= '9') { out = out * 10 + (unsigned long)(c - '0'); if (out > (1ul << 30)) return false; c = std::fgetc(f); }
-      return c == ' ' || c == '\t' || c == '\n' || c == '\r'; // exactly one whitespace byte ends the header
-    };
-    if (std::fgetc(f) != 'P' || std::fgetc(f) != '6') return "unknown image type (this host decodes binary PPM 'P6' only)";
-    unsigned long uw = 0, uh = 0, maxval = 0;
-    if (!token(uw) || !token(uh) || !token(maxval)) return "bad PPM header";
-    if (uw == 0 || uh == 0 || maxval != 255) return "unsupported PPM (need width, height > 0 and maxval 255)";
-    if (uw > (1ul << 30) / uh / 3) return "too large";
-    rgb.resize((std::size_t)uw * uh * 3);
-    if (std::fread(rgb.data(), 1, rgb.size(), f) != rgb.size()) return "truncated PPM";
-    w = uw; h = uh;
-    return nullptr;
-  }
 };
 using texture_t = std::variant<checker_texture, solid_texture, image_texture>; // texture.hpp:154
 

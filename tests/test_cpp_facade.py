@@ -158,18 +158,45 @@ def test_example_main_missing_image_gets_the_fallback_texel(example_bin, tmp_pat
     assert img[:, 40:44].copy().view(np.float32)[:, 0].tolist() == [1.0, 5.0]
 
 
+@pytest.mark.skipif(not Path("/root/reference/images/Xilinx.jpg").exists(), reason="the reference tree is only present in the build container")
+def test_example_main_opens_the_references_own_image_files(example_bin, tmp_path):
+    """run with the reference's own ../images directory, the C++ host decodes Xilinx.jpg and SYCL.png itself
+    (pt/image_io.hpp) and builds byte for byte the tables and the atlas layout the Python host builds from the same files (PIL)."""
+    out = tmp_path / "smoke.bin"
+    r = subprocess.run([str(example_bin), "400", "225", "1", str(tmp_path / "x.png"), str(out), "/root/reference/images"], check=True,
+                       capture_output=True, text=True)
+    assert "ERROR" not in r.stderr
+    n, (hb, mb, tb, cb) = read_dump(out)
+    ps, cam = scenes.build("smoke")
+    assert n == [ps.n_hittables, ps.n_materials, ps.n_textures]
+    assert hb == bytes(ps.hittables)[:len(hb)] and mb == bytes(ps.materials)[:len(mb)] and tb == bytes(ps.textures)[:len(tb)]
+
+
 @pytest.mark.gpu
 def test_example_main_renders_the_python_frame(example_bin, tmp_path, images_dir, orc):
+    from path_tracer_amd import png
     from path_tracer_amd import render as R
+    # the decoded-pixel fixture as the files a main.cpp-style caller finds: SYCL.png (lossless: written from the fixture, decoded by the
+    # C++ host's own PNG decoder) beside Xilinx.ppm (a JPEG cannot be regenerated bit for bit; the .jpg path is covered on the CPU)
+    import shutil
+    xil, syc = scenes.reference_textures()
+    shutil.copy(images_dir / "Xilinx.ppm", tmp_path / "Xilinx.ppm")
+    png.write_png(str(tmp_path / "SYCL.png"), syc)
+    images_dir = tmp_path
+    ps, cam = scenes.build("smoke")
+    fb = R.render_host(96, 54, 8, ps, scenes.make_camera(cam, 96, 54))
+    want = orc.tonemap_rgb8(fb)
     ppm = tmp_path / "out.ppm"
     subprocess.run([str(example_bin), "96", "54", "8", str(ppm), "-", str(images_dir)], check=True)
     raw = ppm.read_bytes()
     header, body = raw.split(b"\n255\n", 1)
     assert header.startswith(b"P6\n96 54")
-    img = np.frombuffer(body, dtype=np.uint8).reshape(54, 96, 3)
-    ps, cam = scenes.build("smoke")
-    fb = R.render_host(96, 54, 8, ps, scenes.make_camera(cam, 96, 54))
-    np.testing.assert_array_equal(img, orc.tonemap_rgb8(fb))
+    np.testing.assert_array_equal(np.frombuffer(body, dtype=np.uint8).reshape(54, 96, 3), want)
+    # ... and out.png (main.cpp:57), written by the C++ host's own PNG writer
+    out_png = tmp_path / "out.png"
+    subprocess.run([str(example_bin), "96", "54", "8", str(out_png), "-", str(images_dir)], check=True)
+    from PIL import Image
+    np.testing.assert_array_equal(np.asarray(Image.open(out_png).convert("RGB")), want)
 
 
 # ---- the N-GPU host path in C++ (pt/distributed.hpp + libpt_dist.so: RCCL gather + un-interleave, no Python) ------------
