@@ -384,7 +384,8 @@ int pt_debug_schedule(const PtScene* scene, int32_t out[2]);
  * op: 0 sin 1 cos 2 log 3 pow5 4 atan2(a,b) 5 asin 6 fmod(a,1) 7 sqrt 8 div(a,b)
  *     9 the shared-reciprocal exact quotient a/b used for rect/box sides (pt_device.hpp: div_exact)
  *     10 the reciprocal 1/a of the ray context, correctly rounded for 2^-40 <= |a| <= 2^40 (rcp_rn_guarded)
- *     11 the square root of a = 0 or 2^-60 <= a <= 4 as the RNG's unit_vec / in_unit_disk take it (sqrt_rn_unit) */
+ *     11 the square root of a = 0 or 2^-60 <= a <= 4 as the RNG's unit_vec / in_unit_disk take it (sqrt_rn_unit)
+ *     12 a / sqrt(b) as the sky of a regular ray takes unit_vector(d).y (b = d.d in [3 * 2^-80, 3 * 2^80]; sky_unit_y) */
 int pt_debug_math(int32_t op, const float* a, const float* b, float* out, int64_t n);
 
 #ifdef __cplusplus

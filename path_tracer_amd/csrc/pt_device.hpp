@@ -579,7 +579,9 @@ __device__ __forceinline__ bool medium_t(P recs, int off, const RayCtx& c, float
   if (t2 > mx) t2 = mx;
   if (t1 >= t2) return false;
   if (t1 < 0) t1 = 0;
-  const float ray_length = sqrt_rn(c.a); // sycl::length(r.direction())
+  float a_here = c.a;
+  asm volatile("" : "+v"(a_here)); // (opaque: the square root stays HERE, behind the boundary tests — hoisted to the top of the iteration it ran for every ray of every wave)
+  const float ray_length = sqrt_rn(a_here); // sycl::length(r.direction())
   const float distance_inside_boundary = (t2 - t1) * ray_length;
   const float hit_distance = R0.y * ptm::logf_(rng_float(rng)); // the in-traversal draw (:65)
   if (hit_distance > distance_inside_boundary) return false;
@@ -1648,12 +1650,14 @@ __device__ __forceinline__ bool tri_pool_scan(glb_f4p gblob, cst_f4p cblob, int 
   return true;
 }
 
-template <bool IMG, int TRIP = 1, int TTRIP = TRIP, bool WHOLE = true, bool BADOUEL = false, bool GRID = true, bool TRIPOOL = false, typename P>
+// RECTBOX: the scene holds rects and boxes only (MATS_RECTBOX_ONLY kernels): the sphere / triangle / medium loops are not compiled in —
+// less code, and nothing of theirs (the medium's sqrt(d.d), say) can be hoisted into the per-iteration prologue of a kernel that never runs it.
+template <bool IMG, int TRIP = 1, int TTRIP = TRIP, bool WHOLE = true, bool BADOUEL = false, bool GRID = true, bool TRIPOOL = false, bool RECTBOX = false, typename P>
 __device__ __forceinline__ void hit_records(P recs, cst_f4p cblob, int kind, int n, int goff,
                                             const RayCtx& c, bool fast, uint32_t& rng, HitState& h) {
   const Ray& r = c.r;
   int off = 0;
-  if (kind == DK_SPHERE) {
+  if (!RECTBOX && kind == DK_SPHERE) {
     auto accept_at = [&](int o) {
       return [&h, &r, recs, goff, o](float t) {
         h.closest = t;
@@ -1686,7 +1690,7 @@ __device__ __forceinline__ void hit_records(P recs, cst_f4p cblob, int kind, int
         if (IMG) { h.u = (ca - R0.x) / (R0.y - R0.x); h.v = (cb - R0.z) / (R0.w - R0.z); }
       }
     }
-  } else if (kind == DK_TRI) {
+  } else if (!RECTBOX && kind == DK_TRI) {
     if constexpr (TRIPOOL && WHOLE) { // a long run with a triangle pool (flag + header offset in the run's aux record)
       const f4 aux = cblob[goff - 1];
       if (as_i(aux.x) != 0 && fast) {
@@ -1719,7 +1723,7 @@ __device__ __forceinline__ void hit_records(P recs, cst_f4p cblob, int kind, int
     for (int i = 0; i < n; ++i, off += SZ_TRI)
       badouel_test(recs[off], recs[off + 1], recs[off + 2], r, PT_TMIN, h.closest,
                    [&](float t) { h.closest = t; h.hit = hit_pack(DK_TRI_B, 0, goff + off); });
-  } else if (kind == DK_BOX) {
+  } else if (kind == DK_BOX || (RECTBOX && kind != DK_RECT)) {
 #ifndef PT_NO_CMPX
     if (fast && !IMG) {
       const unsigned long long exec_all = __builtin_amdgcn_ballot_w64(true); // EXEC as it is around the scan
@@ -1862,7 +1866,7 @@ __device__ __forceinline__ int record_size(int kind) {
 // kernel constants: an s_load lands in SGPRs directly, no LDS round trip + v_readfirstlane per run) and the records from LDS.
 // `cblob`: the blob in global memory through the scalar cache (run headers, sphere-run masks); `blob`: where the records are
 // read from (LDS copy, or the same global blob).
-template <bool IMG, bool BADOUEL = false, bool GRID = true, bool TRIPOOL = false, typename P>
+template <bool IMG, bool BADOUEL = false, bool GRID = true, bool TRIPOOL = false, bool RECTBOX = false, typename P>
 __device__ __forceinline__ void hit_world(P blob, cst_f4p cblob, int n_runs, const RayCtx& c, bool fast, uint32_t& rng, HitState& h) {
   hit_begin(h);
   for (int ri = 0; ri < n_runs; ++ri) {
@@ -1878,7 +1882,7 @@ __device__ __forceinline__ void hit_world(P blob, cst_f4p cblob, int n_runs, con
         }
       }
     }
-    hit_records<IMG, 1, 1, true, BADOUEL, GRID, TRIPOOL>(blob + off, cblob, kind, as_i(runf.z), off, c, fast, rng, h);
+    hit_records<IMG, 1, 1, true, BADOUEL, GRID, TRIPOOL, RECTBOX>(blob + off, cblob, kind, as_i(runf.z), off, c, fast, rng, h);
   }
 }
 
@@ -2082,13 +2086,24 @@ __device__ __forceinline__ void set_face_normal(Rec& rec, const Ray& r, V3 n) {
   rec.normal = rec.front_face ? n : mk(0.0f, 0.0f, 0.0f) - n;
 }
 
-template <typename P>
+// RECTBOX (compile-time; MATS bit 16): the scene's hittables are rects and boxes only — the headline Cornell-style family — so a hit is
+// one of those two kinds and the sphere / triangle / medium branches (three exec-mask branches a wave walks past on every hit) are not
+// compiled in.
+template <bool RECTBOX = false, typename P>
 __device__ __forceinline__ Rec resolve_hit(P blob, int hit, const Ray& r, float t) {
   Rec rec;
   rec.p = r.o + t * r.d; // ray::at ray.hpp:21
   const int off = hit_off(hit);
   const int kind = hit_kind(hit);
   f4 R0 = blob[off], R1 = blob[off + 1];
+  if constexpr (RECTBOX) {
+    int axis;
+    if (kind == DK_RECT) { axis = as_i(R1.z); rec.mat = as_i(R1.y); rec.hittable = as_i(R1.w); }
+    else { axis = hit_side(hit) >> 1; rec.mat = as_i(R0.w); rec.hittable = as_i(R1.w); }
+    V3 n = axis == 0 ? mk(0, 0, 1) : axis == 1 ? mk(0, 1, 0) : mk(1, 0, 0);
+    set_face_normal(rec, r, n);
+    return rec;
+  }
   if (kind == DK_SPHERE) {
     f4 R2 = blob[off + 2];
     V3 n = (rec.p - sphere_center(R0, R1, R2, r.tm)) / R1.x;
@@ -2157,7 +2172,7 @@ __device__ __forceinline__ uint32_t texel_index(float f, uint32_t maxv) {
 // order: lambertian 0, metal 1, dielectric 2, lightsource 3, isotropic 4); bit 8 = a texture other than solid_texture may occur.
 // The generic kernels pass MATS_ALL; a scene of lambertian + lightsource materials over solid textures (the Cornell-style
 // headline scene) runs kernels compiled with MATS_LAMB_LIGHT_SOLID, which carry none of the other branches.
-enum { MATS_ALL = 0x11f, MATS_LAMB_LIGHT_SOLID = 0x009 };
+enum { MATS_ALL = 0x11f, MATS_LAMB_LIGHT_SOLID = 0x009, MATS_RECTBOX_ONLY = 0x10000 /* + every hittable is a rect or a box (resolve_hit) */ };
 
 template <int MATS = MATS_ALL, typename UV>
 __device__ __forceinline__ V3 texture_value(f4 M0, f4 M1, f4 M2, f4 M3, V3 p, UV uv, const uint8_t* __restrict__ atlas) {
@@ -2195,8 +2210,26 @@ __device__ __forceinline__ float reflectance(float cosine, float ref_idx) {
 }
 
 // render.hpp:83-87
-__device__ __forceinline__ V3 sky_color(const Ray& r, V3 att) {
-  V3 ud = r.d / sqrt_rn(dot(r.d, r.d));
+// regular (wave-uniform): every live lane's ray is regular (RayCtx: 2^-40 <= |d_c| <= 2^40), so a = d.d lies in [3 * 2^-80, 3 * 2^80] and
+// only unit_vector(d).y = d.y / sqrt(a) is needed (render.hpp:84-85 reads .y() only): the square root through the hardware estimate +
+// neighbour test (sqrt_rn_unit's form: scale-invariant under x -> 4x, so what is proved for EVERY float of [2^-60, 4] holds for every
+// normal x whose residuals stay normal), the quotient through ONE correctly rounded reciprocal + div_exact's correction (no intermediate
+// leaves the normal range: |q| in [2^-81, 1]).  17 + 12 -> 9 + 8 issue slots, once per iteration (some lane of 64 nearly always misses
+// everything).  Same bits as the IEEE forms: tests/test_gpu_parity.py::test_sky_unit_direction_shortcut_is_exact.
+__device__ __forceinline__ float sky_unit_y(float dy, float a, bool regular) {
+#ifdef PT_NO_SKY_SHORTCUT /* A/B build */
+  regular = false;
+#endif
+  if (regular) {
+    const float len = sqrt_rn_unit(a);
+    const float y = rcp_rn_guarded(len);
+    return div_exact(dy, len, y, dy * y);
+  }
+  asm volatile("" : "+v"(a)); // (opaque: the general square root is not to be hoisted out of this rarely taken path)
+  return dy / sqrt_rn(a);
+}
+__device__ __forceinline__ V3 sky_color(const Ray& r, V3 att, bool regular = false) {
+  V3 ud = mk(0.0f, sky_unit_y(r.d.y, dot(r.d, r.d), regular), 0.0f); // (x and z of the unit vector are never read)
   float hit_pt = 0.5f * (ud.y + 1.0f);
   V3 c = (1.0f - hit_pt) * mk(1.0f, 1.0f, 1.0f) + hit_pt * mk(0.5f, 0.7f, 1.0f);
   return att * c;

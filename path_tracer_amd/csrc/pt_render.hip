@@ -358,16 +358,16 @@ __device__ __forceinline__ void lane_regenerate(Lane& L, const KArgs& a) {
 
 // emitted / scatter / sky for the nearest hit (render.hpp:60-88) and the sample bookkeeping (:100).
 template <int UV, bool FAST = false, int MATS = MATS_ALL, typename Lane, typename PB, typename PM>
-__device__ __forceinline__ void lane_shade(Lane& L, const KArgs& a, const HitState& h, PB recs, PM mats) {
+__device__ __forceinline__ void lane_shade(Lane& L, const KArgs& a, const HitState& h, PB recs, PM mats, bool regular = false) {
   if (!L.live) return;
   if (a.cost) L.cold.count_ray(); // cost-probe pass (wave-uniform)
   V3 out = mk(0.0f, 0.0f, 0.0f);
   bool cont;
   if (h.hit < 0) {
-    out = sky_color(L.ray, L.att);
+    out = sky_color(L.ray, L.att, regular);
     cont = false;
   } else {
-    Rec rec = resolve_hit(recs, h.hit, L.ray, h.closest); // per-lane gather of the one record that was hit
+    Rec rec = resolve_hit<(MATS & MATS_RECTBOX_ONLY) != 0>(recs, h.hit, L.ray, h.closest); // per-lane gather of the one record that was hit
     // UV_TRACKED kernels carried u,v through the scan (stale values included); UV_WINNER derives them from the final hit
     // when an image texture asks; UV_NONE: the scene has no image texture, nothing reads them
     auto uv = [&](float& u, float& v) {
@@ -375,7 +375,7 @@ __device__ __forceinline__ void lane_shade(Lane& L, const KArgs& a, const HitSta
       else if (UV == UV_WINNER) winner_uv(recs, h.hit, L.ray, h.closest, rec, u, v);
       else { u = 0.0f; v = 0.0f; }
     };
-    cont = shade<MATS>(mats, a.atlas, rec, uv, L.ray, L.att, L.rng, out);
+    cont = shade<(MATS & 0x1ff)>(mats, a.atlas, rec, uv, L.ray, L.att, L.rng, out);
     if (cont && ++L.b >= a.depth) { // bounce loop exhausted: black (render.hpp:91)
       out = mk(0.0f, 0.0f, 0.0f);
       cont = false;
@@ -463,6 +463,7 @@ void render_kernel(KArgs a) {
     PT_STAMP(t1);
 #endif
     HitState h;
+    bool regular = false; // (wave-uniform) every live ray is regular: the sky's shortcut (sky_unit_y)
     if constexpr (LDS) {
       if constexpr (COOP) {
         // ordinary and cooperative traversal (few live lanes: each live ray's list split over the idle lanes)
@@ -472,14 +473,15 @@ void render_kernel(KArgs a) {
         RayCtx c = make_ctx(L.ray, a.fast_ok != 0);
         c.live = L.live;
         const bool fast = wave_all_regular(c, L.live);
-        hit_world<IMG, BADOUEL, GRID>((lds_f4p)smem, (cst_f4p)a.blob, a.n_runs, c, fast, L.rng, h);
+        regular = fast;
+        hit_world<IMG, BADOUEL, GRID, false, (MATS & MATS_RECTBOX_ONLY) != 0>((lds_f4p)smem, (cst_f4p)a.blob, a.n_runs, c, fast, L.rng, h);
       }
 #ifdef PT_STAMPS
       asm volatile("" ::"v"(h.closest), "v"(h.hit));
       PT_STAMP(t2);
 #endif
-      if constexpr (MLDS) lane_shade<UV, FAST, MATS>(L, a, h, (lds_f4p)smem, (lds_f4p)smem + a.blob_f4);
-      else lane_shade<UV, FAST, MATS>(L, a, h, (lds_f4p)smem, a.mats);
+      if constexpr (MLDS) lane_shade<UV, FAST, MATS>(L, a, h, (lds_f4p)smem, (lds_f4p)smem + a.blob_f4, regular);
+      else lane_shade<UV, FAST, MATS>(L, a, h, (lds_f4p)smem, a.mats, regular);
 #ifdef PT_STAMPS
       asm volatile("" ::"v"(L.att.x), "v"(L.ray.d.x));
       PT_STAMP(t3);
@@ -489,8 +491,8 @@ void render_kernel(KArgs a) {
       RayCtx c = make_ctx(L.ray, a.fast_ok != 0);
       c.live = L.live;
       const bool fast = wave_all_regular(c, L.live);
-      hit_world<IMG, BADOUEL, GRID, TRIPOOL>((cst_f4p)a.blob, (cst_f4p)a.blob, a.n_runs, c, fast, L.rng, h);
-      lane_shade<UV, FAST, MATS>(L, a, h, a.blob, a.mats);
+      hit_world<IMG, BADOUEL, GRID, TRIPOOL, (MATS & MATS_RECTBOX_ONLY) != 0>((cst_f4p)a.blob, (cst_f4p)a.blob, a.n_runs, c, fast, L.rng, h);
+      lane_shade<UV, FAST, MATS>(L, a, h, a.blob, a.mats, fast);
     }
   }
 #ifdef PT_STAMPS_WALK
@@ -771,6 +773,7 @@ __global__ void math_kernel(int op, const float* __restrict__ a, const float* __
     case 9: { float yy = 1.0f / y; r = div_exact(x, y, yy, x * yy); break; } // the shared-reciprocal quotient (|q| >= 2^-60)
     case 10: r = rcp_rn_guarded(x); break; // RN(1/a) for 2^-40 <= |a| <= 2^40 (pt_device.hpp: make_ctx)
     case 11: r = sqrt_rn_unit(x); break;   // correctly rounded sqrt for x = 0 or 2^-60 <= x <= 4
+    case 12: r = sky_unit_y(x, y, true); break; // unit_vector(d).y = x / sqrt(y) for a regular ray (y = d.d): the sky's shortcut
     default: r = x / y; break;
   }
   out[i] = r;
@@ -968,6 +971,7 @@ struct PtScene {
   float traversal_cost = 0.0f; // estimated VALU instructions of one ray's scan of the list (sphere runs through their lists)
   int grid_spheres = 0;        // spheres that sit in a culling grid (the resident non-cooperative kernels walk it)
   int tri_pooled = 0;          // triangles that sit in a triangle pool (the TRIPOOL kernels query it)
+  bool rectbox_only = false;   // every hittable is a rect or a box (kernels compiled with MATS_RECTBOX_ONLY: resolve_hit)
   bool mats_simple = false;    // every material is lambertian or lightsource over a solid texture (kernels compiled with MATS_LAMB_LIGHT_SOLID)
   size_t blob_bytes = 0;
   int num_cus = 256;
@@ -1131,6 +1135,14 @@ int pt_scene_create_tuned(const PtSceneDesc* desc, const PtTuning* tuning, PtSce
     }
   }
   s->grid_spheres = flat.grid_spheres;
+  s->rectbox_only = desc->n_hittables > 0 && !s->knobs.generic_materials;
+#ifdef PT_NO_RECTBOX /* A/B build */
+  s->rectbox_only = false;
+#endif
+  for (int i = 0; i < desc->n_hittables && s->rectbox_only; i++) {
+    const int k = desc->hittables[i].kind;
+    if (k != PT_HIT_XY_RECT && k != PT_HIT_XZ_RECT && k != PT_HIT_YZ_RECT && k != PT_HIT_BOX) s->rectbox_only = false;
+  }
   s->mats_simple = desc->n_materials > 0 && !s->knobs.generic_materials; // PtTuning.generic_materials: A/B knob (generic shading)
   for (int i = 0; i < desc->n_materials && s->mats_simple; i++) {
     const PtMaterial& m = desc->materials[i];
@@ -1349,6 +1361,13 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
     if constexpr (UV == UV_NONE) { // no image texture and no sphere grid (the headline scene): kernels without the grid walk
       if (s->grid_spheres == 0 && !coop) {
         if (s->mats_simple) { // lambertian + lightsource over solid textures: kernels without the other materials' code
+          if (s->rectbox_only) { // ... and every hittable a rect or a box (the headline scene): resolve_hit without the other kinds
+            constexpr int MSR = MATS_LAMB_LIGHT_SOLID | MATS_RECTBOX_ONLY;
+            if (!lds) return launch(render_kernel<UV, false, false, false, false, false, false, false, false, MSR>);
+            if (mlds && shmem <= kMaxLdsColdScene && !s->knobs.no_cold_lds) return launch(render_kernel<UV, true, true, false, true, false, false, false, false, MSR>);
+            return mlds ? launch(render_kernel<UV, true, true, false, false, false, false, false, false, MSR>)
+                        : launch(render_kernel<UV, true, false, false, false, false, false, false, false, MSR>);
+          }
           constexpr int MS = MATS_LAMB_LIGHT_SOLID;
           if (!lds) return launch(render_kernel<UV, false, false, false, false, false, false, false, false, MS>);
           if (mlds && shmem <= kMaxLdsColdScene && !s->knobs.no_cold_lds) return launch(render_kernel<UV, true, true, false, true, false, false, false, false, MS>);
@@ -1604,8 +1623,8 @@ int pt_debug_camera_rays(const PtCamera* cam, int32_t width, int32_t height, con
 }
 
 int pt_debug_math(int32_t op, const float* a, const float* b, float* out, int64_t n) {
-  if (!a || !out || n < 0 || op < 0 || op > 11) return fail(PT_ERR_INVALID_ARG, "pt_debug_math: bad argument");
-  if ((op == 4 || op == 8 || op == 9) && !b) return fail(PT_ERR_INVALID_ARG, "pt_debug_math: op needs two operands");
+  if (!a || !out || n < 0 || op < 0 || op > 12) return fail(PT_ERR_INVALID_ARG, "pt_debug_math: bad argument");
+  if ((op == 4 || op == 8 || op == 9 || op == 12) && !b) return fail(PT_ERR_INVALID_ARG, "pt_debug_math: op needs two operands");
   if (n == 0) return PT_OK;
   DevBuf<float> da, db, dout;
   PT_HIP(da.alloc(n));

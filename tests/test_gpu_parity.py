@@ -136,6 +136,34 @@ def test_unit_range_sqrt_is_correctly_rounded(lib):
     assert_bit_identical(gpu_math(lib, 11, z, None), np.sqrt(z), "sqrt edge values")
 
 
+def test_sky_unit_direction_shortcut_is_exact(lib):
+    """render.hpp:83-85 for a regular ray (pt_device.hpp: sky_unit_y): unit_vector(d).y = d.y / sqrt(d.d) through the hardware square
+    root + neighbour test and ONE correctly rounded reciprocal + correction instead of the IEEE expansions — the same bits for
+    directions over the whole guarded range 2^-40 <= |d_c| <= 2^40 (d.d from 3 * 2^-80 to 3 * 2^80), adversarial significands
+    included; and the square root form itself for EVERY float of four binades outside sqrt_rn_unit's own test range (it is
+    scale-invariant under x -> 4 x: an even and an odd exponent cover all)."""
+    rng = np.random.default_rng(41)
+    n_ = 3_000_000
+
+    def comp(exp_lo, exp_hi):
+        m = rng.integers(0, 2 ** 23, n_, dtype=np.uint32)
+        m[::7] = 0x7FFFFF - rng.integers(0, 8, len(m[::7]), dtype=np.uint32)
+        m[3::7] = rng.integers(0, 8, len(m[3::7]), dtype=np.uint32)
+        e = rng.integers(exp_lo, exp_hi + 1, n_).astype(np.uint32) + 127
+        sgn = rng.integers(0, 2, n_, dtype=np.uint32) << 31
+        return ((e << 23) | m | sgn).astype(np.uint32).view(np.float32)
+
+    for lo, hi in ((-40, 40), (-2, 2), (38, 40), (-40, -38)):
+        dx, dy, dz = comp(lo, hi), comp(lo, hi), comp(lo, hi)
+        a = ((dx * dx + dy * dy).astype(np.float32) + dz * dz).astype(np.float32)  # dot(d, d), left to right in binary32
+        want = (dy / np.sqrt(a)).astype(np.float32)
+        assert_bit_identical(gpu_math(lib, 12, dy, a), want, f"d.y / sqrt(d.d), exponents {lo}..{hi}")
+    m = np.arange(2 ** 23, dtype=np.uint32)
+    for e in (-81, -80, 80, 81):
+        x = ((np.uint32(e + 127) << 23) | m).astype(np.uint32).view(np.float32)
+        assert_bit_identical(gpu_math(lib, 11, x, None), np.sqrt(x), f"sqrt, exponent {e}")
+
+
 def test_camera_quotients_through_the_reciprocal_are_exact(lib):
     """render.hpp:96-97: (x + xi) / width through div_exact with RN(1/width) — equal to the IEEE quotient for every frame
     size up to 16384 and numerators x + xi with xi a multiple of 2^-32 (checked on random and extreme numerators)."""
