@@ -1319,11 +1319,14 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
     if (s->knobs.blocks_per_cu) per_cu = std::min(per_cu, s->knobs.blocks_per_cu); // tuning knob
     const int resident_blocks = std::max(1, per_cu) * std::max(1, s->num_cus);
     // Queue counters come from a ring of kQueueRing slots.  A slot is reused only after the launch that last used it has
-    // finished: the host waits on that launch's event (more than kQueueRing launches in flight on one scene would
-    // otherwise share a dequeue counter and lose or duplicate pixels).
-    const unsigned int slot = s->next_queue++ % kQueueRing;
-    if (s->ring_done[slot]) PT_HIP(hipEventSynchronize(s->ring_done[slot]));
+    // finished (more than kQueueRing launches in flight on one scene would otherwise share a dequeue counter and lose or
+    // duplicate pixels): the NEW launch's stream waits for that launch's event on the device — the host does not block, so
+    // pt_render stays asynchronous however many renders are queued (round 3 synchronised the host here, with the scene's
+    // scheduling mutex held).
+    const unsigned int slot = s->next_queue % kQueueRing;
+    if (s->ring_done[slot]) PT_HIP(hipStreamWaitEvent(st, s->ring_done[slot], 0));
     else PT_HIP(hipEventCreateWithFlags(&s->ring_done[slot], hipEventDisableTiming));
+    s->next_queue++; // (only once nothing above can fail any more)
     a.queue = s->queues + 2 * slot; // [0] ordinary queue, [1] wide-phase queue
     PT_HIP(hipMemsetAsync(a.queue, 0, 2 * sizeof(unsigned int), st));
     // one wave per tile is enough, except in the wide phase, where a split tile keeps G waves busy (how many tiles are

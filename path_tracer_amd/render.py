@@ -55,6 +55,9 @@ def _params(width, height, samples, depth, shard_index=0, shard_count=1, flags=0
                               int(flags), 0)
 
 
+_DEVICE_SCENE_CACHE = 4  # device scenes kept per PackedScene (one per (device, stream) in use)
+
+
 def _as_device_scene(scene, cache_key=None) -> DeviceScene:
     """DeviceScene of whatever the caller handed over.  With `cache_key` (the asynchronous torch path) the device scene of a
     PackedScene is kept on it, per (device, stream): no re-flatten / re-upload / hipMalloc per call, and — the point — no temporary
@@ -67,9 +70,17 @@ def _as_device_scene(scene, cache_key=None) -> DeviceScene:
         cache_key = None
     if cache_key is None:
         return DeviceScene(scene)
+    # a small LRU per PackedScene: a device scene holds a full copy of the flattened scene (25 MB for the 100 k-triangle mesh) plus
+    # launch workspaces, and the key contains the raw stream handle — programs that create streams on the fly must not pile up a
+    # copy per stream that ever existed (a handle reused after its stream died aliases at worst a scene that is still valid: scene
+    # data is immutable and its workspaces are only touched in launch order of whichever stream uses them next)
     cache = scene.__dict__.setdefault("_pt_device_scenes", {})
-    if cache_key not in cache:
-        cache[cache_key] = DeviceScene(scene)
+    if cache_key in cache:
+        cache[cache_key] = cache.pop(cache_key)  # most recently used last
+        return cache[cache_key]
+    while len(cache) >= _DEVICE_SCENE_CACHE:
+        cache.pop(next(iter(cache)))  # destroyed when the last frame that references it is gone (DeviceScene.__del__)
+    cache[cache_key] = DeviceScene(scene)
     return cache[cache_key]
 
 

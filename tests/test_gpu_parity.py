@@ -1035,3 +1035,23 @@ def test_two_streams_get_two_device_scenes(torch_gpu, orc):
     ref = orc.render_pixels(ps, c.c, 320, 184, 64, xy)
     for k, f in enumerate(frames):
         assert_bit_identical(f.cpu().numpy()[xy[:, 1], xy[:, 0]], ref, f"frame {k}")
+
+
+def test_device_scene_cache_is_bounded(torch_gpu, orc):
+    """render()'s per-PackedScene cache of device scenes is keyed by (device, stream handle); programs that create
+    streams on the fly must not keep a full device copy of the scene per stream that ever existed — it is a small LRU, and an
+    evicted scene lives on exactly as long as a frame rendered from it does."""
+    torch = torch_gpu
+    ps, cam = S.ALL["mixed"]()
+    c = scenes.make_camera(cam, 40, 24)
+    orc.set_math(True)
+    ref = orc.render(ps, c.c, 40, 24, 3)
+    frames = []
+    streams = [torch.cuda.Stream() for _ in range(7)]
+    for st in streams:
+        with torch.cuda.stream(st):
+            frames.append(R.render(40, 24, 3, ps, c))
+    torch.cuda.synchronize()
+    assert len(ps.__dict__["_pt_device_scenes"]) <= 4
+    for k, f in enumerate(frames):
+        assert_bit_identical(f.cpu().numpy(), ref, f"stream {k}")
