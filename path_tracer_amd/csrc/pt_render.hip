@@ -851,6 +851,7 @@ static void tuning_env(PtTuning& t) {
   if (const char* e = std::getenv("PT_MODEL_CHAIN")) t.model_chain = (float)std::atof(e);
   if (const char* e = std::getenv("PT_SCATTER_LOG")) t.scatter_log = std::min(5, std::max(0, std::atoi(e)));
   t.scatter_mode = has("PT_NO_SCATTER") ? -1 : has("PT_LPT_SCATTER") ? 1 : 0;
+  if (const char* e = std::getenv("PT_LANES_CAP")) t.lanes_cap = std::atoi(e) <= 0 ? -1 : std::min(64, std::atoi(e));
 }
 // the caller's struct (possibly from an older header: struct_size bytes are valid) or, for NULL, defaults + environment
 static int resolve_tuning(const PtTuning* user, PtTuning& t, std::string& err) {
@@ -923,6 +924,7 @@ struct Knobs {
   int grid_block = kGridBlock; // PT_GRID_BLOCK (build-time experiment: workgroup size of the grid kernels)
   bool no_scatter = false; // triangle-pool kernels hand out whole tiles' pixels to a wave again (lane_acquire)
   bool generic_materials = false;
+  int lanes_cap = 0;       // PtTuning.lanes_cap: grid kernels on small frames (launch): 0 the rule, -1 whole tiles always, n forced
   Knobs() {}
   explicit Knobs(const PtTuning& t) {
     blocks_per_cu = std::max(0, t.blocks_per_cu);
@@ -937,6 +939,7 @@ struct Knobs {
     scatter_log = std::min(5, std::max(0, t.scatter_log));
     no_scatter = t.scatter_mode < 0; lpt_with_scatter = t.scatter_mode > 0;
     generic_materials = t.generic_materials != 0;
+    lanes_cap = t.lanes_cap < 0 ? -1 : std::min(64, t.lanes_cap);
   }
 };
 
@@ -1306,6 +1309,10 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
   // against 102; shard 0/8 of 4K at 128 spp 61 against 102).  PT_GRID_MIN_TILES restores a threshold.
   const bool use_grid = s->grid_spheres > 0 && resident /* the streaming kernel scans the full lists */ && local_tiles >= s->knobs.grid_min_tiles && !(p->flags & PT_FLAG_FORCE_COOP);
   const bool coop = lds && a.coop_prefix >= 0 && !use_grid && (s->traversal_cost >= kCoopMinTraversal || (p->flags & PT_FLAG_FORCE_COOP));
+  // (small frames through the grid kernels: see `launch`; PT_FLAG_TILE_GRANULAR / PT_FLAG_PIXEL_GRANULAR and the fast mode keep what they ask for)
+  // (only the kernels that walk a sphere grid: the headline family's iteration — slab pass, wave-uniform — does not get shorter with fewer
+  // lanes: its shard 0/8 took 127 ms that way against 40)
+  const bool share_small = use_grid && s->knobs.lanes_cap >= 0 && !(p->flags & (PT_FLAG_TILE_GRANULAR | PT_FLAG_PIXEL_GRANULAR | PT_FLAG_FAST_RNG));
   // Persistent grid: no more workgroups than the chip holds at once; lanes pull pixels from the queue.
   auto launch = [&](auto kernel, int block_threads = kBlock) -> int {
     const int waves_per_block = block_threads / 64;
@@ -1333,6 +1340,28 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
     // split is decided on the device, so such a launch simply fills the chip; surplus waves find the queues empty and exit)
     long long wanted = a.n_split ? (long long)resident_blocks : (launch_units + waves_per_block - 1) / waves_per_block;
     a.lanes_cap = 64;
+    // Frames (or shards) that do not fill the chip several times over are bound by their pixels' sequential chains, not by throughput —
+    // BASELINE config 1 is 1 406 tiles for 4 096 resident waves, a shard of an 8-GPU job about one tile per wave — and a wave that steps
+    // 64 pixels together pays, every iteration, for the LONGEST walk, the largest candidate count and every material among them.  Such a
+    // launch fills the chip and gives each wave only `lanes_cap` lanes' worth of pixels at a time (one pixel per lane, refilled from the
+    // queue: consecutive positions = neighbouring pixels of one tile row, so the walks stay coherent): fewer lanes per wave = a shorter
+    // iteration for the pixels that set the frame time.  Measured on one box (profiles/r04_ab_lanes_cap.txt; rho = pixels per resident
+    // lane): config 1 (rho 0.34) 24.5 ms at 64 lanes, 22.0 at 24, 19.2 at 8, 17.9 at 4; shard 0/8 of the 1080p frame (rho 1.0) 70.9 / 61.6 /
+    // 60.1 / 76.4 ms at 64 / 32 / 16 / 8; shard 0/8 of the 4K frame (rho 4.0) 201.7 / 209.8 / 218.1 at 64 / 48 / 32: lanes = 16 rho fits all
+    // three.  Which lane renders a pixel changes nothing in the image (a pixel's seed is its id).
+    if (share_small && a.scatter_p == 0) {
+      const long long lanes = (long long)resident_blocks * waves_per_block * 64;
+      long long cap = (16 * (long long)a.n_local_pixels + lanes - 1) / lanes; // 16 rho
+      cap = std::min<long long>(64, std::max<long long>(4, (cap + 3) / 4 * 4));
+      if (cap > 24) cap = 64; // (rho 2: 93.9 ms at 32 lanes against 90.9 at 64 — from there on the frame is throughput)
+      if (s->knobs.lanes_cap > 0) cap = std::min(64, s->knobs.lanes_cap); // PtTuning.lanes_cap: forced
+      if (cap < 64) {
+        a.lanes_cap = (int)cap;
+        a.tile_granular = 0;
+        wanted = std::min<long long>(resident_blocks, ((long long)a.n_local_pixels + cap * waves_per_block - 1) / (cap * waves_per_block));
+        wanted = std::max<long long>(wanted, 1);
+      }
+    }
     if (a.scatter_p > 0) { // triangle-pool kernels: fill the chip and share the pixels out evenly (lane_acquire)
       wanted = std::min<long long>(resident_blocks, ((long long)a.n_local_pixels + block_threads - 1) / block_threads * 64); // (at least one pixel per wave)
       wanted = std::max<long long>(wanted, 1);

@@ -9,10 +9,10 @@ cp $SRC/bench_n1.json $DST/${TAG}_bench_n1.json
 cp $(ls -t $(find $SRC/kt -name "*kernel_stats.csv") | head -1) $DST/${TAG}_kernel_stats.csv   # the newest run of this tag
 KT=$(ls -t $(find $SRC/kt -name "*kernel_trace.csv") | head -1)
 (head -1 $KT; grep -E "render_kernel|lpt_order" $KT | head -8) > $DST/${TAG}_kernel_trace_rows.csv
-for p in a b fetch write icache; do
+for p in a b fetch write icache mem1 mem2; do
   [ -d $SRC/pmc_$p ] || continue
   f=$(ls -t $(find $SRC/pmc_$p -name "*counter_collection.csv" 2>/dev/null) 2>/dev/null | head -1)
   [ -n "$f" ] && (head -1 $f; grep -E "render_kernel" $f) > $DST/${TAG}_pmc_$p.csv
 done
-python tools/pmc_summary.py ${PT_FINAL_ROUND:+--final $PT_FINAL_ROUND} $TAG $SCENE $W $H $SPP $DST/${TAG}_pmc_a.csv $DST/${TAG}_pmc_b.csv $DST/${TAG}_pmc_fetch.csv $DST/${TAG}_pmc_write.csv > $DST/${TAG}_pmc_summary.json
+python tools/pmc_summary.py ${PT_FINAL_ROUND:+--final $PT_FINAL_ROUND} $TAG $SCENE $W $H $SPP $DST/${TAG}_pmc_a.csv $DST/${TAG}_pmc_b.csv $DST/${TAG}_pmc_fetch.csv $DST/${TAG}_pmc_write.csv $(ls $DST/${TAG}_pmc_mem1.csv $DST/${TAG}_pmc_mem2.csv 2>/dev/null) > $DST/${TAG}_pmc_summary.json
 cat $DST/${TAG}_pmc_summary.json | python -c "import json,sys; d=json.load(sys.stdin); print(json.dumps(d['derived'], indent=1)); print(d['kernel'])"

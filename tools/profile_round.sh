@@ -21,6 +21,10 @@ rocprofv3 --pmc $P1 --output-format csv -d $OUT/pmc_a -- python3 bench.py --step
 rocprofv3 --pmc $P2 --output-format csv -d $OUT/pmc_b -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline $ARGS > $OUT/pmc_b.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline $ARGS > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline $ARGS > $OUT/pmc_write.log 2>&1
+if [ -n "$PT_PROFILE_MEM" ]; then  # the memory system behind the L1s: L2 hits / misses, what leaves L2 (fabric read requests, the part that goes to DRAM), L1 stalls
+  rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mem1 -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline $ARGS > $OUT/pmc_mem1.log 2>&1
+  rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_DRAM_sum TCP_PENDING_STALL_CYCLES_sum GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mem2 -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline $ARGS > $OUT/pmc_mem2.log 2>&1
+fi
 if [ -n "$PT_PROFILE_ICACHE" ]; then
   rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_BUSY_CYCLES SQ_IFETCH --output-format csv -d $OUT/pmc_icache -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline $ARGS > $OUT/pmc_icache.log 2>&1
 fi
