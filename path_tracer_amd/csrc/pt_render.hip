@@ -1348,11 +1348,11 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
     // iteration for the pixels that set the frame time.  Measured on one box (profiles/r04_ab_lanes_cap.txt; rho = pixels per resident
     // lane): config 1 (rho 0.34) 24.5 ms at 64 lanes, 22.0 at 24, 19.2 at 8, 17.9 at 4; shard 0/8 of the 1080p frame (rho 1.0) 70.9 / 61.6 /
     // 60.1 / 76.4 ms at 64 / 32 / 16 / 8; shard 0/8 of the 4K frame (rho 4.0) 201.7 / 209.8 / 218.1 at 64 / 48 / 32: lanes = 16 rho fits all
-    // three.  Which lane renders a pixel changes nothing in the image (a pixel's seed is its id).
+    // three (rounded to the nearest multiple of 4).  Which lane renders a pixel changes nothing in the image (a pixel's seed is its id).
     if (share_small && a.scatter_p == 0) {
       const long long lanes = (long long)resident_blocks * waves_per_block * 64;
-      long long cap = (16 * (long long)a.n_local_pixels + lanes - 1) / lanes; // 16 rho
-      cap = std::min<long long>(64, std::max<long long>(4, (cap + 3) / 4 * 4));
+      long long cap = (16 * (long long)a.n_local_pixels + lanes / 2) / lanes; // 16 rho
+      cap = std::min<long long>(64, std::max<long long>(4, (cap + 2) / 4 * 4)); // (the nearest multiple of 4: half a tile row)
       if (cap > 24) cap = 64; // (rho 2: 93.9 ms at 32 lanes against 90.9 at 64 — from there on the frame is throughput)
       if (s->knobs.lanes_cap > 0) cap = std::min(64, s->knobs.lanes_cap); // PtTuning.lanes_cap: forced
       if (cap < 64) {
