@@ -255,7 +255,9 @@ void pt_scene_destroy(PtScene* scene);
  *   scatter_log        triangle-pool kernels: log2 of the pixels of one tile a wave takes together (PT_SCATTER_LOG; 0)
  *   scatter_mode       -1: whole tiles per wave (PT_NO_SCATTER); 1: with the cost probe (PT_LPT_SCATTER)
  *   lanes_cap          sphere-grid kernels on frames that do not fill the chip: lanes of a wave that take pixels (PT_LANES_CAP=n; 0: 16 x
- *                      pixels per resident lane, whole tiles from 24 on; -1 or PT_LANES_CAP=0: whole tiles always)                          */
+ *                      pixels per resident lane, whole tiles from 24 on; -1 or PT_LANES_CAP=0: whole tiles always)
+ *   grid_walk          which sphere-grid walk: 1 wave-synchronous (each lane tests its candidate in place), 2 through the LDS pair queue
+ *                      (64 pairs per batch); 0: the launcher's rule (PT_GRID_WALK)                                                          */
 typedef struct PtTuning {
   int32_t struct_size; /* sizeof(PtTuning) of the caller's header */
   int32_t sphere_grid;
@@ -268,8 +270,8 @@ typedef struct PtTuning {
   int32_t blocks_per_cu, cold_state, wide_log2_group, split_tiles_mode, split_tiles, lpt_by_max, probe_spp_max, grid_min_tiles;
   float model_fixed, model_chain;
   int32_t scatter_log, scatter_mode;
-  int32_t lanes_cap;
-  int32_t reserved[7];
+  int32_t lanes_cap, grid_walk;
+  int32_t reserved[6];
 } PtTuning;
 void pt_tuning_init(PtTuning* t);     /* zero + struct_size: the library's defaults                                          */
 void pt_tuning_from_env(PtTuning* t); /* the defaults with the PT_* environment applied: what pt_scene_create(desc, out) uses */

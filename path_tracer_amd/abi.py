@@ -89,7 +89,7 @@ class PtTuning(C.Structure):
                 ("wide_log2_group", C.c_int32), ("split_tiles_mode", C.c_int32), ("split_tiles", C.c_int32),
                 ("lpt_by_max", C.c_int32), ("probe_spp_max", C.c_int32), ("grid_min_tiles", C.c_int32),
                 ("model_fixed", C.c_float), ("model_chain", C.c_float), ("scatter_log", C.c_int32), ("scatter_mode", C.c_int32),
-                ("lanes_cap", C.c_int32), ("reserved", C.c_int32 * 7)]
+                ("lanes_cap", C.c_int32), ("grid_walk", C.c_int32), ("reserved", C.c_int32 * 6)]
 
 
 def tuning(**fields) -> "PtTuning":

@@ -920,7 +920,7 @@ __device__ __forceinline__ void sphere_grid_walk_queued(P recs, P cells, P cand,
 // The whole run (recs = its first record, at blob offset goff).
 // GRID = false: the kernel does not carry the grid walk (the streaming kernel: its register budget belongs to the triangle
 // loop); a run with a grid is then scanned through its full lists.
-template <int K, bool GRID, bool TRIPOOL, typename P, typename AcceptAt>
+template <int K, int GRID, bool TRIPOOL, typename P, typename AcceptAt>
 __device__ __forceinline__ void sphere_scan(P recs, cst_f4p cblob, int n, int goff, const RayCtx& c, HitState& h, AcceptAt accept_at) {
   const f4 aux = cblob[goff - 1];
   const int flags = as_i(aux.w), ns = as_i(aux.z), nm = n - ns;
@@ -979,10 +979,14 @@ __device__ __forceinline__ void sphere_scan(P recs, cst_f4p cblob, int n, int go
   const unsigned long long walk_t0 = __builtin_amdgcn_s_memtime();
   __builtin_amdgcn_sched_barrier(0);
 #endif
-#ifdef PT_WALK_OLD
-  if constexpr (GRID) { if (walk) sphere_grid_walk(recs, recs + w_cell, recs + w_cand, wg0, wg1, frac, goff, c, h, accept_at); }
-#else
-  if constexpr (GRID) {
+  // GRID = 1: the wave-synchronous walk (every lane tests its own candidate in place); GRID = 2: the queued walk (pairs through an LDS
+  // queue, 64 per batch).  Which one a launch takes is the launcher's choice (pt_render.hip: launch_render): measured on the 496-hittable
+  // scene, old / queued kernel ms — 1080p x 256 spp shards 0/1, 0/2, 0/4, 0/8: 114.6 / 113.4, 115.1 / 112.9, 95.4 / 91.6, 62.5 / 60.0; 4K x 256 spp
+  // shards 0/1 ... 0/16: 351.8 / 388.8, 211.0 / 228.0, 141.4 / 149.8, 108.5 / 103.1, 71.8 / 61.6; config 1 (8 lanes per wave): 18.0 / 19.4.  The
+  // queue pays where walks diverge or the launch is bound by its chains; coherent, throughput-bound frames keep the in-place test.
+  // (Both in ONE kernel, chosen per trip by how many lanes it has, was measured too: the second path's registers cost 12 % on every frame.)
+  if constexpr (GRID == 1) { if (walk) sphere_grid_walk(recs, recs + w_cell, recs + w_cand, wg0, wg1, frac, goff, c, h, accept_at); }
+  if constexpr (GRID == 2) {
     if (walk) {
       unsigned long long* slot;
       unsigned int* q;
@@ -991,7 +995,6 @@ __device__ __forceinline__ void sphere_scan(P recs, cst_f4p cblob, int n, int go
       sphere_grid_walk_queued(recs, recs + w_cell, recs + w_cand, wg0, wg1, frac, (flags & 2) != 0, goff, c, h, slot, q, accept_at);
     }
   }
-#endif
 #ifdef PT_STAMPS_WALK
   asm volatile("" ::"v"(h.closest), "v"(h.hit));
   __builtin_amdgcn_sched_barrier(0);
@@ -1652,7 +1655,7 @@ __device__ __forceinline__ bool tri_pool_scan(glb_f4p gblob, cst_f4p cblob, int 
 
 // RECTBOX: the scene holds rects and boxes only (MATS_RECTBOX_ONLY kernels): the sphere / triangle / medium loops are not compiled in —
 // less code, and nothing of theirs (the medium's sqrt(d.d), say) can be hoisted into the per-iteration prologue of a kernel that never runs it.
-template <bool IMG, int TRIP = 1, int TTRIP = TRIP, bool WHOLE = true, bool BADOUEL = false, bool GRID = true, bool TRIPOOL = false, bool RECTBOX = false, typename P>
+template <bool IMG, int TRIP = 1, int TTRIP = TRIP, bool WHOLE = true, bool BADOUEL = false, int GRID = 1, bool TRIPOOL = false, bool RECTBOX = false, typename P>
 __device__ __forceinline__ void hit_records(P recs, cst_f4p cblob, int kind, int n, int goff,
                                             const RayCtx& c, bool fast, uint32_t& rng, HitState& h) {
   const Ray& r = c.r;
@@ -1866,7 +1869,7 @@ __device__ __forceinline__ int record_size(int kind) {
 // kernel constants: an s_load lands in SGPRs directly, no LDS round trip + v_readfirstlane per run) and the records from LDS.
 // `cblob`: the blob in global memory through the scalar cache (run headers, sphere-run masks); `blob`: where the records are
 // read from (LDS copy, or the same global blob).
-template <bool IMG, bool BADOUEL = false, bool GRID = true, bool TRIPOOL = false, bool RECTBOX = false, typename P>
+template <bool IMG, bool BADOUEL = false, int GRID = 1, bool TRIPOOL = false, bool RECTBOX = false, typename P>
 __device__ __forceinline__ void hit_world(P blob, cst_f4p cblob, int n_runs, const RayCtx& c, bool fast, uint32_t& rng, HitState& h) {
   hit_begin(h);
   for (int ri = 0; ri < n_runs; ++ri) {

@@ -420,7 +420,7 @@ __device__ __forceinline__ void lane_prepare(Lane& L, const KArgs& a) {
 // BLOCK: threads per workgroup.  The loop has no barrier, so the workgroup size only decides how many waves share one LDS image of the scene:
 // the 496-hittable scene's 31 KB image + the queued walk's per-wave LDS (1 KB) fit four workgroups per CU, i.e. four waves per SIMD at 256
 // threads and five at 320 (kGridBlock).
-template <int UV, bool LDS, bool MLDS, bool COOP, bool CL = false, bool FAST = false, bool BADOUEL = false, bool GRID = true, bool TRIPOOL = false,
+template <int UV, bool LDS, bool MLDS, bool COOP, bool CL = false, bool FAST = false, bool BADOUEL = false, int GRID = 1, bool TRIPOOL = false,
           int MATS = MATS_ALL, int BLOCK = kBlock>
 __global__ __launch_bounds__(BLOCK, TRIPOOL ? PT_MIN_WAVES_TRIPOOL : CL ? PT_MIN_WAVES_CL : COOP ? (UV ? PT_MIN_WAVES_COOP_IMG : PT_MIN_WAVES_COOP) : (UV ? PT_MIN_WAVES_IMG : PT_MIN_WAVES))
 void render_kernel(KArgs a) {
@@ -690,7 +690,7 @@ __global__ __launch_bounds__(1024) void lpt_order_kernel(const unsigned int* __r
 }
 
 // ---- probes ---------------------------------------------------------------------------------
-template <bool IMG>
+template <bool IMG, int WALK = 1>
 __global__ void bounce_kernel(const f4* __restrict__ blob, int n_runs, const f4* __restrict__ mats,
                               const uint8_t* __restrict__ atlas, const PtBounceIn* __restrict__ in,
                               PtBounceOut* __restrict__ outp, int n, int fast_ok) {
@@ -710,7 +710,7 @@ __global__ void bounce_kernel(const f4* __restrict__ blob, int n_runs, const f4*
   memset(&O, 0, sizeof O);
   RayCtx c = make_ctx(ray, fast_ok != 0);
   HitState h;
-  hit_world<IMG, true, true, true>(blob, (cst_f4p)blob, n_runs, c, wave_all_regular(c, true), rng, h); // every culling structure the scene has
+  hit_world<IMG, true, WALK, true>(blob, (cst_f4p)blob, n_runs, c, wave_all_regular(c, true), rng, h); // every culling structure the scene has (WALK: which sphere-grid walk)
   const float closest = h.closest, hu = h.u, hv = h.v;
   const int hit = h.hit;
   if (hit < 0) {
@@ -851,6 +851,7 @@ static void tuning_env(PtTuning& t) {
   if (const char* e = std::getenv("PT_MODEL_CHAIN")) t.model_chain = (float)std::atof(e);
   if (const char* e = std::getenv("PT_SCATTER_LOG")) t.scatter_log = std::min(5, std::max(0, std::atoi(e)));
   t.scatter_mode = has("PT_NO_SCATTER") ? -1 : has("PT_LPT_SCATTER") ? 1 : 0;
+  if (const char* e = std::getenv("PT_GRID_WALK")) t.grid_walk = std::atoi(e);
   if (const char* e = std::getenv("PT_LANES_CAP")) t.lanes_cap = std::atoi(e) <= 0 ? -1 : std::min(64, std::atoi(e));
 }
 // the caller's struct (possibly from an older header: struct_size bytes are valid) or, for NULL, defaults + environment
@@ -924,6 +925,7 @@ struct Knobs {
   int grid_block = kGridBlock; // PT_GRID_BLOCK (build-time experiment: workgroup size of the grid kernels)
   bool no_scatter = false; // triangle-pool kernels hand out whole tiles' pixels to a wave again (lane_acquire)
   bool generic_materials = false;
+  int grid_walk = 0;       // PtTuning.grid_walk: 0 the launcher's rule, 1 the wave-synchronous walk, 2 the queued walk
   int lanes_cap = 0;       // PtTuning.lanes_cap: grid kernels on small frames (launch): 0 the rule, -1 whole tiles always, n forced
   Knobs() {}
   explicit Knobs(const PtTuning& t) {
@@ -940,6 +942,7 @@ struct Knobs {
     no_scatter = t.scatter_mode < 0; lpt_with_scatter = t.scatter_mode > 0;
     generic_materials = t.generic_materials != 0;
     lanes_cap = t.lanes_cap < 0 ? -1 : std::min(64, t.lanes_cap);
+    grid_walk = (t.grid_walk == 1 || t.grid_walk == 2) ? t.grid_walk : 0;
   }
 };
 
@@ -1309,6 +1312,16 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
   // against 102; shard 0/8 of 4K at 128 spp 61 against 102).  PT_GRID_MIN_TILES restores a threshold.
   const bool use_grid = s->grid_spheres > 0 && resident /* the streaming kernel scans the full lists */ && local_tiles >= s->knobs.grid_min_tiles && !(p->flags & PT_FLAG_FORCE_COOP);
   const bool coop = lds && a.coop_prefix >= 0 && !use_grid && (s->traversal_cost >= kCoopMinTraversal || (p->flags & PT_FLAG_FORCE_COOP));
+  // Which sphere-grid walk (pt_device.hpp: sphere_scan, GRID = 1 / 2): the pair queue where walks diverge or the launch is bound by its
+  // chains — whole tiles per wave or at least 16 lanes (the rule of `launch` below, evaluated for the kernels' four workgroups per CU) — and
+  // not on frames that are both dense (>= 4 M pixels: a tile's rays share their cells) and throughput-bound (>= 6 pixels per resident lane).
+  bool queued_walk = false;
+  if (use_grid) {
+    const double rho = (double)a.n_local_pixels / ((double)s->num_cus * 16.0 * 64.0);
+    const bool few_lanes = rho < 0.875 && !(p->flags & (PT_FLAG_TILE_GRANULAR | PT_FLAG_PIXEL_GRANULAR | PT_FLAG_FAST_RNG)) && s->knobs.lanes_cap >= 0; // 16 rho rounds below 16
+    const bool dense_and_busy = (double)p->width * p->height >= 4.0e6 && rho >= 6.0;
+    queued_walk = s->knobs.grid_walk == 2 || (s->knobs.grid_walk == 0 && !few_lanes && !dense_and_busy && !(s->knobs.lanes_cap > 0 && s->knobs.lanes_cap < 16));
+  }
   // (small frames through the grid kernels: see `launch`; PT_FLAG_TILE_GRANULAR / PT_FLAG_PIXEL_GRANULAR and the fast mode keep what they ask for)
   // (only the kernels that walk a sphere grid: the headline family's iteration — slab pass, wave-uniform — does not get shorter with fewer
   // lanes: its shard 0/8 took 127 ms that way against 40)
@@ -1417,10 +1430,8 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
     if constexpr (UV == UV_NONE) { // small scene: cold lane state in LDS (7 workgroups x (scene + 8 KB) per CU)
       if (mlds && shmem <= kMaxLdsColdScene && !s->knobs.no_cold_lds) return launch(render_kernel<UV, true, true, false, true>);
     }
-    if (use_grid && s->knobs.grid_block != kBlock) { // the queued grid walk: five waves share one LDS image of the scene (render_kernel: BLOCK)
-      return mlds ? launch(render_kernel<UV, true, true, false, false, false, false, true, false, MATS_ALL, kGridBlock>, kGridBlock)
-                  : launch(render_kernel<UV, true, false, false, false, false, false, true, false, MATS_ALL, kGridBlock>, kGridBlock);
-    }
+    if (use_grid && queued_walk) // the sphere-grid walk through the pair queue (pt_device.hpp: sphere_scan says where it pays)
+      return mlds ? launch(render_kernel<UV, true, true, false, false, false, false, 2>) : launch(render_kernel<UV, true, false, false, false, false, false, 2>);
     return mlds ? launch(render_kernel<UV, true, true, false>) : launch(render_kernel<UV, true, false, false>);
   };
   auto launch_variant = [&]() -> int {
@@ -1612,10 +1623,15 @@ int pt_debug_bounce(const PtScene* scene, const PtBounceIn* in, PtBounceOut* out
   PT_HIP(dout.alloc(n));
   PT_HIP(hipMemcpy(din.p, in, (size_t)n * sizeof(PtBounceIn), hipMemcpyHostToDevice));
   dim3 block(64), grid((n + 63) / 64);
-  if (scene->track_uv)
-    hipLaunchKernelGGL(bounce_kernel<true>, grid, block, 0, nullptr, scene->blob, scene->n_runs, scene->mats, scene->atlas, din.p, dout.p, n, scene->fast_ok ? 1 : 0);
+  const bool qw = scene->knobs.grid_walk == 2; // PtTuning.grid_walk = 2: the probe walks sphere grids through the pair queue, like the kernels it stands for
+  if (scene->track_uv && qw)
+    hipLaunchKernelGGL((bounce_kernel<true, 2>), grid, block, 0, nullptr, scene->blob, scene->n_runs, scene->mats, scene->atlas, din.p, dout.p, n, scene->fast_ok ? 1 : 0);
+  else if (scene->track_uv)
+    hipLaunchKernelGGL((bounce_kernel<true, 1>), grid, block, 0, nullptr, scene->blob, scene->n_runs, scene->mats, scene->atlas, din.p, dout.p, n, scene->fast_ok ? 1 : 0);
+  else if (qw)
+    hipLaunchKernelGGL((bounce_kernel<false, 2>), grid, block, 0, nullptr, scene->blob, scene->n_runs, scene->mats, scene->atlas, din.p, dout.p, n, scene->fast_ok ? 1 : 0);
   else
-    hipLaunchKernelGGL(bounce_kernel<false>, grid, block, 0, nullptr, scene->blob, scene->n_runs, scene->mats, scene->atlas, din.p, dout.p, n, scene->fast_ok ? 1 : 0);
+    hipLaunchKernelGGL((bounce_kernel<false, 1>), grid, block, 0, nullptr, scene->blob, scene->n_runs, scene->mats, scene->atlas, din.p, dout.p, n, scene->fast_ok ? 1 : 0);
   PT_HIP(hipGetLastError());
   PT_HIP(hipMemcpy(out, dout.p, (size_t)n * sizeof(PtBounceOut), hipMemcpyDeviceToHost));
   return PT_OK;

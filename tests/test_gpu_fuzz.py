@@ -204,8 +204,10 @@ def random_sphere_field(seed: int):
     return pack(hs), cam
 
 
+@pytest.mark.parametrize("walk", [1, 2])
 @pytest.mark.parametrize("seed", range(12))
-def test_random_sphere_fields_through_the_culling_grid(orc, lib, seed):
+def test_random_sphere_fields_through_the_culling_grid(orc, lib, seed, walk, monkeypatch):
+    monkeypatch.setenv("PT_GRID_WALK", str(walk))  # both sphere-grid walks (PtTuning.grid_walk): in place, and through the pair queue
     ps, cam = random_sphere_field(3000 + seed)
     w, h, spp = 40, 24, 8
     c = scenes.make_camera(cam, w, h)
@@ -530,6 +532,23 @@ def test_path_rays_through_fuzz_scenes(orc, lib, kind, seed):
     c = scenes.make_camera(cam, 40, 24)
     with forced_pools() if kind == "random" else tri_pools() if kind == "triangle" else contextlib.nullcontext():
         checked, bad = follow_paths(lib, orc, ps, c.c, 40, 24, 15000, 12, seed)
+    assert checked >= 15000 and not bad, f"{len(bad)} of {checked} rays differ: " + " | ".join(bad[:3])
+
+
+@pytest.mark.parametrize("kind,seed", [("sphere", 3001), ("sphere", 3004), ("sphere", 3007), ("sphere", 3010), ("smoke", 0)])
+def test_path_rays_through_the_queued_sphere_grid_walk(orc, lib, kind, seed, monkeypatch):
+    """The same ray-level check with PtTuning.grid_walk = 2 (PT_GRID_WALK): the probe kernel then walks sphere grids through the LDS pair
+    queue (64 (ray, sphere) pairs per batch, one 64-bit LDS minimum per hit carrying the tie rule) like the render kernels the launcher
+    picks for divergent or chain-bound launches — on sphere fields (duplicates, moving spheres, spheres that touch) and on the
+    496-hittable scene itself."""
+    from path_rays import follow_paths
+    monkeypatch.setenv("PT_GRID_WALK", "2")
+    if kind == "smoke":
+        ps, cam = scenes.build("smoke", textures="procedural")
+    else:
+        ps, cam = random_sphere_field(seed)
+    c = scenes.make_camera(cam, 40, 24)
+    checked, bad = follow_paths(lib, orc, ps, c.c, 40, 24, 15000, 12, seed + 5)
     assert checked >= 15000 and not bad, f"{len(bad)} of {checked} rays differ: " + " | ".join(bad[:3])
 
 

@@ -926,11 +926,14 @@ def test_badouel_strategy_triangles(orc, lib):
     assert lib.pt_render_host(ds.handle, C.byref(c.c), C.byref(p), fb.ctypes.data_as(FP)) == abi.PT_ERR_INVALID_ARG
 
 
-def test_sphere_grid_is_exact(orc, monkeypatch):
-    """The culling grid of sphere runs (pt_flatten.hpp: build_sphere_grid; pt_device.hpp: sphere_grid_walk) against the
+@pytest.mark.parametrize("walk", [1, 2])
+def test_sphere_grid_is_exact(orc, monkeypatch, walk):
+    """(walk: PtTuning.grid_walk — 1 the wave-synchronous walk, 2 the walk through the LDS pair queue; the launcher would pick by frame.)
+    The culling grid of sphere runs (pt_flatten.hpp: build_sphere_grid; pt_device.hpp: sphere_grid_walk) against the
     oracle's linear scan, bit for bit: the ordinary view; a camera 3 000 units away (primary rays start beyond the grid's
     rlimit: the wave takes the full lists, bounces come back to the grid); a shutter wider than the spheres' interval (ray
     times outside [time0, time1]: full lists); from inside the field looking along it (long walks); every kernel family."""
+    monkeypatch.setenv("PT_GRID_WALK", str(walk))
     ps, cam = S.sphere_field_scene()
     orc.set_math(True)
     views = [dict(cam), dict(cam, look_from=(2000.0, 900.0, 2000.0), vfov=0.4, focus_dist=3000.0, aperture=0.0),

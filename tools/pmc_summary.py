@@ -32,10 +32,13 @@ def main():
         for r in rows:
             dur[r["Dispatch_Id"]] = max(dur[r["Dispatch_Id"]], float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
         frame = max(dur, key=dur.get)
+        here = {}  # this pass's counters (summed over the rows of the frame dispatch: one row per XCD / instance)
         for r in rows:
             if r["Dispatch_Id"] == frame:
-                per[r["Counter_Name"]] = per.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+                here[r["Counter_Name"]] = here.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
                 meta = {k: r[k] for k in ("Kernel_Name", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Grid_Size", "Workgroup_Size")}
+        for k, v in here.items():  # a counter collected in several passes (GRBM_GUI_ACTIVE rides along as each pass's clock): the first pass's value
+            per.setdefault(k, v)
     samples = w * h * spp
     out = {"tag": tag, "scene": scene, "workload": f"{w}x{h}x{spp}", "kernel": meta, "per_launch": per, "derived": {}}
     if final_round is not None:
