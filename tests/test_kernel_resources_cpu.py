@@ -39,12 +39,12 @@ def usage():
 
 
 def test_headline_kernels_fit_seven_waves_without_scratch(usage):
-    # render_kernel<UV_NONE, LDS, MLDS, COOP=false, CL, FAST=false, BADOUEL=false, GRID=false, TRIPOOL=false, MATS>: the instantiations
+    # render_kernel<UV_NONE, LDS, MLDS, COOP=false, CL, FAST=false, BADOUEL=false, GRID=0, TRIPOOL=false, MATS>: the instantiations
     # scenes without a sphere grid run — generic shading (MATS_ALL = 287) and the lambertian + light / solid-texture
-    # specialisation the headline Cornell-style scene takes (MATS = 9); mangled ...render_kernelILi0ELb?ELb?ELb0ELb?ELb0ELb0ELb0ELb0ELi<MATS>E...
+    # specialisation the headline Cornell-style scene takes (MATS = 9); mangled ...render_kernelILi0ELb?ELb?ELb0ELb?ELb0ELb0ELi0ELb0ELi<MATS>E...
     # (65545 = MATS_LAMB_LIGHT_SOLID | MATS_RECTBOX_ONLY, round 4: scenes of rects and boxes only — the headline scene itself — run kernels
     # that carry no sphere / triangle / medium code at all: 64 VGPRs)
-    hot = {k: v for k, v in usage.items() if re.search(r"render_kernelILi0ELb[01]ELb[01]ELb0ELb[01]ELb0ELb0ELb0ELb0ELi(9|287|65545)E", k)}
+    hot = {k: v for k, v in usage.items() if re.search(r"render_kernelILi0ELb[01]ELb[01]ELb0ELb[01]ELb0ELb0ELi0ELb0ELi(9|287|65545)E", k)}
     assert len(hot) == 12, sorted(usage)
     for k, v in hot.items():
         # the kernel the headline config runs (cold lane state in LDS: CL = 1) has no scratch at all; the variants that keep
@@ -58,12 +58,13 @@ def test_grid_walk_and_triangle_pool_kernels(usage):
     """The image-texture kernel cfg1 / cfg3 / cfg4 run (UV_WINNER, LDS, sphere-grid walk) holds 5 waves per SIMD — what the
     scene's 31 KB LDS image allows anyway — without scratch; the triangle-pool kernels (TRIPOOL = true: one ray at a time across the
     wave over global tables) hold 7."""
-    k1 = [v for k, v in usage.items() if re.search(r"render_kernelILi1ELb1ELb0ELb0ELb0ELb0ELb0ELb1ELb0E", k)]
-    # round 4: the queued walk (64 (ray, sphere) pairs per batch) keeps five more values live across a batch: 20 bytes of scratch at the
-    # 96-register budget, stored before and reloaded after the walk — none inside its loops (A/B against 128 registers and no scratch:
-    # equal, profiles/r04_walk_ab.txt)
-    assert len(k1) == 1 and k1[0]["Occupancy [waves/SIMD]"] >= 5 and k1[0]["ScratchSize [bytes/lane]"] <= 24, k1
-    pool = {k: v for k, v in usage.items() if re.search(r"render_kernelILi[012]ELb0ELb0ELb0ELb0ELb[01]ELb0ELb1ELb1E", k)}
+    # GRID = 1: the wave-synchronous walk (no scratch); GRID = 2: the queued walk (64 (ray, sphere) pairs per batch) keeps five more values
+    # live across a batch: 20 bytes of scratch at the 96-register budget, stored before and reloaded after the walk — none inside its loops
+    k1 = [v for k, v in usage.items() if re.search(r"render_kernelILi1ELb1ELb0ELb0ELb0ELb0ELb0ELi1ELb0E", k)]
+    assert len(k1) == 1 and k1[0]["Occupancy [waves/SIMD]"] >= 5 and k1[0]["ScratchSize [bytes/lane]"] == 0, k1
+    k2 = [v for k, v in usage.items() if re.search(r"render_kernelILi1ELb1ELb0ELb0ELb0ELb0ELb0ELi2ELb0E", k)]
+    assert len(k2) == 1 and k2[0]["Occupancy [waves/SIMD]"] >= 5 and k2[0]["ScratchSize [bytes/lane]"] <= 24, k2
+    pool = {k: v for k, v in usage.items() if re.search(r"render_kernelILi[012]ELb0ELb0ELb0ELb0ELb[01]ELb0ELi1ELb1E", k)}
     assert len(pool) == 6, sorted(usage)
     for k, v in pool.items():
         # SEVEN waves — with the stratified deal of pixels the pool is a throughput kernel, and seven waves at 72 VGPRs + 36-52 dwords of
