@@ -12,7 +12,7 @@ the slowest rank's time.  At this kernel speed the fixed frame is bounded by its
 chain — so the line also carries `weak_scaling`: the same measurement on a frame with N x the pixels
 (same scene, camera, aspect, spp; width and height x sqrt(N)), i.e. fixed work per GPU.  `--scaling weak` makes that
 the headline instead (and says so in `metric`, `scaling` and `config`).
-Other BASELINE configs: `--config cfg3` (SmokeSphere 1920x1080x1024), `--config cfg4` (SmokeSphere 3840x2160x4096,
+Other BASELINE configs: `--config cfg1` (SmokeSphere 400x225x64, the reference's own CPU case), `--config cfg3` (SmokeSphere 1920x1080x1024), `--config cfg4` (SmokeSphere 3840x2160x4096,
 the 8-GPU config), `--config cfg5` (100 k triangles 1920x1080x256); `--scene/--width/--height/--spp` override.
 `--mode fast` = the opt-in decorrelated-RNG mode (NOT parity: judged by PSNR; never the default).
 The scene is resident in HBM before the timed region (it is ~1 KB; the boundary hands over host tables, and
@@ -220,6 +220,7 @@ def weak_frame(width: int, height: int, n_gpus: int):
 
 
 CONFIGS = {  # BASELINE.json `configs`
+    "cfg1": dict(scene="smoke", width=400, height=225, spp=64),          # the reference's own CPU-runnable case (main.cpp defaults)
     "cfg2": dict(scene="cornell", width=1920, height=1080, spp=1024),    # the headline: what `metric` is quoted on
     "cfg3": dict(scene="smoke", width=1920, height=1080, spp=1024),
     "cfg4": dict(scene="smoke", width=3840, height=2160, spp=4096),      # the 8-GPU tile-sharded config

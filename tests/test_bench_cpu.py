@@ -115,6 +115,7 @@ def test_multi_gpu_self_launch_and_configs(monkeypatch, capsys):
     assert bench.CONFIGS["cfg2"] == dict(scene="cornell", width=1920, height=1080, spp=1024)
     assert bench.CONFIGS["cfg4"] == dict(scene="smoke", width=3840, height=2160, spp=4096)
     assert bench.CONFIGS["cfg5"]["spp"] == 256 and bench.CONFIGS["cfg3"]["scene"] == "smoke"
+    assert bench.CONFIGS["cfg1"] == dict(scene="smoke", width=400, height=225, spp=64)
 
 
 def test_weak_scaling_frames_keep_pixels_per_gpu_and_aspect():

@@ -10,7 +10,7 @@ python -m pytest tests -m gpu -q > $O/gpu_tests.log 2>&1; echo "pytest rc=$?" >>
 tail -3 $O/gpu_tests.log
 tools/profile_round.sh r04_cornell 3 1 > $O/profile_cornell.log 2>&1                                               # cfg2, the headline
 tools/profile_round.sh r04_smoke 3 1 --config cfg3 > $O/profile_smoke.log 2>&1                                      # cfg3
-tools/profile_round.sh r04_cfg1 20 3 --config cfg3 --width 400 --height 225 --spp 64 > $O/profile_cfg1.log 2>&1    # cfg1: the reference's own workload
+tools/profile_round.sh r04_cfg1 20 3 --config cfg1 > $O/profile_cfg1.log 2>&1    # cfg1: the reference's own workload
 PT_PROFILE_MEM=1 tools/profile_round.sh r04_triangles 1 0 --config cfg5 > $O/profile_triangles.log 2>&1            # cfg5 (+ the memory-system passes)
 python bench.py --steps 20 --warmup 2 > $O/bench_cfg2_steps20.json 2> $O/bench_cfg2_steps20.err
 python bench.py --steps 5 --warmup 1 --mode fast > $O/bench_cfg2_fast_mode.json 2>/dev/null
