@@ -31,6 +31,9 @@ extern __device__ unsigned long long g_stamps[8]; // diagnostic build only (pt_r
 // diagnostic build (triangle pool): [0] scans (waves) [1] live rays [2] grid rounds (64 candidates each) [3] grid cells visited [4] lanes busy over the band's trips [5] [6] [7] band trips (four candidates per lane) of levels 0, 1, 2
 extern __device__ unsigned long long g_tri[12];
 #endif
+#ifdef PT_STAMPS_RUNS
+extern __device__ unsigned long long g_runs[16];
+#endif
 #ifdef PT_STAMPS_WALK
 // diagnostic build: per-workgroup counters of the sphere-grid walk in LDS (cheap ds_add; global atomics per step distort the
 // timing they are meant to explain), flushed once by render_kernel.  [0] cycles inside walks (wave leader's clock) [1] walks
@@ -573,8 +576,27 @@ __device__ __forceinline__ bool medium_t(P recs, int off, const RayCtx& c, float
   f4 R0 = recs[off];
   int bkind = as_i(R0.x);
   float t1, t2;
-  if (!boundary_t(recs, off + 1, bkind, c, -PT_INF, PT_INF, t1)) return false;
-  if (!boundary_t(recs, off + 1, bkind, c, t1 + 0.0001f, PT_INF, t2)) return false;
+  if (bkind == DK_SPHERE) {
+    // The two boundary hits of constant_medium.hpp:35-41 — hit(r, -inf, inf, rec1), hit(r, rec1.t + 0.0001, inf, rec2) — are the SAME sphere
+    // against the SAME ray: centre, b, discriminant, square root and both quotients come out identical in the second call, only the
+    // window differs.  They are evaluated once (one discriminant, one square root, two divisions instead of two, two and up to four) and
+    // sphere.hpp:74-91's selection is applied twice, to the same values: same bits (round 4; the generic two-call form stays for boxes).
+    TimeFrac tf = time_frac_none();
+    const SphereEval e = sphere_eval(recs, off + 1, c, tf);
+    if (!(e.disc > 0)) return false;
+    const float sq = sqrt_rn(e.disc);
+    const float r1 = (-e.b - sq) / c.a, r2 = (-e.b + sq) / c.a;
+    const bool in1 = r1 < PT_INF && r1 > -PT_INF;                 // first root inside (-inf, inf)?
+    if (!in1 && !(r2 < PT_INF && r2 > -PT_INF)) return false;
+    t1 = in1 ? r1 : r2;
+    const float mn2 = t1 + 0.0001f;
+    const bool in2 = r1 < PT_INF && r1 > mn2;                     // the second call looks at the first root again, then at the second
+    if (!in2 && !(r2 < PT_INF && r2 > mn2)) return false;
+    t2 = in2 ? r1 : r2;
+  } else {
+    if (!boundary_t(recs, off + 1, bkind, c, -PT_INF, PT_INF, t1)) return false;
+    if (!boundary_t(recs, off + 1, bkind, c, t1 + 0.0001f, PT_INF, t2)) return false;
+  }
   if (t1 < mn) t1 = mn;
   if (t2 > mx) t2 = mx;
   if (t1 >= t2) return false;
@@ -806,7 +828,7 @@ __device__ __forceinline__ unsigned long long* tri_slots() { __shared__ unsigned
 #define PT_TRI_QUEUE (64 + 64 * (PT_TRI_GRID_PER_LANE > 4 ? PT_TRI_GRID_PER_LANE : 5))
 __device__ __forceinline__ int* tri_queue() { __shared__ int s[4 * PT_TRI_QUEUE]; return s; } // per wave: survivors of the filters waiting for the exact test
 #ifndef PT_MAX_WAVES_PER_BLOCK
-#define PT_MAX_WAVES_PER_BLOCK 5
+#define PT_MAX_WAVES_PER_BLOCK 4
 #endif
 #define PT_SQ_CAP 128 /* 63 left over + one trip's pushes */
 __device__ __forceinline__ unsigned int* sphere_queue() { __shared__ unsigned int s[PT_MAX_WAVES_PER_BLOCK * PT_SQ_CAP]; return s; }
@@ -1873,6 +1895,12 @@ template <bool IMG, bool BADOUEL = false, int GRID = 1, bool TRIPOOL = false, bo
 __device__ __forceinline__ void hit_world(P blob, cst_f4p cblob, int n_runs, const RayCtx& c, bool fast, uint32_t& rng, HitState& h) {
   hit_begin(h);
   for (int ri = 0; ri < n_runs; ++ri) {
+#ifdef PT_STAMPS_RUNS /* diagnostic build: cycles per run of the list (wave leader's clock), g_runs[min(ri, 15)] */
+    const unsigned long long run_t0 = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_sched_barrier(0);
+    struct RunStamp { unsigned long long t0; int ri; const HitState* h; __device__ ~RunStamp() { asm volatile("" ::"v"(h->closest), "v"(h->hit)); __builtin_amdgcn_sched_barrier(0);
+      if ((threadIdx.x & 63) == 0) atomicAdd(&g_runs[ri < 15 ? ri : 15], __builtin_amdgcn_s_memtime() - t0); } } run_stamp{run_t0, ri, &h};
+#endif
     f4 runf = cblob[ri];
     const int off = as_i(runf.y), kind = as_i(runf.x);
     if constexpr (!IMG) {

@@ -34,6 +34,9 @@ __device__ unsigned long long g_stamps[8];
 #ifdef PT_STAMPS_WALK
 __device__ unsigned long long g_walk[8];
 #endif
+#ifdef PT_STAMPS_RUNS
+__device__ unsigned long long g_runs[16];
+#endif
 #ifdef PT_STAMPS_TRI
 __device__ unsigned long long g_tri[12];
 #endif
@@ -1600,6 +1603,13 @@ int pt_debug_stamps(unsigned long long* out8, int reset) { // diagnostic build o
 int pt_debug_tri(unsigned long long* out8, int reset) { // -DPT_STAMPS_TRI: counters of the triangle pool (pt_device.hpp: PT_TRI_COUNT)
   if (out8) PT_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_tri), 12 * sizeof(unsigned long long)));
   if (reset) { unsigned long long z[12] = {0}; PT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_tri), z, sizeof z)); }
+  return PT_OK;
+}
+#endif
+#ifdef PT_STAMPS_RUNS
+int pt_debug_runs(unsigned long long* out16, int reset) { // -DPT_STAMPS_RUNS: cycles per run of the hittable list (pt_device.hpp: hit_world)
+  if (out16) PT_HIP(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_runs), 16 * sizeof(unsigned long long)));
+  if (reset) { unsigned long long z[16] = {0}; PT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_runs), z, sizeof z)); }
   return PT_OK;
 }
 #endif

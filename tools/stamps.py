@@ -17,6 +17,9 @@ cam = scenes.make_camera(cam_args, W, H)
 ds = R.DeviceScene(packed)
 R.render(W, H, 8, ds, cam, shard_index=0, shard_count=N); torch.cuda.synchronize()
 lib.pt_debug_stamps(None, 1)
+if os.environ.get("PT_STAMPS_RUNS"):
+    lib.pt_debug_runs.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+    lib.pt_debug_runs(None, 1)
 WALK = bool(os.environ.get("PT_STAMPS_WALK"))
 if WALK:
     lib.pt_debug_walk.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
@@ -48,6 +51,11 @@ if WALK:
                    "walk_share_of_iteration": cyc / max(tot, 1)}, open(os.environ["PT_WALK_JSON"], "w"), indent=1)
 elif not os.environ.get("PT_STAMPS_POOL"):
     print(f"  gridded sphere runs scanned {out[4]:.3e}; full-list fallback in {out[5]/max(out[4],1):.4f} of them (far origin in {out[6]/max(out[4],1):.4f}), {out[7]/max(out[5],1):.1f} lanes at fault on average")
+if os.environ.get("PT_STAMPS_RUNS"):  # build with EXTRA="-DPT_STAMPS_RUNS": cycles per run of the hittable list
+    lib.pt_debug_runs.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+    rr = (C.c_ulonglong * 16)()
+    lib.pt_debug_runs(rr, 0)
+    print("  cycles per wave-iteration by run of the list:", "  ".join(f"run {i}: {rr[i]/iters:.0f}" for i in range(16) if rr[i]))
 if os.environ.get("PT_STAMPS_POOL"):
     print(f"  slab pool scans {out[4]:.3e}; exact trips per scan {out[5]/max(out[4],1):.3f}, lanes busy per trip {out[7]/max(out[5],1):.1f}, repeated passes per scan {out[6]/max(out[4],1):.4f}")
 print(f"{scene} {spp} spp: kernel {ms:.1f} ms; wave-iterations {iters:.3e}; cycles per wave-iteration: prepare {prep/iters:.0f}  traversal {trav/iters:.0f}  shade {shade/iters:.0f}  (total {tot/iters:.0f}); shares {prep/tot:.2f} {trav/tot:.2f} {shade/tot:.2f}")
