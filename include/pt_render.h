@@ -390,8 +390,16 @@ int pt_debug_schedule(const PtScene* scene, int32_t out[2]);
  *     9 the shared-reciprocal exact quotient a/b used for rect/box sides (pt_device.hpp: div_exact)
  *     10 the reciprocal 1/a of the ray context, correctly rounded for 2^-40 <= |a| <= 2^40 (rcp_rn_guarded)
  *     11 the square root of a = 0 or 2^-60 <= a <= 4 as the RNG's unit_vec / in_unit_disk take it (sqrt_rn_unit)
- *     12 a / sqrt(b) as the sky of a regular ray takes unit_vector(d).y (b = d.d in [3 * 2^-80, 3 * 2^80]; sky_unit_y) */
+ *     12 a / sqrt(b) as the sky of a regular ray takes unit_vector(d).y (b = d.d in [3 * 2^-80, 3 * 2^80]; sky_unit_y)
+ *     13 the checker texture's decision `sin(a) sin(b) sin(1) < 0` as 1.0 / 0.0 (texture.hpp:43-45; checker_sines_negative)    */
 int pt_debug_math(int32_t op, const float* a, const float* b, float* out, int64_t n);
+
+/* The texel (column i, row j) an image texture of width x height texels and frequency freq selects on a sphere whose unit normal at the
+ * hit is n (n_xyz: 3 floats per entry) — texture.hpp:140-157 over sphere.hpp:13-24.  out_ij = what the render kernels take (the texel
+ * straight from the normal where that is provably unambiguous, the reference's chain otherwise: pt_device.hpp sphere_texel_fast),
+ * exact_ij = the reference's chain alone, took_fast = 1 where the short form decided.  2 ints per entry.  For tests.                  */
+int pt_debug_sphere_texel(const float* n_xyz, int64_t n, float freq, int32_t width, int32_t height, int32_t* out_ij, int32_t* exact_ij,
+                          uint8_t* took_fast);
 
 #ifdef __cplusplus
 }

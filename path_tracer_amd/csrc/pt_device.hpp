@@ -138,6 +138,9 @@ __device__ __forceinline__ V3 rng_in_unit_ball(uint32_t& s) {
   float r = rng_float(s);
   float theta = rng_float(s, 0.0f, 2.0f * PT_PI);
   float phi = rng_float(s, 0.0f, PT_PI);
+#ifdef PT_PROBE_NO_BALL
+  return mk(r * (theta - 3.0f) * 0.3f, r * (phi - 1.5f) * 0.6f, r * 0.5f);
+#endif
   float plan_seed = r * ptm::sinf_(phi);
   float z = r * ptm::cosf_(phi);
   return mk(plan_seed * ptm::cosf_(theta), plan_seed * ptm::sinf_(theta), z);
@@ -271,10 +274,80 @@ __device__ __forceinline__ V3 sphere_center(f4 R0, f4 R1, f4 R2, float time) {
 
 // sphere.hpp:13-24
 __device__ __forceinline__ void mercator(V3 p, float& u, float& v) {
+#ifdef PT_PROBE_NO_UV
+  float phi = p.z + p.x, theta = p.y;
+#else
   float phi = ptm::atan2f_(p.z, p.x);
   float theta = ptm::asinf_(p.y);
+#endif
   u = 1.0f - (phi + PT_PI) / (2.0f * PT_PI);
   v = (theta + PT_PI / 2.0f) / PT_PI;
+}
+
+// ---- an image texture on a sphere needs only the TEXEL its (u, v) select (texture.hpp:140-157), and the mercator pair costs two binary64
+// transcendentals with divisions (atan2f_, asinf_: ~135 binary64 instructions, entered by a wave whenever ONE lane shades such a hit: 7 % of
+// the 496-hittable scene's frame, profiles/r04_ab_texel.txt).  The texel indices are floor()s of  c_i = fmod1(u freq) (w - 1),
+// c_j = (1 - fmod1(v freq)) (h - 1),  so an approximation of u, v that is provably within E_uv of the exact chain's values decides them
+// unless c lies within E of an integer — and then (and for every argument outside the approximation's domain: NaN, a pole, |y| > 1,
+// freq <= 0, a texture of one texel) the lane takes the exact chain, as before.
+// The approximation, all binary32: u~ = 1/2 - atan2(z, x) / 2pi as  a P_A(a^2), a = min(|x|,|z|) / max(|x|,|z|) <= 1  (degree 8 in a^2, the
+// 1/2pi folded into the coefficients; |error| < 1e-8) with the octant reflections done in turns (values <= 1/2: every rounding <= 2^-25);
+// v~ = 1/2 + asin(y) / pi as  s P_S(s^2)  with s = |y| for |y| <= 1/2 and s = sqrt((1 - |y|) / 2) (exact difference, 1-ulp root) otherwise
+// (degree 5, |error| < 3e-9).  Against the exact chain (atan2f_ / asinf_ rounded to binary32, then the reference's own binary32 operations)
+// the deviation measured on 2 x 10^8 simulated and 10^8 device-evaluated directions — poles, the seam and the axes over-represented — is
+// <= 1.8e-7 in u and v (tests/test_gpu_parity.py::test_sphere_texel_fast_path_is_exact states the device figure); E_uv = 1e-6 is what the
+// ambiguity test assumes, and the chain behind u adds its own roundings: |c~ - c| <= (w - 1) (freq E_uv + 2 ulp(freq)) + 2 ulp(c)
+// < (w - 1) (freq + 1) 1.25e-6 =: E for w <= 65536.  With E < 1/4, c~ finite and E <= c~ - floor(c~) <= 1 - E, 0 < c~ < w - 1: floor(c) = floor(c~)
+// (an argument of fmod1 on the other side of an integer than its approximation puts c~ within E of 0 or of w - 1: integers).
+__device__ __forceinline__ bool sphere_texel_fast(V3 n, float freq, uint32_t w, uint32_t h, uint32_t& i, uint32_t& j) {
+#ifdef PT_NO_TEXEL_SHORTCUT
+  return false;
+#else
+  const float ax = __builtin_fabsf(n.x), az = __builtin_fabsf(n.z), ay = __builtin_fabsf(n.y);
+  const float mxv = __builtin_fmaxf(ax, az), mnv = __builtin_fminf(ax, az);
+  const float a = mnv * __builtin_amdgcn_rcpf(mxv);
+  const float a2 = a * a;
+  float pa = 0.0004402677f;
+  pa = __builtin_fmaf(pa, a2, -0.00250370614f);
+  pa = __builtin_fmaf(pa, a2, 0.00670641102f);
+  pa = __builtin_fmaf(pa, a2, -0.0118679535f);
+  pa = __builtin_fmaf(pa, a2, 0.0168996621f);
+  pa = __builtin_fmaf(pa, a2, -0.0225964971f);
+  pa = __builtin_fmaf(pa, a2, 0.0318180509f);
+  pa = __builtin_fmaf(pa, a2, -0.0530511774f);
+  pa = __builtin_fmaf(pa, a2, 0.159154937f);
+  float t = a * pa;                 // atan(a) / 2pi in [0, 1/8]
+  t = az > ax ? 0.25f - t : t;      // first quadrant, in turns
+  t = n.x < 0.0f ? 0.5f - t : t;
+  t = n.z < 0.0f ? -t : t;          // atan2(z, x) / 2pi in [-1/2, 1/2]
+  const float u = 0.5f - t;         // 1 - (phi + pi) / 2pi
+  const bool big = ay > 0.5f;
+  const float sv = big ? __builtin_amdgcn_sqrtf((1.0f - ay) * 0.5f) : ay;
+  const float s2 = sv * sv;
+  float ps = 0.0135018695f;
+  ps = __builtin_fmaf(ps, s2, 0.00763752731f);
+  ps = __builtin_fmaf(ps, s2, 0.0144896684f);
+  ps = __builtin_fmaf(ps, s2, 0.0238563605f);
+  ps = __builtin_fmaf(ps, s2, 0.0530520156f);
+  ps = __builtin_fmaf(ps, s2, 0.318309873f);
+  float wv = sv * ps;               // asin(s) / pi
+  wv = big ? __builtin_fmaf(-2.0f, wv, 0.5f) : wv;
+  wv = n.y < 0.0f ? -wv : wv;       // asin(y) / pi in [-1/2, 1/2]
+  const float v = 0.5f + wv;        // (theta + pi/2) / pi
+  const float wm = (float)(w - 1u), hm = (float)(h - 1u);
+  const float E = 1.25e-6f * (freq + 1.0f);
+  const float Ei = wm * E, Ej = hm * E;
+  const float xu = u * freq, xv = v * freq;
+  const float ci = (xu - __builtin_floorf(xu)) * wm;
+  const float cj = (1.0f - (xv - __builtin_floorf(xv))) * hm;
+  const float fi = __builtin_floorf(ci), fj = __builtin_floorf(cj);
+  const float di = ci - fi, dj = cj - fj;
+  // every comparison is written so that a NaN anywhere fails it
+  const bool ok = freq > 0.0f && freq <= 65536.0f && w >= 2u && h >= 2u && w <= 65536u && h <= 65536u && Ei < 0.25f && Ej < 0.25f &&
+                  ay <= 1.0f && ax <= 3.0e38f && az <= 3.0e38f /* (fmin / fmax drop a NaN operand) */ && mxv > 0.0f && ci > 0.0f && ci < wm && cj > 0.0f && cj < hm && di >= Ei && di <= 1.0f - Ei && dj >= Ej && dj <= 1.0f - Ej;
+  i = (uint32_t)fi; j = (uint32_t)fj;
+  return ok;
+#endif
 }
 
 // Roots of sphere.hpp:68-93: calls accept(t) if one lies in (mn, mx) and `valid`.  The acceptance runs INSIDE the
@@ -605,7 +678,11 @@ __device__ __forceinline__ bool medium_t(P recs, int off, const RayCtx& c, float
   asm volatile("" : "+v"(a_here)); // (opaque: the square root stays HERE, behind the boundary tests — hoisted to the top of the iteration it ran for every ray of every wave)
   const float ray_length = sqrt_rn(a_here); // sycl::length(r.direction())
   const float distance_inside_boundary = (t2 - t1) * ray_length;
+#ifdef PT_PROBE_NO_LOG
+  const float hit_distance = R0.y * (rng_float(rng) - 1.0f) * 2.0f;
+#else
   const float hit_distance = R0.y * ptm::logf_(rng_float(rng)); // the in-traversal draw (:65)
+#endif
   if (hit_distance > distance_inside_boundary) return false;
   t_out = t1 + hit_distance / ray_length;
   return true;
@@ -2205,20 +2282,42 @@ __device__ __forceinline__ uint32_t texel_index(float f, uint32_t maxv) {
 // headline scene) runs kernels compiled with MATS_LAMB_LIGHT_SOLID, which carry none of the other branches.
 enum { MATS_ALL = 0x11f, MATS_LAMB_LIGHT_SOLID = 0x009, MATS_RECTBOX_ONLY = 0x10000 /* + every hittable is a rect or a box (resolve_hit) */ };
 
+// texture.hpp:43-45: `sin(a) sin(b) sin(c) < 0` (a, b, c = 10 p).  Only the SIGN of the product is looked at, and for regular arguments
+// (2^-30 <= |.| < 2^30: every factor is then non-zero and at least 2^-30, so the binary32 product of three cannot underflow and its sign is
+// the product of the signs) the sign of a factor follows from its range reduction alone (pt_math.hpp: sin_negative_regular) — 6 binary64
+// operations per sine instead of two degree-6 polynomials (38).  A lane with an argument outside that range (0, denormal-small, huge, NaN:
+// the product may then be a zero or a NaN, never "< 0" by sign alone) evaluates the product itself.  Measured: profiles/r04_ab_checker.txt.
+__device__ __forceinline__ bool checker_sines_negative(float a, float b, float c) {
+#ifndef PT_NO_CHECKER_SHORTCUT
+  const float lo = 9.31322574615478515625e-10f, hi = 1073741824.0f; // 2^-30, 2^30
+  const float mn = __builtin_fminf(__builtin_fminf(__builtin_fabsf(a), __builtin_fabsf(b)), __builtin_fabsf(c));
+  const float mx = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(a), __builtin_fabsf(b)), __builtin_fabsf(c));
+  const bool nan = (a != a) | (b != b) | (c != c); // (fmin / fmax drop a NaN operand)
+  if (!nan && mn >= lo && mx < hi) return (ptm::sin_negative_regular(a) != ptm::sin_negative_regular(b)) != ptm::sin_negative_regular(c);
+#endif
+  const float sines = ptm::sinf_(a) * ptm::sinf_(b) * ptm::sinf_(c);
+  return sines < 0;
+}
+
 template <int MATS = MATS_ALL, typename UV>
 __device__ __forceinline__ V3 texture_value(f4 M0, f4 M1, f4 M2, f4 M3, V3 p, UV uv, const uint8_t* __restrict__ atlas) {
   if constexpr (!(MATS & 0x100)) return xyz(M1); // every texture of the scene is a solid_texture (texture.hpp:25)
   const int tk = as_i(M0.y);
   if (tk == 1) return xyz(M1); // solid
-  if (tk == 0) {               // checker
-    float sines = ptm::sinf_(10.0f * p.x) * ptm::sinf_(10.0f * p.y) * ptm::sinf_(10.0f * p.z);
-    return (sines < 0) ? xyz(M1) : xyz(M2);
-  }
+  if (tk == 0) return checker_sines_negative(10.0f * p.x, 10.0f * p.y, 10.0f * p.z) ? xyz(M1) : xyz(M2); // checker
   const uint32_t w = (uint32_t)as_i(M1.w), h = (uint32_t)as_i(M2.w), offset = (uint32_t)as_i(M3.x);
-  float u, v;
-  uv(u, v); // only image textures look at u,v
-  uint32_t i = texel_index(ptm::fmod1f_(u * M0.w) * (float)(w - 1), w - 1);
-  uint32_t j = texel_index((1.0f - ptm::fmod1f_(v * M0.w)) * (float)(h - 1), h - 1);
+  uint32_t i = 0, j = 0;
+  bool have = false;
+  if constexpr (requires(V3& nn) { uv.sphere_normal(nn); }) { // a sphere's hit: the texel straight from the normal where that is unambiguous
+    V3 nn;
+    if (uv.sphere_normal(nn)) have = sphere_texel_fast(nn, M0.w, w, h, i, j);
+  }
+  if (!have) {
+    float u, v;
+    uv(u, v); // only image textures look at u,v
+    i = texel_index(ptm::fmod1f_(u * M0.w) * (float)(w - 1), w - 1);
+    j = texel_index((1.0f - ptm::fmod1f_(v * M0.w)) * (float)(h - 1), h - 1);
+  }
   uint64_t pix = (uint64_t)j * w + i + offset;
   const float scale = 1.0f / 255;
   return mk((float)atlas[pix * 3] * scale, (float)atlas[pix * 3 + 1] * scale, (float)atlas[pix * 3 + 2] * scale);
@@ -2237,6 +2336,9 @@ __device__ __forceinline__ V3 refract(V3 uv, V3 n, float etai_over_etat) {
 __device__ __forceinline__ float reflectance(float cosine, float ref_idx) {
   float r0 = (1.0f - ref_idx) / (1.0f + ref_idx);
   r0 *= r0;
+#ifdef PT_PROBE_NO_POW5
+  { const float q = 1.0f - cosine; return r0 + (1.0f - r0) * (q * q * q * q * q); }
+#endif
   return r0 + (1.0f - r0) * ptm::pow5f_(1.0f - cosine);
 }
 

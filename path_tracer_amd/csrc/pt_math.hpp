@@ -68,6 +68,16 @@ __device__ __forceinline__ float sinf_(float xf) {
   return (float)((n & 2) ? -v : v);
 }
 
+// The SIGN BIT of sinf_(xf) for a regular argument, 2^-30 <= |xf| < 2^30, from the range reduction alone: sinf_ rounds +-ksin(r) (n even:
+// the sign of r, r != 0 there) or +-kcos(r) (n odd: positive) to binary32, negated when n & 2.  For every such binary32 argument the
+// result is non-zero, at least 2^-30 in magnitude, and has this sign: tests/cpp/checker_sign_exhaustive.c visits all 1.0 x 10^9 of them
+// against the oracle's copy of sinf_.  (What the checker texture needs: texture.hpp:43-45 looks at the sign of a product of three sines.)
+__device__ __forceinline__ bool sin_negative_regular(float xf) {
+  double r;
+  const int n = rem_pio2((double)xf, r);
+  return ((n & 1) ? false : (r < 0.0)) != ((n & 2) != 0);
+}
+
 __device__ __forceinline__ float cosf_(float xf) {
   double x = (double)xf;
   if (!(dabs(x) < 1073741824.0)) {

@@ -359,6 +359,28 @@ __device__ __forceinline__ void lane_regenerate(Lane& L, const KArgs& a) {
   }
 }
 
+// The texture coordinates of a lane's hit, asked for by image textures only (pt_device.hpp: texture_value): (u, v) as the reference
+// defines them, and — for kernels that derive them from the final hit — the sphere's normal itself, from which the texel follows
+// without the mercator pair wherever that is unambiguous (pt_device.hpp: sphere_texel_fast).
+template <int UV, typename PB>
+struct HitUv {
+  PB recs;
+  const HitState& h;
+  const Ray& ray;
+  const Rec& rec;
+  __device__ __forceinline__ void operator()(float& u, float& v) const {
+    if (UV == UV_TRACKED) { u = h.u; v = h.v; }
+    else if (UV == UV_WINNER) winner_uv(recs, h.hit, ray, h.closest, rec, u, v);
+    else { u = 0.0f; v = 0.0f; }
+  }
+  __device__ __forceinline__ bool sphere_normal(V3& n) const {
+    if constexpr (UV == UV_WINNER) {
+      if (hit_kind(h.hit) == DK_SPHERE) { n = rec.normal; return true; } // winner_uv: mercator(rec.normal)
+    }
+    return false;
+  }
+};
+
 // emitted / scatter / sky for the nearest hit (render.hpp:60-88) and the sample bookkeeping (:100).
 template <int UV, bool FAST = false, int MATS = MATS_ALL, typename Lane, typename PB, typename PM>
 __device__ __forceinline__ void lane_shade(Lane& L, const KArgs& a, const HitState& h, PB recs, PM mats, bool regular = false) {
@@ -373,11 +395,7 @@ __device__ __forceinline__ void lane_shade(Lane& L, const KArgs& a, const HitSta
     Rec rec = resolve_hit<(MATS & MATS_RECTBOX_ONLY) != 0>(recs, h.hit, L.ray, h.closest); // per-lane gather of the one record that was hit
     // UV_TRACKED kernels carried u,v through the scan (stale values included); UV_WINNER derives them from the final hit
     // when an image texture asks; UV_NONE: the scene has no image texture, nothing reads them
-    auto uv = [&](float& u, float& v) {
-      if (UV == UV_TRACKED) { u = h.u; v = h.v; }
-      else if (UV == UV_WINNER) winner_uv(recs, h.hit, L.ray, h.closest, rec, u, v);
-      else { u = 0.0f; v = 0.0f; }
-    };
+    const HitUv<UV, PB> uv{recs, h, L.ray, rec};
     cont = shade<(MATS & 0x1ff)>(mats, a.atlas, rec, uv, L.ray, L.att, L.rng, out);
     if (cont && ++L.b >= a.depth) { // bounce loop exhausted: black (render.hpp:91)
       out = mk(0.0f, 0.0f, 0.0f);
@@ -777,9 +795,28 @@ __global__ void math_kernel(int op, const float* __restrict__ a, const float* __
     case 10: r = rcp_rn_guarded(x); break; // RN(1/a) for 2^-40 <= |a| <= 2^40 (pt_device.hpp: make_ctx)
     case 11: r = sqrt_rn_unit(x); break;   // correctly rounded sqrt for x = 0 or 2^-60 <= x <= 4
     case 12: r = sky_unit_y(x, y, true); break; // unit_vector(d).y = x / sqrt(y) for a regular ray (y = d.d): the sky's shortcut
+    case 13: r = checker_sines_negative(x, y, 1.0f) ? 1.0f : 0.0f; break; // texture.hpp:43-45 on (a, b, 1): the checker's sign-only form
     default: r = x / y; break;
   }
   out[i] = r;
+}
+
+// pt_debug_sphere_texel: the texel an image texture on a sphere selects for the unit normal n — what texture_value takes (the fast
+// path where it is unambiguous, the reference's chain otherwise: out_ij), the reference's chain alone (exact_ij), and which one it was.
+__global__ void sphere_texel_kernel(const float* __restrict__ nxyz, long long n, float freq, uint32_t w, uint32_t h, int32_t* __restrict__ out_ij,
+                                    int32_t* __restrict__ exact_ij, uint8_t* __restrict__ fast) {
+  long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const V3 nn = mk(nxyz[3 * k], nxyz[3 * k + 1], nxyz[3 * k + 2]);
+  float u, v;
+  mercator(nn, u, v);
+  const uint32_t ei = texel_index(ptm::fmod1f_(u * freq) * (float)(w - 1), w - 1);
+  const uint32_t ej = texel_index((1.0f - ptm::fmod1f_(v * freq)) * (float)(h - 1), h - 1);
+  uint32_t i = 0, j = 0;
+  const bool took = sphere_texel_fast(nn, freq, w, h, i, j);
+  out_ij[2 * k] = (int32_t)(took ? i : ei); out_ij[2 * k + 1] = (int32_t)(took ? j : ej);
+  exact_ij[2 * k] = (int32_t)ei; exact_ij[2 * k + 1] = (int32_t)ej;
+  fast[k] = took ? 1 : 0;
 }
 
 // PT_FLAG_FAST_RNG: framebuffer = (chunk plane 0 + plane 1 + ... in order) / samples — a fixed order, so the mode is
@@ -1681,8 +1718,8 @@ int pt_debug_camera_rays(const PtCamera* cam, int32_t width, int32_t height, con
 }
 
 int pt_debug_math(int32_t op, const float* a, const float* b, float* out, int64_t n) {
-  if (!a || !out || n < 0 || op < 0 || op > 12) return fail(PT_ERR_INVALID_ARG, "pt_debug_math: bad argument");
-  if ((op == 4 || op == 8 || op == 9 || op == 12) && !b) return fail(PT_ERR_INVALID_ARG, "pt_debug_math: op needs two operands");
+  if (!a || !out || n < 0 || op < 0 || op > 13) return fail(PT_ERR_INVALID_ARG, "pt_debug_math: bad argument");
+  if ((op == 4 || op == 8 || op == 9 || op == 12 || op == 13) && !b) return fail(PT_ERR_INVALID_ARG, "pt_debug_math: op needs two operands");
   if (n == 0) return PT_OK;
   DevBuf<float> da, db, dout;
   PT_HIP(da.alloc(n));
@@ -1695,6 +1732,25 @@ int pt_debug_math(int32_t op, const float* a, const float* b, float* out, int64_
   hipLaunchKernelGGL(math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, op, da.p, b ? db.p : nullptr, dout.p, (long long)n);
   PT_HIP(hipGetLastError());
   PT_HIP(hipMemcpy(out, dout.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+  return PT_OK;
+}
+
+int pt_debug_sphere_texel(const float* n_xyz, int64_t n, float freq, int32_t width, int32_t height, int32_t* out_ij, int32_t* exact_ij, uint8_t* took_fast) {
+  if (!n_xyz || !out_ij || !exact_ij || !took_fast || n < 0 || width < 1 || height < 1) return fail(PT_ERR_INVALID_ARG, "pt_debug_sphere_texel: bad argument");
+  if (n == 0) return PT_OK;
+  DevBuf<float> dn;
+  DevBuf<int32_t> da, db;
+  DevBuf<uint8_t> df;
+  PT_HIP(dn.alloc(3 * n));
+  PT_HIP(da.alloc(2 * n));
+  PT_HIP(db.alloc(2 * n));
+  PT_HIP(df.alloc(n));
+  PT_HIP(hipMemcpy(dn.p, n_xyz, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(sphere_texel_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, dn.p, (long long)n, freq, (uint32_t)width, (uint32_t)height, da.p, db.p, df.p);
+  PT_HIP(hipGetLastError());
+  PT_HIP(hipMemcpy(out_ij, da.p, (size_t)n * 2 * sizeof(int32_t), hipMemcpyDeviceToHost));
+  PT_HIP(hipMemcpy(exact_ij, db.p, (size_t)n * 2 * sizeof(int32_t), hipMemcpyDeviceToHost));
+  PT_HIP(hipMemcpy(took_fast, df.p, (size_t)n, hipMemcpyDeviceToHost));
   return PT_OK;
 }
 

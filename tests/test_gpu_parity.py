@@ -164,6 +164,86 @@ def test_sky_unit_direction_shortcut_is_exact(lib):
         assert_bit_identical(gpu_math(lib, 11, x, None), np.sqrt(x), f"sqrt, exponent {e}")
 
 
+def test_checker_sign_shortcut_is_exact(lib, orc):
+    """texture.hpp:43-45 (pt_device.hpp: checker_sines_negative): `sin(a) sin(b) sin(c) < 0` decided from the range reductions alone for
+    regular arguments, from the product itself otherwise — against the oracle's product on random arguments of every magnitude, on the
+    neighbours of multiples of pi/2 (where a sine changes sign or is smallest), and on zeros, denormals, huge values, infinities and NaNs
+    (where the product underflows, is a zero or a NaN).  tests/cpp/checker_sign_exhaustive.c covers every regular float on the CPU."""
+    rng = np.random.default_rng(77)
+    n = 2_000_000
+    e = rng.integers(-40, 36, n).astype(np.uint32) + 127
+    a = ((e << 23) | rng.integers(0, 2 ** 23, n, dtype=np.uint32) | (rng.integers(0, 2, n, dtype=np.uint32) << 31)).view(np.float32)
+    k = rng.integers(-200000, 200000, 400_000)
+    near = (k * (np.pi / 2)).astype(np.float32)
+    near = (near.view(np.int32) + rng.integers(-3, 4, len(near)).astype(np.int32)).view(np.float32)
+    special = np.float32([0, -0.0, 1e-45, -1e-45, 1e-38, 2.0 ** -30, np.nextafter(np.float32(2.0 ** -30), np.float32(0)), -(2.0 ** -30),
+                          2.0 ** 30, np.nextafter(np.float32(2.0 ** 30), np.float32(0)), -(2.0 ** 30), 3e38, np.inf, -np.inf, np.nan,
+                          1e-20, -1e-20, 1e-15, 3.1415927, -3.1415927, 6.2831855, 1.5707964, 10.0, -10.0])
+    a = np.concatenate([a, near, special, (rng.random(500_000, dtype=np.float32) - 0.5) * np.float32(2e4)]).astype(np.float32)
+    b = rng.permutation(a).astype(np.float32)
+    b[-2000:] = rng.choice(special, 2000)
+    a[:2000] = rng.choice(special, 2000)
+    orc.set_math(True)
+    sa, sb = orc.math(0, a, None), orc.math(0, b, None)
+    s1 = orc.math(0, np.float32([1.0]), None)[0]
+    with np.errstate(all="ignore"):
+        want = (((sa * sb).astype(np.float32) * s1).astype(np.float32) < 0).astype(np.float32)
+    got = gpu_math(lib, 13, a, b)
+    bad = np.nonzero(got != want)[0]
+    assert len(bad) == 0, f"{len(bad)} differ, first a={a[bad[0]]!r} b={b[bad[0]]!r} got {got[bad[0]]} want {want[bad[0]]}"
+    assert want.sum() > 100_000 and (1 - want).sum() > 100_000
+
+
+def _unit_normals(rng, n, kind):
+    v = rng.normal(size=(n, 3))
+    if kind == 1: v[:, rng.integers(0, 3)] *= 1e-3       # near a coordinate plane: the seam, the equator
+    if kind == 2: v[:, 1] *= 30                          # near the poles
+    if kind == 3: v[:, 0] *= 1e-5; v[:, 2] *= 1e-5       # at the poles
+    if kind == 4: v[:, 2] = np.abs(v[:, 2]) * 1e-6; v[:, 0] = -np.abs(v[:, 0])  # the seam phi = +-pi
+    v /= np.linalg.norm(v, axis=1)[:, None]
+    return (v * (1 + rng.normal(size=(n, 1)) * 1e-7)).astype(np.float32)  # (p - centre) / radius is a unit vector up to rounding
+
+
+@pytest.mark.parametrize("freq,w,h", [(1.0, 1024, 512), (5.0, 320, 140), (0.37, 7, 3), (64.0, 4096, 4096)])
+def test_sphere_texel_fast_path_is_exact(lib, orc, freq, w, h):
+    """texture.hpp:140-157 over sphere.hpp:13-24 (pt_device.hpp: sphere_texel_fast): the texel an image texture selects on a sphere, from
+    binary32 approximations of atan2 / asin where their error cannot change a floor(), from the reference's chain otherwise.  What the
+    kernels take must equal the chain on every normal; the chain itself is pinned to the oracle's math here; and the short form must be
+    the one that decides nearly always (it is the point of having it) at the reference's texture sizes."""
+    rng = np.random.default_rng(int(w * 31 + h))
+    n = 4_000_000
+    nn = np.concatenate([_unit_normals(rng, n // 5, k) for k in range(5)])
+    special = np.float32([[0, 1, 0], [0, -1, 0], [1, 0, 0], [-1, 0, 0], [0, 0, 1], [0, 0, -1], [0, 0, 0], [np.nan, 0, 1], [0.6, np.nan, 0.8],
+                          [0, 1.0000001, 0], [1e-30, 1, 1e-30], [-1, 0, -0.0], [-1, 0, 1e-45], [np.inf, 0, 1], [0.5, 0.5, 0.70710677]])
+    nn = np.ascontiguousarray(np.concatenate([nn, special]).astype(np.float32))
+    m = len(nn)
+    out, exact, fast = np.zeros((m, 2), np.int32), np.zeros((m, 2), np.int32), np.zeros(m, np.uint8)
+    abi.check(lib.pt_debug_sphere_texel(nn.ctypes.data_as(abi._FP), m, float(freq), w, h, out.ctypes.data_as(C.POINTER(C.c_int32)),
+                                        exact.ctypes.data_as(C.POINTER(C.c_int32)), fast.ctypes.data_as(C.POINTER(C.c_uint8))), "pt_debug_sphere_texel")
+    bad = np.nonzero((out != exact).any(axis=1))[0]
+    assert len(bad) == 0, f"{len(bad)} texels differ, first normal {nn[bad[0]]!r}: took {out[bad[0]]} chain {exact[bad[0]]} fast={fast[bad[0]]}"
+    # the chain, restated with the oracle's math (texture.hpp:140-157, sphere.hpp:13-24; binary32 left to right)
+    orc.set_math(True)
+    f32, PI = np.float32, np.float32(3.14159265358979323846)
+    with np.errstate(all="ignore"):
+        phi, theta = orc.math(4, nn[:, 2].copy(), nn[:, 0].copy()), orc.math(5, nn[:, 1].copy(), None)
+        u = (f32(1) - ((phi + PI).astype(f32) / (f32(2) * PI)).astype(f32)).astype(f32)
+        v = ((theta + PI / f32(2)).astype(f32) / PI).astype(f32)
+        ci = (orc.math(6, (u * f32(freq)).astype(f32), None) * f32(w - 1)).astype(f32)
+        cj = ((f32(1) - orc.math(6, (v * f32(freq)).astype(f32), None)).astype(f32) * f32(h - 1)).astype(f32)
+
+        def texel(c, mx):
+            r = np.where(c >= f32(mx), mx, np.where(c > 0, np.floor(np.where(np.isfinite(c), c, 0)), 0))
+            return np.where(c > 0, r, 0).astype(np.int64)  # texel_index: !(f > 0) -> 0, f >= max -> max, else truncate
+        want = np.stack([texel(ci, w - 1), texel(cj, h - 1)], axis=1)
+    bad = np.nonzero((exact != want).any(axis=1))[0]
+    assert len(bad) == 0, f"{len(bad)} chain texels differ from the oracle's math, first normal {nn[bad[0]]!r}: {exact[bad[0]]} vs {want[bad[0]]}"
+    share = fast[: n // 5].mean()  # on uniformly random directions
+    assert not fast[-len(special):][[0, 1, 6, 7, 8, 9, 13]].any()  # the poles, the zero vector, NaNs, |y| > 1 and infinities go through the chain
+    if freq * max(w, h) < 20_000:
+        assert share > 0.97, share
+
+
 def test_camera_quotients_through_the_reciprocal_are_exact(lib):
     """render.hpp:96-97: (x + xi) / width through div_exact with RN(1/width) — equal to the IEEE quotient for every frame
     size up to 16384 and numerators x + xi with xi a multiple of 2^-32 (checked on random and extreme numerators)."""

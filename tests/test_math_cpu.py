@@ -76,3 +76,16 @@ def test_fmod1_is_exact(orc):
     a = np.concatenate([(rng.random(100_000, dtype=np.float32) - 0.5) * 50, np.float32([0, -0.0, 1, -1, 2.5, -2.5, 1e10, 8388608.5])]).astype(np.float32)
     p, g = both(orc, FMOD1, a)
     np.testing.assert_array_equal(bits(p), bits(g))
+
+
+def test_checker_sign_only_form_over_every_regular_float(tmp_path):
+    """tests/cpp/checker_sign_exhaustive.c: the sign the device takes from the range reduction alone (pt_math.hpp: sin_negative_regular)
+    equals the sign bit of the oracle's sinf_ for EVERY binary32 argument with 2^-30 <= |a| < 2^30 (1.0e9 of them), and no such sine is
+    smaller than 2^-40 — so the checker's product of three (texture.hpp:43-45) cannot underflow where the shortcut is taken."""
+    import subprocess
+    from pathlib import Path
+    src = Path(__file__).resolve().parent / "cpp" / "checker_sign_exhaustive.c"
+    exe = tmp_path / "checker_sign"
+    subprocess.run(["gcc", "-O2", "-fopenmp", "-o", str(exe), str(src), "-lm"], check=True)
+    out = subprocess.run([str(exe), "1"], check=True, capture_output=True, text=True, timeout=600).stdout
+    assert "checked 1006632960 arguments" in out and out.strip().endswith("ok"), out
