@@ -391,7 +391,8 @@ int pt_debug_schedule(const PtScene* scene, int32_t out[2]);
  *     10 the reciprocal 1/a of the ray context, correctly rounded for 2^-40 <= |a| <= 2^40 (rcp_rn_guarded)
  *     11 the square root of a = 0 or 2^-60 <= a <= 4 as the RNG's unit_vec / in_unit_disk take it (sqrt_rn_unit)
  *     12 a / sqrt(b) as the sky of a regular ray takes unit_vector(d).y (b = d.d in [3 * 2^-80, 3 * 2^80]; sky_unit_y)
- *     13 the checker texture's decision `sin(a) sin(b) sin(1) < 0` as 1.0 / 0.0 (texture.hpp:43-45; checker_sines_negative)    */
+ *     13 the checker texture's decision `sin(a) sin(b) sin(1) < 0` as 1.0 / 0.0 (texture.hpp:43-45; checker_sines_negative)
+ *     14 / 15 sin / cos through the fused form the unit-ball sampler uses (pt_math.hpp: sincosf_)                            */
 int pt_debug_math(int32_t op, const float* a, const float* b, float* out, int64_t n);
 
 /* The texel (column i, row j) an image texture of width x height texels and frequency freq selects on a sphere whose unit normal at the

@@ -141,9 +141,18 @@ __device__ __forceinline__ V3 rng_in_unit_ball(uint32_t& s) {
 #ifdef PT_PROBE_NO_BALL
   return mk(r * (theta - 3.0f) * 0.3f, r * (phi - 1.5f) * 0.6f, r * 0.5f);
 #endif
+#ifdef PT_NO_SINCOS
   float plan_seed = r * ptm::sinf_(phi);
   float z = r * ptm::cosf_(phi);
   return mk(plan_seed * ptm::cosf_(theta), plan_seed * ptm::sinf_(theta), z);
+#else
+  float sp, cp, st, ct; // sin / cos of the two angles: one range reduction per angle (pt_math.hpp: sincosf_)
+  ptm::sincosf_(phi, sp, cp);
+  ptm::sincosf_(theta, st, ct);
+  float plan_seed = r * sp;
+  float z = r * cp;
+  return mk(plan_seed * ct, plan_seed * st, z);
+#endif
 }
 
 // ---- camera: render.hpp:96-99 + camera.hpp:93-100 ----------------------------------------

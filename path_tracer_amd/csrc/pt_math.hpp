@@ -92,6 +92,26 @@ __device__ __forceinline__ float cosf_(float xf) {
   return (float)(((n + 1) & 2) ? -v : v);
 }
 
+// sinf_(xf) and cosf_(xf) from ONE range reduction and one evaluation of each kernel polynomial: the same operations in the same order
+// as the two functions above, hence the same bits (tests/test_gpu_parity.py::test_math_bit_exact, ops 14 / 15).  The two calls side by side
+// do not fuse by themselves — each carries its own out-of-range branch — and rng_in_unit_ball asks for both of two angles: 154 -> 72
+// binary64 instructions per point in the unit ball (metal fuzz, isotropic scatter).
+__device__ __forceinline__ void sincosf_(float xf, float& sn, float& cs) {
+  double x = (double)xf;
+  if (!(dabs(x) < 1073741824.0)) {
+    if (x != x || disinf(x)) { sn = (float)(x - x); cs = sn; return; }
+    sn = 0.0f; cs = 1.0f;
+    return;
+  }
+  double r;
+  int n = rem_pio2(x, r);
+  double s = ksin(r), c = kcos(r);
+  double vs = (n & 1) ? c : s;
+  double vc = (n & 1) ? s : c;
+  sn = (float)((n & 2) ? -vs : vs);
+  cs = (float)(((n + 1) & 2) ? -vc : vc);
+}
+
 __device__ __forceinline__ float logf_(float xf) {
   double x = (double)xf;
   if (x != x) return xf;

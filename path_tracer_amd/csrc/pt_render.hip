@@ -796,6 +796,8 @@ __global__ void math_kernel(int op, const float* __restrict__ a, const float* __
     case 11: r = sqrt_rn_unit(x); break;   // correctly rounded sqrt for x = 0 or 2^-60 <= x <= 4
     case 12: r = sky_unit_y(x, y, true); break; // unit_vector(d).y = x / sqrt(y) for a regular ray (y = d.d): the sky's shortcut
     case 13: r = checker_sines_negative(x, y, 1.0f) ? 1.0f : 0.0f; break; // texture.hpp:43-45 on (a, b, 1): the checker's sign-only form
+    case 14: { float c_; ptm::sincosf_(x, r, c_); break; }  // sin through the fused form
+    case 15: { float s_; ptm::sincosf_(x, s_, r); break; }  // cos through the fused form
     default: r = x / y; break;
   }
   out[i] = r;
@@ -1718,7 +1720,7 @@ int pt_debug_camera_rays(const PtCamera* cam, int32_t width, int32_t height, con
 }
 
 int pt_debug_math(int32_t op, const float* a, const float* b, float* out, int64_t n) {
-  if (!a || !out || n < 0 || op < 0 || op > 13) return fail(PT_ERR_INVALID_ARG, "pt_debug_math: bad argument");
+  if (!a || !out || n < 0 || op < 0 || op > 15) return fail(PT_ERR_INVALID_ARG, "pt_debug_math: bad argument");
   if ((op == 4 || op == 8 || op == 9 || op == 12 || op == 13) && !b) return fail(PT_ERR_INVALID_ARG, "pt_debug_math: op needs two operands");
   if (n == 0) return PT_OK;
   DevBuf<float> da, db, dout;

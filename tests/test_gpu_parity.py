@@ -70,6 +70,8 @@ def test_math_bit_exact(lib, orc, op):
         b = np.concatenate([(rng.random(len(a) - len(special), dtype=np.float32) - 0.5) * 40, special[::-1]]).astype(np.float32)
     orc.set_math(True)
     assert_bit_identical(gpu_math(lib, op, a, b), orc.math(op, a, b), f"math op {op}")
+    if op in (0, 1):  # the fused sin / cos of the unit-ball sampler (pt_math.hpp: sincosf_): the same bits as the two functions
+        assert_bit_identical(gpu_math(lib, 14 + op, a, None), orc.math(op, a, None), f"fused sincos, output {op}")
 
 
 def test_ieee_sqrt_and_div(lib):
