@@ -138,9 +138,6 @@ __device__ __forceinline__ V3 rng_in_unit_ball(uint32_t& s) {
   float r = rng_float(s);
   float theta = rng_float(s, 0.0f, 2.0f * PT_PI);
   float phi = rng_float(s, 0.0f, PT_PI);
-#ifdef PT_PROBE_NO_BALL
-  return mk(r * (theta - 3.0f) * 0.3f, r * (phi - 1.5f) * 0.6f, r * 0.5f);
-#endif
 #ifdef PT_NO_SINCOS
   float plan_seed = r * ptm::sinf_(phi);
   float z = r * ptm::cosf_(phi);
@@ -283,12 +280,8 @@ __device__ __forceinline__ V3 sphere_center(f4 R0, f4 R1, f4 R2, float time) {
 
 // sphere.hpp:13-24
 __device__ __forceinline__ void mercator(V3 p, float& u, float& v) {
-#ifdef PT_PROBE_NO_UV
-  float phi = p.z + p.x, theta = p.y;
-#else
   float phi = ptm::atan2f_(p.z, p.x);
   float theta = ptm::asinf_(p.y);
-#endif
   u = 1.0f - (phi + PT_PI) / (2.0f * PT_PI);
   v = (theta + PT_PI / 2.0f) / PT_PI;
 }
@@ -687,11 +680,7 @@ __device__ __forceinline__ bool medium_t(P recs, int off, const RayCtx& c, float
   asm volatile("" : "+v"(a_here)); // (opaque: the square root stays HERE, behind the boundary tests — hoisted to the top of the iteration it ran for every ray of every wave)
   const float ray_length = sqrt_rn(a_here); // sycl::length(r.direction())
   const float distance_inside_boundary = (t2 - t1) * ray_length;
-#ifdef PT_PROBE_NO_LOG
-  const float hit_distance = R0.y * (rng_float(rng) - 1.0f) * 2.0f;
-#else
   const float hit_distance = R0.y * ptm::logf_(rng_float(rng)); // the in-traversal draw (:65)
-#endif
   if (hit_distance > distance_inside_boundary) return false;
   t_out = t1 + hit_distance / ray_length;
   return true;
@@ -2345,9 +2334,6 @@ __device__ __forceinline__ V3 refract(V3 uv, V3 n, float etai_over_etat) {
 __device__ __forceinline__ float reflectance(float cosine, float ref_idx) {
   float r0 = (1.0f - ref_idx) / (1.0f + ref_idx);
   r0 *= r0;
-#ifdef PT_PROBE_NO_POW5
-  { const float q = 1.0f - cosine; return r0 + (1.0f - r0) * (q * q * q * q * q); }
-#endif
   return r0 + (1.0f - r0) * ptm::pow5f_(1.0f - cosine);
 }
 
