@@ -1359,7 +1359,20 @@ __device__ __forceinline__ bool tri_param(f4 R0, f4 R1, f4 R2, const Ray& r, flo
 }
 __device__ __forceinline__ float rl_f(float v, int src) { return as_f(__builtin_amdgcn_readlane(as_i(v), src)); }
 
+// centroid of a compressed filter record: lo + k step per axis, one multiplication and one addition each, NOT fused — the host measures
+// the deviation eps_c of exactly this decode (pt_tripool.hpp "compressed records")
+__device__ __forceinline__ V3 tri_centroid(unsigned int kx, unsigned int ky, unsigned int kz, f4 H7, f4 H8) {
+  return mk(H7.x + (float)kx * H8.x, H7.y + (float)ky * H8.y, H7.z + (float)kz * H8.z);
+}
+
 __device__ __forceinline__ bool tri_pool_scan(glb_f4p gblob, cst_f4p cblob, int hdr, int goff, const RayCtx& c, HitState& h) {
+#ifndef PT_NO_FILTER_FMA
+  // Everything written in this function is FILTER arithmetic — necessary conditions with explicit slack against exact mathematics
+  // (pt_tripool.hpp), and the uniform walk whose rounding the cells' absolute slack covers — so a product may fuse with the sum that
+  // takes it: one rounding instead of two, never a larger error, and a quarter fewer vector instructions in the filters.  The reference's
+  // own test (tri_param -> tri_eval, functions of their own) and the centroid decode above are compiled as written (-ffp-contract=off).
+#pragma clang fp contract(fast)
+#endif
   const f4 H0 = cblob[hdr], H1 = cblob[hdr + 1], H2 = cblob[hdr + 2], H3 = cblob[hdr + 3], H4 = cblob[hdr + 4], H5 = cblob[hdr + 5], H6 = cblob[hdr + 6];
   const f4 H7 = cblob[hdr + 7], H8 = cblob[hdr + 8], H9 = cblob[hdr + 9]; // the quantisation of the compressed filter records (pt_tripool.hpp)
   const int cell_n = as_i(H9.z);
@@ -1472,7 +1485,7 @@ __device__ __forceinline__ bool tri_pool_scan(glb_f4p gblob, cst_f4p cblob, int 
           unsigned int passmask = 0;
 #pragma unroll
           for (int j = 0; j < PT_TRI_GRID_PER_LANE; j++) {
-            const V3 C = mk(H7.x + (float)(q0[j] & 0xffffu) * H8.x, H7.y + (float)(q0[j] >> 16) * H8.y, H7.z + (float)(q1[j] & 0xffffu) * H8.z);
+            const V3 C = tri_centroid(q0[j] & 0xffffu, q0[j] >> 16, q1[j] & 0xffffu, H7, H8);
             const float rad = as_f((int)(q1[j] & 0xffff0000u)), radl = rad * H9.x;
             const V3 oc = C - ur.o;
             const float m = dot(oc, ur.d);
@@ -1516,7 +1529,7 @@ __device__ __forceinline__ bool tri_pool_scan(glb_f4p gblob, cst_f4p cblob, int 
       const float nlow = 0.98f * H5.z * L * __builtin_amdgcn_rcpf(pn);          // <= |N|
       const float a1 = (dq - dn * H8.w) * nlow - H6.w * L2 * dn;                 // <= |a'| - ea |d|
       const float rr = (H6.y + H6.z * L) * L2 * rho * dn * __builtin_amdgcn_rcpf(a1) * 1.001f; // >= the noise radius; a1 <= 0: no bound
-      const V3 C = mk(H7.x + (float)(w2 & 0xffffu) * H8.x, H7.y + (float)(w2 >> 16) * H8.y, H7.z + (float)(w3 & 0xffffu) * H8.z);
+      const V3 C = tri_centroid(w2 & 0xffffu, w2 >> 16, w3 & 0xffffu, H7, H8);
       return !(a1 > 0.0f) || near_line(C, L + rr + H6.x + H7.w);
     };
     const V3 dh = __builtin_amdgcn_rsqf(ua) * ur.d; // unit direction (a few ulp: covered by the strips' absolute slack)
