@@ -2369,6 +2369,22 @@ __device__ __forceinline__ float sky_unit_y(float dy, float a, bool regular) {
   asm volatile("" : "+v"(a)); // (opaque: the general square root is not to be hoisted out of this rarely taken path)
   return dy / sqrt_rn(a);
 }
+// unit_vector(d) (vec.hpp: v / v.length()) for metal and dielectric scatter (material.hpp:41,74): all three quotients through sky_unit_y's
+// form when every live ray of the wave is regular — one range-proved square root and one correctly rounded reciprocal shared by three
+// corrected quotients (9 + 4 + 15 issue slots) instead of the general square root and three IEEE divisions (17 + 39); the same function of
+// (d_c, d.d) as the sky's, whose test covers every component by symmetry (test_sky_unit_direction_shortcut_is_exact).
+__device__ __forceinline__ V3 unit_direction(V3 d, bool regular) {
+  float a = dot(d, d);
+#ifndef PT_NO_UD_SHORTCUT
+  if (regular) {
+    const float len = sqrt_rn_unit(a);
+    const float y = rcp_rn_guarded(len);
+    return mk(div_exact(d.x, len, y, d.x * y), div_exact(d.y, len, y, d.y * y), div_exact(d.z, len, y, d.z * y));
+  }
+#endif
+  asm volatile("" : "+v"(a)); // (as in sky_unit_y: keep the general square root inside the rarely taken path)
+  return d / sqrt_rn(a);
+}
 __device__ __forceinline__ V3 sky_color(const Ray& r, V3 att, bool regular = false) {
   V3 ud = mk(0.0f, sky_unit_y(r.d.y, dot(r.d, r.d), regular), 0.0f); // (x and z of the unit vector are never read)
   float hit_pt = 0.5f * (ud.y + 1.0f);
@@ -2381,7 +2397,7 @@ __device__ __forceinline__ V3 sky_color(const Ray& r, V3 att, bool regular = fal
 // `uv(u, v)` yields the hit's texture coordinates; it is called before the ray is overwritten.
 template <int MATS = MATS_ALL, typename PM, typename UV>
 __device__ __forceinline__ bool shade(PM mats, const uint8_t* __restrict__ atlas, const Rec& rec,
-                                      UV uv, Ray& ray, V3& att, uint32_t& rng, V3& out) {
+                                      UV uv, Ray& ray, V3& att, uint32_t& rng, V3& out, bool regular = false) {
   PM M = mats + rec.mat * SZ_MATERIAL;
   f4 M0 = M[0], M1 = M[1];
   const int mk_ = as_i(M0.x);
@@ -2393,7 +2409,7 @@ __device__ __forceinline__ bool shade(PM mats, const uint8_t* __restrict__ atlas
   // material.  Per lane nothing moves: each lane takes exactly one material, its draws keep their order (the ball is the
   // first thing metal and isotropic draw; texture values draw nothing).
   V3 ud = mk(0.0f, 0.0f, 0.0f), ball = ud, tv = ud;
-  if constexpr (METAL || GLASS) { if (mk_ == 1 || mk_ == 2) ud = ray.d / sqrt_rn(dot(ray.d, ray.d)); }
+  if constexpr (METAL || GLASS) { if (mk_ == 1 || mk_ == 2) ud = unit_direction(ray.d, regular); } // (regular: wave-uniform)
   if constexpr (METAL || ISO) { if (mk_ == 1 || mk_ >= 4) ball = rng_in_unit_ball(rng); }
   if constexpr (!(MATS & 0x100)) tv = xyz(M1); // solid textures only: every material's colour slot IS its texture value
   else if (mk_ == 0 || mk_ >= 3) tv = texture_value<MATS>(M0, M1, M[2], M[3], rec.p, uv, atlas);

@@ -396,7 +396,7 @@ __device__ __forceinline__ void lane_shade(Lane& L, const KArgs& a, const HitSta
     // UV_TRACKED kernels carried u,v through the scan (stale values included); UV_WINNER derives them from the final hit
     // when an image texture asks; UV_NONE: the scene has no image texture, nothing reads them
     const HitUv<UV, PB> uv{recs, h, L.ray, rec};
-    cont = shade<(MATS & 0x1ff)>(mats, a.atlas, rec, uv, L.ray, L.att, L.rng, out);
+    cont = shade<(MATS & 0x1ff)>(mats, a.atlas, rec, uv, L.ray, L.att, L.rng, out, regular);
     if (cont && ++L.b >= a.depth) { // bounce loop exhausted: black (render.hpp:91)
       out = mk(0.0f, 0.0f, 0.0f);
       cont = false;

@@ -1,3 +1,4 @@
 #!/bin/bash
-python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py tests/test_gpu_scale.py -q -x -k "tri or pool or mesh" 2>&1 | tail -2
-python tools/soak_path_rays.py 2 20000 triangle 2>&1 | grep -v amdgpu | tail -3
+tools/abn.sh "libpt_var_noud.so libpt_render.so libpt_var_noud.so libpt_render.so" smoke 512 1 3840 2160
+tools/abn.sh "libpt_var_noud.so libpt_render.so" smoke 256 8
+python -m pytest tests/test_gpu_parity.py -q -x -k "cfg or smoke or mixed or golden" 2>&1 | tail -2
