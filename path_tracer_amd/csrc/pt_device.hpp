@@ -2304,7 +2304,25 @@ __device__ __forceinline__ bool checker_sines_negative(float a, float b, float c
   const float mn = __builtin_fminf(__builtin_fminf(__builtin_fabsf(a), __builtin_fabsf(b)), __builtin_fabsf(c));
   const float mx = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(a), __builtin_fabsf(b)), __builtin_fabsf(c));
   const bool nan = (a != a) | (b != b) | (c != c); // (fmin / fmax drop a NaN operand)
-  if (!nan && mn >= lo && mx < hi) return (ptm::sin_negative_regular(a) != ptm::sin_negative_regular(b)) != ptm::sin_negative_regular(c);
+  if (!nan && mn >= lo && mx < hi) {
+#ifndef PT_NO_CHECKER_F32
+    // First in binary32: u = |x| fl(1/pi) is within |x| 2^-23 / pi of |x| / pi (the constant's and the product's rounding), so where u lies
+    // at least d = u 2^-21 from both neighbouring integers, floor(|x| / pi) = floor(u) and the sine's sign is (-1)^floor(u) sign(x) — the sign
+    // of the true sine and, that far from a zero of it, of sinf_'s (tests/cpp/checker_sign_exhaustive.c checks every regular binary32
+    // argument for which this form decides).  Arguments past ~2^21 never decide here (d >= 1/2) and take the binary64 reduction below.
+    bool neg = false, decided = true;
+    const float xs[3] = {a, b, c};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const float u = __builtin_fabsf(xs[k]) * 0.318309886183790671538f;
+      const float fl = __builtin_floorf(u), fr = u - fl, d = u * 4.76837158203125e-07f; // 2^-21
+      decided = decided & (fr >= d) & (fr <= 1.0f - d);
+      neg = neg != ((((int)fl & 1) != 0) != (xs[k] < 0.0f));
+    }
+    if (decided) return neg;
+#endif
+    return (ptm::sin_negative_regular(a) != ptm::sin_negative_regular(b)) != ptm::sin_negative_regular(c);
+  }
 #endif
   const float sines = ptm::sinf_(a) * ptm::sinf_(b) * ptm::sinf_(c);
   return sines < 0;

@@ -5,6 +5,7 @@
  * takes the sign of sinf_(a) from the range reduction alone (n = quadrant, r = reduced argument: negative iff (n even and r < 0)
  * xor (n & 2)) and never evaluates the polynomials.  This program checks, for EVERY regular binary32 argument of both signs:
  *   (1) the sign-only form equals the sign bit of ptm_sinf(a), and ptm_sinf(a) is neither zero nor NaN;
+ *   (1b) wherever the binary32 first stage decides (u = |a| fl(1/pi) at least u 2^-21 from an integer), its sign equals that sign bit too;
  *   (2) |ptm_sinf(a)| >= 2^-40, so that a product of three such factors (>= 2^-120) never underflows in binary32 and its sign is
  *       the product of the signs.
  * Prints the smallest |sin| seen and "ok", or the first counter-example.   gcc -O2 -fopenmp checker_sign_exhaustive.c -lm
@@ -23,13 +24,21 @@ static int sign_only(float a) { /* the device's form, restated */
   return neg_v != ((n & 2) != 0);
 }
 
+/* the binary32 first stage (pt_device.hpp: checker_sines_negative): 1 = decided, *neg = its answer */
+static int sign_f32(float a, int* neg) {
+  const float u = fabsf(a) * 0.318309886183790671538f;
+  const float fl = floorf(u), fr = u - fl, d = u * 4.76837158203125e-07f;
+  *neg = ((((int)fl) & 1) != 0) != (a < 0.0f);
+  return (fr >= d) && (fr <= 1.0f - d);
+}
+
 int main(int argc, char** argv) {
   const unsigned stride = argc > 1 ? (unsigned)atoi(argv[1]) : 1u;
   const unsigned lo = (127u - 30u) << 23, hi = (127u + 30u) << 23; /* [2^-30, 2^30) */
   double min_abs = 1.0;
   unsigned bad = 0, first_bad = 0;
-  unsigned long long checked = 0;
-#pragma omp parallel for schedule(static) reduction(min : min_abs) reduction(+ : bad, checked)
+  unsigned long long checked = 0, decided32 = 0;
+#pragma omp parallel for schedule(static) reduction(min : min_abs) reduction(+ : bad, checked, decided32)
   for (unsigned e = lo >> 23; e < (hi >> 23); e++) {
     for (unsigned m = 0; m < (1u << 23); m += stride) {
       /* the stride walks the significands; the last 64 and first 64 of every binade are always visited */
@@ -44,7 +53,11 @@ int main(int argc, char** argv) {
           const float f = ptm_sinf(a);
           unsigned fb;
           memcpy(&fb, &f, 4);
-          const int ok = (f == f) && f != 0.0f && ((int)(fb >> 31) == sign_only(a)) && fabs((double)f) >= 0x1p-40;
+          int neg32 = 0;
+          const int dec32 = sign_f32(a, &neg32);
+          if (dec32) decided32++;
+          const int ok = (f == f) && f != 0.0f && ((int)(fb >> 31) == sign_only(a)) && fabs((double)f) >= 0x1p-40 &&
+                         (!dec32 || neg32 == (int)(fb >> 31));
           if (!ok) {
             bad++;
 #pragma omp critical
@@ -57,6 +70,7 @@ int main(int argc, char** argv) {
     }
   }
   printf("checked %llu arguments, smallest |sinf_| = %.6e (2^%.2f)\n", checked, min_abs, log2(min_abs));
+  printf("the binary32 first stage decided %llu of them\n", decided32);
   if (bad) { printf("FAILED: %u counter-examples, first bits 0x%08x\n", bad, first_bad); return 1; }
   printf("ok\n");
   return 0;
