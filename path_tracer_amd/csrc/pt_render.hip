@@ -1368,6 +1368,8 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
   // (only the kernels that walk a sphere grid: the headline family's iteration — slab pass, wave-uniform — does not get shorter with fewer
   // lanes: its shard 0/8 took 127 ms that way against 40)
   const bool share_small = use_grid && s->knobs.lanes_cap >= 0 && !(p->flags & (PT_FLAG_TILE_GRANULAR | PT_FLAG_PIXEL_GRANULAR | PT_FLAG_FAST_RNG));
+  // (set by launch_uv for the headline family — no sphere grid, no cooperative phase: see `launch`)
+  bool chain_bound_family = false;
   // Persistent grid: no more workgroups than the chip holds at once; lanes pull pixels from the queue.
   auto launch = [&](auto kernel, int block_threads = kBlock) -> int {
     const int waves_per_block = block_threads / 64;
@@ -1378,6 +1380,15 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
       PT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block_threads, shmem));
       s->occupancy[(const void*)kernel] = per_cu;
     }
+    // A headline-family launch with fewer than ~1.6 tiles per wave slot (shard 0 of 3 ... 6 of the 1080p frame) is bound by its heaviest
+    // tiles' sequential chains, and a chain's iteration takes as long as the waves that share its SIMD make it: four waves per SIMD that
+    // take two tiles each, heaviest first, finish before eight that take one.  Cornell-style 1080p x 1024 spp, kernel ms of shard 0 of
+    // N = 3 / 4 / 6 at 8 and at 4 workgroups per CU: 63.3 / 57.8 / 43.4 and 60.3 / 51.1 / 42.8 (profiles/r04_blocks_sweep.txt); whole frames
+    // and halves (>= 2 tiles per slot) keep the full occupancy, and a launch with half a tile per slot takes four per CU by itself.
+    // (Grid and triangle-pool kernels: their own occupancy is the best at every shard count — same file.)
+    if (chain_bound_family && !s->knobs.blocks_per_cu && a.n_split == 0 && a.scatter_p == 0 &&
+        (double)launch_units < 1.6 * (double)per_cu * waves_per_block * std::max(1, s->num_cus))
+      per_cu = std::min(per_cu, 4);
     if (s->knobs.blocks_per_cu) per_cu = std::min(per_cu, s->knobs.blocks_per_cu); // tuning knob
     const int resident_blocks = std::max(1, per_cu) * std::max(1, s->num_cus);
     // Queue counters come from a ring of kQueueRing slots.  A slot is reused only after the launch that last used it has
@@ -1447,6 +1458,7 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
     if (!resident) return launch(render_kernel_stream<UV>);
     if constexpr (UV == UV_NONE) { // no image texture and no sphere grid (the headline scene): kernels without the grid walk
       if (s->grid_spheres == 0 && !coop) {
+        chain_bound_family = true;
         if (s->mats_simple) { // lambertian + lightsource over solid textures: kernels without the other materials' code
           if (s->rectbox_only) { // ... and every hittable a rect or a box (the headline scene): resolve_hit without the other kinds
             constexpr int MSR = MATS_LAMB_LIGHT_SOLID | MATS_RECTBOX_ONLY;
