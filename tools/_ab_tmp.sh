@@ -1,6 +1,9 @@
 #!/bin/bash
-for b in 0 1 2 3 4 6; do
-  echo "PT_BLOCKS_PER_CU=$b"
-  if [ $b = 0 ]; then tools/abn.sh "libpt_render.so" cornell 1024 8; tools/abn.sh "libpt_render.so" cornell 1024 4;
-  else PT_BLOCKS_PER_CU=$b tools/abn.sh "libpt_render.so" cornell 1024 8; PT_BLOCKS_PER_CU=$b tools/abn.sh "libpt_render.so" cornell 1024 4; fi
+for q in 0 256 512 1024; do
+echo "PT_PRIO_STEP=$q"
+export PT_PRIO_STEP=$q
+tools/abn.sh "libpt_render.so" cornell 1024 1; tools/abn.sh "libpt_render.so" cornell 1024 4; tools/abn.sh "libpt_render.so" cornell 1024 8
+tools/abn.sh "libpt_render.so" smoke 512 1; tools/abn.sh "libpt_render.so" smoke 512 8
+tools/abn.sh "libpt_render.so" smoke 512 1 3840 2160; tools/abn.sh "libpt_render.so" smoke 512 8 3840 2160
+tools/abn.sh "libpt_render.so" smoke 64 1 400 225
 done
