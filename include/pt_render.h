@@ -398,9 +398,11 @@ int pt_debug_math(int32_t op, const float* a, const float* b, float* out, int64_
 /* The texel (column i, row j) an image texture of width x height texels and frequency freq selects on a sphere whose unit normal at the
  * hit is n (n_xyz: 3 floats per entry) — texture.hpp:140-157 over sphere.hpp:13-24.  out_ij = what the render kernels take (the texel
  * straight from the normal where that is provably unambiguous, the reference's chain otherwise: pt_device.hpp sphere_texel_fast),
- * exact_ij = the reference's chain alone, took_fast = 1 where the short form decided.  2 ints per entry.  For tests.                  */
+ * exact_ij = the reference's chain alone, took_fast = 1 where the short form decided.  2 ints per entry.  uv4 (optional, 4 floats per
+ * entry): (u, v) of the reference's chain, then (u, v) of the binary32 approximations — their deviation is what the short form's
+ * margin must cover.  For tests.                                                                                                       */
 int pt_debug_sphere_texel(const float* n_xyz, int64_t n, float freq, int32_t width, int32_t height, int32_t* out_ij, int32_t* exact_ij,
-                          uint8_t* took_fast);
+                          uint8_t* took_fast, float* uv4);
 
 #ifdef __cplusplus
 }

@@ -158,7 +158,7 @@ SIGNATURES = {
                                    C.POINTER(C.c_int32), _FP, C.c_int64, C.POINTER(C.c_int32)]),
     "pt_debug_math": (C.c_int, [C.c_int32, _FP, _FP, _FP, C.c_int64]),
     "pt_debug_sphere_texel": (C.c_int, [_FP, C.c_int64, C.c_float, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
-                                        C.POINTER(C.c_uint8)]),
+                                        C.POINTER(C.c_uint8), _FP]),
     "pt_debug_tri_pool": (C.c_int, [C.POINTER(PtSceneDesc), C.POINTER(C.c_int32)]),
 }
 

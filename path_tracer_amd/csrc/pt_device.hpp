@@ -296,15 +296,14 @@ __device__ __forceinline__ void mercator(V3 p, float& u, float& v) {
 // 1/2pi folded into the coefficients; |error| < 1e-8) with the octant reflections done in turns (values <= 1/2: every rounding <= 2^-25);
 // v~ = 1/2 + asin(y) / pi as  s P_S(s^2)  with s = |y| for |y| <= 1/2 and s = sqrt((1 - |y|) / 2) (exact difference, 1-ulp root) otherwise
 // (degree 5, |error| < 3e-9).  Against the exact chain (atan2f_ / asinf_ rounded to binary32, then the reference's own binary32 operations)
-// the deviation measured on 2 x 10^8 simulated and 10^8 device-evaluated directions — poles, the seam and the axes over-represented — is
-// <= 1.8e-7 in u and v (tests/test_gpu_parity.py::test_sphere_texel_fast_path_is_exact states the device figure); E_uv = 1e-6 is what the
-// ambiguity test assumes, and the chain behind u adds its own roundings: |c~ - c| <= (w - 1) (freq E_uv + 2 ulp(freq)) + 2 ulp(c)
+// the deviation is 1.2e-7 at most in u and in v on 2 x 10^8 simulated directions (numpy binary32) and is MEASURED ON THE DEVICE by
+// tests/test_gpu_parity.py::test_sphere_texel_fast_path_is_exact (pt_debug_sphere_texel returns both pairs; poles, the seam and the axes
+// over-represented; the test's bar is 2.5e-7); E_uv = 1e-6, four times that bar, is what the ambiguity test assumes, and the chain behind
+// u adds its own roundings: |c~ - c| <= (w - 1) (freq E_uv + 2 ulp(freq)) + 2 ulp(c)
 // < (w - 1) (freq + 1) 1.25e-6 =: E for w <= 65536.  With E < 1/4, c~ finite and E <= c~ - floor(c~) <= 1 - E, 0 < c~ < w - 1: floor(c) = floor(c~)
 // (an argument of fmod1 on the other side of an integer than its approximation puts c~ within E of 0 or of w - 1: integers).
-__device__ __forceinline__ bool sphere_texel_fast(V3 n, float freq, uint32_t w, uint32_t h, uint32_t& i, uint32_t& j) {
-#ifdef PT_NO_TEXEL_SHORTCUT
-  return false;
-#else
+// the two approximations: u~, v~ of the unit normal n (NaN / garbage outside the domain: sphere_texel_fast's `ok` covers that)
+__device__ __forceinline__ void sphere_uv_fast(V3 n, float& u_out, float& v_out) {
   const float ax = __builtin_fabsf(n.x), az = __builtin_fabsf(n.z), ay = __builtin_fabsf(n.y);
   const float mxv = __builtin_fmaxf(ax, az), mnv = __builtin_fminf(ax, az);
   const float a = mnv * __builtin_amdgcn_rcpf(mxv);
@@ -335,7 +334,17 @@ __device__ __forceinline__ bool sphere_texel_fast(V3 n, float freq, uint32_t w, 
   float wv = sv * ps;               // asin(s) / pi
   wv = big ? __builtin_fmaf(-2.0f, wv, 0.5f) : wv;
   wv = n.y < 0.0f ? -wv : wv;       // asin(y) / pi in [-1/2, 1/2]
-  const float v = 0.5f + wv;        // (theta + pi/2) / pi
+  u_out = u;
+  v_out = 0.5f + wv;                // (theta + pi/2) / pi
+}
+__device__ __forceinline__ bool sphere_texel_fast(V3 n, float freq, uint32_t w, uint32_t h, uint32_t& i, uint32_t& j) {
+#ifdef PT_NO_TEXEL_SHORTCUT
+  return false;
+#else
+  const float ax = __builtin_fabsf(n.x), az = __builtin_fabsf(n.z), ay = __builtin_fabsf(n.y);
+  const float mxv = __builtin_fmaxf(ax, az);
+  float u, v;
+  sphere_uv_fast(n, u, v);
   const float wm = (float)(w - 1u), hm = (float)(h - 1u);
   const float E = 1.25e-6f * (freq + 1.0f);
   const float Ei = wm * E, Ej = hm * E;

@@ -806,7 +806,7 @@ __global__ void math_kernel(int op, const float* __restrict__ a, const float* __
 // pt_debug_sphere_texel: the texel an image texture on a sphere selects for the unit normal n — what texture_value takes (the fast
 // path where it is unambiguous, the reference's chain otherwise: out_ij), the reference's chain alone (exact_ij), and which one it was.
 __global__ void sphere_texel_kernel(const float* __restrict__ nxyz, long long n, float freq, uint32_t w, uint32_t h, int32_t* __restrict__ out_ij,
-                                    int32_t* __restrict__ exact_ij, uint8_t* __restrict__ fast) {
+                                    int32_t* __restrict__ exact_ij, uint8_t* __restrict__ fast, float* __restrict__ uv4) {
   long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
   const V3 nn = mk(nxyz[3 * k], nxyz[3 * k + 1], nxyz[3 * k + 2]);
@@ -819,6 +819,11 @@ __global__ void sphere_texel_kernel(const float* __restrict__ nxyz, long long n,
   out_ij[2 * k] = (int32_t)(took ? i : ei); out_ij[2 * k + 1] = (int32_t)(took ? j : ej);
   exact_ij[2 * k] = (int32_t)ei; exact_ij[2 * k + 1] = (int32_t)ej;
   fast[k] = took ? 1 : 0;
+  if (uv4) { // (u, v) of the reference's chain and of the binary32 approximations: the deviation the short form's margin E_uv covers
+    float uf, vf;
+    sphere_uv_fast(nn, uf, vf);
+    uv4[4 * k] = u; uv4[4 * k + 1] = v; uv4[4 * k + 2] = uf; uv4[4 * k + 3] = vf;
+  }
 }
 
 // PT_FLAG_FAST_RNG: framebuffer = (chunk plane 0 + plane 1 + ... in order) / samples — a fixed order, so the mode is
@@ -1749,22 +1754,26 @@ int pt_debug_math(int32_t op, const float* a, const float* b, float* out, int64_
   return PT_OK;
 }
 
-int pt_debug_sphere_texel(const float* n_xyz, int64_t n, float freq, int32_t width, int32_t height, int32_t* out_ij, int32_t* exact_ij, uint8_t* took_fast) {
+int pt_debug_sphere_texel(const float* n_xyz, int64_t n, float freq, int32_t width, int32_t height, int32_t* out_ij, int32_t* exact_ij, uint8_t* took_fast,
+                          float* uv4) {
   if (!n_xyz || !out_ij || !exact_ij || !took_fast || n < 0 || width < 1 || height < 1) return fail(PT_ERR_INVALID_ARG, "pt_debug_sphere_texel: bad argument");
   if (n == 0) return PT_OK;
   DevBuf<float> dn;
   DevBuf<int32_t> da, db;
   DevBuf<uint8_t> df;
+  DevBuf<float> duv;
+  if (uv4) PT_HIP(duv.alloc(4 * n));
   PT_HIP(dn.alloc(3 * n));
   PT_HIP(da.alloc(2 * n));
   PT_HIP(db.alloc(2 * n));
   PT_HIP(df.alloc(n));
   PT_HIP(hipMemcpy(dn.p, n_xyz, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(sphere_texel_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, dn.p, (long long)n, freq, (uint32_t)width, (uint32_t)height, da.p, db.p, df.p);
+  hipLaunchKernelGGL(sphere_texel_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, dn.p, (long long)n, freq, (uint32_t)width, (uint32_t)height, da.p, db.p, df.p, uv4 ? duv.p : nullptr);
   PT_HIP(hipGetLastError());
   PT_HIP(hipMemcpy(out_ij, da.p, (size_t)n * 2 * sizeof(int32_t), hipMemcpyDeviceToHost));
   PT_HIP(hipMemcpy(exact_ij, db.p, (size_t)n * 2 * sizeof(int32_t), hipMemcpyDeviceToHost));
   PT_HIP(hipMemcpy(took_fast, df.p, (size_t)n, hipMemcpyDeviceToHost));
+  if (uv4) PT_HIP(hipMemcpy(uv4, duv.p, (size_t)n * 4 * sizeof(float), hipMemcpyDeviceToHost));
   return PT_OK;
 }
 

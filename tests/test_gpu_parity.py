@@ -206,7 +206,7 @@ def _unit_normals(rng, n, kind):
     return (v * (1 + rng.normal(size=(n, 1)) * 1e-7)).astype(np.float32)  # (p - centre) / radius is a unit vector up to rounding
 
 
-@pytest.mark.parametrize("freq,w,h", [(1.0, 1024, 512), (5.0, 320, 140), (0.37, 7, 3), (64.0, 4096, 4096)])
+@pytest.mark.parametrize("freq,w,h", [(1.0, 1024, 512), (5.0, 320, 140), (0.37, 7, 3), (64.0, 4096, 4096), (1.0, 65536, 65536)])
 def test_sphere_texel_fast_path_is_exact(lib, orc, freq, w, h):
     """texture.hpp:140-157 over sphere.hpp:13-24 (pt_device.hpp: sphere_texel_fast): the texel an image texture selects on a sphere, from
     binary32 approximations of atan2 / asin where their error cannot change a floor(), from the reference's chain otherwise.  What the
@@ -220,8 +220,16 @@ def test_sphere_texel_fast_path_is_exact(lib, orc, freq, w, h):
     nn = np.ascontiguousarray(np.concatenate([nn, special]).astype(np.float32))
     m = len(nn)
     out, exact, fast = np.zeros((m, 2), np.int32), np.zeros((m, 2), np.int32), np.zeros(m, np.uint8)
+    uv4 = np.zeros((m, 4), np.float32)
     abi.check(lib.pt_debug_sphere_texel(nn.ctypes.data_as(abi._FP), m, float(freq), w, h, out.ctypes.data_as(C.POINTER(C.c_int32)),
-                                        exact.ctypes.data_as(C.POINTER(C.c_int32)), fast.ctypes.data_as(C.POINTER(C.c_uint8))), "pt_debug_sphere_texel")
+                                        exact.ctypes.data_as(C.POINTER(C.c_int32)), fast.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                        uv4.ctypes.data_as(abi._FP)), "pt_debug_sphere_texel")
+    # the deviation of the binary32 approximations from the reference's chain, measured on the device: the short form assumes 1e-6
+    valid = np.isfinite(uv4).all(axis=1) & (np.abs(nn[:, 1]) <= 1) & (np.maximum(np.abs(nn[:, 0]), np.abs(nn[:, 2])) > 0)
+    du = np.abs(uv4[valid, 2].astype(np.float64) - uv4[valid, 0])
+    du = np.minimum(du, 1.0 - du)  # (the seam: u = 0 and u = 1 are the same direction)
+    dv = np.abs(uv4[valid, 3].astype(np.float64) - uv4[valid, 1])
+    assert valid.sum() > 3_500_000 and du.max() <= 2.5e-7 and dv.max() <= 2.5e-7, (du.max(), dv.max())  # (measured: 1.2e-7 both)
     bad = np.nonzero((out != exact).any(axis=1))[0]
     assert len(bad) == 0, f"{len(bad)} texels differ, first normal {nn[bad[0]]!r}: took {out[bad[0]]} chain {exact[bad[0]]} fast={fast[bad[0]]}"
     # the chain, restated with the oracle's math (texture.hpp:140-157, sphere.hpp:13-24; binary32 left to right)
