@@ -257,7 +257,10 @@ void pt_scene_destroy(PtScene* scene);
  *   lanes_cap          sphere-grid kernels on frames that do not fill the chip: lanes of a wave that take pixels (PT_LANES_CAP=n; 0: 16 x
  *                      pixels per resident lane, whole tiles from 24 on; -1 or PT_LANES_CAP=0: whole tiles always)
  *   grid_walk          which sphere-grid walk: 1 wave-synchronous (each lane tests its candidate in place), 2 through the LDS pair queue
- *                      (64 pairs per batch); 0: the launcher's rule (PT_GRID_WALK)                                                          */
+ *                      (64 pairs per batch); 0: the launcher's rule (PT_GRID_WALK)
+ *   heavy_tiles        sphere-grid kernels on launches bound by their heaviest tiles' chains (1.5 ... 6 pixels per resident lane): the first
+ *                      n tiles of the cost-sorted order are handed out 16 pixels at a time, a quarter tile per wave (PT_HEAVY_TILES=n;
+ *                      0: one tile per SIMD of the chip in that range, none outside; -1: never)                                              */
 typedef struct PtTuning {
   int32_t struct_size; /* sizeof(PtTuning) of the caller's header */
   int32_t sphere_grid;
@@ -271,7 +274,8 @@ typedef struct PtTuning {
   float model_fixed, model_chain;
   int32_t scatter_log, scatter_mode;
   int32_t lanes_cap, grid_walk;
-  int32_t reserved[6];
+  int32_t heavy_tiles;
+  int32_t reserved[5];
 } PtTuning;
 void pt_tuning_init(PtTuning* t);     /* zero + struct_size: the library's defaults                                          */
 void pt_tuning_from_env(PtTuning* t); /* the defaults with the PT_* environment applied: what pt_scene_create(desc, out) uses */
@@ -384,6 +388,12 @@ int pt_debug_tri_pool(const PtSceneDesc* desc, int32_t out[8]);
  * through the wide phase, out[1] = lanes per pixel there (0 when the render had no cost-probe pass or used a kernel
  * without that phase).  For tuning the makespan model (csrc/pt_render.hip: lpt_order_kernel) and for tests.            */
 int pt_debug_schedule(const PtScene* scene, int32_t out[2]);
+
+/* What the launcher decided for the LAST frame launch of this scene (csrc/pt_render.hip: launch): out[0] = workgroups launched,
+ * out[1] = lanes of a wave that take pixels (PtTuning.lanes_cap's rule; 64 = whole tiles), out[2] = queue positions at the head of the
+ * cost-sorted order that are handed out 16 pixels at a time (PtTuning.heavy_tiles' rule; 0 = none), out[3] = 1 if the sphere-grid walk
+ * through the LDS pair queue was picked.  For tests of those rules.                                                                  */
+int pt_debug_last_launch(const PtScene* scene, int32_t out[4]);
 
 /* Device math used by the kernel, elementwise over host arrays.
  * op: 0 sin 1 cos 2 log 3 pow5 4 atan2(a,b) 5 asin 6 fmod(a,1) 7 sqrt 8 div(a,b)

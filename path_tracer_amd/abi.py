@@ -89,7 +89,7 @@ class PtTuning(C.Structure):
                 ("wide_log2_group", C.c_int32), ("split_tiles_mode", C.c_int32), ("split_tiles", C.c_int32),
                 ("lpt_by_max", C.c_int32), ("probe_spp_max", C.c_int32), ("grid_min_tiles", C.c_int32),
                 ("model_fixed", C.c_float), ("model_chain", C.c_float), ("scatter_log", C.c_int32), ("scatter_mode", C.c_int32),
-                ("lanes_cap", C.c_int32), ("grid_walk", C.c_int32), ("reserved", C.c_int32 * 6)]
+                ("lanes_cap", C.c_int32), ("grid_walk", C.c_int32), ("heavy_tiles", C.c_int32), ("reserved", C.c_int32 * 5)]
 
 
 def tuning(**fields) -> "PtTuning":
@@ -154,6 +154,7 @@ SIGNATURES = {
     "pt_debug_camera_rays": (C.c_int, [C.POINTER(PtCamera), C.c_int32, C.c_int32, C.POINTER(C.c_int32),
                                        C.POINTER(C.c_uint32), C.POINTER(PtCameraRay), C.c_int32]),
     "pt_debug_schedule": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
+    "pt_debug_last_launch": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "pt_debug_flatten": (C.c_int, [C.POINTER(PtSceneDesc), _FP, C.c_int64, C.POINTER(C.c_int32),
                                    C.POINTER(C.c_int32), _FP, C.c_int64, C.POINTER(C.c_int32)]),
     "pt_debug_math": (C.c_int, [C.c_int32, _FP, _FP, _FP, C.c_int64]),

@@ -100,6 +100,8 @@ struct KArgs {
   const int* order;    // non-NULL: queue position -> local tile, heaviest first
   const int* n_split;  // non-NULL (COOP kernels): [0] how many leading tiles of `order` go through the wide phase, [1] log2 G
   int tile_granular;   // PT_FLAG_TILE_GRANULAR
+  int heavy_pixels;    // > 0 (tile-granular grid kernels, chain-bound launches): the first heavy_pixels queue positions — the heaviest tiles of the
+  int heavy_lanes;     //   cost-sorted order — are taken heavy_lanes pixels at a time, by the first heavy_lanes lanes of a wave (lane_acquire)
   int scatter_p;       // > 0 (triangle-pool kernels): queue positions are dealt to tiles in runs of 2^scatter_log pixels with this stride (lane_acquire)
   int scatter_log;
   int lanes_cap;       // < 64 (triangle-pool kernels, fewer pixels than lanes): only the first lanes_cap lanes of a wave take pixels (lane_acquire)
@@ -247,10 +249,24 @@ __device__ __forceinline__ void lane_acquire(Lane& L, const KArgs& a) {
   if (!L.wide) {
     // tile-granular mode: a wave takes its next 64 pixels only when all of its lanes are idle
     if (k.tile_granular && __builtin_amdgcn_ballot_w64(L.live) != 0) return;
+    // The heaviest tiles in narrower waves.  A tile's time is its heaviest pixel's sequential chain times the wave's iteration, and an
+    // iteration of a wave that steps 16 pixels together is shorter than one that steps 64 (the longest grid walk, the largest candidate
+    // count, every material among them): the 4K frame's heaviest tiles alone take 55 / 48 / 43 ms at 64 / 32 / 16 lanes.  A launch that is
+    // bound by those chains (launch_render: heavy_pixels) hands the head of the cost-sorted queue out heavy_lanes pixels at a time — a
+    // quarter of a tile per wave, the other lanes idle until it is done — and everything behind it as whole tiles.  (The peek races with
+    // other waves' takes: a wave may take a narrow piece just behind the head, or a whole tile just inside it; both are merely other
+    // partitions of the same pixels.)
+    unsigned int take = (unsigned int)__builtin_popcountll(mask);
+    if (k.heavy_pixels > 0 && k.tile_granular) {
+      unsigned int cur = 0;
+      if (lane == leader) cur = __hip_atomic_load(k.queue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      cur = __builtin_amdgcn_readlane(cur, leader);
+      if (cur < (unsigned int)k.heavy_pixels) take = min(take, (unsigned int)k.heavy_lanes);
+    }
     unsigned int base = 0;
-    if (lane == leader) base = atomicAdd(k.queue, (unsigned int)__builtin_popcountll(mask));
+    if (lane == leader) base = atomicAdd(k.queue, take);
     base = __builtin_amdgcn_readlane(base, leader);
-    if (!want) return;
+    if (!want || rank >= take) return;
     i = split_pixels + base + rank;
   }
   if (i >= (unsigned int)k.n_local_pixels) { L.retired = true; return; }
@@ -900,6 +916,7 @@ static void tuning_env(PtTuning& t) {
   t.scatter_mode = has("PT_NO_SCATTER") ? -1 : has("PT_LPT_SCATTER") ? 1 : 0;
   if (const char* e = std::getenv("PT_GRID_WALK")) t.grid_walk = std::atoi(e);
   if (const char* e = std::getenv("PT_LANES_CAP")) t.lanes_cap = std::atoi(e) <= 0 ? -1 : std::min(64, std::atoi(e));
+  if (const char* e = std::getenv("PT_HEAVY_TILES")) t.heavy_tiles = std::atoi(e) <= 0 ? -1 : std::atoi(e);
 }
 // the caller's struct (possibly from an older header: struct_size bytes are valid) or, for NULL, defaults + environment
 static int resolve_tuning(const PtTuning* user, PtTuning& t, std::string& err) {
@@ -974,6 +991,7 @@ struct Knobs {
   bool generic_materials = false;
   int grid_walk = 0;       // PtTuning.grid_walk: 0 the launcher's rule, 1 the wave-synchronous walk, 2 the queued walk
   int lanes_cap = 0;       // PtTuning.lanes_cap: grid kernels on small frames (launch): 0 the rule, -1 whole tiles always, n forced
+  int heavy_tiles = 0;     // PtTuning.heavy_tiles: tiles at the head of the cost-sorted order that are handed out 16 pixels at a time: 0 the rule, -1 never, n forced
   Knobs() {}
   explicit Knobs(const PtTuning& t) {
     blocks_per_cu = std::max(0, t.blocks_per_cu);
@@ -990,6 +1008,7 @@ struct Knobs {
     generic_materials = t.generic_materials != 0;
     lanes_cap = t.lanes_cap < 0 ? -1 : std::min(64, t.lanes_cap);
     grid_walk = (t.grid_walk == 1 || t.grid_walk == 2) ? t.grid_walk : 0;
+    heavy_tiles = t.heavy_tiles < 0 ? -1 : t.heavy_tiles;
   }
 };
 
@@ -1020,6 +1039,7 @@ struct PtScene {
   int coop_prefix = 0;
   int n_hittables = 0;
   mutable bool last_had_wide_phase = false;
+  mutable int last_launch[4] = {0, 0, 0, 0}; // what the launcher decided for the last frame launch: workgroups, lanes_cap, heavy_pixels, queued walk (pt_debug_last_launch)
   mutable int nsplit_override = 0; // PT_SPLIT_TILES tuning knob (host copy must outlive the async upload)
   float traversal_cost = 0.0f; // estimated VALU instructions of one ray's scan of the list (sphere runs through their lists)
   int grid_spheres = 0;        // spheres that sit in a culling grid (the resident non-cooperative kernels walk it)
@@ -1326,6 +1346,7 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
   // default: whole tiles for the resident kernels (coherent primary rays), single pixels for the lock-step
   // streaming kernel (a workgroup waits for its slowest lane); either can be forced
   // (the triangle-pool kernels' iterations are long and per-lane: single pixels, like the streaming kernel)
+  a.heavy_pixels = 0; a.heavy_lanes = 64;
   a.tile_granular = (p->flags & PT_FLAG_TILE_GRANULAR) ? 1 : (p->flags & PT_FLAG_PIXEL_GRANULAR) ? 0 : ((resident && !tri_pool) ? 1 : 0);
   a.scatter_p = 0; a.scatter_log = 0;
   auto set_scatter = [&]() { // (after a.n_local_pixels is final: fast mode multiplies it by the chunks per pixel)
@@ -1433,6 +1454,19 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
         wanted = std::max<long long>(wanted, 1);
       }
     }
+    // Between the launches that the rule above serves (fewer than 1.5 pixels per resident lane) and the ones that are throughput (6 and
+    // more) lie the shards of a multi-GPU job on a big frame — one of 8 GPUs on the 4K frame: 4 pixels per lane — whose time is their
+    // heaviest tiles' chains: whole tiles everywhere, except that the head of the cost-sorted queue (one tile per SIMD of the chip) is handed
+    // out 16 pixels at a time (lane_acquire: heavy_pixels).  Kernel ms of shard 0 of N, whole tiles / with the narrow head — 4K x 512 spp
+    // N = 8 / 6 / 5 / 4: 196.8 / 203.9 / 220.4 / 209.1 -> 162.7 / 169.1 / 217.2 / 208.8; 1080p x 512 spp N = 2 / 3 / 4: 189.3 / 189.2 / 176.2 ->
+    // 165.4 / 159.2 / 155.3; whole frames lose (1080p: 382 -> 435 ms), hence the upper bound (profiles/r04_heavy_tiles.txt).
+    // Needs the cost-sorted order (the probe pass ran) — and changes nothing in the image: a pixel's seed is its id.
+    if (share_small && a.lanes_cap == 64 && a.tile_granular && a.order && a.scatter_p == 0 && !a.cost && s->knobs.heavy_tiles >= 0) {
+      const double lanes = (double)resident_blocks * waves_per_block * 64.0, rho = (double)a.n_local_pixels / lanes;
+      long long tiles = s->knobs.heavy_tiles > 0 ? s->knobs.heavy_tiles : (rho >= 1.5 && rho < 6.0 ? 4LL * std::max(1, s->num_cus) : 0);
+      tiles = std::min<long long>(tiles, a.n_local_pixels / 64 / 2);
+      if (tiles > 0) { a.heavy_pixels = (int)(tiles * 64); a.heavy_lanes = 16; }
+    }
     if (a.scatter_p > 0) { // triangle-pool kernels: fill the chip and share the pixels out evenly (lane_acquire)
       wanted = std::min<long long>(resident_blocks, ((long long)a.n_local_pixels + block_threads - 1) / block_threads * 64); // (at least one pixel per wave)
       wanted = std::max<long long>(wanted, 1);
@@ -1440,6 +1474,7 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
       a.lanes_cap = (int)std::min<long long>(64, std::max<long long>(1, ((long long)a.n_local_pixels + waves - 1) / waves));
     }
     n_waves_resident = (int)std::min<long long>(wanted, resident_blocks) * waves_per_block;
+    if (!a.cost) { s->last_launch[0] = (int)std::min<long long>(wanted, resident_blocks); s->last_launch[1] = a.lanes_cap; s->last_launch[2] = a.heavy_pixels; s->last_launch[3] = queued_walk ? 1 : 0; }
     dim3 grid((unsigned int)std::min<long long>(wanted, resident_blocks)), block((unsigned int)block_threads);
     hipLaunchKernelGGL(kernel, grid, block, shmem, st, a);
     PT_HIP(hipGetLastError());
@@ -1712,6 +1747,13 @@ int pt_debug_schedule(const PtScene* scene, int32_t out[2]) {
   int v[2] = {0, 0};
   PT_HIP(hipMemcpy(v, scene->ws_nsplit, sizeof v, hipMemcpyDeviceToHost));
   out[0] = v[0]; out[1] = v[0] > 0 ? (1 << v[1]) : 0;
+  return PT_OK;
+}
+
+int pt_debug_last_launch(const PtScene* scene, int32_t out[4]) {
+  if (!scene || !out) return fail(PT_ERR_INVALID_ARG, "pt_debug_last_launch: NULL argument");
+  std::lock_guard<std::mutex> lock(scene->sched);
+  for (int k = 0; k < 4; k++) out[k] = scene->last_launch[k];
   return PT_OK;
 }
 

@@ -1016,6 +1016,35 @@ def test_badouel_strategy_triangles(orc, lib):
     assert lib.pt_render_host(ds.handle, C.byref(c.c), C.byref(p), fb.ctypes.data_as(FP)) == abi.PT_ERR_INVALID_ARG
 
 
+def test_heaviest_tiles_in_narrow_pieces_change_nothing(orc, torch_gpu):
+    """PtTuning.heavy_tiles (pt_render.hip: launch / lane_acquire): the head of the cost-sorted tile queue handed out 16 pixels at a time
+    — a quarter tile per wave, for launches bound by their heaviest tiles' chains — is another partition of the same pixels: the frame
+    must equal the whole-tile frame bit for bit and the oracle's on sampled pixels, for head lengths below, at and beyond the tile count
+    (and for a shard, where the launcher's own rule applies the mode)."""
+    import torch
+    ps, cam = S.sphere_field_scene()
+    orc.set_math(True)
+    W, H, spp = 1280, 600, 16  # 12 000 tiles, 1.7 pixels per resident lane (this small scene runs seven workgroups per CU): grid kernels, whole tiles, cost probe — the rule's own range
+    c = scenes.make_camera(cam, W, H)
+    frames = {}
+    for t in (-1, 0, 7, 64, 100000):
+        ds = R.DeviceScene(ps, tuning=abi.tuning(heavy_tiles=t))
+        frames[t] = R.render(W, H, spp, ds, c).cpu().numpy()
+        torch.cuda.synchronize()
+        ll = (C.c_int32 * 4)()
+        abi.check(abi.load_library().pt_debug_last_launch(ds.handle, ll), "pt_debug_last_launch")
+        want = {-1: 0, 0: 1024 * 64, 7: 7 * 64, 64: 64 * 64, 100000: (W // 8) * (H // 8) // 2 * 64}[t]
+        assert ll[1] == 64 and ll[2] == want, (t, list(ll))  # whole tiles + the narrow head of the expected length
+    for t in (0, 7, 64, 100000):
+        assert_bit_identical(frames[t], frames[-1], f"heavy_tiles={t} against whole tiles")
+    xy = np.stack([np.random.default_rng(5).integers(0, W, 1500), np.random.default_rng(6).integers(0, H, 1500)], axis=1).astype(np.int32)
+    assert_bit_identical(frames[64][xy[:, 1], xy[:, 0]], orc.render_pixels(ps, c.c, W, H, spp, xy), "narrow head against the oracle")
+    # a shard in the rule's own range (pixels per resident lane between 1.5 and 6 needs a big frame: forced here, rule-checked in tools/heavy_probe.py)
+    a = R.render(W, H, spp, R.DeviceScene(ps, tuning=abi.tuning(heavy_tiles=32)), c, shard_index=1, shard_count=3)
+    b = R.render(W, H, spp, R.DeviceScene(ps, tuning=abi.tuning(heavy_tiles=-1)), c, shard_index=1, shard_count=3)
+    assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+
+
 @pytest.mark.parametrize("walk", [1, 2])
 def test_sphere_grid_is_exact(orc, monkeypatch, walk):
     """(walk: PtTuning.grid_walk — 1 the wave-synchronous walk, 2 the walk through the LDS pair queue; the launcher would pick by frame.)
