@@ -1045,6 +1045,37 @@ def test_heaviest_tiles_in_narrow_pieces_change_nothing(orc, torch_gpu):
     assert torch.equal(a.view(torch.int32), b.view(torch.int32))
 
 
+def test_launcher_rules_for_chain_bound_launches(torch_gpu):
+    """What launch_render decides, read back through pt_debug_last_launch: the headline family keeps four workgroups per CU when a launch
+    has fewer than 1.6 tiles per wave slot (a shard of 3 - 6 of the 1080p frame) and its full occupancy otherwise; the 496-hittable scene's
+    whole 1080p frame runs whole tiles through the queued walk, its shard 0/3 whole tiles with the narrow head, its shard 0/8 the
+    lanes_cap regime.  (The images under these rules are covered by the parity tests; this pins the decisions.)"""
+    import torch
+    lib = abi.load_library()
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+
+    def decided(ds, cam, n):
+        R.render(1920, 1080, 16, ds, cam, shard_index=0, shard_count=n)
+        torch.cuda.synchronize()
+        ll = (C.c_int32 * 4)()
+        abi.check(lib.pt_debug_last_launch(ds.handle, ll), "pt_debug_last_launch")
+        return list(ll)
+
+    packed, cam_args = scenes.build("cornell")
+    cam, ds = scenes.make_camera(cam_args, 1920, 1080), None
+    ds = R.DeviceScene(packed)
+    full = decided(ds, cam, 1)[0]
+    assert full >= 6 * cus and decided(ds, cam, 2)[0] == full          # whole frame and halves: every wave slot
+    assert decided(ds, cam, 4)[0] == 4 * cus and decided(ds, cam, 3)[0] == 4 * cus
+    assert decided(ds, cam, 8)[0] <= 4 * cus                             # half a tile per slot: one wave per tile
+    packed, cam_args = scenes.build("smoke")
+    cam, ds = scenes.make_camera(cam_args, 1920, 1080), R.DeviceScene(packed)
+    assert decided(ds, cam, 1)[1:] == [64, 0, 1]
+    assert decided(ds, cam, 3)[1:] == [64, 4 * cus * 64, 1]
+    one_of_8 = decided(ds, cam, 8)
+    assert one_of_8[1] == 16 and one_of_8[2] == 0
+
+
 @pytest.mark.parametrize("walk", [1, 2])
 def test_sphere_grid_is_exact(orc, monkeypatch, walk):
     """(walk: PtTuning.grid_walk — 1 the wave-synchronous walk, 2 the walk through the LDS pair queue; the launcher would pick by frame.)
