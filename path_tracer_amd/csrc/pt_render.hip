@@ -255,7 +255,8 @@ __device__ __forceinline__ void lane_acquire(Lane& L, const KArgs& a) {
     // bound by those chains (launch_render: heavy_pixels) hands the head of the cost-sorted queue out heavy_lanes pixels at a time — a
     // quarter of a tile per wave, the other lanes idle until it is done — and everything behind it as whole tiles.  (The peek races with
     // other waves' takes: a wave may take a narrow piece just behind the head, or a whole tile just inside it; both are merely other
-    // partitions of the same pixels.)
+    // partitions of the same pixels.  At launch every resident wave peeks an untouched queue, so the head is never shorter than one piece per
+    // wave — a quarter of the resident waves in tiles, which is the rule's own length; shorter forced heads measure the same.)
     unsigned int take = (unsigned int)__builtin_popcountll(mask);
     if (k.heavy_pixels > 0 && k.tile_granular) {
       unsigned int cur = 0;
