@@ -15,6 +15,7 @@ from path_tracer_amd import abi
 HERE = Path(__file__).resolve().parent
 LIB = HERE / "liboracle.so"
 REF_KAT = HERE / "_ref" / "xorshift_kat"
+REF_VISIT_KAT = REF_KAT.parent / "visit_kat"  # the reference's own visit.hpp (dev_visit), compiled as it lies (oracle/Makefile)
 
 
 class OrcCounters(C.Structure):

@@ -19,6 +19,8 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <new>
+#include <stdexcept>
 #include <vector>
 
 namespace pt::image_io {
@@ -74,7 +76,9 @@ struct Canon { // canonical Huffman code: symbols ordered by (length, symbol)
     return -1;
   }
 };
-inline const char* inflate(const uint8_t* src, std::size_t n, std::vector<uint8_t>& out) {
+// max_out: the largest output the caller can use (a PNG's (stride + 1) * height): a stream that expands past it is rejected as soon as it
+// does, so a small hostile file cannot make the decoder allocate without bound
+inline const char* inflate(const uint8_t* src, std::size_t n, std::vector<uint8_t>& out, std::size_t max_out = (std::size_t)1 << 32) {
   static const uint16_t lbase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
   static const uint8_t lext[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
   static const uint16_t dbase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
@@ -89,6 +93,7 @@ inline const char* inflate(const uint8_t* src, std::size_t n, std::vector<uint8_
       if (b.at + 4 > n) return "truncated stored block";
       const unsigned len = src[b.at] | (src[b.at + 1] << 8), nlen = src[b.at + 2] | (src[b.at + 3] << 8);
       if ((len ^ 0xffffu) != nlen || b.at + 4 + len > n) return "corrupt stored block";
+      if (len > max_out - out.size()) return "deflate stream larger than the image it belongs to";
       out.insert(out.end(), src + b.at + 4, src + b.at + 4 + len);
       b.at += 4 + len;
     } else if (type == 1 || type == 2) {
@@ -129,7 +134,7 @@ inline const char* inflate(const uint8_t* src, std::size_t n, std::vector<uint8_
       for (;;) {
         int sym = lit.decode(b);
         if (sym < 0) return "bad literal/length code";
-        if (sym < 256) out.push_back((uint8_t)sym);
+        if (sym < 256) { if (out.size() >= max_out) return "deflate stream larger than the image it belongs to"; out.push_back((uint8_t)sym); }
         else if (sym == 256) break;
         else {
           sym -= 257;
@@ -139,6 +144,7 @@ inline const char* inflate(const uint8_t* src, std::size_t n, std::vector<uint8_
           if (ds < 0 || ds >= 30) return "bad distance code";
           const std::size_t d = dbase[ds] + b.get(dext[ds]);
           if (b.bad || d > out.size()) return "distance too far back";
+          if ((std::size_t)l > max_out - out.size()) return "deflate stream larger than the image it belongs to";
           const std::size_t from = out.size() - d;
           for (int k = 0; k < l; k++) out.push_back(out[from + (std::size_t)k]);
         }
@@ -198,9 +204,9 @@ inline const char* decode_png(const std::vector<uint8_t>& f, Image& im) {
   if (!depth_ok) return "bad PNG bit depth";
   if (ctype == 3 && palette.size() < 3) return "palette PNG without a palette";
   if ((idat[0] & 15) != 8 || ((idat[0] << 8) | idat[1]) % 31 != 0 || (idat[1] & 32)) return "bad zlib header";
-  std::vector<uint8_t> raw;
-  if (const char* e = inflate(idat.data() + 2, idat.size() - 6, raw)) return e;
   const std::size_t stride = ((std::size_t)w * channels * depth + 7) / 8, bpp = (std::size_t)(channels * depth + 7) / 8;
+  std::vector<uint8_t> raw;
+  if (const char* e = inflate(idat.data() + 2, idat.size() - 6, raw, (stride + 1) * (std::size_t)h)) return e;
   if (raw.size() < (stride + 1) * h) return "PNG pixel data too short";
   if (adler32(raw.data(), raw.size()) != be32(&idat[idat.size() - 4])) return "bad zlib checksum";
   std::vector<uint8_t> prev(stride, 0);
@@ -277,6 +283,9 @@ inline int jdecode(JBits& b, const JHuff& t) {
   return -1;
 }
 inline int jextend(int v, int s) { return s && v < (1 << (s - 1)) ? v - (1 << s) + 1 : v; }
+// a dequantised coefficient, in 64 bits, limited to +-2^20 (a valid 8-bit stream stays below 2^16; 16-bit quantisation tables times 15-bit
+// values of a crafted one would overflow int — and the inverse DCT's 32-bit workspace — otherwise)
+inline int jclampc(long long v) { return (int)(v < -(1ll << 20) ? -(1ll << 20) : v > (1ll << 20) ? (1ll << 20) : v); }
 inline uint8_t jrange(int v) { // the post-IDCT range limit of the IJG code: a table indexed with the low 10 bits of (value), centred on 128
   const int i = v & 1023;
   return (uint8_t)(i < 128 ? i + 128 : i < 512 ? 255 : i < 896 ? 0 : i - 896);
@@ -360,6 +369,8 @@ inline const char* decode_jpeg(const std::vector<uint8_t>& f, Image& im) {
       H = (s[1] << 8) | s[2]; W = (s[3] << 8) | s[4];
       const int nc = s[5];
       if (W == 0 || H == 0 || (nc != 1 && nc != 3) || n < 6 + 3 * (std::size_t)nc) return nc == 4 ? "CMYK JPEG not supported" : "bad JPEG frame header";
+      if ((uint64_t)W * (uint64_t)H > (1ull << 28)) return "JPEG too large"; // (the PNG path's limit; checked BEFORE anything is sized by the header)
+      if (sof) return "JPEG with more than one frame header";
       comp.resize((std::size_t)nc);
       for (int i = 0; i < nc; i++) {
         comp[(std::size_t)i].id = s[6 + 3 * i]; comp[(std::size_t)i].h = s[7 + 3 * i] >> 4; comp[(std::size_t)i].v = s[7 + 3 * i] & 15; comp[(std::size_t)i].tq = s[8 + 3 * i] & 3;
@@ -446,8 +457,9 @@ inline const char* decode_jpeg(const std::vector<uint8_t>& f, Image& im) {
                 std::memset(coef, 0, sizeof coef);
                 const int t = jdecode(b, dc[c->td]);
                 if (t < 0 || t > 15) return "bad DC code";
-                c->pred += jextend(b.receive(t), t);
-                coef[0] = c->pred * qt[c->tq][0];
+                c->pred += jextend(b.receive(t), t); // |difference| < 2^15 and |pred| <= 2^15 before: no overflow
+                if (c->pred < -32768 || c->pred > 32767) return "DC coefficient out of range";
+                coef[0] = jclampc((long long)c->pred * qt[c->tq][0]);
                 for (int k = 1; k < 64;) {
                   const int rs = jdecode(b, ac[c->ta]);
                   if (rs < 0) return "bad AC code";
@@ -455,7 +467,7 @@ inline const char* decode_jpeg(const std::vector<uint8_t>& f, Image& im) {
                   if (sz == 0) { if (r == 15) { k += 16; continue; } break; }
                   k += r;
                   if (k > 63) return "AC run past the block";
-                  coef[zigzag[k]] = jextend(b.receive(sz), sz) * qt[c->tq][zigzag[k]];
+                  coef[zigzag[k]] = jclampc((long long)jextend(b.receive(sz), sz) * qt[c->tq][zigzag[k]]);
                   k++;
                 }
                 const int px = (inter ? xx * c->h + bx : xx) * 8, py = (inter ? yy * c->v + by : yy) * 8;
@@ -567,9 +579,12 @@ inline const char* load_rgb8(const char* path, Image& im) {
   std::vector<uint8_t> f;
   if (!detail::read_file(path, f)) return "can't fopen";
   static const uint8_t png_sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
-  if (f.size() >= 8 && !std::memcmp(f.data(), png_sig, 8)) return detail::decode_png(f, im);
-  if (f.size() >= 3 && f[0] == 0xff && f[1] == 0xd8 && f[2] == 0xff) return detail::decode_jpeg(f, im);
-  if (f.size() >= 2 && f[0] == 'P' && f[1] == '6') return detail::decode_ppm(f, im);
+  try { // the documented contract is "a failure reason, the caller falls back" (texture.hpp:106-111): an allocation failure is one
+    if (f.size() >= 8 && !std::memcmp(f.data(), png_sig, 8)) return detail::decode_png(f, im);
+    if (f.size() >= 3 && f[0] == 0xff && f[1] == 0xd8 && f[2] == 0xff) return detail::decode_jpeg(f, im);
+    if (f.size() >= 2 && f[0] == 'P' && f[1] == '6') return detail::decode_ppm(f, im);
+  } catch (const std::bad_alloc&) { return "out of memory"; }
+    catch (const std::length_error&) { return "out of memory"; }
   return "unknown image type (this host decodes PNG, baseline JPEG and binary PPM 'P6')";
 }
 

@@ -1,6 +1,7 @@
 // Test driver of pt/image_io.hpp (tests/test_image_io_cpu.py):
 //   image_io_main decode IN OUT.rgb      -> "W H\n" + raw RGB8, or exit code 3 and the failure reason on stderr
 //   image_io_main encode W H IN.rgb OUT.png
+//   image_io_main many FILE...           -> one line per file: "ok W H" or "err <reason>" (corrupt-file sweeps under ASan / UBSan)
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -25,6 +26,16 @@ int main(int argc, char** argv) {
     if (!f || std::fread(rgb.data(), 1, rgb.size(), f) != rgb.size()) return 2;
     std::fclose(f);
     return pt::image_io::write_png(argv[5], rgb.data(), w, h) ? 0 : 2;
+  }
+  if (argc >= 3 && !std::strcmp(argv[1], "many")) { // hostile-input sweep: decode every file named, one line each; a crash / sanitizer report is the failure
+    for (int i = 2; i < argc; i++) {
+      pt::image_io::Image im;
+      const char* e = pt::image_io::load_rgb8(argv[i], im);
+      if (e) std::printf("err %s\n", e);
+      else if (im.rgb.size() != im.width * im.height * 3) { std::printf("BAD size\n"); return 4; }
+      else std::printf("ok %zu %zu\n", im.width, im.height);
+    }
+    return 0;
   }
   return 1;
 }

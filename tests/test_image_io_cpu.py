@@ -191,3 +191,52 @@ def test_png_writer_round_trips(tool, tmp_path, size):
     from path_tracer_amd import png
     png.write_png(str(tmp_path / "py.png"), img)
     np.testing.assert_array_equal(decode(tool, tmp_path / "py.png", tmp_path), img)  # and the Python host's writer is read back
+
+
+def test_corrupt_and_hostile_files_fail_with_a_reason(tool, tmp_path):
+    """truncated, bit-flipped and size-lying files must come back as a failure reason — no crash, no sanitizer report
+    (the tool is built with -fsanitize=address,undefined), no allocation sized by a hostile header."""
+    rng = np.random.default_rng(11)
+    files = []
+    seeds = []
+    for k, (fmt, kw) in enumerate([("JPEG", dict(quality=80, subsampling=2)), ("JPEG", dict(quality=60, subsampling=0, restart_marker_blocks=2)),
+                                    ("PNG", {}), ("PNG", dict(compress_level=0))]):
+        p = tmp_path / f"seed{k}.{fmt.lower()}"
+        PIL.fromarray(picture(41, 29, k)).save(p, fmt, **kw)
+        seeds.append(p.read_bytes())
+    n = 0
+    for k, data in enumerate(seeds):
+        for cut in sorted(set(int(c) for c in np.linspace(1, len(data) - 1, 24))):   # truncations
+            q = tmp_path / f"t{k}_{cut}"; q.write_bytes(data[:cut]); files.append(q)
+        for _ in range(60):                                                            # bit flips (1 - 4 per file)
+            b = bytearray(data)
+            for _ in range(int(rng.integers(1, 5))):
+                b[int(rng.integers(2, len(b)))] ^= 1 << int(rng.integers(0, 8))
+            q = tmp_path / f"f{k}_{n}"; q.write_bytes(bytes(b)); files.append(q); n += 1
+    # a 65535 x 65535 JPEG frame header on a tiny file: rejected before anything is allocated
+    jpg = bytearray(seeds[0])
+    sof = jpg.index(b"\xff\xc0")
+    jpg[sof + 5:sof + 9] = b"\xff\xff\xff\xff"
+    q = tmp_path / "huge.jpg"; q.write_bytes(bytes(jpg)); files.append(q)
+    # 16-bit quantisation tables of 0xffff + the largest DC differences: the products stay in range (UBSan would report the overflow)
+    jpg = bytearray(seeds[1])
+    dqt = jpg.index(b"\xff\xdb")
+    ln = (jpg[dqt + 2] << 8) | jpg[dqt + 3]
+    table = bytes([0x10]) + b"\xff\xff" * 64                   # Pq = 1 (16 bit), Tq = 0
+    jpg[dqt:dqt + 2 + ln] = b"\xff\xdb" + struct.pack(">H", 2 + len(table)) + table
+    q = tmp_path / "q16.jpg"; q.write_bytes(bytes(jpg)); files.append(q)
+    # a PNG whose IDAT expands far beyond (stride + 1) * height: stopped at the image's own size
+    def chunk(tag, body):
+        return struct.pack(">I", len(body)) + tag + body + struct.pack(">I", zlib.crc32(tag + body) & 0xffffffff)
+    bomb = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 4, 4, 8, 2, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(b"\0" * (64 << 20), 9)) + chunk(b"IEND", b"")
+    q = tmp_path / "bomb.png"; q.write_bytes(bomb); files.append(q)
+    r = subprocess.run([str(tool), "many"] + [str(f) for f in files], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == len(files)
+    by = dict(zip([f.name for f in files], lines))
+    assert by["huge.jpg"] == "err JPEG too large", by["huge.jpg"]
+    assert by["bomb.png"].startswith("err deflate stream larger"), by["bomb.png"]
+    assert by["q16.jpg"].startswith(("ok", "err")), by["q16.jpg"]
+    assert all(l.startswith(("ok ", "err ")) for l in lines)
+    assert sum(l.startswith("err") for l in lines) > len(lines) // 4      # truncations and most flips in headers / CRCs are refused

@@ -34,6 +34,30 @@ def test_xorshift_matches_reference_binary_live(orc):
         assert orc.xorshift_stream(seed, 64) == [int(v) for v in vals.split()]
 
 
+def test_dev_visit_dispatches_by_variant_index_live(orc):
+    """oracle/_ref/visit_kat is the reference's own visit.hpp:51-67 compiled from /root/reference: dev_visit selects the alternative
+    whose position in the variant equals index(), and hands the callable THAT alternative — so the ABI's integer tags
+    (include/pt_render.h: PT_HIT_* / PT_MAT_* / PT_TEX_*, the rect axis, the medium's boundary kind), which are the reference's
+    variant positions, name the code path the reference would take."""
+    if not orc.REF_VISIT_KAT.exists():
+        pytest.skip("oracle/_ref not built (reference tree absent)")
+    from path_tracer_amd import abi
+    out = subprocess.run([str(orc.REF_VISIT_KAT)], capture_output=True, text=True, check=True).stdout.strip().splitlines()
+    rows = [l.split() for l in out]
+    fam = {}
+    for name, index, tag, payload in rows:
+        fam.setdefault(name, []).append((int(index), int(tag), int(payload)))
+    assert {k: len(v) for k, v in fam.items()} == {"hittable": 5, "material": 5, "texture": 3, "rectangle": 3, "volume": 2}
+    for name, items in fam.items():
+        for pos, (index, tag, payload) in enumerate(items):
+            assert index == pos and payload == 1000 + pos, (name, pos, index, payload)   # the alternative that was constructed is the one visited
+            if name != "volume":
+                assert tag == index, (name, index, tag)                                   # ABI tag == variant position
+    assert [t for _, t, _ in fam["hittable"]] == [abi.PT_HIT_SPHERE, abi.PT_HIT_XY_RECT, abi.PT_HIT_TRIANGLE, abi.PT_HIT_BOX, abi.PT_HIT_CONSTANT_MEDIUM]
+    assert [t for _, t, _ in fam["material"]] == [abi.PT_MAT_LAMBERTIAN, abi.PT_MAT_METAL, abi.PT_MAT_DIELECTRIC, abi.PT_MAT_LIGHTSOURCE, abi.PT_MAT_ISOTROPIC]
+    assert [t for _, t, _ in fam["texture"]] == [abi.PT_TEX_CHECKER, abi.PT_TEX_SOLID, abi.PT_TEX_IMAGE]
+
+
 def test_survey_known_answers(orc):
     """values recorded from the reference headers (glibc libm)."""
     import ctypes as C
