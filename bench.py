@@ -173,6 +173,20 @@ def ops_per_sample(ctr: dict) -> float:
     return total / n
 
 
+KERNEL_SOURCES = ("pt_render.hip", "pt_device.hpp", "pt_math.hpp", "pt_flatten.hpp", "pt_tripool.hpp")
+
+
+def kernels_sha16(root=None):
+    """sha256 over the sources the render kernels are compiled from: identifies the build a PMC recording belongs to (tools/pmc_summary.py
+    writes the same hash into every summary).  The PMC-derived fields of the bench line are RECORDINGS (profiles/*_pmc_summary.json), not
+    measurements of this run: when the recording's hash differs from the tree's they are nulled and the line says so."""
+    import hashlib
+    hsh = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        hsh.update(((Path(root) if root else ROOT) / "path_tracer_amd" / "csrc" / name).read_bytes())
+    return hsh.hexdigest()[:16]
+
+
 def pmc_traffic(scene: str, w: int, h: int, spp: int, profiles_dir=None):
     """HBM bytes per launch of the render kernel from the committed rocprofv3 PMC summary of the same workload
     (FETCH_SIZE and WRITE_SIZE are collected in their own --pmc passes: tools/pmc_summary.py).
@@ -193,7 +207,7 @@ def pmc_traffic(scene: str, w: int, h: int, spp: int, profiles_dir=None):
         if best is not None and rnd == best_round:
             raise RuntimeError(f"two final PMC summaries of round {rnd} for {scene} {w}x{h}x{spp}: {best[1]} and {f.name}")
         if best is None or rnd > best_round:
-            best, best_round = (d["derived"]["hbm_bytes_per_launch"], f.name, d["derived"]), rnd
+            best, best_round = (d["derived"]["hbm_bytes_per_launch"], f.name, d["derived"], d.get("kernels_sha16"), d.get("recorded_at_head")), rnd
     return best
 
 
@@ -425,8 +439,21 @@ def main() -> None:
             orc.render(packed, bcam.c, bw, bh, gs, DEPTH)
             dtg = time.perf_counter() - t1
             orc.set_math(True)
+            # one thread on its own, on a slice of the same sample (~3 s): what a "core" of this host is worth, and how the
+            # OpenMP run scales over the threads it used (row-dynamic schedule)
+            nthreads = orc.load().orc_max_threads()
+            orc.load().orc_set_threads(1)
+            s1 = max(1, int(round(bs * 3.0 / max(dt, 1e-3) / max(nthreads, 1))))
+            t1 = time.perf_counter()
+            orc.render(packed, bcam.c, bw, bh, s1, DEPTH)
+            dt1 = time.perf_counter() - t1
+            orc.load().orc_set_threads(nthreads)
+            one_thread = bw * bh * s1 / dt1 / 1e6
             cpu_line = {"value": round(bw * bh * bs / dt / 1e6, 3), "unit": "Msamples/s",
-                        "cores": orc.load().orc_max_threads(), "kind": "port",
+                        "cores": nthreads, "kind": "port",
+                        "affinity_cpus": len(os.sched_getaffinity(0)), "os_cpu_count": os.cpu_count(),
+                        "one_thread_value": round(one_thread, 4), "one_thread_sample": f"{bw}x{bh}, {s1} spp ({dt1:.1f} s), 1 OpenMP thread",
+                        "thread_scaling_efficiency": round(bw * bh * bs / dt / 1e6 / (one_thread * max(nthreads, 1)), 3),
                         "sample": f"same scene, {bw}x{bh}, {bs} spp, depth {DEPTH} ({bw * bh * bs / 1e6:.1f} Msamples, {dt:.1f} s), OpenMP CPU oracle, portable math",
                         "value_glibc_math": round(bw * bh * gs / dtg / 1e6, 3),
                         "sample_glibc_math": f"{bw}x{bh}, {gs} spp ({dtg:.1f} s), same oracle with glibc's float libm"}
@@ -447,6 +474,13 @@ def main() -> None:
                               + ("; fast mode is NOT expected to be bit-identical" if args.mode == "fast" else "")}
         # the committed counters are those of the parity kernels with default flags: any other mode / flag set gets nulls
         pmc = pmc_traffic(scene_name, W, H, SPP) if (world == 1 and args.flags == 0) else None
+        # ... and they are RECORDINGS: they describe the build they were recorded on.  A recording of another build (its kernel-source hash
+        # differs from this tree's) is not reported as if it were this run's: every PMC-derived field is nulled, the line says which
+        # recording was refused.  (tools/pmc_summary.py stamps kernels_sha16 / recorded_at_head; older summaries carry neither = stale.)
+        kernels_now = kernels_sha16()
+        pmc_record = {"file": pmc[1], "kernels_sha16": pmc[3], "recorded_at_head": pmc[4], "matches_this_build": pmc[3] == kernels_now} if pmc else None
+        if pmc and pmc[3] != kernels_now:
+            pmc = None
         kernel_samples_per_s = samples_per_step / (kern_ms * 1e-3)  # whole job; each rank renders 1/world of it
         ops_reference = ops
         if ops_culled:  # a kernel that provably skips tests is priced for the algorithm it runs; the reference's figure rides beside
@@ -496,6 +530,8 @@ def main() -> None:
                                               if ops_culled else "the reference's algorithm as written"),
                          "algorithmic_ops_per_sample_reference": round(ops_reference, 1),
                          "traffic": pmc[0] if pmc else None, "traffic_source": pmc[1] if pmc else None,
+                         # which recording the PMC-derived fields (traffic, hbm, *_pmc, executed_over_algorithmic) come from; nulled when stale
+                         "pmc_recording": pmc_record, "kernels_sha16": kernels_now, "recorded_at_head": pmc_record["recorded_at_head"] if pmc_record else None,
                          # north-star evidence: HBM is not the limiter, VALU issue is busy (PMC of the committed profile)
                          "hbm": {"achieved_gbs": round(pmc[0] / (kern_ms * 1e-3) / 1e9, 3), "peak_gbs": 8000.0,
                                  "frac": round(mem_frac, 6), "traffic_over_algorithmic": round(pmc[0] / algorithmic_bytes, 2)} if pmc else None,

@@ -74,6 +74,8 @@ def load() -> C.CDLL:
     lib.orc_tonemap_rgb8.argtypes = [_FP, C.c_int32, C.c_int32, C.POINTER(C.c_uint8)]
     lib.orc_tonemap_rgb8.restype = None
     lib.orc_max_threads.restype = C.c_int
+    lib.orc_set_threads.restype = None
+    lib.orc_set_threads.argtypes = [C.c_int]
     _lib = lib
     return lib
 

@@ -649,6 +649,9 @@ static void add_counters(OrcCounters* dst, const OrcCounters* src) {
   for (size_t i = 0; i < sizeof(OrcCounters) / sizeof(uint64_t); i++) d[i] += s[i];
 }
 
+void orc_set_threads(int n) { /* bench.py's cpu_baseline: the 1-thread rate beside the all-threads one */
+  if (n > 0) omp_set_num_threads(n);
+}
 int orc_max_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

@@ -92,6 +92,7 @@ int orc_math(int32_t op, const float* a, const float* b, float* out, int64_t n);
 void orc_tonemap_rgb8(const float* fb, int32_t width, int32_t height, uint8_t* rgb8);
 
 int orc_max_threads(void);
+void orc_set_threads(int n); /* omp_set_num_threads */
 
 #ifdef __cplusplus
 }

@@ -218,3 +218,21 @@ def test_culled_algorithm_pricing_for_the_triangle_pool(orc):
     live = bench.ops_per_sample_culled_tri(ctr.as_dict(), bench.TRI_POOL["triangles"])
     assert abs(live / bench.ALGORITHMIC_OPS_PER_SAMPLE_CULLED["triangles"] - 1) < 0.02
     assert live < 0.06 * bench.ops_per_sample(ctr.as_dict())
+
+
+def test_pmc_recordings_carry_the_build_they_belong_to(tmp_path):
+    """VERDICT r04 (weak 8 / item 6-iii): the PMC-derived fields of the bench line are recordings under profiles/.  Every summary
+    tools/pmc_summary.py writes is stamped with the hash of the kernel sources it was recorded on; bench.py computes the same hash
+    of the tree it runs from and refuses (nulls) a recording of another build."""
+    import importlib.util as iu
+    bench = load_bench()
+    spec = iu.spec_from_file_location("pmc_summary", ROOT / "tools" / "pmc_summary.py")
+    tool = iu.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    assert tool.kernels_sha16() == bench.kernels_sha16() and len(bench.kernels_sha16()) == 16
+    assert tool.KERNEL_SOURCES == bench.KERNEL_SOURCES
+    rec = {"final": True, "round": 9, "scene": "cornell", "workload": "8x8x1", "derived": {"hbm_bytes_per_launch": 1.0},
+           "kernels_sha16": "0" * 16, "recorded_at_head": "abc"}
+    (tmp_path / "x_pmc_summary.json").write_text(json.dumps(rec))
+    got = bench.pmc_traffic("cornell", 8, 8, 1, tmp_path)
+    assert got[3] == "0" * 16 and got[4] == "abc" and got[3] != bench.kernels_sha16()   # main() nulls the PMC fields for such a record

@@ -14,5 +14,6 @@ for p in a b fetch write icache mem1 mem2; do
   f=$(ls -t $(find $SRC/pmc_$p -name "*counter_collection.csv" 2>/dev/null) 2>/dev/null | head -1)
   [ -n "$f" ] && (head -1 $f; grep -E "render_kernel" $f) > $DST/${TAG}_pmc_$p.csv
 done
+[ -f $SRC/kernels_sha16.txt ] && export PT_KERNELS_SHA16=$(cat $SRC/kernels_sha16.txt)
 python tools/pmc_summary.py ${PT_FINAL_ROUND:+--final $PT_FINAL_ROUND} $TAG $SCENE $W $H $SPP $DST/${TAG}_pmc_a.csv $DST/${TAG}_pmc_b.csv $DST/${TAG}_pmc_fetch.csv $DST/${TAG}_pmc_write.csv $(ls $DST/${TAG}_pmc_mem1.csv $DST/${TAG}_pmc_mem2.csv 2>/dev/null) > $DST/${TAG}_pmc_summary.json
 cat $DST/${TAG}_pmc_summary.json | python -c "import json,sys; d=json.load(sys.stdin); print(json.dumps(d['derived'], indent=1)); print(d['kernel'])"

@@ -8,8 +8,30 @@ render kernel: per-launch counter sums plus the derived figures DESIGN.md quotes
 """
 import collections
 import csv
+import hashlib
 import json
+import subprocess
 import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+KERNEL_SOURCES = ("pt_render.hip", "pt_device.hpp", "pt_math.hpp", "pt_flatten.hpp", "pt_tripool.hpp")
+
+
+def kernels_sha16(root=ROOT):
+    """sha256 over the sources the render kernels are compiled from (path_tracer_amd/csrc): what a PMC recording belongs to.
+    bench.py carries the same function; a recording whose hash differs from the tree's is reported as stale (its fields nulled)."""
+    hsh = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        hsh.update((root / "path_tracer_amd" / "csrc" / name).read_bytes())
+    return hsh.hexdigest()[:16]
+
+
+def git_head(root=ROOT):
+    try:
+        return subprocess.run(["git", "-C", str(root), "rev-parse", "HEAD"], capture_output=True, text=True, check=True).stdout.strip()[:12]
+    except Exception:  # noqa: BLE001  (the GPU box's snapshot has no .git: the source hash below is what identifies the build)
+        return None
 
 
 def main():
@@ -43,6 +65,10 @@ def main():
     out = {"tag": tag, "scene": scene, "workload": f"{w}x{h}x{spp}", "kernel": meta, "per_launch": per, "derived": {}}
     if final_round is not None:
         out["final"], out["round"] = True, final_round
+    import os
+    # the build these counters were recorded on: the hash tools/profile_round.sh took on the GPU box (PT_KERNELS_SHA16), else this tree's
+    out["kernels_sha16"] = os.environ.get("PT_KERNELS_SHA16") or kernels_sha16()
+    out["recorded_at_head"] = git_head()     # (None on the GPU box; tools/collect_profiles.sh fills it in when it copies the summary)
     d = out["derived"]
     if "GRBM_GUI_ACTIVE" in per:
         cyc = per["GRBM_GUI_ACTIVE"] / 8  # summed over the 8 XCDs
