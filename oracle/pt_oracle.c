@@ -650,7 +650,11 @@ static void add_counters(OrcCounters* dst, const OrcCounters* src) {
 }
 
 void orc_set_threads(int n) { /* bench.py's cpu_baseline: the 1-thread rate beside the all-threads one */
+#ifdef _OPENMP
   if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
 }
 int orc_max_threads(void) {
 #ifdef _OPENMP

@@ -89,7 +89,8 @@ class PtTuning(C.Structure):
                 ("wide_log2_group", C.c_int32), ("split_tiles_mode", C.c_int32), ("split_tiles", C.c_int32),
                 ("lpt_by_max", C.c_int32), ("probe_spp_max", C.c_int32), ("grid_min_tiles", C.c_int32),
                 ("model_fixed", C.c_float), ("model_chain", C.c_float), ("scatter_log", C.c_int32), ("scatter_mode", C.c_int32),
-                ("lanes_cap", C.c_int32), ("grid_walk", C.c_int32), ("heavy_tiles", C.c_int32), ("reserved", C.c_int32 * 5)]
+                ("lanes_cap", C.c_int32), ("grid_walk", C.c_int32), ("heavy_tiles", C.c_int32),
+                ("tri_rho", C.c_float * 2), ("tri_budget_mb", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
 def tuning(**fields) -> "PtTuning":
@@ -99,6 +100,8 @@ def tuning(**fields) -> "PtTuning":
     for k, v in fields.items():
         if k == "tri_res":
             t.tri_res[:] = list(v)
+        elif k == "tri_rho":
+            t.tri_rho[:] = list(v)
         else:
             setattr(t, k, v)
     return t
@@ -161,6 +164,7 @@ SIGNATURES = {
     "pt_debug_sphere_texel": (C.c_int, [_FP, C.c_int64, C.c_float, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                         C.POINTER(C.c_uint8), _FP]),
     "pt_debug_tri_pool": (C.c_int, [C.POINTER(PtSceneDesc), C.POINTER(C.c_int32)]),
+    "pt_debug_flatten_pool": (C.c_int, [C.POINTER(PtSceneDesc), C.POINTER(PtTuning), C.POINTER(C.c_float), C.c_int64, C.POINTER(C.c_int64)]),
 }
 
 LIB_NAME = "libpt_render.so"

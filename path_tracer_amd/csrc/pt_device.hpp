@@ -28,7 +28,7 @@
 extern __device__ unsigned long long g_stamps[8]; // diagnostic build only (pt_render.hip)
 #endif
 #ifdef PT_STAMPS_TRI
-// diagnostic build (triangle pool): [0] scans (waves) [1] live rays [2] grid rounds (64 candidates each) [3] grid cells visited [4] lanes busy over the band's trips [5] [6] [7] band trips (four candidates per lane) of levels 0, 1, 2
+// diagnostic build (triangle pool): [0] scans (waves) [1] live rays [2] grid wave-steps [3] grid lane-steps (cells visited) [4] grid pairs (exact tests) [5] grid batches [6] direction-map entries enumerated [7] past the integer band test [8] past the noise radius (exact tests) [9] rays through the second map [10] rays that streamed every band record [11] band trips (128 entries)
 extern __device__ unsigned long long g_tri[12];
 #endif
 #ifdef PT_STAMPS_RUNS
@@ -59,11 +59,15 @@ enum { DK_SPHERE = 0, DK_RECT = 1, DK_TRI = 2, DK_BOX = 3, DK_MEDIUM = 4, DK_TRI
 // record sizes in f4 units
 enum { SZ_SPHERE = 3, SZ_RECT = 2, SZ_TRI = 3, SZ_BOX = 2, SZ_MEDIUM = 4, SZ_MATERIAL = 4 };
 
-// hit id: [23:0] record offset in the blob (f4 units), [26:24] box side, [29:27] device kind; -1 = none
-__device__ __forceinline__ int hit_pack(int kind, int side, int off) { return (kind << 27) | (side << 24) | off; }
-__device__ __forceinline__ int hit_kind(int h) { return (h >> 27) & 7; }
-__device__ __forceinline__ int hit_side(int h) { return (h >> 24) & 7; }
-__device__ __forceinline__ int hit_off(int h) { return h & 0xffffff; }
+// hit id: [24:0] record offset in the blob (f4 units: 33.5 M records, i.e. 11 M triangles), [27:25] box side, [30:28] device kind; -1 = none
+// (pt_flatten.hpp: kHitOffBits / kHitSideShift / kHitKindShift are the same numbers)
+#define PT_HIT_SIDE_SHIFT 25
+#define PT_HIT_KIND_SHIFT 28
+#define PT_HIT_OFF_MASK 0x1ffffff
+__device__ __forceinline__ int hit_pack(int kind, int side, int off) { return (kind << PT_HIT_KIND_SHIFT) | (side << PT_HIT_SIDE_SHIFT) | off; }
+__device__ __forceinline__ int hit_kind(int h) { return (h >> PT_HIT_KIND_SHIFT) & 7; }
+__device__ __forceinline__ int hit_side(int h) { return (h >> PT_HIT_SIDE_SHIFT) & 7; }
+__device__ __forceinline__ int hit_off(int h) { return h & PT_HIT_OFF_MASK; }
 
 __device__ __forceinline__ float as_f(int i) { return __int_as_float(i); }
 __device__ __forceinline__ int as_i(float f) { return __float_as_int(f); }
@@ -546,7 +550,7 @@ __device__ __forceinline__ bool box_fast(f4 R0, f4 R1, const RayCtx& c, float mx
 // run under the narrowed mask, and one s_mov restores it: 10 + 6 + 2 + 1 = 19 slots per side and no epilogue.  The block
 // is ONE asm statement, so nothing the compiler schedules can run under the narrowed mask; it declares what it touches
 // (closest, hit in/out; vcc clobbered: v_cmpx_e32 also writes it; EXEC is restored before the block ends).
-// `hit_base` = hit id of this box with side 0, in a VGPR; side S adds S << 24 (hit_pack).
+// `hit_base` = hit id of this box with side 0, in a VGPR; side S adds S << PT_HIT_SIDE_SHIFT (hit_pack).
 template <int AX, int S>
 __device__ __forceinline__ void rect_side_cmpx(float a0, float a1, float b0, float b1, float k, const RayCtx& c,
                                                unsigned long long exec_all, int hit_base, float& closest, int& hit) {
@@ -567,7 +571,7 @@ __device__ __forceinline__ void rect_side_cmpx(float a0, float a1, float b0, flo
       "s_mov_b64 exec, %[all]"
       : [cl] "+v"(closest), [hit] "+v"(hit)
       : [t] "v"(t), [a] "v"(a), [b] "v"(b), [a0] "v"(a0), [a1] "v"(a1), [b0] "v"(b0), [b1] "v"(b1), [tmin] "s"(PT_TMIN),
-        [sbits] "n"(S << 24), [base] "v"(hit_base), [all] "s"(exec_all)
+        [sbits] "n"(S << PT_HIT_SIDE_SHIFT), [base] "v"(hit_base), [all] "s"(exec_all)
       : "vcc");
 }
 
@@ -906,11 +910,11 @@ __device__ __forceinline__ void sphere_grid_walk(P recs, P cells, P cand, f4 g0,
 // 129, 436 -> 447 ms — with 7 listed spheres the per-lane gather + recomputation costs more than the ~4 shared root blocks it replaces).
 // (the triangle pool's per-wave LDS arrays — tri_pool_scan below — declared here because kernels that carry both lend them to this walk)
 __device__ __forceinline__ unsigned long long* tri_slots() { __shared__ unsigned long long s[256]; return s; }
-#ifndef PT_TRI_GRID_PER_LANE
-#define PT_TRI_GRID_PER_LANE 4 /* grid candidates per lane and trip; 8 (one trip per cell, 159 VGPRs = three waves per SIMD) measured 4 % slower */
+#ifndef PT_TRI_ABLATE
+#define PT_TRI_ABLATE 0 /* timing experiments only: 1 no grid, 2 no direction maps (every ray streams every band record), 4 no band stage at all (wrong images) */
 #endif
-#define PT_TRI_QUEUE (64 + 64 * (PT_TRI_GRID_PER_LANE > 4 ? PT_TRI_GRID_PER_LANE : 5))
-__device__ __forceinline__ int* tri_queue() { __shared__ int s[4 * PT_TRI_QUEUE]; return s; } // per wave: survivors of the filters waiting for the exact test
+#define PT_TRI_QUEUE 192 /* >= 63 left over + one trip's 64 pushes (the grid's pairs; the band stage's survivors), and >= PT_SQ_CAP */
+__device__ __forceinline__ int* tri_queue() { __shared__ int s[4 * PT_TRI_QUEUE]; return s; } // per wave: what waits for the exact test
 #ifndef PT_MAX_WAVES_PER_BLOCK
 #define PT_MAX_WAVES_PER_BLOCK 4
 #endif
@@ -1302,13 +1306,13 @@ __device__ __forceinline__ void slab_pool(P blob, cst_f4p cblob, int pool_off, i
 }
 
 // ---- a long run of Moller-Trumbore triangles, culled exactly ("triangle pool") ----------------------------------------------
-// pt_tripool.hpp states what the tables are and proves that the three candidate sources below — the grid walk for the
-// triangles a ray does not graze, the cube-map strips for the ones it does, the always list for slivers — contain every
-// triangle the reference's scan could accept.  Every candidate runs the reference's own instructions (tri_eval + the second
-// half below) with the scan's acceptance spelled out for any order: min <= t <= closest, and an equal t replaces the
-// holder unless the holder is a LATER record (triangle.hpp:91 accepts t == max: the last in list order wins; records keep
-// list order in the blob).  Re-testing a triangle is therefore a no-op, and a triangle found by two sources is harmless.
-// The tables live in global memory (tens of MB: this path belongs to scenes far beyond LDS).
+// pt_tripool.hpp states what the tables are and proves that the two candidate sources below — the fine grid for the triangles a
+// ray does not graze, the direction map for the ones it does (slivers included) — contain every triangle the reference's scan
+// could accept.  Every candidate runs the reference's own test (tri_param = tri_eval + the second half) with the scan's
+// acceptance spelled out for any order: min <= t <= closest, and an equal t replaces the holder unless the holder is a LATER
+// record (triangle.hpp:91 accepts t == max: the last in list order wins; records keep list order in the blob).  Re-testing a
+// triangle is therefore a no-op, and a triangle found by both sources is harmless.
+// The tables live in a buffer of their own in global memory (`pool`: up to gigabytes — this path belongs to scenes far beyond LDS).
 #ifdef PT_STAMPS_TRI
 #define PT_TRI_COUNT(i, v) do { const unsigned long long v_ = (unsigned long long)(v); if ((threadIdx.x & 63) == 0) atomicAdd(&g_tri[i], v_); } while (0)
 #else
@@ -1318,38 +1322,41 @@ __device__ __forceinline__ void slab_pool(P blob, cst_f4p cblob, int pool_off, i
 #define PT_TRI_WAVE_BITS(m) (__builtin_popcountll(__builtin_amdgcn_ballot_w64(((m) & 1u) != 0)) + __builtin_popcountll(__builtin_amdgcn_ballot_w64(((m) & 2u) != 0)) + \
                              __builtin_popcountll(__builtin_amdgcn_ballot_w64(((m) & 4u) != 0)) + __builtin_popcountll(__builtin_amdgcn_ballot_w64(((m) & 8u) != 0)))
 
-__device__ __forceinline__ unsigned int gdword(glb_f4p gblob, int base_f4, int i) { return ((const __attribute__((address_space(1))) unsigned int*)(gblob + base_f4))[i]; }
+__device__ __forceinline__ unsigned int gdword(glb_f4p pool, unsigned int base_f4, unsigned int i) { return ((const __attribute__((address_space(1))) unsigned int*)(pool + base_f4))[i]; }
+__device__ __forceinline__ unsigned int sdword(glb_f4p pool, unsigned int base_f4, unsigned int i) { // wave-uniform address: through the scalar cache
+  return ((const __attribute__((address_space(4))) unsigned int*)(unsigned long long)(pool + base_f4))[i];
+}
 
 // returns false when some live lane's ray is outside what the pool is exact for (irregular, or its origin beyond rlimit): the
 // caller then scans the whole run.
 //
-// SIMD shape: ONE RAY AT A TIME, ITS CANDIDATES ACROSS THE 64 LANES.  The first versions let every lane walk its own ray
-// (its own grid cells, its own strips): ~18 of 64 lanes busy per trip, every load a per-lane gather, 5 M lane-instructions
-// per sample — no better than the full scan's 6.7 M, and bound by the latency of its scattered loads.  The
-// full scan is fast because a triangle fetch is shared by 64 rays; the transposed scan shares a RAY among 64 triangles
-// instead: the wave takes its live rays one after the other (the ray's context read from its lane with v_readlane: scalar
-// operands from then on), and for that ray
-//   (1) walks the grid once (a uniform DDA), the candidates of each cell dealt to the lanes k0 + lane, k0 + 64 + lane, ...
-//       (coalesced loads of the inline COMPRESSED filter records: 8 + 8 bytes per candidate);
-//   (2) looks up the rows of every cube-map level that the ray's strip can reach, one or two per lane, concatenates their
-//       candidate ranges (a wave scan + an LDS row table) and splits that sequence evenly: 256 candidates per trip, groups of
-//       four lanes on consecutive 16-byte compressed records;
-//   the survivors of the filters are queued in LDS and run the reference's test 64 at a time with the uniform ray, on their
-//   triangle's records in a Morton-ordered copy of the run; a hit goes into the ray's slot of a
-//   per-wave LDS table with ONE 64-bit atomic minimum: key = (bits of t) << 32 | (0xffffff - record offset), so that the
-//   smallest t wins and, among equal t, the LAST record in list order — the scan's own acceptance (triangle.hpp:91 accepts
-//   t == max); the slot starts as the ray's hit so far (earlier runs have smaller offsets: an equal t loses to any triangle,
-//   as in the scan).  Every candidate's t is independent of the running maximum, so the order of the tests does not matter.
-//   (3) The always list runs the other way round: 64 entries in the lanes (one coalesced load), the live rays in the inner loop.
-#ifndef PT_TRI_ABLATE
-#define PT_TRI_ABLATE 0 /* timing experiments only: 1 no grid, 2 no band levels, 4 no always list (wrong images) */
-#endif
+// Round 5: TWO SIMD SHAPES, one per candidate source (rounds 3-4 took every ray through grid, band levels and always list one
+// at a time, 12 500 wave-instructions per ray; profiles/r04_tripool_counters.txt).
+//   (1) GRID, EVERY LANE ITS OWN RAY.  The cells are fine (a few tens of triangles; listed by box AND plane slab) and a ray ends
+//       at its first hit after a handful of them, so a per-lane 3-D DDA is cheap; what the lanes find in their cells is not tested
+//       lane by lane (a gather and ~100 instructions at a few lanes) but as PAIRS: per wave-step the lanes' candidate ranges are
+//       concatenated (a wave scan) and the wave runs the reference's test on 64 (ray, triangle) pairs per trip, each lane fetching
+//       its pair's ray from the owner lane (ds_bpermute) and the triangle's records from a Morton-ordered copy of the run (a cell's
+//       triangles are neighbours in it).  A hit lowers the owner's slot of a per-wave LDS table with ONE 64-bit atomic minimum:
+//       key = (bits of t) << 32 | (0xffffffff - record offset), so that the smallest t wins and, among equal t, the LAST record
+//       in list order — the scan's own acceptance; the slot starts as the ray's hit so far (earlier runs have smaller offsets: an
+//       equal t loses to any triangle, as in the scan).  Every candidate's t is independent of the running maximum, so the
+//       order and the batching of the tests do not matter; a lane reads its slot back before a step looks at the limit.
+//   (2) DIRECTION MAP, ONE RAY AT A TIME, ITS CANDIDATES ACROSS THE 64 LANES.  The grazing candidates of a ray are a long list
+//       (1 000 - 3 000 entries: the bin of its direction in the map of its rho class) of which a handful survive: the wave takes
+//       its live rays one after the other (the ray's context read from its lane with v_readlane: scalar operands from then on),
+//       streams the bin's entries 256 per trip (coalesced), gathers each entry's 16-byte compressed band record and runs
+//       stage 1 — the band test alone, in integers; survivors are queued and meet stage 2 — the noise-radius filter — 64 at a
+//       time, and what survives that is queued again and runs the reference's test 64 at a time, into the same slots.
+//       The grid goes first: the nearest hit it finds is nearly always the final one, and nothing here depends on that.
 typedef short short2_t __attribute__((ext_vector_type(2)));
-#define PT_TRI_BQUEUE 640
-__device__ __forceinline__ int* tri_bqueue() { __shared__ int s[4 * PT_TRI_BQUEUE]; return s; } // per wave (2 x (63 + 256) ints are needed): band candidates past the integer band test, (record, index) pairs
-__device__ __forceinline__ int* tri_rows() { __shared__ int s[4 * 264]; return s; } // per wave: the row table of the strip being scanned
+#define PT_TRI_BQUEUE 192
+// per wave (63 + 128 entries are needed): band candidates past the integer band test — the compressed record itself (stage 2 reads it from
+// here: a second gather of the record cost a TA cycle per lane, and this kernel is bound by those) and the candidate's position
+__device__ __forceinline__ f4* tri_bqueue() { __shared__ f4 s[4 * PT_TRI_BQUEUE]; return s; }
+__device__ __forceinline__ int* tri_bqueue_idx() { __shared__ int s[4 * PT_TRI_BQUEUE]; return s; }
 __device__ __forceinline__ unsigned long long tri_key(float t, int off) {
-  return ((unsigned long long)(unsigned int)as_i(t) << 32) | (unsigned long long)(unsigned int)(0xffffff - off);
+  return ((unsigned long long)(unsigned int)as_i(t) << 32) | (unsigned long long)(0xffffffffu - (unsigned int)off);
 }
 // triangle.hpp:58-89: everything but the range test on t; false = rejected by |a|, u, v or u + v
 __device__ __forceinline__ bool tri_param(f4 R0, f4 R1, f4 R2, const Ray& r, float& t) {
@@ -1368,43 +1375,148 @@ __device__ __forceinline__ bool tri_param(f4 R0, f4 R1, f4 R2, const Ray& r, flo
 }
 __device__ __forceinline__ float rl_f(float v, int src) { return as_f(__builtin_amdgcn_readlane(as_i(v), src)); }
 
-// centroid of a compressed filter record: lo + k step per axis, one multiplication and one addition each, NOT fused — the host measures
+// centroid of a compressed band record: lo + k step per axis, one multiplication and one addition each, NOT fused — the host measures
 // the deviation eps_c of exactly this decode (pt_tripool.hpp "compressed records")
 __device__ __forceinline__ V3 tri_centroid(unsigned int kx, unsigned int ky, unsigned int kz, f4 H7, f4 H8) {
   return mk(H7.x + (float)kx * H8.x, H7.y + (float)ky * H8.y, H7.z + (float)kz * H8.z);
 }
 
-__device__ __forceinline__ bool tri_pool_scan(glb_f4p gblob, cst_f4p cblob, int hdr, int goff, const RayCtx& c, HitState& h) {
+__device__ __forceinline__ bool tri_pool_scan(glb_f4p pool, cst_f4p cblob, int hdr, int goff, const RayCtx& c, HitState& h) {
 #ifndef PT_NO_FILTER_FMA
   // Everything written in this function is FILTER arithmetic — necessary conditions with explicit slack against exact mathematics
-  // (pt_tripool.hpp), and the uniform walk whose rounding the cells' absolute slack covers — so a product may fuse with the sum that
-  // takes it: one rounding instead of two, never a larger error, and a quarter fewer vector instructions in the filters.  The reference's
-  // own test (tri_param -> tri_eval, functions of their own) and the centroid decode above are compiled as written (-ffp-contract=off).
+  // (pt_tripool.hpp), and the walk whose rounding the cells' absolute slack covers — so a product may fuse with the sum that
+  // takes it: one rounding instead of two, never a larger error.  The reference's own test (tri_param -> tri_eval, functions of
+  // their own) and the centroid decode above are compiled as written (-ffp-contract=off).
 #pragma clang fp contract(fast)
 #endif
   const f4 H0 = cblob[hdr], H1 = cblob[hdr + 1], H2 = cblob[hdr + 2], H3 = cblob[hdr + 3], H4 = cblob[hdr + 4], H5 = cblob[hdr + 5], H6 = cblob[hdr + 6];
-  const f4 H7 = cblob[hdr + 7], H8 = cblob[hdr + 8], H9 = cblob[hdr + 9]; // the quantisation of the compressed filter records (pt_tripool.hpp)
-  const int cell_n = as_i(H9.z);
+  const f4 H7 = cblob[hdr + 7], H8 = cblob[hdr + 8]; // the quantisation of the compressed band records (pt_tripool.hpp)
   const V3 oc_own = c.r.o - xyz(H2);
   const float oc2_own = dot(oc_own, oc_own);
   if (__builtin_amdgcn_ballot_w64(c.live && !(c.reg && oc2_own <= H3.x)) != 0) return false;
-  const int cell_first = as_i(H4.x), cell_cand = as_i(H4.y), tri_sorted = as_i(H4.z), cell_q = as_i(H4.w), acheap = as_i(H5.x);
+  const unsigned int cell_first = (unsigned int)as_i(H4.x), cell_cand = (unsigned int)as_i(H4.y), tri_sorted = (unsigned int)as_i(H4.z), band_rec = (unsigned int)as_i(H4.w);
   const int lane = threadIdx.x & 63;
   unsigned long long* const slot = tri_slots() + (threadIdx.x & ~63); // this wave's 64 slots
   const unsigned long long key0 = h.hit >= 0 ? tri_key(h.closest, hit_off(h.hit)) : ((unsigned long long)0x7f800000u << 32);
   slot[lane] = key0;
-  // band test of triangle i for a ray: |d . g_i| <= |d| (rho + c_i); rho and |d| rounded up
-  const float rho_own = (__builtin_amdgcn_sqrtf(oc2_own) + H2.w) * 1.000002f;
-  const float dn_own = __builtin_amdgcn_sqrtf(c.a) * 1.000002f;
   const unsigned long long live = __builtin_amdgcn_ballot_w64(c.live);
   PT_TRI_COUNT(0, 1);
   PT_TRI_COUNT(1, __builtin_popcountll(live));
-  // Survivors of the filters do not run the exact test on the spot (a few lanes busy per trip, each with its own gather): they
-  // are QUEUED per wave in LDS — entry >= 0: the triangle's position in the Morton-ordered copy; entry < 0: ~(dword index in
-  // the blob of that position: a band candidate, whose index is not loaded before it is needed) — and tested 64 at a time.
-  int* const tq = tri_queue() + (threadIdx.x >> 6) * PT_TRI_QUEUE;
+  int* const tq = tri_queue() + (threadIdx.x >> 6) * PT_TRI_QUEUE; // per wave: what waits for the exact test
   const unsigned long long below = (1ull << lane) - 1ull;
-  int qn = 0; // entries queued (uniform)
+  const Ray& r = c.r;
+  // ---- (1) the grid: every lane walks its own ray; (lane, triangle) pairs through the queue, 64 per batch ------------------------
+#if !(PT_TRI_ABLATE & 1)
+  {
+    const float inv = H0.w, cell = H1.w, kappa = H3.y;
+    const int nx = as_i(H1.x), ny = as_i(H1.y), nz = as_i(H1.z);
+    const float gx = (r.o.x - H0.x) * inv, gy = (r.o.y - H0.y) * inv, gz = (r.o.z - H0.z) * inv; // origin in cell units
+    const float rx = c.yx * cell, ry = c.yy * cell, rz = c.yz * cell;                         // 1 / (direction in cell units)
+    const float ax = (0.0f - gx) * rx, bx = ((float)nx - gx) * rx;
+    const float ay = (0.0f - gy) * ry, by = ((float)ny - gy) * ry;
+    const float az = (0.0f - gz) * rz, bz = ((float)nz - gz) * rz;
+    const float t_in = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
+    const float t_out = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
+    const float t0 = __builtin_fmaxf(t_in, 0.0f);
+    float closest = h.closest; // the slot's t as last read back
+    // closest (1 + kappa) — closest lowered by every hit so far — then the walk's own slack (relative 1e-4)
+    auto limit = [&]() { const float m = __builtin_fminf(t_out, closest + closest * kappa); return m + (__builtin_fabsf(m) * 1e-4f + 1e-4f); };
+    bool active = c.live && t0 <= limit();
+    const float px = gx + t0 * (r.d.x * inv), py = gy + t0 * (r.d.y * inv), pz = gz + t0 * (r.d.z * inv);
+    int ix = min(max((int)__builtin_floorf(px), 0), nx - 1);
+    int iy = min(max((int)__builtin_floorf(py), 0), ny - 1);
+    int iz = min(max((int)__builtin_floorf(pz), 0), nz - 1);
+    const bool fx = r.d.x > 0.0f, fy = r.d.y > 0.0f, fz = r.d.z > 0.0f;
+    float tmx = ((float)(ix + (fx ? 1 : 0)) - gx) * rx, tmy = ((float)(iy + (fy ? 1 : 0)) - gy) * ry, tmz = ((float)(iz + (fz ? 1 : 0)) - gz) * rz;
+    const float dtx = __builtin_fabsf(rx), dty = __builtin_fabsf(ry), dtz = __builtin_fabsf(rz);
+    const int stx = fx ? 1 : -1, sty = fy ? 1 : -1, stz = fz ? 1 : -1;
+    // The cells' candidate ranges are EXPANDED over the wave: an inclusive scan of the lanes' counts gives every (lane, candidate) entry of
+    // this wave-step a position p in [0, T); trip by trip the 64 lanes take positions p = base + lane, find the entry's owner (the lane
+    // whose range contains p: a binary search over the scan, six ds_bpermute steps) and read it (neighbouring lanes, neighbouring
+    // addresses).  An entry whose triangle the owner's PREVIOUS cell lists as well is dropped — it was tested there, or where that
+    // cell's predecessor listed it: the entry carries one bit per face neighbour (pt_tripool.hpp), the owner says through which face it
+    // came — which removes the two out of three tests that repeated one made a cell earlier.  What is left is queued per wave in LDS as
+    // (owner << 26 | triangle) and, 64 pairs at a time, runs the reference's test for the owner's ray.
+    // (The first version let every lane loop over ITS cell's list: a wave-step took as many trips as its fullest cell has candidates,
+    // most of them at a handful of lanes — 1 844 ms at 1080p x 8 spp against 568 ms of round 4's kernel.)
+    int qn = 0; // pairs queued (wave-uniform)
+    auto test_batch = [&]() { // 64 pairs (the top of the queue) through the reference's test
+      __builtin_amdgcn_wave_barrier();
+      const int n = min(qn, 64);
+      const bool on = lane < n;
+      const unsigned int e = (unsigned int)tq[qn - n + (on ? lane : 0)];
+      const int src = (int)(e >> 26);
+      PT_TRI_COUNT(5, 1);
+      PT_TRI_COUNT(4, n);
+      Ray r2; // the pair's ray, from its owner's registers
+      r2.o = mk(__shfl(r.o.x, src, 64), __shfl(r.o.y, src, 64), __shfl(r.o.z, src, 64));
+      r2.d = mk(__shfl(r.d.x, src, 64), __shfl(r.d.y, src, 64), __shfl(r.d.z, src, 64));
+      r2.tm = 0.0f;
+      if (on) {
+        const unsigned int o = tri_sorted + 3u * (e & 0x3ffffffu);
+        const f4 R0 = pool[o], R1 = pool[o + 1], R2 = pool[o + 2];
+        float t;
+        if (tri_param(R0, R1, R2, r2, t) && !(t < PT_TMIN)) atomicMin(&slot[src], tri_key(t, goff + 3 * as_i(R2.w)));
+      }
+      qn -= n;
+      __builtin_amdgcn_wave_barrier();
+    };
+    unsigned int k0 = 0, k1 = 0; // this cell's candidate range
+    int came = 6;                // the face through which the walk entered this cell: 0 from -x, 1 from +x, 2 -y, 3 +y, 4 -z, 5 +z; 6: the walk's first cell
+    if (active) { const int ci = (iz * ny + iy) * nx + ix; k0 = gdword(pool, cell_first, (unsigned int)ci); k1 = gdword(pool, cell_first, (unsigned int)ci + 1u); }
+    while (__builtin_amdgcn_ballot_w64(active) != 0) {
+      PT_TRI_COUNT(2, 1);
+      PT_TRI_COUNT(3, __builtin_popcountll(__builtin_amdgcn_ballot_w64(active)));
+      // the next cell (the axis whose boundary comes first; branch-free) and its range, requested BEFORE this cell's candidates are tested
+      const float tn = __builtin_fminf(tmx, __builtin_fminf(tmy, tmz));
+      const bool sx = tmx == tn, sy = !sx & (tmy == tn), sz = !sx & !sy;
+      const int jx = ix + (sx ? stx : 0), jy = iy + (sy ? sty : 0), jz = iz + (sz ? stz : 0);
+      const bool inside = ((unsigned)jx < (unsigned)nx) & ((unsigned)jy < (unsigned)ny) & ((unsigned)jz < (unsigned)nz);
+      unsigned int n0 = 0, n1 = 0;
+      if (active & inside) { const int cj = (jz * ny + jy) * nx + jx; n0 = gdword(pool, cell_first, (unsigned int)cj); n1 = gdword(pool, cell_first, (unsigned int)cj + 1u); }
+      int incl = (int)(k1 - k0); // (0 for a lane that does not walk)
+#pragma unroll
+      for (int dd = 1; dd < 64; dd <<= 1) { const int o2 = __shfl_up(incl, dd, 64); incl += lane >= dd ? o2 : 0; }
+      const int T = __builtin_amdgcn_readlane(incl, 63);
+      const int kbase = (int)k1 - incl; // candidate index of position p for this lane's range: kbase + p
+      const unsigned int skip_bit = came < 6 ? (1u << (26 + came)) : 0u;
+      for (int base = 0; base < T; base += 64) {
+        const int p = base + lane;
+        const bool on = p < T;
+        // owner: the first lane whose inclusive count exceeds p (lanes without candidates repeat their predecessor's count and are never first)
+        int lo = 0;
+#pragma unroll
+        for (int st = 32; st >= 1; st >>= 1) { const int v = __shfl(incl, lo + st - 1, 64); lo += v <= p ? st : 0; }
+        const int src = on ? lo : lane;
+        const int kb = __shfl(kbase, src, 64);
+        const unsigned int sb = (unsigned int)__shfl((int)skip_bit, src, 64);
+        bool keep = false;
+        unsigned int e = 0;
+        if (on) { e = gdword(pool, cell_cand, (unsigned int)(kb + p)); keep = (e & sb) == 0u; }
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+        if (keep) tq[qn + __builtin_popcountll(m & below)] = (int)(((unsigned int)src << 26) | (e & 0x3ffffffu));
+        qn += __builtin_popcountll(m);
+        if (qn >= 64) test_batch();
+      }
+      if (T > 0) { // (the limit below looks at the nearest hit so far: everything queued is tested first)
+        if (qn > 0) test_batch();
+        closest = as_f((int)(unsigned int)(slot[lane] >> 32));
+      }
+      // step: the walk ends where the next cell lies outside the grid or begins beyond the nearest hit so far
+      active = active & inside & !(tn > limit());
+      came = sx ? (fx ? 0 : 1) : sy ? (fy ? 2 : 3) : (fz ? 4 : 5); // stepped +x: entered through the new cell's -x face, ...
+      ix = jx; iy = jy; iz = jz;
+      tmx += sx ? dtx : 0.0f; tmy += sy ? dty : 0.0f; tmz += sz ? dtz : 0.0f;
+      k0 = active ? n0 : 0u; k1 = active ? n1 : 0u;
+    }
+  }
+#endif
+  // ---- (2) the direction map: the triangles a ray grazes, one ray at a time ------------------------------------------------------
+  // band test of triangle i for a ray: |d . n~_i| <= |d| (pn (rho + KQ L + KT / L) + eps_n); rho and |d| rounded up
+  const float rho_own = (__builtin_amdgcn_sqrtf(oc2_own) + H2.w) * 1.000002f;
+  const float dn_own = __builtin_amdgcn_sqrtf(c.a) * 1.000002f;
+  const int n_tri = as_i(H3.z), n_maps = (PT_TRI_ABLATE & 2) ? 0 : as_i(H3.w);
+  int qn = 0; // entries queued for the exact test (uniform)
   auto push = [&](bool p, int e) {
     const unsigned long long m = __builtin_amdgcn_ballot_w64(p);
     if (p) tq[qn + __builtin_popcountll(m & below)] = e;
@@ -1416,10 +1528,8 @@ __device__ __forceinline__ bool tri_pool_scan(glb_f4p gblob, cst_f4p cblob, int 
     while (qn > keep) {
       const int n = min(qn, 64);
       if (lane < n) {
-        const int e = tq[qn - n + lane];
-        const int pos = e >= 0 ? e : (int)gdword(gblob, 0, ~e);
-        const int o = tri_sorted + 3 * pos;
-        const f4 R0 = gblob[o], R1 = gblob[o + 1], R2 = gblob[o + 2];
+        const unsigned int o = tri_sorted + 3u * (unsigned int)tq[qn - n + lane];
+        const f4 R0 = pool[o], R1 = pool[o + 1], R2 = pool[o + 2];
         float t;
         if (tri_param(R0, R1, R2, ur, t) && !(t < PT_TMIN)) atomicMin(&slot[src], tri_key(t, goff + 3 * as_i(R2.w)));
       }
@@ -1427,106 +1537,48 @@ __device__ __forceinline__ bool tri_pool_scan(glb_f4p gblob, cst_f4p cblob, int 
     }
     __builtin_amdgcn_wave_barrier();
   };
-  for (unsigned long long todo = live; todo != 0; todo &= todo - 1) {
+  // Every lane looks up ITS ray's list first (the bin of its direction in the map of its rho class — or, beyond the last class, every
+  // triangle): two gathers for the whole wave instead of two dependent scalar loads at the head of every ray's turn.
+  unsigned int first_own = 0, last_own = (unsigned int)n_tri, cand_own = 0;
+  int listed_own = 0;
+  {
+    const f4 D0 = cblob[hdr + 9], D1 = cblob[hdr + 10];
+    const bool c0 = n_maps > 0 && rho_own <= D0.y, c1 = n_maps > 1 && rho_own <= D1.y;
+    if (c.live && (c0 || c1)) {
+      const f4 D = c0 ? D0 : D1;
+      const int R = as_i(D.x);
+      const float adx = __builtin_fabsf(r.d.x), ady = __builtin_fabsf(r.d.y), adz = __builtin_fabsf(r.d.z);
+      // face k = the largest |component| (exact comparisons); (p, q) = (d_a, d_b) / d_k with a = k + 1, b = k + 2 (mod 3)
+      const int k = (adx >= ady && adx >= adz) ? 0 : (ady >= adz ? 1 : 2);
+      const float dk = k == 0 ? r.d.x : k == 1 ? r.d.y : r.d.z, da = k == 0 ? r.d.y : k == 1 ? r.d.z : r.d.x, db = k == 0 ? r.d.z : k == 1 ? r.d.x : r.d.y;
+      const float rk = __builtin_amdgcn_rcpf(dk), halfR = 0.5f * (float)R;
+      const int ci = min(max((int)__builtin_floorf((da * rk + 1.0f) * halfR), 0), R - 1), cj = min(max((int)__builtin_floorf((db * rk + 1.0f) * halfR), 0), R - 1);
+      const unsigned int bin = (unsigned int)((k * R + cj) * R + ci);
+      const unsigned int foff = (unsigned int)as_i(D.z);
+      first_own = gdword(pool, foff, bin); last_own = gdword(pool, foff, bin + 1u);
+      cand_own = (unsigned int)as_i(D.w);
+      listed_own = c0 ? 1 : 2;
+    }
+  }
+  for (unsigned long long todo = (PT_TRI_ABLATE & 4) ? 0ull : live; todo != 0; todo &= todo - 1) {
     const int src = __builtin_ctzll(todo);
     Ray ur;
-    ur.o = mk(rl_f(c.r.o.x, src), rl_f(c.r.o.y, src), rl_f(c.r.o.z, src));
-    ur.d = mk(rl_f(c.r.d.x, src), rl_f(c.r.d.y, src), rl_f(c.r.d.z, src));
+    ur.o = mk(rl_f(r.o.x, src), rl_f(r.o.y, src), rl_f(r.o.z, src));
+    ur.d = mk(rl_f(r.d.x, src), rl_f(r.d.y, src), rl_f(r.d.z, src));
     ur.tm = 0.0f;
-    const float ua = rl_f(c.a, src), uyx = rl_f(c.yx, src), uyy = rl_f(c.yy, src), uyz = rl_f(c.yz, src);
-    const float rho = rl_f(rho_own, src), dn = rl_f(dn_own, src);
-    // does the ray's LINE pass within `rad` of the point C?  (both filters of pt_tripool.hpp; necessary conditions)
-    auto near_line = [&](V3 C, float rad) {
+    const float ua = rl_f(c.a, src), rho = rl_f(rho_own, src), dn = rl_f(dn_own, src);
+    const unsigned int first = (unsigned int)__builtin_amdgcn_readlane((int)first_own, src), last = (unsigned int)__builtin_amdgcn_readlane((int)last_own, src);
+    const unsigned int cand_off = (unsigned int)__builtin_amdgcn_readlane((int)cand_own, src);
+    const int listed_k = __builtin_amdgcn_readlane(listed_own, src);
+    const bool listed = listed_k != 0;
+    PT_TRI_COUNT(9, listed_k == 2 ? 1 : 0);
+    PT_TRI_COUNT(10, listed ? 0 : 1);
+    // band test, then the noise-radius filter: the line within L + kr rho |d| / (|a'| - ea |d|) of the centroid
+    // on the 16-byte compressed record (pt_tripool.hpp "compressed records"; every quantity rounded to the safe side)
+    auto near_line = [&](V3 C, float rad) { // does the ray's LINE pass within `rad` of the point C?
       const V3 x = cross(C - ur.o, ur.d);
       return dot(x, x) <= rad * rad * ua * 1.00001f;
     };
-    // ---- (1) the grid: cells of the segment [0, closest (1 + kappa)], one uniform walk -----------------------------------------
-#if !(PT_TRI_ABLATE & 1)
-    {
-      const float inv = H0.w, cell = H1.w, kappa = H3.y;
-      const int nx = as_i(H1.x), ny = as_i(H1.y), nz = as_i(H1.z);
-      const float gx = (ur.o.x - H0.x) * inv, gy = (ur.o.y - H0.y) * inv, gz = (ur.o.z - H0.z) * inv;
-      const float rx = uyx * cell, ry = uyy * cell, rz = uyz * cell;
-      const float ax = (0.0f - gx) * rx, bx = ((float)nx - gx) * rx;
-      const float ay = (0.0f - gy) * ry, by = ((float)ny - gy) * ry;
-      const float az = (0.0f - gz) * rz, bz = ((float)nz - gz) * rz;
-      const float t_in = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
-      const float t_out = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
-      const float t0 = __builtin_fmaxf(t_in, 0.0f);
-      // closest (1 + kappa) — closest = the slot's t, lowered by every hit so far — then the walk's own slack (relative 1e-4)
-      auto limit = [&]() {
-        const float cl = as_f((int)(unsigned int)(slot[src] >> 32));
-        const float m = __builtin_fminf(t_out, cl + cl * kappa);
-        return m + (__builtin_fabsf(m) * 1e-4f + 1e-4f);
-      };
-      bool active = t0 <= limit();
-      const float px = gx + t0 * (ur.d.x * inv), py = gy + t0 * (ur.d.y * inv), pz = gz + t0 * (ur.d.z * inv);
-      int ix = min(max((int)__builtin_floorf(px), 0), nx - 1);
-      int iy = min(max((int)__builtin_floorf(py), 0), ny - 1);
-      int iz = min(max((int)__builtin_floorf(pz), 0), nz - 1);
-      const bool fx = ur.d.x > 0.0f, fy = ur.d.y > 0.0f, fz = ur.d.z > 0.0f;
-      float tmx = ((float)(ix + (fx ? 1 : 0)) - gx) * rx, tmy = ((float)(iy + (fy ? 1 : 0)) - gy) * ry, tmz = ((float)(iz + (fz ? 1 : 0)) - gz) * rz;
-      const float dtx = __builtin_fabsf(rx), dty = __builtin_fabsf(ry), dtz = __builtin_fabsf(rz);
-      const int stx = fx ? 1 : -1, sty = fy ? 1 : -1, stz = fz ? 1 : -1;
-      while (__builtin_amdgcn_readfirstlane((int)active) != 0) { // (every lane computes the same walk)
-        const int ci = __builtin_amdgcn_readfirstlane((iz * ny + iy) * nx + ix);
-        PT_TRI_COUNT(3, 1);
-        // (requesting the NEXT cell's range here, before this cell's candidates are processed, measured 12 % slower: scalar loads and
-        // LDS share a counter, so the first LDS wait of the processing waits for the prefetch as well)
-        const int k0 = (int)dword_at(cblob + cell_first, ci), k1 = (int)dword_at(cblob + cell_first, ci + 1);
-        for (int base = k0; base < k1; base += 64 * PT_TRI_GRID_PER_LANE) { // PT_TRI_GRID_PER_LANE candidates per lane and trip: k = base + 64 j + lane
-          PT_TRI_COUNT(2, 1);
-          unsigned int q0[PT_TRI_GRID_PER_LANE], q1[PT_TRI_GRID_PER_LANE], n0[PT_TRI_GRID_PER_LANE], n1[PT_TRI_GRID_PER_LANE];
-          int gi[PT_TRI_GRID_PER_LANE];
-#pragma unroll
-          for (int j = 0; j < PT_TRI_GRID_PER_LANE; j++) { // (the arrays carry 256 spare entries: no clamping)
-            const int k = base + 64 * j + lane;
-            q0[j] = gdword(gblob, cell_q, 2 * k); q1[j] = gdword(gblob, cell_q, 2 * k + 1); gi[j] = (int)gdword(gblob, cell_cand, k);
-            n0[j] = gdword(gblob, cell_n, 2 * k); n1[j] = gdword(gblob, cell_n, 2 * k + 1);
-          }
-          // filter (i) of pt_tripool.hpp on the compressed records: the walked SEGMENT [0, lim] passes within the radius of the
-          // centroid — the line within it, and the centroid's projection neither more than it behind the origin nor beyond lim —
-          // for the TIGHT radius, or for the LOOSE one if the pair also passes the band test at Mg ("compressed records").
-          // (A second stage for the loose-only candidates — queue them, band test 64 at a time — removes 3 % of the instructions; it
-          // cost 10 % while the frame time was the heaviest wave's chain and is neutral, 2.314 against 2.315 s, now.  Not kept.)
-          const float cl = as_f((int)(unsigned int)(slot[src] >> 32));
-          const float lim_ua = (cl + cl * kappa) * ua * 1.00001f;
-          unsigned int passmask = 0;
-#pragma unroll
-          for (int j = 0; j < PT_TRI_GRID_PER_LANE; j++) {
-            const V3 C = tri_centroid(q0[j] & 0xffffu, q0[j] >> 16, q1[j] & 0xffffu, H7, H8);
-            const float rad = as_f((int)(q1[j] & 0xffff0000u)), radl = rad * H9.x;
-            const V3 oc = C - ur.o;
-            const float m = dot(oc, ur.d);
-            const V3 x = cross(oc, ur.d);
-            const float xx = dot(x, x), sm = 1.001f * rad * dn, sml = 1.001f * radl * dn;
-            const bool in_t = (xx <= rad * rad * ua * 1.00001f) & (m >= -sm) & (m <= lim_ua + sm);
-            const bool in_l = (xx <= radl * radl * ua * 1.00001f) & (m >= -sml) & (m <= lim_ua + sml);
-            const float nx = (float)((int)(n0[j] << 16) >> 16), ny = (float)((int)n0[j] >> 16), nz = (float)((int)(n1[j] << 16) >> 16);
-            const float pne = as_f((int)(n1[j] & 0xffff0000u));
-            const float dq = __builtin_fabsf(ur.d.x * nx + ur.d.y * ny + ur.d.z * nz) * 3.0518509e-5f;
-            const bool mid = dq <= dn * (H9.y * pne * (rho + H5.y * (2.0f * rad)) + H8.w) * 1.00001f;
-            const bool pass = (base + 64 * j + lane < k1) & (in_t | (in_l & mid));
-            passmask |= pass ? (1u << j) : 0u;
-          }
-          PT_TRI_COUNT(8, PT_TRI_WAVE_BITS(passmask));
-#pragma unroll
-          for (int j = 0; j < PT_TRI_GRID_PER_LANE; j++) push((passmask >> j) & 1u, gi[j]);
-          drain(63, ur, src); // whole batches of 64
-        }
-        drain(0, ur, src); // the rest before the walk looks at the limit again
-        const float tn = __builtin_fminf(tmx, __builtin_fminf(tmy, tmz));
-        const bool sx = tmx == tn, sy = !sx & (tmy == tn), sz = !sx & !sy;
-        ix += sx ? stx : 0; iy += sy ? sty : 0; iz += sz ? stz : 0;
-        const bool inside = ((unsigned)ix < (unsigned)nx) & ((unsigned)iy < (unsigned)ny) & ((unsigned)iz < (unsigned)nz);
-        active = inside & !(tn > limit());
-        tmx += sx ? dtx : 0.0f; tmy += sy ? dty : 0.0f; tmz += sz ? dtz : 0.0f;
-      }
-    }
-#endif
-    // ---- (2) the cube-map levels: the triangles this ray grazes (narrow bands) ------------------------------------------------------
-    // band test, then the noise-radius filter: the line within L + kr rho |d| / (|a'| - ea |d|) of the centroid
-    // on the 16-byte compressed record (pt_tripool.hpp "compressed records"; every quantity rounded to the safe side)
     auto band_pass = [&](f4 Q) {
       const unsigned int w0 = (unsigned int)as_i(Q.x), w1 = (unsigned int)as_i(Q.y), w2 = (unsigned int)as_i(Q.z), w3 = (unsigned int)as_i(Q.w);
       const float nx = (float)((int)(w0 << 16) >> 16), ny = (float)((int)w0 >> 16), nz = (float)((int)(w1 << 16) >> 16);
@@ -1541,12 +1593,12 @@ __device__ __forceinline__ bool tri_pool_scan(glb_f4p gblob, cst_f4p cblob, int 
       const V3 C = tri_centroid(w2 & 0xffffu, w2 >> 16, w3 & 0xffffu, H7, H8);
       return !(a1 > 0.0f) || near_line(C, L + rr + H6.x + H7.w);
     };
-    const V3 dh = __builtin_amdgcn_rsqf(ua) * ur.d; // unit direction (a few ulp: covered by the strips' absolute slack)
+    const V3 dh = __builtin_amdgcn_rsqf(ua) * ur.d; // unit direction (a few ulp: covered by the integer test's absolute slack)
     // Two stages.  Stage 1, on every enumerated candidate: the band test alone, in INTEGERS — the record's normal is three 16-bit
     // integers k / 32767, the ray's unit direction is rounded to the same grid once per ray, and two v_dot2_i32_i16 give
     // S = kn . kd exactly (|S| <= 32767^2 (1 + 1e-4): no overflow); |d^ . n^| <= |S| / 32767^2 + eps_n + eps_d with
     // eps_d = sqrt(3) / (2 * 32767) + 1e-6 (the rounding of the direction and of rsq), so the test below passes whenever the band
-    // test of pt_tripool.hpp does.  Its survivors (about a quarter) are queued and run the full filter 64 at a time (stage 2).
+    // test of pt_tripool.hpp does.  Its survivors are queued and run the full filter 64 at a time (stage 2).
     const int kdx = (int)__builtin_rintf(dh.x * 32767.0f), kdy = (int)__builtin_rintf(dh.y * 32767.0f), kdz = (int)__builtin_rintf(dh.z * 32767.0f);
     short2_t dxy, dz0;
     { const unsigned int a = ((unsigned int)kdx & 0xffffu) | ((unsigned int)kdy << 16), b = (unsigned int)kdz & 0xffffu; __builtin_memcpy(&dxy, &a, 4); __builtin_memcpy(&dz0, &b, 4); }
@@ -1561,11 +1613,12 @@ __device__ __forceinline__ bool tri_pool_scan(glb_f4p gblob, cst_f4p cblob, int 
       const float rL = __builtin_amdgcn_rcpf(L) * 1.00001f;
       return sa <= (pn * (rho + H5.y * L + H5.w * rL) + e1s) * 1.0737e9f; // 32767^2 (1 + 2e-5)
     };
-    int* const bq = tri_bqueue() + (threadIdx.x >> 6) * PT_TRI_BQUEUE;
+    f4* const bq = tri_bqueue() + (threadIdx.x >> 6) * PT_TRI_BQUEUE;
+    int* const bqi = tri_bqueue_idx() + (threadIdx.x >> 6) * PT_TRI_BQUEUE;
     int bn = 0;
-    auto bpush = [&](bool p, int e0, int e1) {
+    auto bpush = [&](bool p, int e, f4 Q) {
       const unsigned long long m = __builtin_amdgcn_ballot_w64(p);
-      if (p) { const int at = 2 * (bn + __builtin_popcountll(m & below)); bq[at] = e0; bq[at + 1] = e1; }
+      if (p) { const int at = bn + __builtin_popcountll(m & below); bq[at] = Q; bqi[at] = e; }
       bn += __builtin_popcountll(m);
     };
     auto drain_band = [&](int keep) {
@@ -1573,202 +1626,60 @@ __device__ __forceinline__ bool tri_pool_scan(glb_f4p gblob, cst_f4p cblob, int 
       while (bn > keep) {
         const int n = min(bn, 64);
         bool pass = false;
-        int e1 = 0;
-        if (lane < n) { // (the candidate's position in the Morton copy is fetched beside its record: no dependent gather in the exact stage)
-          const int at = 2 * (bn - n + lane);
-          e1 = (int)gdword(gblob, 0, ~bq[at + 1]);
-          pass = band_pass(gblob[bq[at]]);
-        }
+        int e = 0;
+        if (lane < n) { e = bqi[bn - n + lane]; pass = band_pass(bq[bn - n + lane]); }
         bn -= n;
-        PT_TRI_COUNT(9, __builtin_popcountll(__builtin_amdgcn_ballot_w64(pass)));
-        push(pass, e1);
+        PT_TRI_COUNT(8, __builtin_popcountll(__builtin_amdgcn_ballot_w64(pass)));
+        push(pass, e);
         drain(63, ur, src);
       }
       __builtin_amdgcn_wave_barrier();
     };
-    // (All rows of all levels and faces as ONE sequence — one look-up stage, one pair of scans, one row table of up to 576 rows, no
-    // ragged last trip per (level, face) — was built and measured: bit-exact, but 168 VGPRs (three waves per SIMD) and no faster.)
-    const int n_levels = (PT_TRI_ABLATE & 2) ? 0 : as_i(H3.w);
-    for (int lv = 0; lv < n_levels; ++lv) {
-      const f4 L0 = cblob[hdr + 10 + 3 * lv], T0 = cblob[hdr + 11 + 3 * lv], T1 = cblob[hdr + 12 + 3 * lv];
-      const int R = as_i(L0.x);
-      if (as_i(L0.y) == 0) continue;
-      const float W = 1.7320509f * (rho * L0.z + L0.w) * 1.00001f + 2e-5f; // |A p + B q + C| <= sqrt(3) tau on the face of n's largest component
-      const float step = 2.0f / (float)R, halfR = 0.5f * (float)R;
-      for (int face = 0; face < 3; ++face) {
-        const float A = face == 0 ? dh.y : face == 1 ? dh.z : dh.x; // face k: (p, q) = (n_a, n_b) / n_k, a = k + 1, b = k + 2 (mod 3)
-        const float B = face == 0 ? dh.z : face == 1 ? dh.x : dh.y;
-        const float C = face == 0 ? dh.x : face == 1 ? dh.y : dh.z;
-        if (!(__builtin_fabsf(A) + __builtin_fabsf(B) + W >= __builtin_fabsf(C))) continue; // the strip cannot meet the square (uniform)
-        // rows along the axis with the smaller coefficient; the other coordinate solved: y(x) = -(C + mn x) / mj.  Orientation 0
-        // (|A| >= |B|): rows are q-rows, cells contiguous in p; orientation 1: rows are p-columns, cells contiguous in q.
-        const bool swp = __builtin_fabsf(B) > __builtin_fabsf(A);
-        const float mj = swp ? B : A, mn = swp ? A : B;
-        const float ninv = -1.0f / mj;
-        const float hw = W * __builtin_fabsf(ninv) * 1.00001f + 2e-5f;
-        const int tf = swp ? as_i(T1.x) : as_i(T0.x), tc = swp ? as_i(T1.y) : as_i(T0.y), tr = swp ? as_i(T1.z) : as_i(T0.z);
-        // The strip's rows, BALANCED over the lanes.  Row populations are very uneven (the 100 k-triangle mesh: 1.3 triangles per cell of
-        // level 0 on average, 337 in the fullest), so "a row per lane" left ~6 of 64 lanes busy for ~20 trips.  Instead: every lane
-        // looks up the candidate range of its row(s); a wave scan turns the lengths into positions of one concatenated sequence of T
-        // candidates (row table in LDS, empty rows dropped); lane l takes positions [l per, (l + 1) per), four per trip.
-        const int rpl = R > 64 ? 2 : 1; // rows per lane (R <= 128)
-        int rk0[2] = {0, 0}, rlen[2] = {0, 0};
+    // 128 entries per trip: lane l takes entries base + l, base + 64 + l.  The loop is a two-stage software pipeline — while the records
+    // of trip i are tested, the records of trip i + 1 are being gathered and the indices of trip i + 2 loaded — because a ray's turn is a
+    // chain of dependent loads (index -> record, a microsecond each from beyond L2) and ~20 trips long: un-pipelined, that latency was
+    // what a wave waited for (both arrays carry spare entries behind their end: no clamping; what lies beyond `last` is masked).
+    constexpr int PER = 2;
+    auto load_idx = [&](unsigned int base, int (&idx)[PER]) {
 #pragma unroll
-        for (int q = 0; q < 2; q++) {
-          const int rr = lane * rpl + q;
-          if (q < rpl && rr < R) { // this lane's row: its candidate range (two loads)
-            const float x0 = -1.0f + (float)rr * step, x1 = x0 + step;
-            const float y0 = (C + mn * x0) * ninv, y1 = (C + mn * x1) * ninv;
-            const float ylo = __builtin_fminf(y0, y1) - hw, yhi = __builtin_fmaxf(y0, y1) + hw;
-            const int c0 = (int)__builtin_floorf((__builtin_fmaxf(ylo, -1.0f) + 1.0f) * halfR);
-            const int c1 = min((int)__builtin_floorf((__builtin_fminf(yhi, 1.0f) + 1.0f) * halfR), R - 1);
-            if (yhi >= -1.0f && ylo <= 1.0f && c0 <= c1) { // (NaN: nothing)
-              const int base = (face * R + rr) * R;
-              rk0[q] = (int)gdword(gblob, tf, base + c0);
-              rlen[q] = (int)gdword(gblob, tf, base + c1 + 1) - rk0[q];
-            }
-          }
-        }
-        const int mine = rlen[0] + rlen[1];
-        int incl = mine;
+      for (int j = 0; j < PER; j++) { const unsigned int k = base + 64u * (unsigned int)j + (unsigned int)lane; idx[j] = listed ? (int)gdword(pool, cand_off, k) : (int)k; }
+    };
+    auto load_rec = [&](const int (&idx)[PER], f4 (&Q)[PER]) {
 #pragma unroll
-        for (int dd = 1; dd < 64; dd <<= 1) { const int o = __shfl_up(incl, dd, 64); incl += lane >= dd ? o : 0; }
-        const int T = __builtin_amdgcn_readlane(incl, 63);
-        if (T == 0) continue;
-        const unsigned long long f0 = __builtin_amdgcn_ballot_w64(rlen[0] > 0), f1 = __builtin_amdgcn_ballot_w64(rlen[1] > 0);
-        const int dense = __builtin_popcountll(f0 & below) + __builtin_popcountll(f1 & below); // non-empty rows before this lane's
-        const int nr = __builtin_popcountll(f0) + __builtin_popcountll(f1);
-        int* const rpos = tri_rows() + (threadIdx.x >> 6) * 264; // [0, 132): first position of every non-empty row (+ sentinel T)
-        int* const rbas = rpos + 132;                                // [132, 264): first candidate - first position
-        int pos = incl - mine;
-        if (rlen[0] > 0) { rpos[dense] = pos; rbas[dense] = rk0[0] - pos; }
-        if (rlen[1] > 0) { const int d1 = dense + (rlen[0] > 0 ? 1 : 0); rpos[d1] = pos + rlen[0]; rbas[d1] = rk0[1] - (pos + rlen[0]); }
-        if (lane == 0) rpos[nr] = T;
-        // 256 positions per trip; a GROUP OF FOUR LANES reads sixteen consecutive candidates (load j: positions 4 j ... 4 j + 3 of the
-        // sixteen, one 64-byte line per group) — a load instruction touches 16 lines, not 64 (lane-private chunks did: DESIGN.md §3)
-        for (int base = 0; base < T; base += 256) {
-          PT_TRI_COUNT(5 + (lv < 1 ? lv : 1), 1);
-          const int p = base + ((lane >> 2) << 4) + (lane & 3);
-          PT_TRI_COUNT(4, __builtin_popcountll(__builtin_amdgcn_ballot_w64(p < T)));
-          unsigned int passmask = 0;
-          int kk[4] = {0, 0, 0, 0};
-          if (p < T) {
-            int r; // the row of position p: the last one that starts at or before it
-            { int lo = 0, hi = nr; // rpos[lo] <= p < rpos[hi]
+      for (int j = 0; j < PER; j++) Q[j] = pool[band_rec + (unsigned int)idx[j]];
+    };
+    int idxA[PER], idxB[PER], idxC[PER];
+    f4 QA[PER], QB[PER];
+    // (indices past `last` read spare or foreign entries: clamp what they point at to a valid record)
+    auto clamp_idx = [&](int (&idx)[PER]) {
 #pragma unroll
-              for (int it = 0; it < 8; it++) { const int mid = (lo + hi) >> 1; const bool up = mid > lo && rpos[mid] <= p; lo = up ? mid : lo; hi = up ? hi : (mid > lo ? mid : hi); }
-              r = lo; }
-            int rnext = rpos[r + 1], rb = rbas[r];
+      for (int j = 0; j < PER; j++) idx[j] = min(max(idx[j], 0), n_tri + 127);
+    };
+    load_idx(first, idxA); clamp_idx(idxA);
+    load_idx(first + 64u * PER, idxB);
+    load_rec(idxA, QA);
+    for (unsigned int base = first; base < last; base += 64u * PER) {
+      PT_TRI_COUNT(11, 1);
+      load_idx(base + 128u * PER, idxC); // two trips ahead
+      clamp_idx(idxB);
+      load_rec(idxB, QB);                // one trip ahead
+      unsigned int passmask = 0;
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-              const int pj = min(p + 4 * j, T - 1); // (a tail position repeats the last candidate: masked out below)
-              while (pj >= rnext) { ++r; rnext = rpos[r + 1]; rb = rbas[r]; } // non-empty rows only: a few steps at most
-              kk[j] = rb + pj;
-            }
-            f4 Q[4];
+      for (int j = 0; j < PER; j++) passmask |= (base + 64u * (unsigned int)j + (unsigned int)lane < last && band_stage1(QA[j])) ? (1u << j) : 0u;
+      PT_TRI_COUNT(6, min(64u * PER, last - base));
+      PT_TRI_COUNT(7, PT_TRI_WAVE_BITS(passmask));
 #pragma unroll
-            for (int j = 0; j < 4; j++) Q[j] = gblob[tr + kk[j]];
-            __builtin_amdgcn_sched_barrier(0);
+      for (int j = 0; j < PER; j++) bpush((passmask >> j) & 1u, idxA[j], QA[j]);
+      drain_band(63);
 #pragma unroll
-            for (int j = 0; j < 4; j++) passmask |= (p + 4 * j < T && band_stage1(Q[j])) ? (1u << j) : 0u;
-          }
-          PT_TRI_COUNT(10, PT_TRI_WAVE_BITS(passmask));
-#pragma unroll
-          for (int j = 0; j < 4; j++) bpush((passmask >> j) & 1u, tr + kk[j], ~(4 * tc + kk[j]));
-          drain_band(63);
-        }
-      }
+      for (int j = 0; j < PER; j++) { idxA[j] = idxB[j]; QA[j] = QB[j]; idxB[j] = idxC[j]; }
     }
     drain_band(0);
     drain(0, ur, src);
   }
-  // ---- (3) the always list: 64 entries in the lanes (one coalesced load), the live rays in the inner loop ---------------------------
-  // The inner loop runs the band test only; (ray, entry) PAIRS that pass are queued (the band queue's storage is idle now) and take
-  // the noise-radius filter 64 pairs at a time, every lane with the context of ITS pair's ray (ds_bpermute); the pairs that pass
-  // that are queued again (the survivor queue's storage) and run the reference's test 64 at a time.  Slivers pass the band test for
-  // a large share of the rays, and ~29 pairs per ray reach the exact test: testing them where they arise kept the wave at a few
-  // lanes for most of the loop.
-  const int n_always = (PT_TRI_ABLATE & 4) ? 0 : as_i(H3.z);
-  const int astr = as_i(H9.w);
-  int* const aq = tri_bqueue() + (threadIdx.x >> 6) * PT_TRI_BQUEUE; // pairs (lane of the ray, entry) past the band test
-  int an = 0, xn = 0;                                       // (tq: pairs past the noise radius)
-  auto pair_push = [&](int* q, int& n, bool p, int s2, int e) {
-    const unsigned long long m = __builtin_amdgcn_ballot_w64(p);
-    if (p) { const int at = 2 * (n + __builtin_popcountll(m & below)); q[at] = s2; q[at + 1] = e; }
-    n += __builtin_popcountll(m);
-  };
-  auto ray_of = [&](int s2, Ray& r2) { // the ray of lane s2, in every lane its own s2
-    r2.o = mk(__shfl(c.r.o.x, s2, 64), __shfl(c.r.o.y, s2, 64), __shfl(c.r.o.z, s2, 64));
-    r2.d = mk(__shfl(c.r.d.x, s2, 64), __shfl(c.r.d.y, s2, 64), __shfl(c.r.d.z, s2, 64));
-    r2.tm = 0.0f;
-  };
-  auto exact_pairs = [&](int keep) {
-    __builtin_amdgcn_wave_barrier();
-    while (xn > keep) {
-      const int n = min(xn, 64);
-      const bool on = lane < n;
-      const int at = 2 * (xn - n + (on ? lane : 0));
-      const int s2 = tq[at], e = tq[at + 1];
-      Ray r2;
-      ray_of(s2, r2);
-      if (on) { // (the entry's triangle: a gather from the always list's arrays)
-        const f4 R0 = gblob[acheap + 2 * astr + e], R1 = gblob[acheap + 3 * astr + e], R2 = gblob[acheap + 4 * astr + e];
-        float t;
-        if (tri_param(R0, R1, R2, r2, t) && !(t < PT_TMIN)) atomicMin(&slot[s2], tri_key(t, goff + 3 * as_i(R2.w)));
-      }
-      xn -= n;
-    }
-    __builtin_amdgcn_wave_barrier();
-  };
-  auto filter_pairs = [&](int keep) {
-    __builtin_amdgcn_wave_barrier();
-    while (an > keep) {
-      const int n = min(an, 64);
-      const bool on = lane < n;
-      const int at = 2 * (an - n + (on ? lane : 0));
-      const int s2 = aq[at], e = aq[at + 1];
-      Ray r2;
-      ray_of(s2, r2);
-      const float ua = __shfl(c.a, s2, 64), rho = __shfl(rho_own, s2, 64), dn = __shfl(dn_own, s2, 64);
-      bool pass = false;
-      if (on) {
-        const f4 G = gblob[acheap + e], Bc = gblob[acheap + astr + e];
-        const float dg = __builtin_fabsf(r2.d.x * G.x + r2.d.y * G.y + r2.d.z * G.z);
-        const float L = Bc.w, L2 = L * L;
-        const float a1 = dg * (H5.z * L) - H6.w * L2 * dn;
-        const float rr = (H6.y + H6.z * L) * L2 * rho * dn / a1;
-        const float rad = L + rr + H6.x;
-        const V3 x = cross(xyz(Bc) - r2.o, r2.d);
-        pass = !(a1 > 0.0f) || dot(x, x) <= rad * rad * ua * 1.00001f;
-      }
-      an -= n;
-      PT_TRI_COUNT(11, __builtin_popcountll(__builtin_amdgcn_ballot_w64(pass)));
-      pair_push(tq, xn, pass, s2, e);
-      exact_pairs(63);
-    }
-    __builtin_amdgcn_wave_barrier();
-  };
-  for (int base = 0; base < n_always; base += 64) {
-    const int e = base + lane;
-    const bool on = e < n_always;
-    f4 G = f4{0, 0, 0, 0};
-    if (on) G = gblob[acheap + e];
-    for (unsigned long long todo = live; todo != 0; todo &= todo - 1) {
-      const int src = __builtin_ctzll(todo);
-      const float dx = rl_f(c.r.d.x, src), dy = rl_f(c.r.d.y, src), dz = rl_f(c.r.d.z, src);
-      const float rho = rl_f(rho_own, src), dn = rl_f(dn_own, src);
-      const float dg = __builtin_fabsf(dx * G.x + dy * G.y + dz * G.z);
-      const bool p1 = on & (dg <= dn * (rho + G.w));
-      PT_TRI_COUNT(7, __builtin_popcountll(__builtin_amdgcn_ballot_w64(p1)));
-      pair_push(aq, an, p1, src, e);
-      filter_pairs(63);
-    }
-  }
-  filter_pairs(0);
-  exact_pairs(0);
   // each lane reads its own ray's slot back: changed = some triangle of this run is the nearest hit so far
   const unsigned long long kf = slot[lane];
-  if (kf != key0) { h.closest = as_f((int)(unsigned int)(kf >> 32)); h.hit = hit_pack(DK_TRI, 0, 0xffffff - (int)(unsigned int)(kf & 0xffffffu)); }
+  if (kf != key0) { h.closest = as_f((int)(unsigned int)(kf >> 32)); h.hit = hit_pack(DK_TRI, 0, (int)(0xffffffffu - (unsigned int)(kf & 0xffffffffull))); }
   return true;
 }
 
@@ -1776,7 +1687,7 @@ __device__ __forceinline__ bool tri_pool_scan(glb_f4p gblob, cst_f4p cblob, int 
 // less code, and nothing of theirs (the medium's sqrt(d.d), say) can be hoisted into the per-iteration prologue of a kernel that never runs it.
 template <bool IMG, int TRIP = 1, int TTRIP = TRIP, bool WHOLE = true, bool BADOUEL = false, int GRID = 1, bool TRIPOOL = false, bool RECTBOX = false, typename P>
 __device__ __forceinline__ void hit_records(P recs, cst_f4p cblob, int kind, int n, int goff,
-                                            const RayCtx& c, bool fast, uint32_t& rng, HitState& h) {
+                                            const RayCtx& c, bool fast, uint32_t& rng, HitState& h, glb_f4p pool = nullptr) {
   const Ray& r = c.r;
   int off = 0;
   if (!RECTBOX && kind == DK_SPHERE) {
@@ -1816,8 +1727,7 @@ __device__ __forceinline__ void hit_records(P recs, cst_f4p cblob, int kind, int
     if constexpr (TRIPOOL && WHOLE) { // a long run with a triangle pool (flag + header offset in the run's aux record)
       const f4 aux = cblob[goff - 1];
       if (as_i(aux.x) != 0 && fast) {
-        const glb_f4p gblob = (glb_f4p)(unsigned long long)cblob; // the same blob, for per-lane loads
-        if (tri_pool_scan(gblob, cblob, as_i(aux.y), goff, c, h)) return;
+        if (tri_pool_scan(pool, cblob, as_i(aux.y), goff, c, h)) return;
       }
     }
     auto accept_at = [&](int o) { return [&h, goff, o](float t) { h.closest = t; h.hit = hit_pack(DK_TRI, 0, goff + o); }; };
@@ -1989,7 +1899,7 @@ __device__ __forceinline__ int record_size(int kind) {
 // `cblob`: the blob in global memory through the scalar cache (run headers, sphere-run masks); `blob`: where the records are
 // read from (LDS copy, or the same global blob).
 template <bool IMG, bool BADOUEL = false, int GRID = 1, bool TRIPOOL = false, bool RECTBOX = false, typename P>
-__device__ __forceinline__ void hit_world(P blob, cst_f4p cblob, int n_runs, const RayCtx& c, bool fast, uint32_t& rng, HitState& h) {
+__device__ __forceinline__ void hit_world(P blob, cst_f4p cblob, int n_runs, const RayCtx& c, bool fast, uint32_t& rng, HitState& h, const f4* pool = nullptr) {
   hit_begin(h);
   for (int ri = 0; ri < n_runs; ++ri) {
 #ifdef PT_STAMPS_RUNS /* diagnostic build: cycles per run of the list (wave leader's clock), g_runs[min(ri, 15)] */
@@ -2010,7 +1920,7 @@ __device__ __forceinline__ void hit_world(P blob, cst_f4p cblob, int n_runs, con
         }
       }
     }
-    hit_records<IMG, 1, 1, true, BADOUEL, GRID, TRIPOOL, RECTBOX>(blob + off, cblob, kind, as_i(runf.z), off, c, fast, rng, h);
+    hit_records<IMG, 1, 1, true, BADOUEL, GRID, TRIPOOL, RECTBOX>(blob + off, cblob, kind, as_i(runf.z), off, c, fast, rng, h, (glb_f4p)pool);
   }
 }
 

@@ -25,10 +25,31 @@ static_assert(sizeof(F4) == 16);
 inline float as_f(int32_t i) { float f; std::memcpy(&f, &i, 4); return f; }
 
 enum { DK_SPHERE = 0, DK_RECT = 1, DK_TRI = 2, DK_BOX = 3, DK_MEDIUM = 4, DK_TRI_B = 5 /* Badouel-strategy triangles */ };
+// hit id (pt_device.hpp: hit_pack): [24:0] record offset in the blob (F4 units), [27:25] box side, [30:28] device kind
+enum { kHitOffBits = 25, kHitSideShift = 25, kHitKindShift = 28 };
 
+// The pool buffer is described, not materialised, on the host: a list of segments (offset in F4 units, the dwords that go there), the big
+// ones MOVED out of the TriPool — a copy of the 100 k-triangle mesh's 0.6 GB of maps into one contiguous host vector cost seconds of
+// first-touch page faults.  pt_scene_create uploads segment by segment into a zeroed device buffer; pt_debug_flatten_pool assembles them.
+struct PoolSegment { uint64_t at_f4; std::vector<uint32_t> dwords; };
+struct PoolLayout {
+  std::vector<PoolSegment> segments;
+  uint64_t size_f4 = 0;
+  uint32_t put(std::vector<uint32_t>&& v, int spare_f4) { // returns the segment's offset; `spare_f4` zeroed records follow it (the scans may load a whole chunk without clamping)
+    const uint64_t at = size_f4;
+    size_f4 += (v.size() + 3) / 4 + (uint64_t)spare_f4;
+    segments.push_back(PoolSegment{at, std::move(v)});
+    return (uint32_t)at;
+  }
+  void assemble(F4* out) const { // out: size_f4 records
+    std::memset((void*)out, 0, (size_t)size_f4 * 16);
+    for (const PoolSegment& sg : segments) if (!sg.dwords.empty()) std::memcpy((void*)(out + sg.at_f4), sg.dwords.data(), sg.dwords.size() * 4);
+  }
+};
 struct Flat {
   std::vector<F4> blob; // [n_runs run headers][records; a sphere run is preceded by its offset lists + aux F4]
   std::vector<F4> mats; // 4 F4 per material, texture inlined
+  PoolLayout pool;      // tables of the triangle pools (pt_tripool.hpp): a buffer of their own, addressed by 32-bit F4 offsets from the pools' headers
   int32_t n_runs = 0;
   bool has_image = false;
   bool has_medium = false;
@@ -40,7 +61,9 @@ struct Flat {
   int pooled = 0;           // rects and boxes that sit in a slab pool (pt_device.hpp: slab_pool)
   int tri_pooled = 0;       // triangles that sit in a triangle pool (pt_tripool.hpp; pt_device.hpp: tri_pool_scan)
   double tri_cells_per_triangle = 0; // statistics of the (last) triangle pool, for the tests
-  int tri_always = 0, tri_level_counts[3] = {0, 0, 0};
+  int tri_wide = 0, tri_maps = 0;   // triangles whose band covers every direction; direction maps built
+  long long tri_map_entries[2] = {0, 0};
+  int tri_map_res[2] = {0, 0};
 };
 
 inline int device_kind(int32_t k) {
@@ -276,119 +299,56 @@ inline void put_box(std::vector<F4>& b, const float* f, int32_t mat, int32_t hid
 
 // box_cull: 0 = no slab pools, 1 = where the cost model says they pay, 2 = every stretch of >= 2 rects / boxes (tests)
 // In front of a triangle run's records: ONE aux F4 = (1 if the run has a triangle pool else 0, header offset, 0, 0), and for a
-// pooled run, before it, the pool's tables and its header (pt_device.hpp: tri_pool_scan reads them):
-//   H0 (grid origin xyz, 1 / cell)   H1 (nx, ny, nz, cell)   H2 (centre xyz, R)   H3 (rlimit^2, kappa, n_always, n_levels)
-//   H4 (cell_first, cell_cand (positions in the Morton-ordered copy), that copy of the run's records, the grid candidates' inline
-//       8-byte filter records: blob offsets)
-//   H5 (always-list entries: blob offset; KQ; P / L; KT)          H6 (ball_abs, kr_a, kr_b, ea)
+// pooled run, before it, the pool's header (pt_device.hpp: tri_pool_scan reads it through the scalar cache).  The pool's TABLES
+// live in a second buffer (Flat::pool -> PtScene::pool): round 4 kept them in the blob, whose record offsets are hit-id bits, so a
+// mesh of 830 k triangles lost its pool; the tables are addressed by 32-bit F4 offsets into their own buffer (64 GB).
+//   H0 (grid origin xyz, 1 / cell)   H1 (nx, ny, nz, cell)   H2 (centre xyz, R)   H3 (rlimit^2, kappa, triangles, direction maps)
+//   H4 (cell_first, cell_cand (positions in the Morton-ordered copy), that copy of the run's records, the band records in the
+//       same order: pool offsets)
+//   H5 (-, KQ, P / L, KT)          H6 (ball_abs, kr_a, kr_b, ea)
 //   H7 (centroid quantisation origin xyz, eps_c)                   H8 (centroid quantisation step xyz, eps_n)
-//   H9 (loose / tight grid radius, Mg / M, the grid candidates' inline 8-byte (normal, pn) records: blob offset, stride of the
-//       always list's five arrays)
-//   per level k, three F4: (R, triangles, pn_max, qn_max) (first, cand, inline band records of orientation 0) (... of orientation 1)
-inline int32_t put_tri_pool(std::vector<F4>& b, const TriPool& tp, const PtHittable* tri) {
-  // (every array is followed by spare entries: the scans load whole chunks of four without clamping)
-  auto put_u32 = [&](const std::vector<uint32_t>& v) { const int32_t at = (int32_t)b.size(); put_dwords(b, v.data(), v.size()); for (int k = 0; k < 3; k++) b.push_back({0, 0, 0, 0}); return at; };
-  // COMPRESSED filter records inline beside the candidate lists, in candidate order (a wave streams a cell's / a strip's
-  // candidates from consecutive addresses): grid candidates 8 bytes (quantised centroid, bfloat16 filter radius), band candidates
-  // 16 bytes (quantised unit normal, pn, centroid, L) — pt_tripool.hpp "compressed records"; only the survivors of the filters
-  // fetch the triangle's own records (by index, from the run).  Always-list entries stay exact: band record (g, c), (centroid, L),
-  // and the triangle's three records (v0, material)(edge1, hittable index)(edge2, triangle index in the run), five F4.
-  auto put_inline = [&](const std::vector<uint32_t>& idx, auto rec_of) {
-    const int32_t at = (int32_t)b.size();
-    for (uint32_t i : idx) rec_of(i);
-    for (int k = 0; k < 20; k++) b.push_back({0, 0, 0, 0});
-    return at;
-  };
-  auto put_q = [&](const std::vector<uint32_t>& idx, const std::vector<uint32_t>& q, int per, int spare_f4) {
-    const int32_t at = (int32_t)b.size();
-    std::vector<uint32_t> v;
-    v.reserve(idx.size() * (size_t)per);
-    for (uint32_t i : idx) for (int k = 0; k < per; k++) v.push_back(q[(size_t)i * per + k]);
-    put_dwords(b, v.data(), v.size());
-    for (int k = 0; k < spare_f4; k++) b.push_back({0, 0, 0, 0});
-    return at;
-  };
-  auto tri_rec = [&](uint32_t i) {
+//   per direction map k, one F4: (R, rho_max, first: pool offset, candidates (positions in the Morton copy): pool offset)
+enum { kTriPoolHeaderF4 = 9, kTriPoolMaxMaps = 2 };
+inline int32_t put_tri_pool(std::vector<F4>& b, PoolLayout& pool, TriPool& tp, const PtHittable* tri, int count) {
+  // the run's records in MORTON order of the centroids (R2.w = the triangle's index in the run, for the tie rule): pt_tripool.hpp
+  const size_t ntri = (size_t)count;
+  const std::vector<uint32_t>& order = tp.order;
+  auto bits = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
+  std::vector<uint32_t> recs;
+  recs.reserve(12 * ntri);
+  for (uint32_t i : order) {
     const float* f = tri[i].f;
-    b.push_back({f[0], f[1], f[2], as_f(tri[i].material)});
-    b.push_back({f[3] - f[0], f[4] - f[1], f[5] - f[2], 0.0f});
-    b.push_back({f[6] - f[0], f[7] - f[1], f[8] - f[2], as_f((int32_t)i)});
-  };
-  auto band_rec = [&](uint32_t i) {
-    b.push_back(F4{tp.cheap[(size_t)i * 4], tp.cheap[(size_t)i * 4 + 1], tp.cheap[(size_t)i * 4 + 2], tp.cheap[(size_t)i * 4 + 3]});
-    b.push_back(F4{tp.ball[(size_t)i * 4], tp.ball[(size_t)i * 4 + 1], tp.ball[(size_t)i * 4 + 2], tp.ball[(size_t)i * 4 + 3]});
-  };
-  // The survivors of the grid filter gather their triangle's records, and a cell's survivors are neighbours in space: a copy of the
-  // run's records in MORTON order of the centroids (R2.w = the triangle's index in the run, for the tie rule) turns those gathers
-  // into reads of a few nearby lines; a cell's candidates are listed by position in that copy, ascending.
-  const size_t ntri = tp.grid_q.size() / 2;
-  std::vector<uint32_t> order(ntri), pos_of(ntri);
-  {
-    auto spread = [](uint32_t v) { uint64_t x = v & 0xffffu; x = (x | (x << 32)) & 0x1f00000000ffffull; x = (x | (x << 16)) & 0x1f0000ff0000ffull;
-                                   x = (x | (x << 8)) & 0x100f00f00f00f00full; x = (x | (x << 4)) & 0x10c30c30c30c30c3ull; return (x | (x << 2)) & 0x1249249249249249ull; };
-    std::vector<uint64_t> code(ntri);
-    for (size_t i = 0; i < ntri; i++) {
-      const uint32_t a = tp.grid_q[2 * i], c = tp.grid_q[2 * i + 1];
-      code[i] = spread(a & 0xffffu) | (spread(a >> 16) << 1) | (spread(c & 0xffffu) << 2);
-      order[i] = (uint32_t)i;
-    }
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return code[x] < code[y]; });
-    for (size_t p = 0; p < ntri; p++) pos_of[order[p]] = (uint32_t)p;
+    const float e1[3] = {f[3] - f[0], f[4] - f[1], f[5] - f[2]}, e2[3] = {f[6] - f[0], f[7] - f[1], f[8] - f[2]};
+    const uint32_t r[12] = {bits(f[0]), bits(f[1]), bits(f[2]), (uint32_t)tri[i].material, bits(e1[0]), bits(e1[1]), bits(e1[2]), 0u, bits(e2[0]), bits(e2[1]), bits(e2[2]), i};
+    recs.insert(recs.end(), r, r + 12);
   }
-  const int32_t tri_sorted = put_inline(order, tri_rec);
-  std::vector<uint32_t> cell_sorted(tp.cell_cand), cell_pos(tp.cell_cand.size());
-  for (size_t c = 0; c + 1 < tp.cell_first.size(); c++)
-    std::sort(cell_sorted.begin() + tp.cell_first[c], cell_sorted.begin() + tp.cell_first[c + 1], [&](uint32_t x, uint32_t y) { return pos_of[x] < pos_of[y]; });
-  for (size_t k = 0; k < cell_sorted.size(); k++) cell_pos[k] = pos_of[cell_sorted[k]];
-  // (the grid scan reads up to 512 entries past a cell's last candidate: spare entries behind the arrays)
-  const int32_t cell_first = put_u32(tp.cell_first);
-  const int32_t cell_cand = (int32_t)b.size();
-  put_dwords(b, cell_pos.data(), cell_pos.size());
-  for (int k = 0; k < 132; k++) b.push_back({0, 0, 0, 0});
-  const int32_t cell_q = put_q(cell_sorted, tp.grid_q, 2, 260), cell_n = put_q(cell_sorted, tp.grid_n, 2, 260);
-  // always-list entries, structure of arrays: five arrays of n_always (+ spare) F4 — (g, c) (centroid, L) (v0, material) (edge1, -)
-  // (edge2, triangle index) — so that the 64 lanes of a tile read consecutive records of each
-  const int32_t always = put_u32(tp.always);
-  const int32_t astride = (int32_t)tp.always.size() + 4;
-  const int32_t acheap = (int32_t)b.size();
-  for (int part = 0; part < 5; part++) {
-    for (uint32_t i : tp.always) {
-      const float* f = tri[i].f;
-      switch (part) {
-        case 0: b.push_back(F4{tp.cheap[(size_t)i * 4], tp.cheap[(size_t)i * 4 + 1], tp.cheap[(size_t)i * 4 + 2], tp.cheap[(size_t)i * 4 + 3]}); break;
-        case 1: b.push_back(F4{tp.ball[(size_t)i * 4], tp.ball[(size_t)i * 4 + 1], tp.ball[(size_t)i * 4 + 2], tp.ball[(size_t)i * 4 + 3]}); break;
-        case 2: b.push_back({f[0], f[1], f[2], as_f(tri[i].material)}); break;
-        case 3: b.push_back({f[3] - f[0], f[4] - f[1], f[5] - f[2], 0.0f}); break;
-        default: b.push_back({f[6] - f[0], f[7] - f[1], f[8] - f[2], as_f((int32_t)i)}); break;
-      }
-    }
-    for (int k = 0; k < 4; k++) b.push_back({0, 0, 0, 0});
+  const uint32_t tri_sorted = pool.put(std::move(recs), 12);
+  std::vector<uint32_t> bandv;
+  bandv.reserve(4 * ntri);
+  for (uint32_t i : order) bandv.insert(bandv.end(), &tp.band_q[4 * (size_t)i], &tp.band_q[4 * (size_t)i] + 4);
+  const uint32_t band = pool.put(std::move(bandv), 260); // (the full stream reads up to 128 records past the last one: dead records)
+  const uint32_t cell_first = pool.put(std::move(tp.cell_first), 2);
+  const uint32_t cell_cand = pool.put(std::move(tp.cell_cand), 20);
+  uint32_t mfirst[kTriPoolMaxMaps] = {0, 0}, mcand[kTriPoolMaxMaps] = {0, 0};
+  const int n_maps = std::min((int)tp.maps.size(), (int)kTriPoolMaxMaps);
+  for (int k = 0; k < n_maps; k++) {
+    TriDirMap& dm = tp.maps[(size_t)k];
+    mfirst[k] = pool.put(std::move(dm.first), 2);
+    mcand[k] = pool.put(std::move(dm.cand), 132); // (the pipelined scan loads indices up to three trips of 128 past a list's end)
   }
-  int32_t lfirst[3][2], lcand[3][2], lrec[3][2];
-  for (int k = 0; k < 3; k++)
-    for (int o = 0; o < 2; o++) {
-      lfirst[k][o] = put_u32(tp.levels[(size_t)k].first[o]);
-      std::vector<uint32_t> lpos(tp.levels[(size_t)k].cand[o]); // (positions in the Morton-ordered copy, like the grid's)
-      for (uint32_t& v : lpos) v = pos_of[v];
-      lcand[k][o] = put_u32(lpos);
-      lrec[k][o] = put_q(tp.levels[(size_t)k].cand[o], tp.band_q, 4, 20);
-    }
   const int32_t hdr = (int32_t)b.size();
   b.push_back({tp.origin[0], tp.origin[1], tp.origin[2], tp.inv_cell});
   b.push_back({as_f(tp.n[0]), as_f(tp.n[1]), as_f(tp.n[2]), tp.cell});
   b.push_back({tp.centre[0], tp.centre[1], tp.centre[2], tp.R});
-  b.push_back({tp.rlimit2, tp.kappa, as_f((int32_t)tp.always.size()), as_f(3)});
-  b.push_back({as_f(cell_first), as_f(cell_cand), as_f(tri_sorted), as_f(cell_q)});
-  b.push_back({as_f(acheap), tp.kq, tp.p_per_L, tp.kt});
+  b.push_back({tp.rlimit2, tp.kappa, as_f((int32_t)ntri), as_f(n_maps)});
+  b.push_back({as_f((int32_t)cell_first), as_f((int32_t)cell_cand), as_f((int32_t)tri_sorted), as_f((int32_t)band)});
+  b.push_back({0.0f, tp.kq, tp.p_per_L, tp.kt});
   b.push_back({tp.ball_abs, tp.kr_a, tp.kr_b, tp.ea});
   b.push_back({tp.cq_lo[0], tp.cq_lo[1], tp.cq_lo[2], tp.eps_c});
   b.push_back({tp.cq_step[0], tp.cq_step[1], tp.cq_step[2], tp.eps_n});
-  b.push_back({tp.k_loose, tp.m_scale, as_f(cell_n), as_f(astride)});
-  for (int k = 0; k < 3; k++) {
-    const TriPoolLevel& L = tp.levels[(size_t)k];
-    b.push_back({as_f(L.R), as_f((int32_t)L.cand[0].size()), L.pn_max, L.qn_max});
-    b.push_back({as_f(lfirst[k][0]), as_f(lcand[k][0]), as_f(lrec[k][0]), 0});
-    b.push_back({as_f(lfirst[k][1]), as_f(lcand[k][1]), as_f(lrec[k][1]), 0});
+  for (int k = 0; k < kTriPoolMaxMaps; k++) {
+    if (k < n_maps) b.push_back({as_f(tp.maps[(size_t)k].R), tp.maps[(size_t)k].rho_max, as_f((int32_t)mfirst[k]), as_f((int32_t)mcand[k])});
+    else b.push_back({as_f(0), -1.0f, as_f(0), as_f(0)});
   }
   return hdr;
 }
@@ -506,21 +466,16 @@ inline int flatten(const PtSceneDesc* sc, Flat& out, std::string& err, bool allo
     if (run.kind == DK_TRI) { // (Badouel-strategy runs have no pool: one parity-completeness loop)
       int32_t hdr = 0;
       bool pooled = false;
-      // The pool's tables ride in the blob, whose record offsets are 24 bits (hit ids, tri_key): ~17 F4 per triangle (grid lists +
-      // inline filter records + the Morton-ordered copy + the band levels) beside the 3 F4 of the records themselves.  A run whose
-      // tables would push the blob past 2^24 F4 (~830 k triangles) is flattened WITHOUT a pool — the streaming full scan, as before
-      // round 3 — instead of building gigabytes of tables only to fail with PT_ERR_TOO_LARGE; pt_scene_create's retry covers what this
-      // estimate misses.
-      const bool pool_fits = (double)b.size() + 20.0 * (double)run.count < (double)(1u << 24);
-      if (allow_tri_pool && pool_fits) {
-        const TriPool tp = build_tri_pool(&sc->hittables[run.first], run.count, tri_tune);
-        if (tp.ok) {
-          hdr = put_tri_pool(b, tp, &sc->hittables[run.first]);
+      if (allow_tri_pool) {
+        TriPool tp = build_tri_pool(&sc->hittables[run.first], run.count, tri_tune);
+        if (tp.ok && out.pool.size_f4 + 8ull * (size_t)run.count + tp.cell_cand.size() / 4 < (1ull << 31)) {
+          out.tri_cells_per_triangle = tp.mean_cells_per_triangle;
+          out.tri_wide = tp.wide;
+          out.tri_maps = (int)tp.maps.size();
+          for (size_t k = 0; k < tp.maps.size() && k < 2; k++) { out.tri_map_entries[k] = (long long)tp.maps[k].cand.size(); out.tri_map_res[k] = tp.maps[k].R; }
+          hdr = put_tri_pool(b, out.pool, tp, &sc->hittables[run.first], run.count);
           pooled = true;
           out.tri_pooled += run.count;
-          out.tri_cells_per_triangle = tp.mean_cells_per_triangle;
-          out.tri_always = (int)tp.always.size();
-          for (int k = 0; k < 3; k++) out.tri_level_counts[k] = (int)tp.levels[(size_t)k].cand[0].size();
         }
       }
       b.push_back({as_f(pooled ? 1 : 0), as_f(hdr), 0, 0});
@@ -530,7 +485,7 @@ inline int flatten(const PtSceneDesc* sc, Flat& out, std::string& err, bool allo
       const PtHittable& h = sc->hittables[i];
       const float* f = h.f;
       if (pool_n > 0 && i >= pool_first && i < pool_first + pool_n && (run.kind == DK_BOX || run.kind == DK_RECT))
-        b[pool_x + 2 * (size_t)(i - pool_first)].w = as_f((int32_t)((run.kind << 27) | (int32_t)b.size())); // hit_pack(kind, 0, offset)
+        b[pool_x + 2 * (size_t)(i - pool_first)].w = as_f((int32_t)((run.kind << kHitKindShift) | (int32_t)b.size())); // hit_pack(kind, 0, offset)
       switch (h.kind) {
         case PT_HIT_SPHERE: put_sphere(b, f, h.material, i); break;
         case PT_HIT_XY_RECT: case PT_HIT_XZ_RECT: case PT_HIT_YZ_RECT: {
@@ -557,7 +512,7 @@ inline int flatten(const PtSceneDesc* sc, Flat& out, std::string& err, bool allo
       }
     }
   }
-  if (b.size() >= (1u << 24)) { err = "scene too large for 24-bit record offsets"; return PT_ERR_TOO_LARGE; }
+  if (b.size() >= (1u << kHitOffBits)) { err = "scene too large for 25-bit record offsets (33.5 M records of 16 bytes)"; return PT_ERR_TOO_LARGE; }
   return PT_OK;
 }
 

@@ -85,6 +85,7 @@ struct KArgs {
   Cam cam;
   const f4* blob;
   const f4* mats;
+  const f4* pool;      // tables of the triangle pools (pt_flatten.hpp: put_tri_pool); NULL when the scene has none
   const uint8_t* atlas;
   float* fb;
   int n_runs, blob_f4, mats_f4;
@@ -529,7 +530,7 @@ void render_kernel(KArgs a) {
       RayCtx c = make_ctx(L.ray, a.fast_ok != 0);
       c.live = L.live;
       const bool fast = wave_all_regular(c, L.live);
-      hit_world<IMG, BADOUEL, GRID, TRIPOOL, (MATS & MATS_RECTBOX_ONLY) != 0>((cst_f4p)a.blob, (cst_f4p)a.blob, a.n_runs, c, fast, L.rng, h);
+      hit_world<IMG, BADOUEL, GRID, TRIPOOL, (MATS & MATS_RECTBOX_ONLY) != 0>((cst_f4p)a.blob, (cst_f4p)a.blob, a.n_runs, c, fast, L.rng, h, a.pool);
       lane_shade<UV, FAST, MATS>(L, a, h, a.blob, a.mats, fast);
     }
   }
@@ -729,7 +730,7 @@ __global__ __launch_bounds__(1024) void lpt_order_kernel(const unsigned int* __r
 
 // ---- probes ---------------------------------------------------------------------------------
 template <bool IMG, int WALK = 1>
-__global__ void bounce_kernel(const f4* __restrict__ blob, int n_runs, const f4* __restrict__ mats,
+__global__ void bounce_kernel(const f4* __restrict__ blob, int n_runs, const f4* __restrict__ mats, const f4* __restrict__ pool,
                               const uint8_t* __restrict__ atlas, const PtBounceIn* __restrict__ in,
                               PtBounceOut* __restrict__ outp, int n, int fast_ok) {
   int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -748,7 +749,7 @@ __global__ void bounce_kernel(const f4* __restrict__ blob, int n_runs, const f4*
   memset(&O, 0, sizeof O);
   RayCtx c = make_ctx(ray, fast_ok != 0);
   HitState h;
-  hit_world<IMG, true, WALK, true>(blob, (cst_f4p)blob, n_runs, c, wave_all_regular(c, true), rng, h); // every culling structure the scene has (WALK: which sphere-grid walk)
+  hit_world<IMG, true, WALK, true>(blob, (cst_f4p)blob, n_runs, c, wave_all_regular(c, true), rng, h, pool); // every culling structure the scene has (WALK: which sphere-grid walk)
   const float closest = h.closest, hu = h.u, hv = h.v;
   const int hit = h.hit;
   if (hit < 0) {
@@ -901,6 +902,8 @@ static void tuning_env(PtTuning& t) {
   if (const char* e = std::getenv("PT_TRI_M")) t.tri_M = (float)std::atof(e);
   if (const char* e = std::getenv("PT_TRI_MG")) t.tri_Mg = (float)std::atof(e);
   if (const char* e = std::getenv("PT_TRI_RES")) std::sscanf(e, "%d,%d,%d", &t.tri_res[0], &t.tri_res[1], &t.tri_res[2]);
+  if (const char* e = std::getenv("PT_TRI_RHO")) std::sscanf(e, "%f,%f", &t.tri_rho[0], &t.tri_rho[1]);
+  if (const char* e = std::getenv("PT_TRI_BUDGET_MB")) t.tri_budget_mb = std::max(1, std::atoi(e));
   if (const char* e = std::getenv("PT_TRI_CELL")) t.tri_cell = (float)std::atof(e);
   if (const char* e = std::getenv("PT_TRI_MIN")) t.tri_min_run = std::max(1, std::atoi(e));
   if (has("PT_NO_MATSPEC")) t.generic_materials = 1;
@@ -947,19 +950,19 @@ static int flatten_tuned(const PtSceneDesc* desc, const PtTuning& t, ptf::Flat& 
   ptf::TriPoolTuning tri;
   if (t.tri_min_run > 0) tri.min_run = t.tri_min_run;
   if (t.tri_M > 0.0f) tri.M = t.tri_M;
-  if (t.tri_Mg > 0.0f) tri.Mg = t.tri_Mg;
-  if (t.tri_res[0] > 0 && t.tri_res[1] > 0 && t.tri_res[2] > 0) { tri.res[0] = t.tri_res[0]; tri.res[1] = t.tri_res[1]; tri.res[2] = t.tri_res[2]; }
+  if (t.tri_res[0] > 0) tri.dm_res[0] = t.tri_res[0];
+  if (t.tri_res[1] > 0) tri.dm_res[1] = t.tri_res[1];
+  if (t.tri_rho[0] > 0.0f) tri.dm_rho[0] = t.tri_rho[0];
+  if (t.tri_rho[1] != 0.0f) tri.dm_rho[1] = t.tri_rho[1]; // (< 0: no second map)
+  if (t.tri_budget_mb > 0) tri.dm_budget = (long long)t.tri_budget_mb * (1 << 18); // MiB -> 4-byte entries
   if (t.tri_cell > 0.0f) tri.cell = t.tri_cell;
+  if (const char* e = std::getenv("PT_TRI_GRID_BUDGET")) tri.grid_budget = (float)std::atof(e); // (experiments only: not a PtTuning field)
   int rc = ptf::flatten(desc, flat, err, allow_grid, box_cull, tune, allow_tri, tri);
-  if (rc == PT_ERR_TOO_LARGE && allow_tri) { // the pool's tables overflowed the 24-bit record offsets: the scene without a pool may still fit
-    std::string err2;
-    if (ptf::flatten(desc, flat, err2, allow_grid, box_cull, tune, false, tri) == PT_OK) rc = PT_OK;
-  }
   if (rc) return rc;
   if (flat.grid_spheres > 0 && flat.blob.size() * 16 > kMaxLdsBlob) {
     ptf::Flat plain;
     std::string err2;
-    if (ptf::flatten(desc, plain, err2, false, box_cull, tune, allow_tri, tri) == PT_OK && plain.blob.size() * 16 <= kMaxLdsBlob) flat = std::move(plain);
+    if (flat.tri_pooled == 0 && ptf::flatten(desc, plain, err2, false, box_cull, tune, allow_tri, tri) == PT_OK && plain.blob.size() * 16 <= kMaxLdsBlob) flat = std::move(plain);
   }
   return PT_OK;
 }
@@ -1030,6 +1033,8 @@ struct DevBuf {
 struct PtScene {
   f4* blob = nullptr;
   f4* mats = nullptr;
+  f4* pool = nullptr;   // tables of the triangle pools (a buffer of their own: up to gigabytes)
+  size_t pool_bytes = 0;
   uint8_t* atlas = nullptr;
   int n_runs = 0, blob_f4 = 0, mats_f4 = 0;
   bool has_image = false;
@@ -1151,6 +1156,22 @@ int pt_debug_flatten_tuned(const PtSceneDesc* desc, const PtTuning* tuning, floa
   return PT_OK;
 }
 
+int pt_debug_flatten_pool(const PtSceneDesc* desc, const PtTuning* tuning, float* pool_out, int64_t pool_cap_f4, int64_t* n_pool_f4) {
+  ptf::Flat flat;
+  std::string err;
+  PtTuning t;
+  int rc = resolve_tuning(tuning, t, err);
+  if (rc) return fail(rc, err);
+  rc = flatten_tuned(desc, t, flat, err);
+  if (rc) return fail(rc, err);
+  if (n_pool_f4) *n_pool_f4 = (int64_t)flat.pool.size_f4;
+  if (pool_out) {
+    if (pool_cap_f4 < (int64_t)flat.pool.size_f4) return fail(PT_ERR_INVALID_ARG, "pool buffer too small");
+    flat.pool.assemble((ptf::F4*)pool_out);
+  }
+  return PT_OK;
+}
+
 int pt_debug_tri_pool(const PtSceneDesc* desc, int32_t out[8]) {
   if (!out) return fail(PT_ERR_INVALID_ARG, "pt_debug_tri_pool: NULL argument");
   ptf::Flat flat;
@@ -1159,8 +1180,9 @@ int pt_debug_tri_pool(const PtSceneDesc* desc, int32_t out[8]) {
   tuning_env(t);
   int rc = flatten_tuned(desc, t, flat, err);
   if (rc) return fail(rc, err);
-  out[0] = flat.tri_pooled; out[1] = flat.tri_always;
-  for (int k = 0; k < 3; k++) out[2 + k] = flat.tri_level_counts[k];
+  out[0] = flat.tri_pooled; out[1] = flat.tri_wide;
+  out[2] = (int32_t)(flat.tri_map_entries[0] >> 10); out[3] = (int32_t)(flat.tri_map_entries[1] >> 10);
+  out[4] = (flat.tri_map_res[0] << 16) | flat.tri_map_res[1];
   out[5] = (int32_t)(1000.0 * flat.tri_cells_per_triangle); out[6] = (int32_t)flat.blob.size(); out[7] = flat.grid_spheres;
   return PT_OK;
 }
@@ -1231,6 +1253,13 @@ int pt_scene_create_tuned(const PtSceneDesc* desc, const PtTuning* tuning, PtSce
   s->mats = s->blob + flat.blob.size();
   if (blob_bytes) PT_TRY(hipMemcpy(s->blob, flat.blob.data(), blob_bytes, hipMemcpyHostToDevice));
   if (mats_bytes) PT_TRY(hipMemcpy(s->mats, flat.mats.data(), mats_bytes, hipMemcpyHostToDevice));
+  if (flat.pool.size_f4) { // the triangle pools' tables: zeroed (spare records between the tables), then table by table from where the builder left them
+    s->pool_bytes = (size_t)flat.pool.size_f4 * 16;
+    PT_TRY(hipMalloc((void**)&s->pool, s->pool_bytes));
+    PT_TRY(hipMemset(s->pool, 0, s->pool_bytes));
+    for (const ptf::PoolSegment& sg : flat.pool.segments)
+      if (!sg.dwords.empty()) PT_TRY(hipMemcpy(s->pool + sg.at_f4, sg.dwords.data(), sg.dwords.size() * 4, hipMemcpyHostToDevice));
+  }
   size_t atlas_bytes = flat.has_image ? (size_t)desc->atlas_bytes : 0;
   PT_TRY(hipMalloc((void**)&s->atlas, std::max<size_t>(atlas_bytes, 16)));
   if (atlas_bytes) PT_TRY(hipMemcpy(s->atlas, desc->atlas, atlas_bytes, hipMemcpyHostToDevice));
@@ -1244,6 +1273,7 @@ int pt_scene_create_tuned(const PtSceneDesc* desc, const PtTuning* tuning, PtSce
 void pt_scene_destroy(PtScene* s) {
   if (!s) return;
   if (s->blob) (void)hipFree(s->blob);
+  if (s->pool) (void)hipFree(s->pool);
   if (s->atlas) (void)hipFree(s->atlas);
   if (s->queues) (void)hipFree(s->queues);
   for (hipEvent_t e : s->ring_done) if (e) (void)hipEventDestroy(e);
@@ -1313,7 +1343,7 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
   std::lock_guard<std::mutex> lock(s->sched);
   KArgs a;
   std::memcpy(&a.cam, cam, sizeof(Cam));
-  a.blob = s->blob; a.mats = s->mats; a.atlas = s->atlas; a.fb = fb;
+  a.blob = s->blob; a.mats = s->mats; a.pool = s->pool; a.atlas = s->atlas; a.fb = fb;
   a.n_runs = s->n_runs; a.blob_f4 = s->blob_f4; a.mats_f4 = s->mats_f4; a.n_hittables = s->n_hittables;
   a.width = p->width; a.height = p->height; a.samples = p->samples; a.depth = p->depth;
   a.inv_w = 1.0f / (float)p->width; a.inv_h = 1.0f / (float)p->height; // host IEEE division: correctly rounded
@@ -1727,13 +1757,13 @@ int pt_debug_bounce(const PtScene* scene, const PtBounceIn* in, PtBounceOut* out
   dim3 block(64), grid((n + 63) / 64);
   const bool qw = scene->knobs.grid_walk == 2; // PtTuning.grid_walk = 2: the probe walks sphere grids through the pair queue, like the kernels it stands for
   if (scene->track_uv && qw)
-    hipLaunchKernelGGL((bounce_kernel<true, 2>), grid, block, 0, nullptr, scene->blob, scene->n_runs, scene->mats, scene->atlas, din.p, dout.p, n, scene->fast_ok ? 1 : 0);
+    hipLaunchKernelGGL((bounce_kernel<true, 2>), grid, block, 0, nullptr, scene->blob, scene->n_runs, scene->mats, scene->pool, scene->atlas, din.p, dout.p, n, scene->fast_ok ? 1 : 0);
   else if (scene->track_uv)
-    hipLaunchKernelGGL((bounce_kernel<true, 1>), grid, block, 0, nullptr, scene->blob, scene->n_runs, scene->mats, scene->atlas, din.p, dout.p, n, scene->fast_ok ? 1 : 0);
+    hipLaunchKernelGGL((bounce_kernel<true, 1>), grid, block, 0, nullptr, scene->blob, scene->n_runs, scene->mats, scene->pool, scene->atlas, din.p, dout.p, n, scene->fast_ok ? 1 : 0);
   else if (qw)
-    hipLaunchKernelGGL((bounce_kernel<false, 2>), grid, block, 0, nullptr, scene->blob, scene->n_runs, scene->mats, scene->atlas, din.p, dout.p, n, scene->fast_ok ? 1 : 0);
+    hipLaunchKernelGGL((bounce_kernel<false, 2>), grid, block, 0, nullptr, scene->blob, scene->n_runs, scene->mats, scene->pool, scene->atlas, din.p, dout.p, n, scene->fast_ok ? 1 : 0);
   else
-    hipLaunchKernelGGL((bounce_kernel<false, 1>), grid, block, 0, nullptr, scene->blob, scene->n_runs, scene->mats, scene->atlas, din.p, dout.p, n, scene->fast_ok ? 1 : 0);
+    hipLaunchKernelGGL((bounce_kernel<false, 1>), grid, block, 0, nullptr, scene->blob, scene->n_runs, scene->mats, scene->pool, scene->atlas, din.p, dout.p, n, scene->fast_ok ? 1 : 0);
   PT_HIP(hipGetLastError());
   PT_HIP(hipMemcpy(out, dout.p, (size_t)n * sizeof(PtBounceOut), hipMemcpyDeviceToHost));
   return PT_OK;

@@ -12,13 +12,16 @@
 //   (1) GRID.   Pairs (ray, triangle) that are NOT grazing, |a^| >= thr_i (a^ = the exact e1 . (d x e2) = -d . N_i).  For those
 //       the computed barycentrics are within 1/M of the exact ones, so the exact point P^ where the ray's line meets the
 //       triangle's plane lies within sigma_i of the triangle, and the computed t is within the same distance (along the ray,
-//       plus a relative 1/M_a) of P^'s exact parameter.  The triangle is listed in every cell of a uniform grid that its
-//       bounding box, grown by sigma'_i, touches; the ray walks the cells of its segment [0, closest (1 + kappa)].
-//   (2) BAND.   Pairs that ARE grazing, |d^ . n^_i| < tau_i(rho): the unit normals of the triangles with a narrow band are
-//       bucketed on a cube map (three faces, antipodes identified); the set { n : |d^ . n| <= tau } is a great-circle strip,
-//       which central projection turns into a STRAIGHT strip on each face: rasterised per ray, per face, row by row.
-//   (3) ALWAYS. Triangles whose band is too wide for a map (slivers: tau_i ~ 1 / sin(angle between the edges)) are kept in
-//       a plain list that every ray scans — through the same cheap band test, so that only the grazing ones are tested.
+//       plus a relative 1/M_a) of P^'s exact parameter.  The triangle is listed in every cell of a fine uniform grid that meets
+//       its bounding box grown by sigma'_i AND the slab |n^_i . (x - v0)| <= sigma'_i around its plane (every point within
+//       sigma'_i of the triangle is in both); every lane walks ITS ray through the cells of its segment [0, closest (1 + kappa)].
+//   (2) BAND.   Pairs that ARE grazing, |d^ . n^_i| < tau_i(rho).  Round 5: indexed by the RAY'S DIRECTION, not by the
+//       triangle's normal.  A cube map over unit directions (three faces, antipodes identified: the test is even in d); bin D
+//       lists every triangle i for which SOME direction of D satisfies |d^ . n^_i| <= tau_i(rho_max) — the triangle's band is a
+//       great-circle strip of directions, which central projection turns into a STRAIGHT strip on each face, rasterised per
+//       triangle at build time.  A ray reads ONE contiguous list (the bin of its direction); tau grows with rho, so there is a
+//       map per class of rho (rho <= rho_max_k) and rays beyond the last class stream every triangle's band record.  Slivers —
+//       bands so wide that they cover most directions (rounds 3-4: an "always list") — are simply listed in most bins.
 //   Every candidate then runs the reference's own test (tri_eval / tri_finish, the same instructions as the brute-force
 //   scan) with the unordered acceptance rule (the last triangle in list order wins an equal t: triangle.hpp:91 accepts
 //   t == max), so testing a triangle twice or out of order changes nothing.
@@ -48,7 +51,16 @@
 //     sigma'_i = (6/M + 6/M_a + 1.2/(M-1)) L_i  <=  8.5 L_i / (M - 1)        (M >= 8, M_a >= 64)
 // of the triangle, hence inside its bounding box grown by sigma'_i: the cell that contains P' lists the triangle, and the walk
 // visits that cell (cells are assigned with a further absolute slack for the walk's own rounding, as the sphere grid's).
+// P' is within sigma'_i of a point of the triangle's PLANE too, so |n^_i . (P' - v0)| <= sigma'_i: a cell with centre m and half
+// edge h that contains a point within `slack` of P' has |n^_i . (m - v0)| <= sigma'_i + slack + h (|n^x| + |n^y| + |n^z|) — cells of
+// the grown box that fail this are not listed (a triangle's box holds ~3 times the cells its slab does).
 // Grazing, |a^| < thr_i, is |d^ . N_i| < rho P_i + Q_i: the band test, evaluated with N'_i = N_i rounded to binary32.
+// The direction map lists triangle i in bin D = (face k, [p0, p1] x [q0, q1]) — directions d ~ e_k + p e_a + q e_b — iff
+//     min over the bin's rectangle (grown by eps_bin for the device's own rounding of p, q) of |n_k + p n_a + q n_b|
+//         <=  tau_i(rho_max) sqrt(1 + p^2 + q^2)max over the rectangle,
+// which holds whenever some direction of the bin passes the real band test |d^ . n^_i| <= tau_i(rho) for a rho <= rho_max
+// (tau_i grows with rho).  The device picks face k = argmax |d_c| (exact comparisons), p = d_a / d_k, q = d_b / d_k through a
+// reciprocal (|error| < 4e-7 for |p|, |q| <= 1) and reads bin (floor((p + 1) R / 2), floor((q + 1) R / 2)), clamped: eps_bin = 4e-6.
 // tests/test_tripool_cpu.py checks these inequalities on float32 emulations of the reference's test (random and adversarial
 // grazing rays); the GPU suite checks the walked structure against the oracle's brute-force scan, bit for bit.
 #pragma once
@@ -56,6 +68,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "../../include/pt_render.h"
@@ -63,23 +76,22 @@
 namespace ptf {
 
 struct TriPoolTuning {
-  float M = 12.0f;      // PT_TRI_M (swept 8 ... 32 on cfg5: profiles/r03_tripool_sweep*.log): barycentric slack 1/M; the band width grows with M, the boxes' growth sigma' with 1/M
-  float Mg = 96.0f;     // PT_TRI_MG: the grid's TIGHT slack (pairs with |a^| >= thr(Mg) are found within sigma'(Mg) of the triangle; the others of the grid's share, thr(M) <= |a^| < thr(Mg), pass a band test at Mg: see "compressed records")
+  float M = 12.0f;      // PT_TRI_M (swept 6 ... 48 on cfg5, round 5: profiles/r05_tripool_sweep.txt): barycentric slack 1/M — the grid's boxes grow with 1/M (sigma'), the bands with M.  Round 5: the grid is walked per lane and costs little, the band candidates are the expensive ones: the optimum moved from 12 towards smaller M
   float Ma = 256.0f;    // relative slack of t: the walk runs to max (1 + 2.2 / (Ma - 1))
-  float cell = 0.7f;    // PT_TRI_CELL (swept 0.35 ... 3.0; 0.5 / 0.7 / 1.0 / 1.4: 2.51 / 2.50 / 2.53 / 2.56 s at 1080p x 32 spp): grid cell edge in units of the median grown box extent
-  int res[3] = {128, 64, 32}; // PT_TRI_RES=a,b,c (128,32,16 / 128,64,32 / 128,128,64: 2.53 / 2.41 / 2.40 s at 1080p x 32 spp): cube-map resolution of the three band levels (powers of two <= 128: the device deals a level's rows to the 64 lanes)
+  float cell = 0.22f;   // PT_TRI_CELL: grid cell edge in units of the median grown box extent
+  float grid_budget = 160.0f;         // cell entries per triangle the grid may take (cells are enlarged until the estimate fits)
+  int dm_res[2] = {256, 64};          // PT_TRI_RES=a,b: resolution of the direction maps of the two rho classes (<= 1024)
+  float dm_rho[2] = {4.0f, 16.0f};    // PT_TRI_RHO=a,b: class k serves rays with rho <= dm_rho[k] * R (R = radius of the v0's); beyond the last: every band record
+  long long dm_budget = 600ll << 20;  // entries (4 bytes each) the direction maps may take together; a map that does not fit is built at half the resolution, or not at all
   int min_run = 4096;   // PT_TRI_MIN: shorter triangle runs are scanned as before (PT_TRICULL=1: 256)
+  int threads = 0;      // build threads (0: hardware concurrency, at most 16); the tables do not depend on it
 };
 
-struct TriPoolLevel {
+struct TriDirMap {
   int R = 0;
-  float pn_max = 0.0f, qn_max = 0.0f; // the strip of a ray is |A p + B q + C| <= sqrt(3) (rho pn_max + qn_max)
-  // Two copies of the map, one per way a ray can walk a face: orientation 0 has the cells of a q-row (fixed cj) contiguous in
-  // ci, orientation 1 the cells of a p-column (fixed ci) contiguous in cj — so that the cells a ray's strip covers in one row
-  // are ONE contiguous candidate range either way.  first: 3 R R + 1 prefix offsets; cand: triangle index in the run.
-  // (The band record of every candidate rides inline beside its index, in candidate order: see put_tri_pool.)
-  std::vector<uint32_t> first[2];
-  std::vector<uint32_t> cand[2];
+  float rho_max = 0;                // rays with rho <= rho_max read this map
+  std::vector<uint32_t> first;      // 3 R R + 1 prefix offsets; bin = (face * R + row(q)) * R + column(p)
+  std::vector<uint32_t> cand;       // position in the Morton-ordered copy of the run, ascending within a bin
 };
 
 struct TriPool {
@@ -88,31 +100,129 @@ struct TriPool {
   int n[3] = {1, 1, 1};
   float centre[3] = {0, 0, 0}, R = 0, rlimit2 = 0, kappa = 0;
   std::vector<uint32_t> cell_first; // n cells + 1
-  std::vector<uint32_t> cell_cand;  // triangle index in the run
-  std::vector<TriPoolLevel> levels;
-  std::vector<uint32_t> always;
-  std::vector<float> cheap;         // 4 floats per triangle: g = N' / P, c = Q / P      band test: |d . g| < |d| (rho + c)
+  std::vector<uint32_t> cell_cand;  // [25:0] position in the Morton-ordered copy of the run, ascending within a cell; [31:26] which face neighbours list it too
+  std::vector<uint32_t> order;      // position in the Morton-ordered copy -> triangle index in the run
+  std::vector<TriDirMap> maps;      // by ascending rho_max
   std::vector<float> ball;          // 4 floats per triangle: centroid C, L = longest stored edge (every vertex is within L of C)
-  std::vector<float> grid_radius;   // per triangle: Rv + sigma' + ball_abs, Rv = the largest distance of a vertex from C (the grid filter's radius)
-  float p_per_L = 0, k_sigma = 0, ball_abs = 0, kr_a = 0, kr_b = 0, ea = 0; // constants of the two distance filters (see build_tri_pool)
-  // COMPRESSED filter records (what the device streams: the filters are necessary conditions, so any relaxation of them is
-  // still exact — see "compressed records" in build_tri_pool): per triangle 2 dwords for the grid, 4 for the band
-  float cq_lo[3] = {0, 0, 0}, cq_step[3] = {0, 0, 0}, eps_c = 0, eps_n = 0, kq = 0, kt = 0, k_loose = 0, m_scale = 0;
-  std::vector<uint32_t> grid_q; // (cq.x | cq.y << 16) (cq.z | bf16(tight radius) << 16)
-  std::vector<uint32_t> grid_n; // (nq.x | nq.y << 16) (nq.z | bf16(pn_eff) << 16)
+  std::vector<char> dead;           // triangles no ray can hit (an edge of zero length): in no table
+  float p_per_L = 0, ball_abs = 0, kr_a = 0, kr_b = 0, ea = 0; // constants of the noise-radius filter (see build_tri_pool)
+  // COMPRESSED band records (what the device gathers: the filters are necessary conditions, so any relaxation of them is
+  // still exact — see "compressed records" in build_tri_pool): 4 dwords per triangle
+  float cq_lo[3] = {0, 0, 0}, cq_step[3] = {0, 0, 0}, eps_c = 0, eps_n = 0, kq = 0, kt = 0;
   std::vector<uint32_t> band_q; // (nq.x | nq.y << 16) (nq.z | bf16(pn) << 16) (cq.x | cq.y << 16) (cq.z | bf16(L) << 16)
   // statistics for the tests / DESIGN
   double mean_cells_per_triangle = 0;
+  int wide = 0; // triangles whose band at the first map's rho_max covers every direction (tau >= 1, or no normal at all)
 };
+
+namespace detail {
+// f(p, q) = nk + p na + nb q over the rectangle [pl, ph] x [ql, qh]: is min |f| <= W possible, and for which p?  Returns false when no p qualifies.
+inline bool strip_columns(double nk, double na, double nb, double ql, double qh, double W, double& pa, double& pb) {
+  const double lo_c = nk + std::min(ql * nb, qh * nb), hi_c = nk + std::max(ql * nb, qh * nb); // f_min(p) = p na + lo_c, f_max(p) = p na + hi_c
+  // need f_min(p) <= W and f_max(p) >= -W
+  if (na == 0.0) { pa = -2.0; pb = 2.0; return lo_c <= W && hi_c >= -W; }
+  const double x0 = (-W - hi_c) / na, x1 = (W - lo_c) / na;
+  pa = std::min(x0, x1); pb = std::max(x0, x1);
+  return true;
+}
+} // namespace detail
+
+// one direction map: triangle i (unit normal nrm, band half-width tau[i] at rho_max; tau = INFINITY: every bin) -> bins
+// `order`: position in the Morton-ordered copy of the run -> triangle; the map lists POSITIONS, ascending within a bin (a bin's gathers walk
+// the record arrays forwards), which falls out of visiting the triangles in that order.
+inline bool build_dir_map(TriDirMap& dm, int R, const std::vector<double>& nrm, const std::vector<double>& tau, const std::vector<char>& dead, int count,
+                          const std::vector<uint32_t>& order, long long budget, int n_threads) {
+  dm.R = R;
+  const size_t nb = (size_t)3 * R * R;
+  const double eps_bin = 4e-6, step = 2.0 / R;
+  const int T = std::max(1, n_threads);
+  // every thread walks its own contiguous slice of the triangles, in order; pass 0 counts per (thread, bin), pass 1 writes: the table is
+  // the single-threaded one whatever T is
+  auto raster = [&](int i, auto&& emit) { // emit(first bin of a row, columns c0 .. c1)
+    const double* nn = &nrm[(size_t)i * 3];
+    const double t = tau[(size_t)i];
+    if (!(t < 1.0)) { for (size_t b = 0; b < nb; b += (size_t)R) emit(b, 0, R - 1); return; } // covers every direction
+    for (int k = 0; k < 3; k++) {
+      const int a = (k + 1) % 3, b = (k + 2) % 3;
+      const double nk = nn[k], na = nn[a], nbv = nn[b];
+      const double W3 = t * 1.7320508075688772 * (1 + 1e-9) + 1e-12;
+      if (std::fabs(nk) - (std::fabs(na) + std::fabs(nbv)) * (1.0 + eps_bin) > W3) continue; // the strip misses this face
+      for (int j = 0; j < R; j++) {
+        const double ql = -1.0 + j * step - eps_bin, qh = -1.0 + (j + 1) * step + eps_bin;
+        const double qm2 = std::max(ql * ql, qh * qh);
+        double W = t * std::sqrt(2.0 + qm2 + 4 * eps_bin) * (1 + 1e-9) + 1e-12, pa, pb; // |p| <= 1 + eps_bin
+        if (!detail::strip_columns(nk, na, nbv, ql, qh, W, pa, pb)) continue;
+        pa = std::max(pa, -1.0 - eps_bin); pb = std::min(pb, 1.0 + eps_bin);
+        if (pa > pb) continue;
+        { // once more with the |p| the first pass allows (still conservative: every qualifying p lies inside [pa, pb])
+          const double pm2 = std::max(pa * pa, pb * pb);
+          W = t * std::sqrt(1.0 + pm2 + qm2) * (1 + 1e-9) + 1e-12;
+          double pa2, pb2;
+          if (!detail::strip_columns(nk, na, nbv, ql, qh, W, pa2, pb2)) continue;
+          pa = std::max(pa, pa2); pb = std::min(pb, pb2);
+          if (pa > pb) continue;
+        }
+        const int c0 = std::max(0, std::min(R - 1, (int)std::floor((pa - eps_bin + 1.0) * 0.5 * R)));
+        const int c1 = std::max(0, std::min(R - 1, (int)std::floor((pb + eps_bin + 1.0) * 0.5 * R)));
+        emit(((size_t)k * R + j) * R, c0, c1);
+      }
+    }
+  };
+  std::vector<std::vector<uint32_t>> cnt((size_t)T);
+  auto slice = [&](int t, int& i0, int& i1) { i0 = (int)((long long)count * t / T); i1 = (int)((long long)count * (t + 1) / T); };
+  {
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; t++)
+      th.emplace_back([&, t]() {
+        cnt[(size_t)t].assign(nb, 0);
+        int i0, i1;
+        slice(t, i0, i1);
+        uint32_t* const cn = cnt[(size_t)t].data();
+        for (int p = i0; p < i1; p++) {
+          const int i = (int)order[(size_t)p];
+          if (!dead[(size_t)i]) raster(i, [&](size_t row, int c0, int c1) { for (int c = c0; c <= c1; c++) cn[row + (size_t)c]++; });
+        }
+      });
+    for (auto& x : th) x.join();
+  }
+  dm.first.assign(nb + 1, 0);
+  unsigned long long total = 0;
+  for (size_t b = 0; b < nb; b++) {
+    dm.first[b] = (uint32_t)total;
+    for (int t = 0; t < T; t++) { const uint32_t c = cnt[(size_t)t][b]; cnt[(size_t)t][b] = (uint32_t)total; total += c; } // -> this thread's cursor in the bin
+    if (total > (unsigned long long)budget || total >= (1ull << 32)) return false;
+  }
+  dm.first[nb] = (uint32_t)total;
+  dm.cand.resize((size_t)total);
+  {
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; t++)
+      th.emplace_back([&, t]() {
+        int i0, i1;
+        slice(t, i0, i1);
+        uint32_t* const cur = cnt[(size_t)t].data();
+        uint32_t* const out = dm.cand.data();
+        for (int p = i0; p < i1; p++) {
+          const int i = (int)order[(size_t)p];
+          if (!dead[(size_t)i]) raster(i, [&](size_t row, int c0, int c1) { for (int c = c0; c <= c1; c++) out[cur[row + (size_t)c]++] = (uint32_t)p; });
+        }
+      });
+    for (auto& x : th) x.join();
+  }
+  return true;
+}
 
 inline TriPool build_tri_pool(const PtHittable* h, int count, TriPoolTuning tune = TriPoolTuning()) {
   TriPool tp;
-  if (count < tune.min_run) return tp;
+  if (count < tune.min_run || count >= (1 << 26)) return tp; // (table entries carry a triangle's position in 26 bits)
   const double u = std::ldexp(1.0, -24), SAFE = 1.5;
-  const double M = std::max(8.0, (double)tune.M), Ma = std::max(64.0, (double)tune.Ma);
+  // (the bound of the header holds for any M > 1; sigma' below is its general form.  M >= 2 keeps the second-order terms SAFE covers small.)
+  const double M = std::max(2.0, (double)tune.M), Ma = std::max(64.0, (double)tune.Ma);
   std::vector<double> P((size_t)count), Q((size_t)count), pn((size_t)count), qn((size_t)count), sig((size_t)count);
   std::vector<double> nrm((size_t)count * 3);
-  std::vector<char> dead((size_t)count, 0);
+  std::vector<char> slab_ok((size_t)count, 0); // the unit normal is well conditioned in binary64 (sin of the edges' angle >= 1e-6): the plane slab may be used
+  std::vector<char>& dead = tp.dead;
+  dead.assign((size_t)count, 0);
   double c[3] = {0, 0, 0};
   for (int i = 0; i < count; i++) {
     const float* f = h[i].f;
@@ -124,10 +234,9 @@ inline TriPool build_tri_pool(const PtHittable* h, int count, TriPoolTuning tune
   double R = 0;
   std::vector<double> ext;
   ext.reserve((size_t)count);
-  tp.cheap.assign((size_t)count * 4, 0.0f);
   tp.ball.assign((size_t)count * 4, 0.0f);
-  std::vector<double> rv_of; // per LIVE triangle, in order
-  std::vector<int> live_index((size_t)count, -1);
+  int n_live = 0;
+  const double sig_per_L = 6.0 / M + 6.0 / Ma + 1.2 / (M - 1.0); // sigma'_i / L_i (header: the three terms of the bound)
   for (int i = 0; i < count; i++) {
     const float* f = h[i].f;
     // the edges as the flattener stores them (binary32 differences: triangle.hpp:65-66)
@@ -142,29 +251,17 @@ inline TriPool build_tri_pool(const PtHittable* h, int count, TriPoolTuning tune
     // a = e1 . (d x e2) is a sum of products of edge components: an edge pair whose cross product is exactly 0 in every
     // component the reference can form (both edges zero, or one zero) gives a = +-0 for every ray: |a| < 1e-7, never accepted
     if (!(L > 0.0) || l1 == 0.0 || l2 == 0.0) { dead[(size_t)i] = 1; continue; }
-    live_index[(size_t)i] = (int)rv_of.size();
+    n_live++;
     P[(size_t)i] = M * 17.5 * u * L * SAFE;
     Q[(size_t)i] = (Ma * 7.0 + 4.0) * u * l1 * l2 * SAFE + std::ldexp(1.0, -40);
-    sig[(size_t)i] = 8.5 * L / (M - 1.0);
-    const float Np[3] = {(float)N[0], (float)N[1], (float)N[2]}; // N' = N rounded to binary32 (the 4 u of Q_i)
-    for (int k = 0; k < 3; k++) tp.cheap[(size_t)i * 4 + k] = (float)((double)Np[k] / P[(size_t)i]);
-    tp.cheap[(size_t)i * 4 + 3] = (float)(Q[(size_t)i] / P[(size_t)i] * (1.0 + 4 * u));
+    sig[(size_t)i] = sig_per_L * L * (1 + 8 * u);
     if (nN > 0.0) {
       pn[(size_t)i] = P[(size_t)i] / nN; qn[(size_t)i] = Q[(size_t)i] / nN;
       for (int k = 0; k < 3; k++) nrm[(size_t)i * 3 + k] = N[k] / nN;
+      slab_ok[(size_t)i] = nN >= 1e-6 * l1 * l2;
     } else { pn[(size_t)i] = qn[(size_t)i] = INFINITY; }
     for (int k = 0; k < 3; k++) tp.ball[(size_t)i * 4 + k] = (float)(f[k] + (e1[k] + e2[k]) / 3.0); // centroid of v0, v0 + e1, v0 + e2
     tp.ball[(size_t)i * 4 + 3] = (float)(L * (1 + 2 * u));
-    {
-      double rv = 0;
-      const double cx[3] = {tp.ball[(size_t)i * 4], tp.ball[(size_t)i * 4 + 1], tp.ball[(size_t)i * 4 + 2]}; // the ROUNDED centroid the device uses
-      for (int v = 0; v < 3; v++) {
-        double d2 = 0;
-        for (int k = 0; k < 3; k++) { const double pv = (double)f[k] + (v == 1 ? e1[k] : v == 2 ? e2[k] : 0.0); d2 += (pv - cx[k]) * (pv - cx[k]); }
-        rv = std::max(rv, std::sqrt(d2));
-      }
-      rv_of.push_back(rv);
-    }
     double emax = 0;
     for (int k = 0; k < 3; k++) {
       const double lo = std::min({(double)f[k], (double)f[3 + k], (double)f[6 + k]}), hi = std::max({(double)f[k], (double)f[3 + k], (double)f[6 + k]});
@@ -172,7 +269,7 @@ inline TriPool build_tri_pool(const PtHittable* h, int count, TriPoolTuning tune
     }
     ext.push_back(emax);
   }
-  if (ext.size() < (size_t)tune.min_run) return tp;
+  if (n_live < tune.min_run) return tp;
   R *= 1.0 + 8 * u;
   // ---- (1) the grid -----------------------------------------------------------------------------------------------------
   std::nth_element(ext.begin(), ext.begin() + ext.size() / 2, ext.end());
@@ -192,31 +289,31 @@ inline TriPool build_tri_pool(const PtHittable* h, int count, TriPoolTuning tune
     box_of(i, 0.0, blo, bhi);
     for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], blo[k]); hi[k] = std::max(hi[k], bhi[k]); }
   }
-  for (;;) { // at most 2^21 cells, at most 256 per axis
+  for (;;) { // at most 2^22 cells, at most 512 per axis
     double total = 1;
     bool fits = true;
     for (int k = 0; k < 3; k++) {
-      const double nk = std::max(1.0, std::ceil((hi[k] - lo[k] + 4e-3 * cell) / cell));
-      if (nk > 256) fits = false;
-      tp.n[k] = (int)std::min(nk, 256.0);
+      const double nk = std::max(1.0, std::ceil((hi[k] - lo[k] + 1.6e-2 * cell) / cell));
+      if (nk > 512) fits = false;
+      tp.n[k] = (int)std::min(nk, 512.0);
       total *= nk;
     }
-    // ... and a bounded candidate table: every (cell, triangle) entry carries the triangle's three records inline, and a few
-    // triangles that span the whole grid (cells are sized for the median one) would otherwise list themselves in every cell
+    // ... and a bounded candidate table: a few triangles that span the whole grid (cells are sized for the median one) would
+    // otherwise list themselves in every cell (the estimate counts box cells; the plane slab keeps about a third of them)
     double entries = 0;
-    if (fits && total <= 2097152.0) {
-      for (int i = 0; i < count && entries <= 1e9; i++) {
+    if (fits && total <= 4194304.0) {
+      for (int i = 0; i < count && entries <= 1e10; i++) {
         if (dead[(size_t)i]) continue;
         double blo[3], bhi[3], e = 1;
         box_of(i, 0.0, blo, bhi);
         for (int k = 0; k < 3; k++) e *= std::min((double)tp.n[k], (bhi[k] - blo[k]) / cell + 2.0);
         entries += e;
       }
-      if (entries <= std::max(24.0 * (double)ext.size(), 65536.0)) break;
+      if (entries <= std::max((double)tune.grid_budget * (double)n_live, 65536.0)) break;
     }
     cell *= 1.25;
   }
-  const double slack = 1e-3 * cell; // the walk's own rounding (the ray must start within rlimit: below)
+  const double slack = 4e-3 * cell; // the walk's own rounding (the ray must start within rlimit: below)
   double half_diag2 = 0;
   for (int k = 0; k < 3; k++) {
     const double extk = tp.n[k] * cell, mid = 0.5 * (lo[k] + hi[k]);
@@ -228,16 +325,14 @@ inline TriPool build_tri_pool(const PtHittable* h, int count, TriPoolTuning tune
   tp.inv_cell = (float)(1.0 / cell);
   tp.R = (float)R;
   tp.kappa = (float)(2.2 / (Ma - 1.0));
-  // ---- two distance filters in front of the exact test (both necessary conditions of an acceptance, so neither can lose one)
-  // (i) grid candidates (pairs that are not grazing): P' — a point of the ray's line — is within sigma'_i of the triangle, and
-  //     every point of the triangle is within L_i of its centroid C_i: the line passes within L_i (1 + 8.5 / (M - 1)) of C_i.
-  // (ii) band candidates: whatever |a^| is, an accepted pair has |beta - u/a| <= (du + da) / |a^| (same for gamma), so P^ — on the
-  //     ray's line — lies within r = 6 (du + dv + da) L_i / |a^| of the triangle: the line passes within L_i + r of C_i, with
+  // ---- the distance filter in front of the exact test of a BAND candidate (a necessary condition of an acceptance, so it cannot lose one)
+  // Whatever |a^| is, an accepted pair has |beta - u/a| <= (du + da) / |a^| (same for gamma), so P^ — on the ray's line — lies
+  // within r = 6 (du + dv + da) L_i / |a^| of the triangle: the line passes within L_i + r of the centroid C_i (every point of the
+  // triangle is within L_i of it), with
   //     r <= kr(L_i) rho |d| / (|a'| - ea(L_i) |d|),  kr = 6 SAFE u L^2 (17.5 + 7 L / R),  ea = 4 u L^2  (|a' - a^| <= ea |d|;
   //     rho >= R lets the da term ride on rho).  The device evaluates |(C - o) x d|^2 <= radius^2 |d|^2 in binary32: its
   //     rounding (and the centroid's) is covered by ball_abs = 64 u (rlimit + R + diagonal) added to every radius.
   tp.p_per_L = (float)(M * 17.5 * u * SAFE);
-  tp.k_sigma = (float)((1.0 + 8.5 / (M - 1.0)) * (1 + 8 * u));
   tp.kr_a = (float)(6 * SAFE * u * 17.5 * (1 + 8 * u));
   tp.kr_b = (float)(6 * SAFE * u * 7.0 / std::max(R, 1e-30) * (1 + 8 * u));
   tp.ea = (float)(4 * u * (1 + 8 * u));
@@ -250,106 +345,101 @@ inline TriPool build_tri_pool(const PtHittable* h, int count, TriPoolTuning tune
     if (!(rl > 0)) return tp;
     tp.rlimit2 = (float)(rl * rl * 0.99);
     tp.ball_abs = (float)(64 * u * (rl + R + 2 * std::sqrt(half_diag2)));
-    // (i) tightened: every point of the triangle is within Rv_i (its farthest vertex) of the centroid, so the line passes within
-    // Rv_i + sigma'_i of it
-    tp.grid_radius.assign((size_t)count, 0.0f);
-    for (int i = 0; i < count; i++)
-      if (!dead[(size_t)i]) tp.grid_radius[(size_t)i] = (float)((rv_of[(size_t)live_index[(size_t)i]] + sig[(size_t)i]) * (1 + 8 * u) + tp.ball_abs);
   }
   const double inv = (double)tp.inv_cell; // assign with the float value the device uses
   const size_t ncell = (size_t)tp.n[0] * tp.n[1] * tp.n[2];
-  std::vector<uint32_t> cnt(ncell + 1, 0);
-  auto cells_of = [&](int i, int c0[3], int c1[3]) {
+  // a cell of the grown box is listed only if it also meets the slab around the triangle's plane (header): |n^ . (m - v0)| <= sigma' + slack + h |n^|_1
+  auto for_cells = [&](int i, auto&& emit) {
     double blo[3], bhi[3];
     box_of(i, slack, blo, bhi);
+    int c0[3], c1[3];
     for (int k = 0; k < 3; k++) {
       c0[k] = std::max(0, std::min(tp.n[k] - 1, (int)std::floor((blo[k] - tp.origin[k]) * inv)));
       c1[k] = std::max(0, std::min(tp.n[k] - 1, (int)std::floor((bhi[k] - tp.origin[k]) * inv)));
     }
+    const bool flat = slab_ok[(size_t)i] != 0; // has a normal that binary64 resolves (else: every cell of the box)
+    const double* nn = &nrm[(size_t)i * 3];
+    const double hc = 0.5 / inv, reach = sig[(size_t)i] + slack + hc * (std::fabs(nn[0]) + std::fabs(nn[1]) + std::fabs(nn[2])) * (1 + 1e-9) + 1e-9 * cell;
+    const float* f = h[i].f;
+    for (int z = c0[2]; z <= c1[2]; z++)
+      for (int y = c0[1]; y <= c1[1]; y++)
+        for (int x = c0[0]; x <= c1[0]; x++) {
+          if (flat) {
+            const double mx = tp.origin[0] + (x + 0.5) / inv, my = tp.origin[1] + (y + 0.5) / inv, mz = tp.origin[2] + (z + 0.5) / inv;
+            if (std::fabs(nn[0] * (mx - f[0]) + nn[1] * (my - f[1]) + nn[2] * (mz - f[2])) > reach) continue;
+          }
+          emit(((size_t)z * tp.n[1] + y) * tp.n[0] + x);
+        }
   };
+  // The survivors of the filters gather their triangle's records, and a cell's candidates are neighbours in space: the device reads a
+  // copy of the run's records in MORTON order of the centroids (21 bits per axis over the centroids' box), and every table lists a triangle
+  // by its position in that copy, ascending — which falls out of filling the tables in that order.
+  {
+    double clo[3] = {1e300, 1e300, 1e300}, chi[3] = {-1e300, -1e300, -1e300};
+    for (int i = 0; i < count; i++)
+      for (int k = 0; k < 3; k++) { clo[k] = std::min(clo[k], (double)tp.ball[(size_t)i * 4 + k]); chi[k] = std::max(chi[k], (double)tp.ball[(size_t)i * 4 + k]); }
+    auto spread = [](uint64_t x) { x &= 0x1fffffull; x = (x | (x << 32)) & 0x1f00000000ffffull; x = (x | (x << 16)) & 0x1f0000ff0000ffull;
+                                   x = (x | (x << 8)) & 0x100f00f00f00f00full; x = (x | (x << 4)) & 0x10c30c30c30c30c3ull; return (x | (x << 2)) & 0x1249249249249249ull; };
+    std::vector<uint64_t> code((size_t)count);
+    for (int i = 0; i < count; i++) {
+      uint64_t q[3];
+      for (int k = 0; k < 3; k++) { const double w = chi[k] - clo[k]; q[k] = w > 0 ? (uint64_t)std::min(2097151.0, std::max(0.0, ((double)tp.ball[(size_t)i * 4 + k] - clo[k]) / w * 2097151.0)) : 0; }
+      code[(size_t)i] = spread(q[0]) | (spread(q[1]) << 1) | (spread(q[2]) << 2);
+    }
+    tp.order.resize((size_t)count);
+    for (int i = 0; i < count; i++) tp.order[(size_t)i] = (uint32_t)i;
+    std::stable_sort(tp.order.begin(), tp.order.end(), [&](uint32_t x, uint32_t y) { return code[x] < code[y]; });
+  }
+  std::vector<uint32_t> cnt(ncell + 1, 0);
   size_t total_entries = 0;
   for (int i = 0; i < count; i++) {
     if (dead[(size_t)i]) continue;
-    int c0[3], c1[3];
-    cells_of(i, c0, c1);
-    for (int z = c0[2]; z <= c1[2]; z++)
-      for (int y = c0[1]; y <= c1[1]; y++)
-        for (int x = c0[0]; x <= c1[0]; x++) { cnt[((size_t)z * tp.n[1] + y) * tp.n[0] + x]++; total_entries++; }
+    for_cells(i, [&](size_t ci) { cnt[ci]++; total_entries++; });
   }
-  if (total_entries >= (1u << 28)) return tp;
+  if (total_entries >= (1u << 30)) return tp;
   tp.cell_first.assign(ncell + 1, 0);
   for (size_t k = 0; k < ncell; k++) tp.cell_first[k + 1] = tp.cell_first[k] + cnt[k];
   tp.cell_cand.assign(total_entries, 0);
-  std::vector<uint32_t> cur(tp.cell_first.begin(), tp.cell_first.end() - 1);
-  for (int i = 0; i < count; i++) { // in list order: a cell's candidates ascend
-    if (dead[(size_t)i]) continue;
-    int c0[3], c1[3];
-    cells_of(i, c0, c1);
-    for (int z = c0[2]; z <= c1[2]; z++)
-      for (int y = c0[1]; y <= c1[1]; y++)
-        for (int x = c0[0]; x <= c1[0]; x++) tp.cell_cand[cur[((size_t)z * tp.n[1] + y) * tp.n[0] + x]++] = (uint32_t)i;
-  }
-  tp.mean_cells_per_triangle = (double)total_entries / std::max<size_t>(1, ext.size());
-  // ---- (2) band levels on the cube map of normals, (3) the always list -----------------------------------------------------
-  // level k takes the triangles whose band half-width at the reference distance, tau_i = rho_ref pn_i + qn_i, is <= tau_k
-  const double rho_ref = 3.0 * R;
-  const double tau_cap[3] = {0.004, 0.016, 0.064};
-  int res[3];
-  for (int k = 0; k < 3; k++) { res[k] = 16; while (res[k] < tune.res[k] && res[k] < 128) res[k] *= 2; } // powers of two in [16, 128]
-  tp.levels.resize(3);
-  std::vector<int> level_of((size_t)count, -1);
-  for (int i = 0; i < count; i++) {
-    if (dead[(size_t)i]) continue;
-    const double tau = rho_ref * pn[(size_t)i] + qn[(size_t)i];
-    int lv = 3;
-    for (int k = 0; k < 3; k++) if (tau <= tau_cap[k]) { lv = k; break; }
-    if (lv == 3) { tp.always.push_back((uint32_t)i); continue; }
-    level_of[(size_t)i] = lv;
-    TriPoolLevel& L = tp.levels[(size_t)lv];
-    L.pn_max = std::max(L.pn_max, (float)(pn[(size_t)i] * (1 + 4 * u)));
-    L.qn_max = std::max(L.qn_max, (float)(qn[(size_t)i] * (1 + 4 * u)));
-  }
-  for (int lv = 0; lv < 3; lv++) {
-    TriPoolLevel& L = tp.levels[(size_t)lv];
-    L.R = res[lv];
-    const size_t nc = (size_t)3 * L.R * L.R;
-    auto map_cell = [&](int i, int orient) -> size_t {
-      const double* nn = &nrm[(size_t)i * 3];
-      int k = 0;
-      if (std::fabs(nn[1]) > std::fabs(nn[k])) k = 1;
-      if (std::fabs(nn[2]) > std::fabs(nn[k])) k = 2;
-      const int a = (k + 1) % 3, b = (k + 2) % 3; // face k: (p, q) = (n_a, n_b) / n_k
-      const double p = nn[a] / nn[k], q = nn[b] / nn[k];
-      const int ci = std::max(0, std::min(L.R - 1, (int)std::floor((p + 1.0) * 0.5 * L.R)));
-      const int cj = std::max(0, std::min(L.R - 1, (int)std::floor((q + 1.0) * 0.5 * L.R)));
-      return orient == 0 ? ((size_t)k * L.R + cj) * L.R + ci : ((size_t)k * L.R + ci) * L.R + cj;
-    };
-    for (int orient = 0; orient < 2; orient++) {
-      std::vector<uint32_t> cn(nc + 1, 0);
-      for (int i = 0; i < count; i++) if (level_of[(size_t)i] == lv) cn[map_cell(i, orient)]++;
-      L.first[orient].assign(nc + 1, 0);
-      for (size_t k = 0; k < nc; k++) L.first[orient][k + 1] = L.first[orient][k] + cn[k];
-      L.cand[orient].assign(L.first[orient][nc], 0);
-      std::vector<uint32_t> cu(L.first[orient].begin(), L.first[orient].end() - 1);
-      for (int i = 0; i < count; i++) if (level_of[(size_t)i] == lv) L.cand[orient][cu[map_cell(i, orient)]++] = (uint32_t)i;
+  {
+    std::vector<uint32_t> cur(tp.cell_first.begin(), tp.cell_first.end() - 1);
+    // Each entry also says in which of the cell's six face neighbours the triangle is listed as well (bits 26 ... 31: -x +x -y +y -z +z):
+    // a walk steps from cell to cell through faces, and a triangle that the cell it comes from lists has been tested there already
+    // (or where that cell's predecessor listed it, and so on back to the first cell of the chain) — a (ray, triangle) pair's test does
+    // not depend on the cell it is made in, so the device skips it (tri_pool_scan).  2^26 positions: build_tri_pool's caller checks the count.
+    std::vector<uint32_t> own; // the cells of one triangle, sorted
+    const long long sx = 1, sy = tp.n[0], sz = (long long)tp.n[0] * tp.n[1];
+    for (int p = 0; p < count; p++) { // in Morton order: a cell's candidates ascend
+      const int i = (int)tp.order[(size_t)p];
+      if (dead[(size_t)i]) continue;
+      own.clear();
+      for_cells(i, [&](size_t ci) { own.push_back((uint32_t)ci); });
+      std::sort(own.begin(), own.end());
+      for (uint32_t ci : own) {
+        const int x = (int)(ci % (uint32_t)tp.n[0]), y = (int)((ci / (uint32_t)tp.n[0]) % (uint32_t)tp.n[1]), z = (int)(ci / (uint32_t)(tp.n[0] * tp.n[1]));
+        auto has = [&](bool in_grid, long long c2) { return in_grid && std::binary_search(own.begin(), own.end(), (uint32_t)c2); };
+        uint32_t bits = 0;
+        bits |= has(x > 0, (long long)ci - sx) ? 1u : 0u;
+        bits |= has(x + 1 < tp.n[0], (long long)ci + sx) ? 2u : 0u;
+        bits |= has(y > 0, (long long)ci - sy) ? 4u : 0u;
+        bits |= has(y + 1 < tp.n[1], (long long)ci + sy) ? 8u : 0u;
+        bits |= has(z > 0, (long long)ci - sz) ? 16u : 0u;
+        bits |= has(z + 1 < tp.n[2], (long long)ci + sz) ? 32u : 0u;
+        tp.cell_cand[cur[ci]++] = (uint32_t)p | (bits << 26);
+      }
     }
   }
+  tp.mean_cells_per_triangle = (double)total_entries / std::max(1, n_live);
   // ---- compressed records --------------------------------------------------------------------------------------------------
-  // The scan is bound by the bytes it streams, and both filters are NECESSARY conditions of an acceptance: any
-  // relaxation keeps the pool exact.  So the device reads them from quantised records, every quantity rounded to the safe side:
+  // Both band filters are NECESSARY conditions of an acceptance: any relaxation keeps the pool exact.  So the device reads them
+  // from quantised records, every quantity rounded to the safe side:
   //   centroid  C~ = cq_lo + k cq_step, k a 16-bit integer per axis; |C~ - C| <= eps_c (measured below on the device's own
   //             binary32 decode) is added to every radius;
-  //   radius / L / pn  as bfloat16 rounded UP (relative 2^-7);
+  //   L / pn  as bfloat16 rounded UP (relative 2^-7);
   //   unit normal  n~ = (kx, ky, kz) / 32767, |n~ - N/|N|| <= eps_n (measured): |d . n~| <= |d . N|/|N| + |d| eps_n.
-  // The GRID's filter has two radii.  The bound of the header holds for any M >= 8: a pair with |a^| >= thr(Mg) (Mg = 96 >> M) has
-  // its P' within sigma'(Mg) = (6/Mg + 6/Ma + 1.2/(Mg-1)) L of the triangle — the TIGHT radius Rv + sigma'(Mg), stored per candidate;
-  // the rest of the grid's share, thr(M) <= |a^| < thr(Mg), lies within the LOOSE radius Rv + sigma'(M) <= tight (1 + 2 (8.5/(M-1) -
-  // sigma'(Mg)/L)) (every edge is <= 2 Rv), and satisfies the band test at Mg:  |d . N/|N|| < |d| (rho pn Mg/M + qn)  — evaluated on
-  // n~ with pn_eff = pn (1 + KT / (L R)) >= pn + (the 2^-40 term of qn) / rho  (rho >= R) and L <= 2 tight.  A candidate is tested
-  // exactly when  within(tight) or (within(loose) and band(Mg)).  The cells list a triangle by its box grown by sigma'(M), as before.
   // Band test in normalised form: |d . N'| <= |d| (rho P + Q) <=> |d . N/|N|| <= |d| (rho pn + qn), pn = P/|N|, qn = Q/|N|, and
   // with 1/|N| = pn / (kP L):  qn = pn (kQ l1 l2 / (kP L) + 2^-40 / (kP L)) <= pn (KQ L + KT / L)   (l1 l2 <= L^2) — so the
   // record needs pn and L only.  The noise radius needs |a'| = |d . N'| >= (|d . n~| - |d| eps_n) |N| and |N| >= 0.98 kP L~/pn~.
+  // A triangle without a normal (|N| = 0: parallel edges) gets the record that passes every filter: n~ = 0, pn~ = the largest bfloat16.
   {
     double clo[3] = {1e300, 1e300, 1e300}, chi[3] = {-1e300, -1e300, -1e300};
     for (int i = 0; i < count; i++) {
@@ -363,7 +453,7 @@ inline TriPool build_tri_pool(const PtHittable* h, int count, TriPoolTuning tune
       if (b & 0xffffu) b += 0x10000u;
       return b >> 16;
     };
-    auto bf16_val = [](uint32_t h) { const uint32_t b = h << 16; float f; std::memcpy(&f, &b, 4); return f; };
+    auto bf16_val = [](uint32_t hh) { const uint32_t b = hh << 16; float f; std::memcpy(&f, &b, 4); return f; };
     std::vector<uint32_t> cq((size_t)count * 3, 0);
     double dev_c = 0, dev_n = 0;
     for (int i = 0; i < count; i++) {
@@ -383,23 +473,14 @@ inline TriPool build_tri_pool(const PtHittable* h, int count, TriPoolTuning tune
     tp.eps_c = (float)(dev_c * (1 + 1e-6) + 1e-37);
     tp.kq = (float)((Ma * 7.0 + 4.0) / (M * 17.5) * 1.001);
     tp.kt = (float)(std::ldexp(1.0, -40) / (M * 17.5 * u * SAFE) * 1.02);
-    const double Mg = std::max(M, (double)tune.Mg);
-    const double sig_g = (6.0 / Mg + 6.0 / Ma + 1.2 / (Mg - 1.0)) * (1 + 8 * u); // sigma'(Mg) / L
-    tp.k_loose = (float)((1.0 + 2.0 * std::max(0.0, 8.5 / (M - 1.0) - sig_g)) * (1 + 1e-6));
-    tp.m_scale = (float)(Mg / M * (1 + 1e-6));
-    tp.grid_q.assign((size_t)count * 2, 0);
-    tp.grid_n.assign((size_t)count * 2, 0);
     tp.band_q.assign((size_t)count * 4, 0);
-    std::vector<double> nq_dev((size_t)count, 0.0);
     for (int i = 0; i < count; i++) {
-      if (dead[(size_t)i]) continue;
+      if (dead[(size_t)i]) continue; // (an all-zero record: pn~ = L~ = 0 makes the band test compare against a NaN, which fails)
       const uint32_t* c3 = &cq[(size_t)i * 3];
-      const double Ld = tp.ball[(size_t)i * 4 + 3];
-      const float rg = (float)((rv_of[(size_t)live_index[(size_t)i]] + sig_g * Ld) * (1 + 8 * u) + tp.ball_abs + tp.eps_c);
-      tp.grid_q[(size_t)i * 2] = c3[0] | (c3[1] << 16);
-      tp.grid_q[(size_t)i * 2 + 1] = c3[2] | (bf16_up(rg * (1 + 2e-7f)) << 16);
-      tp.grid_n[(size_t)i * 2 + 1] = 0x7f7fu << 16; // (|N| = 0: no direction — the band test at Mg always passes)
-      if (!(pn[(size_t)i] < 1e30)) continue; // (|N| = 0: always list, exact records)
+      const uint32_t Lh = bf16_up(tp.ball[(size_t)i * 4 + 3]);
+      tp.band_q[(size_t)i * 4 + 2] = c3[0] | (c3[1] << 16);
+      tp.band_q[(size_t)i * 4 + 3] = c3[2] | (Lh << 16);
+      if (!(pn[(size_t)i] < 1e30)) { tp.band_q[(size_t)i * 4 + 1] = 0x7f7fu << 16; continue; } // no (usable) normal: passes every filter
       int32_t nq[3];
       double d2 = 0;
       for (int k = 0; k < 3; k++) {
@@ -407,21 +488,45 @@ inline TriPool build_tri_pool(const PtHittable* h, int count, TriPoolTuning tune
         d2 += (nq[k] / 32767.0 - nrm[(size_t)i * 3 + k]) * (nq[k] / 32767.0 - nrm[(size_t)i * 3 + k]);
       }
       dev_n = std::max(dev_n, std::sqrt(d2));
-      const uint32_t pnh = bf16_up((float)(pn[(size_t)i] * (1 + 1e-6))), Lh = bf16_up(tp.ball[(size_t)i * 4 + 3]);
-      {
-        const double pe = pn[(size_t)i] * (1.0 + (double)tp.kt / (Ld * std::max(R, 1e-30))) * (1 + 1e-6);
-        tp.grid_n[(size_t)i * 2] = ((uint32_t)nq[0] & 0xffffu) | ((uint32_t)nq[1] << 16);
-        tp.grid_n[(size_t)i * 2 + 1] = ((uint32_t)nq[2] & 0xffffu) | ((pe < 3e38 ? bf16_up((float)pe) : 0x7f7fu) << 16);
-      }
+      const uint32_t pnh = bf16_up((float)(pn[(size_t)i] * (1 + 1e-6)));
       tp.band_q[(size_t)i * 4] = ((uint32_t)nq[0] & 0xffffu) | ((uint32_t)nq[1] << 16);
       tp.band_q[(size_t)i * 4 + 1] = ((uint32_t)nq[2] & 0xffffu) | (pnh << 16);
-      tp.band_q[(size_t)i * 4 + 2] = c3[0] | (c3[1] << 16);
-      tp.band_q[(size_t)i * 4 + 3] = c3[2] | (Lh << 16);
       // the closed form really bounds this triangle's qn (and pn~, L~ are finite): otherwise no pool
       const double pnv = bf16_val(pnh), Lv = bf16_val(Lh);
       if (!(pnv < 1e30 && Lv < 1e30 && qn[(size_t)i] * (1 + 8 * u) <= pnv * ((double)tp.kq * Lv + (double)tp.kt / Lv))) return tp;
     }
     tp.eps_n = (float)(dev_n * (1 + 1e-6) + 3e-6); // + the binary32 rounding of d . (kx, ky, kz) / 32767 and of N'/|N'| against N/|N|
+  }
+  // ---- (2) the direction maps ------------------------------------------------------------------------------------------------
+  // class k: rays with rho <= rho_max_k; triangle i is listed by tau_i = rho_max_k pn_i + qn_i (what the real band test admits for such a ray)
+  {
+    int T = tune.threads > 0 ? tune.threads : (int)std::thread::hardware_concurrency();
+    T = std::max(1, std::min(T, 16));
+    long long budget = tune.dm_budget;
+    std::vector<double> tau((size_t)count, 0.0);
+    for (int k = 0; k < 2; k++) {
+      if (!(tune.dm_rho[k] > 0.0f) || tune.dm_res[k] < 4) continue;
+      const double rho_max = (double)tune.dm_rho[k] * R;
+      if (!tp.maps.empty() && !(rho_max > tp.maps.back().rho_max)) continue;
+      int wide = 0;
+      for (int i = 0; i < count; i++) {
+        if (dead[(size_t)i]) continue;
+        tau[(size_t)i] = pn[(size_t)i] < 1e30 ? (rho_max * pn[(size_t)i] + qn[(size_t)i]) * (1 + 1e-6) + 1e-9 : INFINITY;
+        if (!(tau[(size_t)i] < 1.0)) wide++;
+      }
+      if (tp.maps.empty()) tp.wide = wide;
+      for (int res = std::min(1024, tune.dm_res[k]); res >= 16; res /= 2) { // a map over budget is tried at half the resolution
+        if (count >= 65536) { // (a cheap estimate first — every 32nd triangle — so that a hopeless resolution does not cost a full counting pass)
+          std::vector<uint32_t> sample;
+          for (int p = 0; p < count; p += 32) sample.push_back(tp.order[(size_t)p]);
+          TriDirMap probe;
+          if (!build_dir_map(probe, res, nrm, tau, dead, (int)sample.size(), sample, budget / 24, 1)) continue;
+        }
+        TriDirMap dm;
+        dm.rho_max = (float)(rho_max * (1 - 1e-6));
+        if (build_dir_map(dm, res, nrm, tau, dead, count, tp.order, budget, T)) { budget -= (long long)dm.cand.size(); tp.maps.push_back(std::move(dm)); break; }
+      }
+    }
   }
   tp.ok = true;
   return tp;

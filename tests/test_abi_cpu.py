@@ -144,8 +144,8 @@ def test_flatten_slab_pools(lib):
     assert pool[4].tolist()[:3] == [0, 4, 2] and pool[5].tolist()[:3] == [1, 4, 5.5]    # xz_rect: x, the plane y = 4, z
     assert pool[8 + 4].tolist()[:3] == [0, 4, 2] and pool[8 + 5, 1] == -np.inf and pool[8 + 5, 0] == 1 and pool[8 + 5, 2] == 5.5
     ids = pool[8::2].view(np.int32)[:, 3]
-    assert (ids >> 27).tolist() == [3, 3, 1, 3]
-    assert (ids & 0xffffff).tolist() == [runs[0, 1], runs[0, 1] + 2, runs[1, 1], runs[2, 1]]
+    assert (ids >> 28).tolist() == [3, 3, 1, 3]              # hit_pack: kind at bit 28, 25-bit record offsets (round 5)
+    assert (ids & 0x1ffffff).tolist() == [runs[0, 1], runs[0, 1] + 2, runs[1, 1], runs[2, 1]]
     for r in (1, 2):
         assert blob[runs[r, 1] - 1].view(np.int32)[1] == 0                                # members, not heads
     assert blob[runs[4, 1] - 1].view(np.int32)[1] == 0                                    # a single box: not worth it

@@ -3,17 +3,21 @@ of the reference's Moller-Trumbore test (triangle.hpp:58-100: same operations, s
 for adversarial rays that lie almost in a triangle's plane:
 
   every (ray, triangle) pair the emulated test accepts is either GRAZING by the pool's own band test
-  (|d . N'_i| < |d| (rho P_i + Q_i): it is then a band / always-list candidate), or NOT grazing and then
-  (a) the exact line-plane point, clamped onto the forward ray, lies inside the triangle's box grown by sigma'_i
-      (so the grid cell that contains that point lists the triangle), and
+  (|d . N'_i| < |d| (rho P_i + Q_i): it is then listed in the bin of the ray's direction in the direction map of its rho class), or
+  NOT grazing and then
+  (a) the exact line-plane point, clamped onto the forward ray, lies inside the triangle's box grown by sigma'_i AND within sigma'_i of
+      its plane (so the grid cell that contains that point lists the triangle), and
   (b) the computed t is within kappa (relative) + 1.2 L_i / ((M - 1) |d|) of the exact parameter (so the walk's range
       [0, closest (1 + kappa)] reaches that cell);
-  and in every case the ray's LINE passes within the radius the two distance filters allow of the centroid.
+  and in every case the ray's LINE passes within the radius the noise filter allows of the centroid.
 
-The GPU suite then checks the walked structure end to end against the oracle, bit for bit (tests/test_gpu_fuzz.py)."""
+The tables themselves (pt_debug_flatten / pt_debug_flatten_pool: what pt_scene_create uploads) are then checked against these
+definitions — the grid's cell lists, the direction maps' bins, the compressed band records.  The GPU suite checks the walked structure
+end to end against the oracle, bit for bit (tests/test_gpu_fuzz.py)."""
 import ctypes as C
 
 import numpy as np
+import pytest
 
 from path_tracer_amd import abi, scenes
 from path_tracer_amd.scene import hittable_dtype
@@ -21,7 +25,7 @@ from path_tracer_amd.scene import hittable_dtype
 f32 = np.float32
 U = 2.0 ** -24
 M, MA, SAFE = 12.0, 256.0, 1.5   # pt_tripool.hpp: TriPoolTuning defaults and SAFE
-MG = 96.0                        # the grid's tight slack (TriPoolTuning::Mg)
+SIG_PER_L = 6 / M + 6 / MA + 1.2 / (M - 1)
 
 
 def cross32(a, b):
@@ -34,31 +38,104 @@ def dot32(a, b):
     return (((a[..., 0] * b[..., 0]).astype(f32) + (a[..., 1] * b[..., 1]).astype(f32)).astype(f32) + (a[..., 2] * b[..., 2]).astype(f32)).astype(f32)
 
 
-def test_accepted_pairs_are_band_or_grid_candidates():
-    ps, _ = scenes.triangle_mesh_scene(n_triangles=20_000)
+class Pool:
+    """The pool's header and tables, parsed back out of what the flattener produces (host-only)."""
+
+    def __init__(self, lib, ps, tuning=None):
+        n_f4, n_runs, flags = C.c_int32(), C.c_int32(), C.c_int32()
+        FP = C.POINTER(C.c_float)
+        tp = C.byref(tuning) if tuning is not None else None
+        abi.check(lib.pt_debug_flatten_tuned(C.byref(ps.desc), tp, None, 0, C.byref(n_f4), C.byref(n_runs), None, 0, C.byref(flags)), "pt_debug_flatten")
+        blob = np.zeros((n_f4.value, 4), f32)
+        abi.check(lib.pt_debug_flatten_tuned(C.byref(ps.desc), tp, blob.ctypes.data_as(FP), len(blob), C.byref(n_f4), C.byref(n_runs), None, 0, C.byref(flags)), "pt_debug_flatten")
+        assert flags.value & 4, "no triangle pool"
+        n_pool = C.c_int64()
+        abi.check(lib.pt_debug_flatten_pool(C.byref(ps.desc), tp, None, 0, C.byref(n_pool)), "pt_debug_flatten_pool")
+        pool = np.zeros((n_pool.value, 4), f32)
+        abi.check(lib.pt_debug_flatten_pool(C.byref(ps.desc), tp, pool.ctypes.data_as(FP), len(pool), C.byref(n_pool)), "pt_debug_flatten_pool")
+        self.blob, self.pool = blob, pool
+        bi = blob.view(np.int32)
+        self.pu = pool.view(np.uint32).reshape(-1)
+        tri = [r for r in bi[:n_runs.value] if r[0] == 2][0]
+        self.first, self.count = int(tri[1]), int(tri[2])
+        assert bi[self.first - 1][0] == 1
+        hdr = int(bi[self.first - 1][1])
+        self.H, self.Hi = blob[hdr:hdr + 11], bi[hdr:hdr + 11]
+        H, Hi = self.H, self.Hi
+        self.origin, self.inv_cell = H[0][:3].astype(np.float64), float(H[0][3])
+        self.n = [int(x) for x in Hi[1][:3]]
+        self.cell = float(H[1][3])
+        self.centre, self.R = H[2][:3].astype(np.float64), float(H[2][3])
+        self.rlimit2, self.kappa, self.n_tri, self.n_maps = float(H[3][0]), float(H[3][1]), int(Hi[3][2]), int(Hi[3][3])
+        self.cell_first, self.cell_cand, self.tri_sorted, self.band = [int(x) & 0xffffffff for x in Hi[4]]
+        self.kq, self.p_per_L, self.kt = float(H[5][1]), float(H[5][2]), float(H[5][3])
+        self.cq_lo, self.eps_c = H[7][:3], float(H[7][3])
+        self.cq_step, self.eps_n = H[8][:3], float(H[8][3])
+        self.maps = [dict(R=int(Hi[9 + k][0]), rho_max=float(H[9 + k][1]), first=int(Hi[9 + k][2]) & 0xffffffff, cand=int(Hi[9 + k][3]) & 0xffffffff)
+                     for k in range(self.n_maps)]
+        srt = pool[self.tri_sorted: self.tri_sorted + 3 * self.count].reshape(self.count, 3, 4)
+        self.sorted_recs = srt
+        self.orig = srt[:, 2, 3].view(np.int32).astype(np.int64)            # Morton position -> triangle index in the run
+        self.pos_of = np.empty(self.count, np.int64)
+        self.pos_of[self.orig] = np.arange(self.count)
+        ncell = self.n[0] * self.n[1] * self.n[2]
+        self.cf = self.pu[4 * self.cell_first: 4 * self.cell_first + ncell + 1].astype(np.int64)
+        raw = self.pu[4 * self.cell_cand: 4 * self.cell_cand + int(self.cf[-1])].astype(np.int64)
+        self.cc = raw & 0x3ffffff        # position in the Morton-ordered copy
+        self.cc_bits = raw >> 26         # which of the six face neighbours list the triangle too (-x +x -y +y -z +z)
+
+    def cell_list(self, ix, iy, iz):
+        c = (iz * self.n[1] + iy) * self.n[0] + ix
+        return self.cc[self.cf[c]:self.cf[c + 1]]
+
+    def bin_list(self, k, d):
+        """The device's bin of direction d (binary32, as tri_pool_scan computes it) in map k: Morton positions listed there."""
+        m = self.maps[k]
+        R = m["R"]
+        d = d.astype(f32)
+        ad = np.abs(d)
+        face = 0 if (ad[0] >= ad[1] and ad[0] >= ad[2]) else (1 if ad[1] >= ad[2] else 2)
+        dk, da, db = d[face], d[(face + 1) % 3], d[(face + 2) % 3]
+        rk = f32(1.0) / dk
+        ci = int(min(max(np.floor((f32(da * rk) + f32(1.0)) * f32(0.5 * R)), 0), R - 1))
+        cj = int(min(max(np.floor((f32(db * rk) + f32(1.0)) * f32(0.5 * R)), 0), R - 1))
+        b = (face * R + cj) * R + ci
+        fr = self.pu[4 * m["first"] + b: 4 * m["first"] + b + 2].astype(np.int64)
+        return self.pu[4 * m["cand"] + fr[0]: 4 * m["cand"] + fr[1]].astype(np.int64)
+
+
+def mesh_arrays(ps):
     h = np.frombuffer(ps.hittables, dtype=hittable_dtype)
     f = h["f"][1:-1].astype(f32)
     v0 = f[:, 0:3]
     e1, e2 = (f[:, 3:6] - v0).astype(f32), (f[:, 6:9] - v0).astype(f32)
+    return v0, e1, e2
+
+
+def test_accepted_pairs_are_band_or_grid_candidates(lib):
+    ps, _ = scenes.triangle_mesh_scene(n_triangles=20_000)
+    pool = Pool(lib, ps)
+    assert pool.n_maps == 2 and pool.count == 20_000
+    v0, e1, e2 = mesh_arrays(ps)
     e1d, e2d, v0d = e1.astype(np.float64), e2.astype(np.float64), v0.astype(np.float64)
     Nd = np.cross(e1d, e2d)
+    nN = np.linalg.norm(Nd, axis=1)
+    nh_all = Nd / nN[:, None]
     l1, l2 = np.linalg.norm(e1d, axis=1), np.linalg.norm(e2d, axis=1)
     L = np.maximum(l1, l2)
     P = M * 17.5 * U * L * SAFE
     Q = (MA * 7 + 4) * U * l1 * l2 * SAFE + 2.0 ** -40
-    sig = 8.5 * L / (M - 1)
-    Pg = MG * 17.5 * U * L * SAFE                       # the grid's TIGHT radius: pairs with |a^| >= thr(MG)
-    sig_g = (6 / MG + 6 / MA + 1.2 / (MG - 1)) * L
+    sig = SIG_PER_L * L
     centre = v0d.mean(0)
     R = np.linalg.norm(v0d - centre, axis=1).max()
+    assert abs(R / pool.R - 1) < 1e-5 and np.allclose(centre, pool.centre, atol=1e-5)
     lo = np.minimum(np.minimum(v0d, v0d + e1d), v0d + e2d)
     hi = np.maximum(np.maximum(v0d, v0d + e1d), v0d + e2d)
     cen = v0d + (e1d + e2d) / 3
-    rv = np.max(np.stack([np.linalg.norm(v0d - cen, axis=1), np.linalg.norm(v0d + e1d - cen, axis=1), np.linalg.norm(v0d + e2d - cen, axis=1)]), axis=0)
     Np = Nd.astype(f32).astype(np.float64)
     kr = 6 * SAFE * U * L * L * (17.5 + 7 * L / R)
     rng = np.random.default_rng(5)
-    stats = dict(accepted=0, band=0, grid=0, tight=0, loose=0)
+    stats = dict(accepted=0, band=0, grid=0, far=0)
 
     def check(o, d):
         o, d = o.astype(f32), d.astype(f32)
@@ -78,6 +155,7 @@ def test_accepted_pairs_are_band_or_grid_candidates():
         rho = np.linalg.norm(od - centre) + R
         ap = np.abs(Np @ dd)
         band = ap < dn * (rho * P + Q)
+        lists = {}
         for i in np.nonzero(ok)[0]:
             stats["accepted"] += 1
             # distance of the ray's line from the centroid
@@ -87,25 +165,26 @@ def test_accepted_pairs_are_band_or_grid_candidates():
                 a1 = ap[i] - 4 * U * L[i] * L[i] * dn
                 if a1 > 0:
                     assert dist_line <= L[i] + kr[i] * rho * dn / a1, ("noise-radius filter", i)
+                # ... and the pair is in the bin of this direction, in the map of the ray's rho class
+                k = next((k for k, m in enumerate(pool.maps) if rho * 1.000003 <= m["rho_max"]), None)
+                if k is None:
+                    stats["far"] += 1      # beyond the last class: the device streams every band record
+                    continue
+                if k not in lists:
+                    lists[k] = set(pool.bin_list(k, d).tolist())
+                assert int(pool.pos_of[i]) in lists[k], ("direction map", k, i)
                 continue
             stats["grid"] += 1
             a_ = -(dd @ Nd[i])
             th = (e2d[i] @ np.cross(od - v0d[i], e1d[i])) / a_
             Pp = od + max(th, 0.0) * dd
             assert np.max(np.maximum(np.maximum(lo[i] - Pp, Pp - hi[i]), 0)) <= sig[i], ("grown box", i)
+            assert abs(nh_all[i] @ (Pp - v0d[i])) <= sig[i], ("plane slab", i)
             assert abs(float(t[i]) - th) <= 2.2 / (MA - 1) * abs(th) + 1.2 * L[i] / ((M - 1) * dn) + 1e-12, ("t", i)
-            assert dist_line <= L[i] * (1 + 8.5 / (M - 1)), ("grid ball filter", i)
-            # the two-radius filter of the compressed grid records: not grazing at MG -> the walked point P' within Rv + sigma'(MG)
-            # of the centroid (tight); otherwise the pair passes the band test at MG by definition, and P' is within Rv + sigma'(M)
-            # <= (Rv + sigma'(MG)) (1 + 2 (8.5 / (M - 1) - sigma'(MG) / L)) (loose: every edge is <= 2 Rv)
-            assert L[i] <= 2 * rv[i] * (1 + 1e-12)
-            if ap[i] >= dn * (rho * Pg[i] + Q[i]):
-                stats["tight"] += 1
-                assert np.max(np.maximum(np.maximum(lo[i] - Pp, Pp - hi[i]), 0)) <= sig_g[i], ("tight box", i)
-                assert np.linalg.norm(Pp - cen[i]) <= rv[i] + sig_g[i], ("tight ball", i)
-            else:
-                stats["loose"] += 1
-                assert np.linalg.norm(Pp - cen[i]) <= (rv[i] + sig_g[i]) * (1 + 2 * (8.5 / (M - 1) - sig_g[i] / L[i])), ("loose ball", i)
+            # the cell that contains P' lists the triangle
+            cxyz = np.floor((Pp - pool.origin) * pool.inv_cell).astype(int)
+            if np.all(cxyz >= 0) and np.all(cxyz < pool.n):
+                assert int(pool.pos_of[i]) in pool.cell_list(*cxyz), ("grid cell", i)
 
     for _ in range(60):
         o = rng.uniform([-3, 0, -3], [3, 3, 3])
@@ -121,21 +200,70 @@ def test_accepted_pairs_are_band_or_grid_candidates():
         d = (np.cos(ang) * t1 + np.sin(ang) * t2 + nh * 10 ** rng.uniform(-8, -2) * rng.choice([-1, 1])) * rng.uniform(0.3, 2)
         target = v0d[i] + rng.uniform(-0.2, 1.2) * e1d[i] + rng.uniform(-0.2, 1.2) * e2d[i] + rng.normal(size=3) * 10 ** rng.uniform(-7, -3)
         check(target - d / np.linalg.norm(d) * rng.uniform(0.01, 12), d)
-    assert stats["accepted"] > 3000 and stats["band"] > 20 and stats["grid"] > 2000 and stats["tight"] > 1500 and stats["loose"] > 50, stats
+    for _ in range(60):    # ... and from far away (the second rho class and beyond)
+        i = int(rng.integers(n))
+        nh = Nd[i] / max(np.linalg.norm(Nd[i]), 1e-300)
+        t1 = e1d[i] / l1[i]
+        d = (t1 + nh * 10 ** rng.uniform(-6, -2)) * rng.uniform(0.3, 2)
+        check(cen[i] - d / np.linalg.norm(d) * rng.uniform(15, 90), d)
+    assert stats["accepted"] > 3000 and stats["band"] > 20 and stats["grid"] > 2000, stats
+
+
+def test_direction_maps_list_every_triangle_a_direction_can_graze(lib):
+    """The maps against their definition: for random directions (and directions on bin borders and face edges) every triangle whose
+    REAL band test |d^ . n^_i| <= rho_max pn_i + qn_i can pass is listed in the device's bin of that direction — and the maps are not
+    trivially full."""
+    ps, _ = scenes.triangle_mesh_scene(n_triangles=6000, seed=3)
+    pool = Pool(lib, ps)
+    v0, e1, e2 = mesh_arrays(ps)
+    e1d, e2d = e1.astype(np.float64), e2.astype(np.float64)
+    Nd = np.cross(e1d, e2d)
+    nN = np.linalg.norm(Nd, axis=1)
+    nh = Nd / nN[:, None]
+    l1, l2 = np.linalg.norm(e1d, axis=1), np.linalg.norm(e2d, axis=1)
+    L = np.maximum(l1, l2)
+    pn = M * 17.5 * U * SAFE * L / nN
+    qn = ((MA * 7 + 4) * U * l1 * l2 * SAFE + 2.0 ** -40) / nN
+    rng = np.random.default_rng(8)
+    dirs = [rng.normal(size=3) for _ in range(300)]
+    for k, m in enumerate(pool.maps):   # directions that sit on bin borders and on the cube's edges / corners
+        R = m["R"]
+        for _ in range(100):
+            p, q = (rng.integers(0, R + 1, 2) * 2.0 / R - 1.0)
+            face = int(rng.integers(3))
+            d = np.zeros(3); d[face] = rng.choice([-1.0, 1.0]); d[(face + 1) % 3] = p * d[face]; d[(face + 2) % 3] = q * d[face]
+            dirs.append(d * rng.uniform(0.1, 3))
+    listed_share = []
+    for k, m in enumerate(pool.maps):
+        rho_max = m["rho_max"] * (1 + 2e-6)
+        tau = rho_max * pn + qn
+        for d in dirs:
+            d32 = np.asarray(d, f32)
+            dh = d32.astype(np.float64) / np.linalg.norm(d32.astype(np.float64))
+            graze = np.nonzero(np.abs(nh @ dh) <= tau)[0]
+            got = set(pool.bin_list(k, d32).tolist())
+            missing = [int(i) for i in graze if int(pool.pos_of[i]) not in got]
+            assert not missing, (k, d, missing[:5])
+            listed_share.append(len(got) / pool.count)
+    assert np.mean(listed_share) < 0.5
 
 
 def test_pool_thresholds_and_tables(lib, monkeypatch):
     """Long triangle runs (>= 4096) get a pool by default — the 100 k-triangle mesh of BASELINE config 5 does — shorter ones only
-    with PT_TRICULL=1 (>= 256: the fuzz fields), none with PT_NO_TRICULL; every triangle sits in exactly one of {three band
-    levels, always list}, and the blob grows by the inline candidate records."""
+    with PT_TRICULL=1 (>= 256: the fuzz fields), none with PT_NO_TRICULL; the tables live in a buffer of their own, the blob grows by
+    the pool's header only."""
     ps, _ = scenes.triangle_mesh_scene()
     st = (C.c_int32 * 8)()
     abi.check(lib.pt_debug_tri_pool(C.byref(ps.desc), st), "pt_debug_tri_pool")
-    assert st[0] == 100_000 and st[1] + st[2] + st[3] + st[4] == 100_000
-    assert 2000 < st[5] < 30000 and 1.5e7 < st[6] * 16 < 2.0e8
+    assert st[0] == 100_000 and 0 <= st[1] < 2000
+    assert st[2] > 10_000 and st[3] > 5_000 and (st[4] >> 16) == 128 and (st[4] & 0xffff) == 64      # both direction maps, in K entries
+    assert 5000 < st[5] < 100000 and st[6] * 16 < 5.0e6                                             # cells per triangle (x 1000); the blob stays the plain 4.8 MB
     n_f4, n_runs, flags = C.c_int32(), C.c_int32(), C.c_int32()
     abi.check(lib.pt_debug_flatten(C.byref(ps.desc), None, 0, C.byref(n_f4), C.byref(n_runs), None, 0, C.byref(flags)), "pt_debug_flatten")
     assert flags.value & 4 and n_runs.value == 3
+    n_pool = C.c_int64()
+    abi.check(lib.pt_debug_flatten_pool(C.byref(ps.desc), None, None, 0, C.byref(n_pool)), "pt_debug_flatten_pool")
+    assert 1.0e8 < n_pool.value * 16 < 3.0e9
     small, _ = scenes.triangle_mesh_scene(n_triangles=1000)
     abi.check(lib.pt_debug_tri_pool(C.byref(small.desc), st), "pt_debug_tri_pool")
     assert st[0] == 0                       # 1000 triangles: full scan by default
@@ -146,115 +274,114 @@ def test_pool_thresholds_and_tables(lib, monkeypatch):
     for sc in (ps, small):
         abi.check(lib.pt_debug_tri_pool(C.byref(sc.desc), st), "pt_debug_tri_pool")
         assert list(st)[:6] == [0] * 6
-    abi.check(lib.pt_debug_tri_pool(C.byref(ps.desc), st), "pt_debug_tri_pool")
-    assert st[6] * 16 < 5.0e6               # the plain blob: 4.8 MB
+        abi.check(lib.pt_debug_flatten_pool(C.byref(sc.desc), None, None, 0, C.byref(n_pool)), "pt_debug_flatten_pool")
+        assert n_pool.value == 0
 
 
-def test_meshes_too_large_for_a_pool_fall_back_to_the_plain_blob(lib):
-    """the pool's tables ride in the blob (~17 records of 16 bytes per triangle beside the triangle's own 3) and
-    record offsets are 24 bits, so a mesh of a million triangles — which flattens to 50 MB without a pool and rendered fine before
-    round 3 — must not fail with PT_ERR_TOO_LARGE because the pool is on by default: it is flattened WITHOUT a pool."""
-    ps, _ = scenes.triangle_mesh_scene(n_triangles=1_050_000)
+def test_large_meshes_keep_their_pool(lib):
+    """rounds 3-4 kept the pool's tables in the blob, whose 24-bit record offsets are hit-id bits — a
+    mesh beyond ~830 k triangles lost its pool (8x slower class), one beyond 5.5 M failed to flatten.  The tables now live in their own
+    buffer (32-bit offsets of 16-byte records) and hit ids carry 25-bit offsets: a 2 M-triangle mesh is pooled (its direction maps
+    within a small budget here, to keep the CPU suite quick), and the plain blob of a 6 M-triangle mesh fits."""
+    ps, _ = scenes.triangle_mesh_scene(n_triangles=2_000_000)
     st = (C.c_int32 * 8)()
-    abi.check(lib.pt_debug_tri_pool(C.byref(ps.desc), st), "pt_debug_tri_pool")
-    assert st[0] == 0                                           # no pool
-    assert 1_050_000 * 3 < st[6] < 1_050_000 * 3 + 64           # the plain blob: three records per triangle + headers
-    assert st[6] < (1 << 24)
+    t = abi.tuning(tri_budget_mb=64)
+    n_f4, n_runs, flags = C.c_int32(), C.c_int32(), C.c_int32()
+    abi.check(lib.pt_debug_flatten_tuned(C.byref(ps.desc), C.byref(t), None, 0, C.byref(n_f4), C.byref(n_runs), None, 0, C.byref(flags)), "pt_debug_flatten_tuned")
+    assert flags.value & 4                                        # tri_pooled
+    assert 2_000_000 * 3 < n_f4.value < 2_000_000 * 3 + 64        # the blob: three records per triangle + headers
+    n_pool = C.c_int64()
+    abi.check(lib.pt_debug_flatten_pool(C.byref(ps.desc), C.byref(t), None, 0, C.byref(n_pool)), "pt_debug_flatten_pool")
+    assert n_pool.value > 2_000_000 * 4
+    del ps
+    big, _ = scenes.triangle_mesh_scene(n_triangles=6_000_000)
+    t = abi.tuning(tri_pool=-1)
+    abi.check(lib.pt_debug_flatten_tuned(C.byref(big.desc), C.byref(t), None, 0, C.byref(n_f4), C.byref(n_runs), None, 0, C.byref(flags)), "pt_debug_flatten_tuned")
+    assert (1 << 24) < 6_000_000 * 3 < n_f4.value < (1 << 25)
 
 
-def test_compressed_filter_records_round_to_the_safe_side(lib, monkeypatch):
-    """The device streams QUANTISED filter records (pt_tripool.hpp "compressed records").  Parse them back out of the flattened
-    blob of a 3000-triangle field and check every one against the triangle it stands for: centroid within eps_c, unit normal within
-    eps_n, tight radius >= Rv + sigma'(MG) L, pn_eff >= pn (1 + KT / (L R)), band pn >= pn, L >= L, and the closed form
-    pn (KQ L + KT / L) >= qn; the Morton-ordered copy is a permutation of the run's records that remembers each triangle's index."""
+def test_compressed_band_records_round_to_the_safe_side(lib, monkeypatch):
+    """The device gathers QUANTISED band records (pt_tripool.hpp "compressed records").  Parse them back out of the pool of a
+    3000-triangle field and check every one against the triangle it stands for: centroid within eps_c, unit normal within eps_n,
+    pn >= pn, L >= L, and the closed form pn (KQ L + KT / L) >= qn; the Morton-ordered copy is a permutation of the run's records that
+    remembers each triangle's index; cell lists and bins ascend in it."""
     monkeypatch.setenv("PT_TRICULL", "1")
     ps, _ = scenes.triangle_mesh_scene(n_triangles=3000, seed=77)
-    n_f4, n_runs, flags = C.c_int32(), C.c_int32(), C.c_int32()
-    abi.check(lib.pt_debug_flatten(C.byref(ps.desc), None, 0, C.byref(n_f4), C.byref(n_runs), None, 0, C.byref(flags)), "pt_debug_flatten")
-    blob = np.zeros((n_f4.value, 4), f32)
-    FP = C.POINTER(C.c_float)
-    abi.check(lib.pt_debug_flatten(C.byref(ps.desc), blob.ctypes.data_as(FP), len(blob), C.byref(n_f4), C.byref(n_runs), None, 0, C.byref(flags)), "pt_debug_flatten")
-    assert flags.value & 4
-    bi = blob.view(np.int32)
-    bu = blob.view(np.uint32).reshape(-1)
-    runs = bi[:n_runs.value]
-    tri = [r for r in runs if r[0] == 2][0]
-    first, count = int(tri[1]), int(tri[2])
-    assert bi[first - 1][0] == 1
-    hdr = int(bi[first - 1][1])
-    H = blob[hdr:hdr + 10]
-    Hi = bi[hdr:hdr + 10]
-    cell_first, cell_cand, tri_sorted, cell_q = [int(x) for x in Hi[4]]
-    kq, p_per_L, kt = float(H[5][1]), float(H[5][2]), float(H[5][3])
-    cq_lo, eps_c = H[7][:3].astype(np.float64), float(H[7][3])
-    cq_step, eps_n = H[8][:3].astype(np.float64), float(H[8][3])
-    k_loose, m_scale, cell_n = float(H[9][0]), float(H[9][1]), int(Hi[9][2])
-    assert abs(m_scale - MG / M) < 1e-3 and 2.0 < k_loose < 2.5
-    nx, ny, nz = [int(x) for x in Hi[1][:3]]
-    ncell = nx * ny * nz
-    cf = bu[4 * cell_first: 4 * cell_first + ncell + 1].astype(np.int64)
-    total = int(cf[-1])
-    pos = bu[4 * cell_cand: 4 * cell_cand + total].astype(np.int64)
-    gq = bu[4 * cell_q: 4 * cell_q + 2 * total].reshape(-1, 2)
-    gn = bu[4 * cell_n: 4 * cell_n + 2 * total].reshape(-1, 2)
-    srt = blob[tri_sorted: tri_sorted + 3 * count].reshape(count, 3, 4)
-    orig = srt[:, 2, 3].view(np.int32).astype(np.int64)
+    pool = Pool(lib, ps)
+    count, orig, srt = pool.count, pool.orig, pool.sorted_recs
     assert sorted(orig.tolist()) == list(range(count))                      # a permutation ...
-    recs = blob[first: first + 3 * count].reshape(count, 3, 4)
+    recs = pool.blob[pool.first: pool.first + 3 * count].reshape(count, 3, 4)
     assert np.array_equal(srt[:, :, :3], recs[orig][:, :, :3])               # ... of the run's own records (v0, edge1, edge2)
+    ncell = pool.n[0] * pool.n[1] * pool.n[2]
     for c in range(ncell):
-        assert np.all(np.diff(pos[cf[c]:cf[c + 1]]) > 0)                      # a cell's candidates ascend in the Morton copy
+        assert np.all(np.diff(pool.cc[pool.cf[c]:pool.cf[c + 1]]) > 0)        # a cell's candidates ascend in the Morton copy
+    # the neighbour bits of every entry against the lists themselves
+    nx, ny, nz = pool.n
+    sets = [set(pool.cc[pool.cf[c]:pool.cf[c + 1]].tolist()) for c in range(ncell)]
+    rng = np.random.default_rng(4)
+    for c in rng.integers(0, ncell, 300):
+        x, y, z = int(c % nx), int((c // nx) % ny), int(c // (nx * ny))
+        nbr = [(x > 0, c - 1), (x + 1 < nx, c + 1), (y > 0, c - nx), (y + 1 < ny, c + nx), (z > 0, c - nx * ny), (z + 1 < nz, c + nx * ny)]
+        for pos, bits in zip(pool.cc[pool.cf[c]:pool.cf[c + 1]], pool.cc_bits[pool.cf[c]:pool.cf[c + 1]]):
+            want = sum((1 << k) for k, (ok, c2) in enumerate(nbr) if ok and int(pos) in sets[int(c2)])
+            assert int(bits) == want, (c, int(pos), int(bits), want)
+    for m in pool.maps:
+        nb = 3 * m["R"] * m["R"]
+        fr = pool.pu[4 * m["first"]: 4 * m["first"] + nb + 1].astype(np.int64)
+        cand = pool.pu[4 * m["cand"]: 4 * m["cand"] + int(fr[-1])].astype(np.int64)
+        assert np.all(np.diff(fr) >= 0) and cand.max() < count
+        for b in np.random.default_rng(1).integers(0, nb, 400):
+            assert np.all(np.diff(cand[fr[b]:fr[b + 1]]) > 0)                 # a bin's candidates too
     # the triangles, in float64
     v0 = recs[:, 0, :3].astype(np.float64); e1 = recs[:, 1, :3].astype(np.float64); e2 = recs[:, 2, :3].astype(np.float64)
     N = np.cross(e1, e2); nN = np.linalg.norm(N, axis=1)
     l1, l2 = np.linalg.norm(e1, axis=1), np.linalg.norm(e2, axis=1)
     L = np.maximum(l1, l2)
     cen = (v0 + (e1 + e2) / 3).astype(f32).astype(np.float64)                # the rounded centroid the host measures from
-    rv = np.max(np.stack([np.linalg.norm(v0 - cen, axis=1), np.linalg.norm(v0 + e1 - cen, axis=1), np.linalg.norm(v0 + e2 - cen, axis=1)]), axis=0)
-    centre = H[2][:3].astype(np.float64); R = float(H[2][3])
     pn = M * 17.5 * U * SAFE * L / nN
     qn = ((MA * 7 + 4) * U * l1 * l2 * SAFE + 2.0 ** -40) / nN
-    sig_g = (6 / MG + 6 / MA + 1.2 / (MG - 1)) * L
     bf = lambda hi16: (hi16.astype(np.uint32) << 16).view(f32).astype(np.float64)
     s16 = lambda v: ((v.astype(np.int64) & 0xffff) ^ 0x8000) - 0x8000
-    t = orig[pos]                                                            # the triangle of every grid entry
-    lo32, st32 = H[7][:3].astype(f32), H[8][:3].astype(f32)
+    lo32, st32 = pool.cq_lo.astype(f32), pool.cq_step.astype(f32)
     dec = lambda kx, ky, kz: np.stack([(lo32[a] + (k.astype(f32) * st32[a]).astype(f32)).astype(f32) for a, k in enumerate((kx, ky, kz))], -1).astype(np.float64)  # the device's binary32 decode
-    C_dec = dec(gq[:, 0] & 0xffff, gq[:, 0] >> 16, gq[:, 1] & 0xffff)
-    dev = np.linalg.norm(C_dec - cen[t], axis=1)
-    assert np.all(dev <= eps_c * (1 + 1e-6) + 1e-12), (dev.max(), eps_c, int(np.argmax(dev)), cq_step)
-    assert np.all(bf(gq[:, 1] >> 16) >= rv[t] + sig_g[t] + eps_c)
-    n_dec = np.stack([s16(gn[:, 0]), s16(gn[:, 0] >> 16), s16(gn[:, 1])], -1) / 32767.0
-    assert np.all(np.linalg.norm(n_dec - N[t] / nN[t][:, None], axis=1) <= eps_n)
-    assert np.all(bf(gn[:, 1] >> 16) >= pn[t] * (1 + kt / (L[t] * R)))
-    # band records of the three levels (both orientations)
-    n_band = 0
-    for lv in range(3):
-        T = bi[hdr + 10 + 3 * lv: hdr + 13 + 3 * lv]
-        Rl = int(T[0][0])
-        for o in (1, 2):
-            tf, tc, tr = [int(x) for x in T[o][:3]]
-            nc = 3 * Rl * Rl
-            fr = bu[4 * tf: 4 * tf + nc + 1].astype(np.int64)
-            k = int(fr[-1])
-            idx = orig[bu[4 * tc: 4 * tc + k].astype(np.int64)]     # (listed by position in the Morton copy, like the grid's)
-            q = bu[4 * tr: 4 * tr + 4 * k].reshape(-1, 4)
-            nd = np.stack([s16(q[:, 0]), s16(q[:, 0] >> 16), s16(q[:, 1])], -1) / 32767.0
-            assert np.all(np.linalg.norm(nd - N[idx] / nN[idx][:, None], axis=1) <= eps_n)
-            pq, Lq = bf(q[:, 1] >> 16), bf(q[:, 3] >> 16)
-            assert np.all(pq >= pn[idx]) and np.all(pq <= pn[idx] * 1.01) and np.all(Lq >= L[idx]) and np.all(Lq <= L[idx] * 1.01)
-            assert np.all(pq * (kq * Lq + kt / Lq) >= qn[idx])
-            Cd = dec(q[:, 2] & 0xffff, q[:, 2] >> 16, q[:, 3] & 0xffff)
-            assert np.all(np.linalg.norm(Cd - cen[idx], axis=1) <= eps_c * (1 + 1e-6) + 1e-12)
-            n_band += k
-    assert total > 3000 and n_band > 3000
+    q = pool.pu[4 * pool.band: 4 * pool.band + 4 * count].reshape(-1, 4)     # in Morton order
+    idx = orig
+    nd = np.stack([s16(q[:, 0]), s16(q[:, 0] >> 16), s16(q[:, 1])], -1) / 32767.0
+    assert np.all(np.linalg.norm(nd - N[idx] / nN[idx][:, None], axis=1) <= pool.eps_n)
+    pq, Lq = bf(q[:, 1] >> 16), bf(q[:, 3] >> 16)
+    assert np.all(pq >= pn[idx]) and np.all(pq <= pn[idx] * 1.01) and np.all(Lq >= L[idx]) and np.all(Lq <= L[idx] * 1.01)
+    assert np.all(pq * (pool.kq * Lq + pool.kt / Lq) >= qn[idx])
+    Cd = dec(q[:, 2] & 0xffff, q[:, 2] >> 16, q[:, 3] & 0xffff)
+    assert np.all(np.linalg.norm(Cd - cen[idx], axis=1) <= pool.eps_c * (1 + 1e-6) + 1e-12)
+    assert int(pool.cf[-1]) > 3000
+
+
+def test_triangles_without_a_normal_and_dead_ones(lib, monkeypatch):
+    """Edges that are parallel (|N| = 0) leave no direction to index: such a triangle is listed in every bin with the record that passes
+    every filter; a triangle with an edge of zero length can never be accepted (a = +-0 for every ray) and is in no table."""
+    monkeypatch.setenv("PT_TRICULL", "1")
+    ps, _ = scenes.triangle_mesh_scene(n_triangles=400, seed=5)
+    h = np.frombuffer(ps.hittables, dtype=hittable_dtype)
+    f = h["f"]
+    f[10, 3:6] = f[10, 0:3] + f32([0.1, 0.0, 0.0]); f[10, 6:9] = f[10, 0:3] + f32([0.25, 0.0, 0.0])     # parallel edges
+    f[11, 3:6] = f[11, 0:3]                                                                              # a zero edge
+    pool = Pool(lib, ps)
+    p10, p11 = int(pool.pos_of[9]), int(pool.pos_of[10])                     # (hittable 0 is the ground sphere: run index = hittable - 1)
+    q = pool.pu[4 * pool.band: 4 * pool.band + 4 * pool.count].reshape(-1, 4)
+    assert (q[p10, 1] >> 16) == 0x7f7f and (q[p10, 0] == 0)
+    assert np.all(q[p11] == 0)
+    rng = np.random.default_rng(2)
+    for _ in range(50):
+        got = pool.bin_list(0, rng.normal(size=3).astype(f32))
+        assert p10 in got and p11 not in got
+    assert p11 not in pool.cc
 
 
 def test_integer_band_test_is_conservative():
     """Stage 1 of the band filter (pt_device.hpp: band_stage1) evaluates |d^ . n^| in integers: n^ and the ray's unit direction are
     rounded to k / 32767 per component and S = kn . kd is exact (two v_dot2_i32_i16).  Whenever the real band condition
     |d^ . n^| <= thr holds, the device's comparison  |S| <= (thr + eps_n + eps_d) * 32767^2 (1 + 2e-5)  must hold — emulated here in
-    binary32 for random and for barely-inside pairs, with thr across the range of the three levels; and |S| stays below 2^31."""
+    binary32 for random and for barely-inside pairs, with thr across the range of band widths; and |S| stays below 2^31."""
     rng = np.random.default_rng(11)
     n_pairs = 400_000
     n = rng.normal(size=(n_pairs, 3)); n /= np.linalg.norm(n, axis=1)[:, None]

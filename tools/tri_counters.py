@@ -1,6 +1,6 @@
 """Counters of the triangle pool from a diagnostic build (make -C path_tracer_amd/csrc stamps EXTRA=-DPT_STAMPS_TRI):
     PT_RENDER_LIB=path_tracer_amd/libpt_stamps.so python tools/tri_counters.py [spp] [width height]
-per ray: grid tests, band (cheap) tests, exact tests from the band / always list; lanes busy per trip; fallbacks."""
+per ray: grid cells and exact tests, direction-map entries, survivors of the two band stages; rays per rho class."""
 import ctypes as C, os, sys
 os.environ.setdefault('PT_TRICULL', '1')
 from pathlib import Path
@@ -17,26 +17,27 @@ cam = scenes.make_camera(cam_args, W, H)
 ds = R.DeviceScene(packed)
 st = (C.c_int32 * 8)()
 lib.pt_debug_tri_pool(C.byref(packed.desc), st)
-print("pool: triangles", st[0], "always", st[1], "levels", list(st)[2:5], "cells per triangle", st[5] / 1000, "blob MB", st[6] * 16 / 1e6)
+print("pool: triangles", st[0], "wide", st[1], "map entries (K)", list(st)[2:4], "map resolutions", st[4] >> 16, st[4] & 0xffff, "cells per triangle", st[5] / 1000, "blob MB", st[6] * 16 / 1e6)
 R.render(W, H, 1, ds, cam, flags=abi.PT_FLAG_NO_LPT); torch.cuda.synchronize()
 lib.pt_debug_tri(None, 1)
 fb, ms = R.render(W, H, spp, ds, cam, flags=abi.PT_FLAG_NO_LPT, timed=True)
 o = (C.c_ulonglong * 12)()
 lib.pt_debug_tri(o, 0)
-scans, rays, grid, alw, lanes, b0, b1, b2 = [o[i] for i in range(8)]
-rays = max(rays, 1)
-print(f"{W}x{H}x{spp}: {ms:.1f} ms = {W*H*spp/ms/1e3:.2f} Msamples/s; wave scans {scans:.3e}, live rays per scan {rays/max(scans,1):.1f}")
-print(f"per ray: grid survivors (exact tests) {o[8]/rays:.1f}; band: past the integer band test {o[10]/rays:.1f}, survivors (exact tests) {o[9]/rays:.1f}")
-print(f"per ray: always list: pairs past the band test {o[7]/rays:.1f}, exact tests {o[11]/rays:.1f} (band trips of levels 1 and 2 are counted together)")
-print(f"per ray: grid rounds {grid/rays:.1f}; band trips level 0 / levels 1 + 2: {b0/rays:.1f} / {b1/rays:.1f} (lanes busy per trip {lanes/max(b0+b1,1):.1f}); grid cells visited {alw/rays:.1f}")
+# [0] scans [1] live rays [2] grid wave-steps [3] grid lane-steps [4] grid pairs (exact tests) [5] grid batches [6] map entries enumerated
+# [7] past the integer band test [8] past the noise radius (exact tests) [9] rays through the second map [10] rays that streamed everything [11] band trips
+scans, rays = max(o[0], 1), max(o[1], 1)
+print(f"{W}x{H}x{spp}: {ms:.1f} ms = {W*H*spp/ms/1e3:.2f} Msamples/s; wave scans {scans:.3e}, live rays per scan {rays/scans:.1f}")
+print(f"grid, per ray: cells visited {o[3]/rays:.1f}, exact tests {o[4]/rays:.1f}; per scan: wave-steps {o[2]/scans:.1f} (lanes per step {o[3]/max(o[2],1):.1f}), batches {o[5]/scans:.1f} (pairs per batch {o[4]/max(o[5],1):.1f})")
+print(f"direction map, per ray: entries enumerated {o[6]/rays:.1f} in {o[11]/rays:.1f} trips, past the integer band test {o[7]/rays:.1f}, past the noise radius (exact tests) {o[8]/rays:.1f}")
+print(f"rays through the second map {o[9]/rays:.4f}, rays that streamed every record {o[10]/rays:.4f}")
 
 if os.environ.get("PT_TRI_JSON"):  # the record bench.py prices the culled algorithm with (profiles/<tag>_tripool_counters.json)
     import json
     final = {"final": True, "round": int(os.environ["PT_FINAL_ROUND"])} if os.environ.get("PT_FINAL_ROUND") else {}
-    lanes_per_trip = lanes / max(b0 + b1, 1)
     json.dump({**final, "scene": "triangles", "workload": f"{W}x{H}x{spp}",
                "note": "in-kernel counters of the triangle pool, diagnostic build (make -C path_tracer_amd/csrc stamps EXTRA=-DPT_STAMPS_TRI), tools/tri_counters.py",
-               "per_ray": {"exact_tests": (o[8] + o[9] + o[11]) / rays, "grid_filter_tests": grid / rays * 64 * 4, "band_tests": (b0 + b1) / rays * lanes_per_trip * 4,
-                           "always_tests": float(st[1]), "noise_radius_tests": (o[10] + o[7]) / rays, "grid_cells": alw / rays},
-               "pool": {"triangles": st[0], "always": st[1], "levels": list(st)[2:5], "blob_bytes": st[6] * 16}},
+               "per_ray": {"exact_tests": (o[4] + o[8]) / rays, "grid_filter_tests": 0.0, "band_tests": o[6] / rays,
+                           "always_tests": 0.0, "noise_radius_tests": o[7] / rays, "grid_cells": o[3] / rays,
+                           "grid_exact_tests": o[4] / rays, "band_exact_tests": o[8] / rays, "second_map_share": o[9] / rays, "full_stream_share": o[10] / rays},
+               "pool": {"triangles": st[0], "wide": st[1], "map_entries_k": list(st)[2:4], "map_res": [st[4] >> 16, st[4] & 0xffff], "blob_bytes": st[6] * 16}},
               open(os.environ["PT_TRI_JSON"], "w"), indent=1)
