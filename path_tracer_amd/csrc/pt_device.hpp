@@ -1323,6 +1323,16 @@ __device__ __forceinline__ void slab_pool(P blob, cst_f4p cblob, int pool_off, i
                              __builtin_popcountll(__builtin_amdgcn_ballot_w64(((m) & 4u) != 0)) + __builtin_popcountll(__builtin_amdgcn_ballot_w64(((m) & 8u) != 0)))
 
 __device__ __forceinline__ unsigned int gdword(glb_f4p pool, unsigned int base_f4, unsigned int i) { return ((const __attribute__((address_space(1))) unsigned int*)(pool + base_f4))[i]; }
+// a dword of a table that is streamed (a direction map's list, a cell's candidate list).  Non-temporal loads here — so that the streams
+// would not push the re-read tables out of an XCD's 4 MB L2 — measured 30 % SLOWER (1080p x 8 spp: 430 against 333 ms, three alternating
+// runs, profiles/r05_ab_tripool.txt): neighbouring rays read the same bins and cells, the lists ARE re-read.  PT_NT_LOADS restores the experiment.
+__device__ __forceinline__ unsigned int gdword_stream(glb_f4p pool, unsigned int base_f4, unsigned int i) {
+#ifdef PT_NT_LOADS
+  return __builtin_nontemporal_load(((const __attribute__((address_space(1))) unsigned int*)(pool + base_f4)) + i);
+#else
+  return gdword(pool, base_f4, i);
+#endif
+}
 __device__ __forceinline__ unsigned int sdword(glb_f4p pool, unsigned int base_f4, unsigned int i) { // wave-uniform address: through the scalar cache
   return ((const __attribute__((address_space(4))) unsigned int*)(unsigned long long)(pool + base_f4))[i];
 }
@@ -1492,7 +1502,7 @@ __device__ __forceinline__ bool tri_pool_scan(glb_f4p pool, cst_f4p cblob, int h
         const unsigned int sb = (unsigned int)__shfl((int)skip_bit, src, 64);
         bool keep = false;
         unsigned int e = 0;
-        if (on) { e = gdword(pool, cell_cand, (unsigned int)(kb + p)); keep = (e & sb) == 0u; }
+        if (on) { e = gdword_stream(pool, cell_cand, (unsigned int)(kb + p)); keep = (e & sb) == 0u; }
         const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
         if (keep) tq[qn + __builtin_popcountll(m & below)] = (int)(((unsigned int)src << 26) | (e & 0x3ffffffu));
         qn += __builtin_popcountll(m);
@@ -1642,7 +1652,7 @@ __device__ __forceinline__ bool tri_pool_scan(glb_f4p pool, cst_f4p cblob, int h
     constexpr int PER = 2;
     auto load_idx = [&](unsigned int base, int (&idx)[PER]) {
 #pragma unroll
-      for (int j = 0; j < PER; j++) { const unsigned int k = base + 64u * (unsigned int)j + (unsigned int)lane; idx[j] = listed ? (int)gdword(pool, cand_off, k) : (int)k; }
+      for (int j = 0; j < PER; j++) { const unsigned int k = base + 64u * (unsigned int)j + (unsigned int)lane; idx[j] = listed ? (int)gdword_stream(pool, cand_off, k) : (int)k; }
     };
     auto load_rec = [&](const int (&idx)[PER], f4 (&Q)[PER]) {
 #pragma unroll
