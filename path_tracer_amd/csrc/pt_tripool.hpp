@@ -116,6 +116,29 @@ struct TriPool {
 };
 
 namespace detail {
+// squared distance from the point p to the triangle (a, a + e1, a + e2) — the closest-point regions of a triangle (vertex / edge / face)
+inline double point_triangle_dist2(const double p[3], const double a[3], const double e1[3], const double e2[3]) {
+  auto dot = [](const double* x, const double* y) { return x[0] * y[0] + x[1] * y[1] + x[2] * y[2]; };
+  double ap[3] = {p[0] - a[0], p[1] - a[1], p[2] - a[2]};
+  const double d1 = dot(e1, ap), d2 = dot(e2, ap);
+  auto len2 = [&](double s, double t) { double w[3]; for (int k = 0; k < 3; k++) w[k] = ap[k] - s * e1[k] - t * e2[k]; return dot(w, w); };
+  if (d1 <= 0 && d2 <= 0) return len2(0, 0);                                   // vertex a
+  double bp[3] = {ap[0] - e1[0], ap[1] - e1[1], ap[2] - e1[2]};
+  const double d3 = dot(e1, bp), d4 = dot(e2, bp);
+  if (d3 >= 0 && d4 <= d3) return len2(1, 0);                                  // vertex b
+  const double vc = d1 * d4 - d3 * d2;
+  if (vc <= 0 && d1 >= 0 && d3 <= 0) return len2(d1 / (d1 - d3), 0);           // edge ab
+  double cp[3] = {ap[0] - e2[0], ap[1] - e2[1], ap[2] - e2[2]};
+  const double d5 = dot(e1, cp), d6 = dot(e2, cp);
+  if (d6 >= 0 && d5 <= d6) return len2(0, 1);                                  // vertex c
+  const double vb = d5 * d2 - d1 * d6;
+  if (vb <= 0 && d2 >= 0 && d6 <= 0) return len2(0, d2 / (d2 - d6));           // edge ac
+  const double va = d3 * d6 - d5 * d4;
+  if (va <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) { const double w = (d4 - d3) / ((d4 - d3) + (d5 - d6)); return len2(1 - w, w); } // edge bc
+  const double den = va + vb + vc;
+  if (!(den > 0)) return std::min(len2(0, 0), std::min(len2(1, 0), len2(0, 1))); // (degenerate: a vertex is never farther than the true distance + an edge)
+  return len2(vb / den, vc / den);                                             // the face
+}
 // f(p, q) = nk + p na + nb q over the rectangle [pl, ph] x [ql, qh]: is min |f| <= W possible, and for which p?  Returns false when no p qualifies.
 inline bool strip_columns(double nk, double na, double nb, double ql, double qh, double W, double& pa, double& pb) {
   const double lo_c = nk + std::min(ql * nb, qh * nb), hi_c = nk + std::max(ql * nb, qh * nb); // f_min(p) = p na + lo_c, f_max(p) = p na + hi_c
@@ -361,12 +384,22 @@ inline TriPool build_tri_pool(const PtHittable* h, int count, TriPoolTuning tune
     const double* nn = &nrm[(size_t)i * 3];
     const double hc = 0.5 / inv, reach = sig[(size_t)i] + slack + hc * (std::fabs(nn[0]) + std::fabs(nn[1]) + std::fabs(nn[2])) * (1 + 1e-9) + 1e-9 * cell;
     const float* f = h[i].f;
+    // ... and (round 5) only if its centre is within sigma' + slack + the cell's half diagonal of the TRIANGLE itself: P' is within
+    // sigma' of the triangle and within slack of a point of the cell, whose centre is at most half a diagonal from there (the box and the
+    // slab are cheaper to test and cut most cells; this one rounds the grown box's corners and edges off).  Conservative for a
+    // degenerate triangle: the distance to a vertex is used where the face is lost, never more than an edge beyond the truth — such
+    // triangles skip the test (they are slivers of the band's share anyway).
+    const double v0d[3] = {f[0], f[1], f[2]};
+    const double e1d[3] = {(double)(float)(f[3] - f[0]), (double)(float)(f[4] - f[1]), (double)(float)(f[5] - f[2])};
+    const double e2d[3] = {(double)(float)(f[6] - f[0]), (double)(float)(f[7] - f[1]), (double)(float)(f[8] - f[2])};
+    const double rad = sig[(size_t)i] + slack + hc * 1.7320508075688772 * (1 + 1e-9) + 1e-9 * cell, rad2 = rad * rad;
     for (int z = c0[2]; z <= c1[2]; z++)
       for (int y = c0[1]; y <= c1[1]; y++)
         for (int x = c0[0]; x <= c1[0]; x++) {
           if (flat) {
-            const double mx = tp.origin[0] + (x + 0.5) / inv, my = tp.origin[1] + (y + 0.5) / inv, mz = tp.origin[2] + (z + 0.5) / inv;
-            if (std::fabs(nn[0] * (mx - f[0]) + nn[1] * (my - f[1]) + nn[2] * (mz - f[2])) > reach) continue;
+            const double m[3] = {tp.origin[0] + (x + 0.5) / inv, tp.origin[1] + (y + 0.5) / inv, tp.origin[2] + (z + 0.5) / inv};
+            if (std::fabs(nn[0] * (m[0] - f[0]) + nn[1] * (m[1] - f[1]) + nn[2] * (m[2] - f[2])) > reach) continue;
+            if (detail::point_triangle_dist2(m, v0d, e1d, e2d) > rad2) continue;
           }
           emit(((size_t)z * tp.n[1] + y) * tp.n[0] + x);
         }

@@ -1,5 +1,5 @@
 """The product's HOST-side builders under AddressSanitizer + UBSan: pt_flatten.hpp + pt_tripool.hpp build the
-sphere grids, slab pools, cube-map strips, Morton-ordered copies and quantised records with raw offsets, and only the ORACLE had a
+sphere grids, slab pools, the triangle pools' fine grids (neighbour bits), direction maps, Morton-ordered copies and quantised records with raw offsets, and only the ORACLE had a
 sanitizer build.  A host-only TU (tests/cpp/flatten_host.cpp) is compiled with g++ -fsanitize=address,undefined and flattens the
 Cornell-style scene, the 496-hittable scene, the 100 k-triangle mesh (with its triangle pool) and 50 fuzz scenes — degenerate and
 duplicated triangles, zero-radius spheres, single-element and empty runs, boxes of no volume, non-finite coordinates — in a subprocess
@@ -23,7 +23,7 @@ from path_tracer_amd import abi, scenes
 from path_tracer_amd.scene import hittable_dtype, pack_tables
 san = C.CDLL(sys.argv[2])
 san.flat_check.argtypes = [C.POINTER(abi.PtSceneDesc), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_uint64),
-                           C.POINTER(C.c_int32), C.POINTER(C.c_float), C.c_int64]
+                           C.POINTER(C.c_int32), C.POINTER(C.c_float), C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_float), C.c_int64]
 lib = abi.load_library()  # the shipped (uninstrumented) flattener, host-only entry point
 
 
@@ -37,15 +37,26 @@ def product_blob(ps):
     return 0, blob
 
 
-def check(name, ps, tri_min=0, compare=True):
-    n, h, st = C.c_int64(), C.c_uint64(), (C.c_int32 * 4)()
-    rc = san.flat_check(C.byref(ps.desc), 1, 1, 1, tri_min, C.byref(n), C.byref(h), st, None, 0)
+def check(name, ps, tri_min=0, compare=True, compare_pool=True):
+    n, h, st, npool = C.c_int64(), C.c_uint64(), (C.c_int32 * 4)(), C.c_int64()
+    rc = san.flat_check(C.byref(ps.desc), 1, 1, 1, tri_min, C.byref(n), C.byref(h), st, None, 0, C.byref(npool), None, 0)
     prc, ref = product_blob(ps) if compare else (rc, None)
     assert rc == prc, (name, rc, prc)
     if rc == 0 and compare:
         blob = np.zeros(n.value * 4, np.float32)
-        assert san.flat_check(C.byref(ps.desc), 1, 1, 1, tri_min, C.byref(n), C.byref(h), st, blob.ctypes.data_as(C.POINTER(C.c_float)), n.value) == 0
+        pool = np.zeros(max(npool.value, 1) * 4, np.float32) if compare_pool else None
+        FP = C.POINTER(C.c_float)
+        assert san.flat_check(C.byref(ps.desc), 1, 1, 1, tri_min, C.byref(n), C.byref(h), st, blob.ctypes.data_as(FP), n.value, C.byref(npool),
+                              pool.ctypes.data_as(FP) if compare_pool else None, npool.value if compare_pool else 0) == 0
         assert blob.tobytes() == ref.tobytes(), name
+        # the triangle pools' tables (their own buffer): the shipped library's, byte for byte
+        pn = C.c_int64()
+        abi.check(lib.pt_debug_flatten_pool(C.byref(ps.desc), None, None, 0, C.byref(pn)), "pool size")
+        assert pn.value == npool.value, (name, pn.value, npool.value)
+        if compare_pool and pn.value:
+            pref = np.zeros(pn.value * 4, np.float32)
+            abi.check(lib.pt_debug_flatten_pool(C.byref(ps.desc), None, pref.ctypes.data_as(FP), pn.value, C.byref(pn)), "pool")
+            assert pool.tobytes() == pref.tobytes(), name + " (pool tables)"
     return rc, list(st)
 
 
@@ -54,8 +65,11 @@ for name in ("cornell", "smoke"):
     rc, st = check(name, ps)
     assert rc == 0 and st[0] >= 3, (name, st)
 ps, _ = scenes.build("triangles", n_triangles=100_000)
-rc, st = check("triangles 100k", ps)
+rc, st = check("triangles 100k", ps, compare_pool=False)  # (its maps are ~2 GB: built and checksummed under the sanitizers, sizes compared)
 assert rc == 0 and st[3] == 100_000, st  # the whole run sits in a triangle pool
+ps, _ = scenes.build("triangles", n_triangles=6_000)
+rc, st = check("triangles 6k", ps)                        # the same builders at a size whose tables are compared byte for byte
+assert rc == 0 and st[3] == 6_000, st
 
 # fuzz: what a caller can put into the tables, including what no sane scene contains
 os.environ["PT_TRICULL"] = "1"  # the shipped library's threshold for the comparison blob (pt_debug_flatten reads the knob): pools from 256 triangles
