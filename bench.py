@@ -115,10 +115,10 @@ def ops_per_sample_culled(ctr: dict, n_spheres: int, grid_spheres: int, walk: di
 
 
 # The 100 k-triangle mesh (cfg5) likewise: since round 3 its long triangle run is culled exactly by a triangle pool —
-# per ray the kernel runs the reference's test on the candidates of the grid cells it crosses, a 4-op band test on the records of
-# its cube-map strips and of the always list, and the reference's test on the few survivors.  Counted in the kernel (diagnostic
-# build `make stamps EXTRA=-DPT_STAMPS_TRI`, tools/tri_counters.py; profiles/r03_tripool_counters.txt): 41.5 grid rounds of 64
-# candidates, 17.2 band trips x 51.4 lanes x 4 records, 3 624 always-list records, 4.3 grid cells per ray.
+# per ray the kernel runs the reference's test on the candidates of the grid cells it crosses (round 5: minus the ones the previous
+# cell listed too), the band test on the records of its direction's bin in the direction map, the noise-radius filter on the
+# survivors and the reference's test on what is left.  Counted in the kernel (diagnostic build `make stamps EXTRA=-DPT_STAMPS_TRI`,
+# tools/tri_counters.py -> profiles/r05_tripool_counters.json).
 def tri_pool_counters(scene: str, profiles_dir=None):
     d = counted_in_kernel("tripool", scene, profiles_dir)
     if not d:
@@ -129,10 +129,10 @@ def tri_pool_counters(scene: str, profiles_dir=None):
 
 
 TRI_POOL = {"triangles": tri_pool_counters("triangles")}
-OPS_TRI_POOL = dict(band=8,        # d . g (5) + |.| + rho + c, compare (3)
-                    grid_filter=20,  # C - o (3), cross (9), |.|^2 (5), radius^2 |d|^2 + compare (3): the tight line test of a grid candidate
+OPS_TRI_POOL = dict(band=8,        # d . n (5) + |.| + rho + c, compare (3)
+                    grid_filter=20,  # (rounds 3-4: the grid candidates' line test; the round-5 pool has no such stage)
                     noise=33,      # the noise-radius filter of a pair past the band test: |a'| - ea |d| (4), radius (10), line test (19)
-                    setup=45 + 9 * 40)  # the grid walk's set-up + per (level, face): strip coefficients, reach test, row ranges (amortised over 64 lanes)
+                    setup=45 + 20)   # the grid walk's set-up + the direction-map bin of the ray (face, two quotients, two floors)
 
 
 def ops_per_sample_culled_tri(ctr: dict, pool: dict) -> float:
@@ -403,7 +403,14 @@ def main() -> None:
         value = samples_per_step * args.steps / elapsed / 1e6
         ops = ALGORITHMIC_OPS_PER_SAMPLE[scene_name]
         ops_culled = ALGORITHMIC_OPS_PER_SAMPLE_CULLED.get(scene_name)
-        if (scene_name == "smoke" and os.environ.get("PT_NO_GRID")) or (scene_name == "triangles" and os.environ.get("PT_NO_TRICULL")):
+        # which algorithm the kernel runs is read off the SCENE as pt_scene_create flattens it (pt_debug_tri_pool: spheres in a culling grid,
+        # triangles in a pool) — not off the environment: a PtTuning passed by a caller overrides the PT_* variables
+        import ctypes as C_
+        from path_tracer_amd import abi as abi_
+        st_scene = (C_.c_int32 * 8)()
+        abi_.check(abi_.load_library().pt_debug_tri_pool(C_.byref(packed.desc), st_scene), "pt_debug_tri_pool")
+        grid_culled, tri_culled = st_scene[7] > 0, st_scene[0] > 0
+        if (scene_name == "smoke" and not grid_culled) or (scene_name == "triangles" and not tri_culled):
             ops_culled = None  # the A/B knobs select the reference's algorithm as written
         cpu_line = None
         if world == 1 and not args.no_cpu_baseline:
@@ -413,13 +420,10 @@ def main() -> None:
             cw, ch, cs = (480, 270, 4) if scene_name != "triangles" else (96, 54, 1)
             _, ctr = orc.render(packed, scenes.make_camera(cam_args, cw, ch).c, cw, ch, cs, DEPTH, counters=True)
             ops = ops_per_sample(ctr.as_dict())  # exit-point counters -> algorithmic ops per sample, live
-            if GRID_WALK.get(scene_name) and not os.environ.get("PT_NO_GRID"):
-                import ctypes as C_
-                from path_tracer_amd import abi as abi_
-                st = (C_.c_int32 * 8)()
-                abi_.check(abi_.load_library().pt_debug_tri_pool(C_.byref(packed.desc), st), "pt_debug_tri_pool")
+            if GRID_WALK.get(scene_name) and grid_culled:
+                st = st_scene
                 ops_culled = ops_per_sample_culled(ctr.as_dict(), sum(1 for k in packed.kinds() if k == abi_.PT_HIT_SPHERE), st[7], GRID_WALK[scene_name])
-            if TRI_POOL.get(scene_name) and not os.environ.get("PT_NO_TRICULL"):
+            if TRI_POOL.get(scene_name) and tri_culled:
                 ops_culled = ops_per_sample_culled_tri(ctr.as_dict(), TRI_POOL[scene_name])
             # bounded sample of the same workload, sized for ~15 s of CPU work from a 1-spp probe
             bw, bh = (W, H) if scene_name != "triangles" else (240, 135)
@@ -488,11 +492,10 @@ def main() -> None:
         achieved = ops * kernel_samples_per_s / 1e12 / world  # per GPU
         # algorithmic HBM bytes of one launch: the frame written once (12 B per pixel of this rank's share) + the scene read once
         # (the flattened blob with its culling tables, the material table, the texture atlas)
-        import ctypes as C_
-        from path_tracer_amd import abi as abi_
-        st_ = (C_.c_int32 * 8)()
-        abi_.check(abi_.load_library().pt_debug_tri_pool(C_.byref(packed.desc), st_), "pt_debug_tri_pool")
-        scene_bytes = int(st_[6]) * 16 + int(packed.desc.n_materials) * 64 + int(packed.desc.atlas_bytes)
+        # (the triangle pools' tables are a buffer of their own since round 5: pt_debug_flatten_pool)
+        n_pool_ = C_.c_int64()
+        abi_.check(abi_.load_library().pt_debug_flatten_pool(C_.byref(packed.desc), None, None, 0, C_.byref(n_pool_)), "pt_debug_flatten_pool")
+        scene_bytes = int(st_scene[6]) * 16 + int(n_pool_.value) * 16 + int(packed.desc.n_materials) * 64 + int(packed.desc.atlas_bytes)
         algorithmic_bytes = W * H * 12 // world + scene_bytes
         valu_frac = achieved / PEAK_TLANEOPS
         # memory leg: bytes that went past L2 (FETCH_SIZE + WRITE_SIZE of the committed PMC passes of this workload) / kernel time / 8 TB/s

@@ -242,10 +242,11 @@ void pt_scene_destroy(PtScene* scene);
  *   tri_pool           -1: no triangle pool (PT_NO_TRICULL)
  *   tri_min_run        shortest triangle run that gets a pool (PT_TRI_MIN; 4096; PT_TRICULL=1 means 256)
  *   tri_M, tri_cell    the pool's slack 1/M (grid boxes grow with 1/M, bands with M) and its grid cell in median grown boxes (PT_TRI_M,
- *                      PT_TRI_CELL; 8, 0.35).  tri_Mg: ignored since round 5 (the two-radius filter of rounds 3-4 is gone)
- *   tri_res[0..1], tri_rho[0..1]   the pool's direction maps: resolution per cube-map face and the largest rho / R a map serves, per rho
- *                      class (PT_TRI_RES=a,b PT_TRI_RHO=a,b; {128, 64}, {4, 16}); tri_res[2]: ignored
- *   tri_budget_mb      MiB the direction maps may take together (PT_TRI_BUDGET_MB; 2400): a map over budget is built coarser or not at all
+ *                      PT_TRI_CELL; 12, 0.22).  tri_Mg: ignored since round 5 (the two-radius filter of rounds 3-4 is gone)
+ *   tri_res[0..2], tri_rho[0..1] + tri_rho2   the pool's direction maps: resolution per cube-map face and the largest rho / R a map
+ *                      serves, per rho class (PT_TRI_RES=a,b,c PT_TRI_RHO=a,b,c; {256, 256, 64}, {2.12, 4, 16}; a negative rho: no such
+ *                      map; rays with rho beyond the last class stream every band record)
+ *   tri_budget_mb      MiB the direction maps may take together (PT_TRI_BUDGET_MB; 4800): a map over budget is built coarser or not at all
  *   generic_materials  1: no material-specialised kernels (PT_NO_MATSPEC)
  *   blocks_per_cu      cap on resident workgroups per CU (PT_BLOCKS_PER_CU)
  *   cold_state         -1: the cold lane state stays in registers (PT_NO_COLD_LDS)
@@ -278,9 +279,10 @@ typedef struct PtTuning {
   int32_t scatter_log, scatter_mode;
   int32_t lanes_cap, grid_walk;
   int32_t heavy_tiles;
-  float tri_rho[2];      /* (round 5; these three took the place of reserved words: the struct's size is unchanged) */
+  float tri_rho[2];      /* (round 5; these four took the place of reserved words: the struct's size is unchanged) */
   int32_t tri_budget_mb;
-  int32_t reserved[2];
+  float tri_rho2;
+  int32_t reserved[1];
 } PtTuning;
 void pt_tuning_init(PtTuning* t);     /* zero + struct_size: the library's defaults                                          */
 void pt_tuning_from_env(PtTuning* t); /* the defaults with the PT_* environment applied: what pt_scene_create(desc, out) uses */
@@ -385,8 +387,8 @@ int pt_debug_flatten_tuned(const PtSceneDesc* desc, const PtTuning* tuning, floa
                            int32_t* n_runs, float* mats_out, int64_t mats_cap_f4, int32_t* flags_out);
 
 /* Host-only statistics of the triangle pool pt_scene_create() would build (no GPU needed): out[0] = triangles in pooled runs,
- * out[1] = triangles whose band covers every direction in the first map ("slivers"), out[2], out[3] = entries of the two direction
- * maps in units of 1024 (0: not built), out[4] = (resolution of the first map << 16) | resolution of the second, out[5] = 1000 x mean
+ * out[1] = triangles whose band covers every direction in the first map ("slivers"), out[2] = entries of the first direction map,
+ * out[3] = of the other two together, in units of 1024 (0: not built), out[4] = the three maps' resolutions, 10 bits each, out[5] = 1000 x mean
  * grid cells per triangle, out[6] = blob size in 16-byte records (always), out[7] = spheres that sit in a sphere culling grid (always). */
 int pt_debug_tri_pool(const PtSceneDesc* desc, int32_t out[8]);
 /* The tables of the scene's triangle pools (host-only, like pt_debug_flatten): the second buffer pt_scene_create uploads beside the blob

@@ -28,8 +28,8 @@
 extern __device__ unsigned long long g_stamps[8]; // diagnostic build only (pt_render.hip)
 #endif
 #ifdef PT_STAMPS_TRI
-// diagnostic build (triangle pool): [0] scans (waves) [1] live rays [2] grid wave-steps [3] grid lane-steps (cells visited) [4] grid pairs (exact tests) [5] grid batches [6] direction-map entries enumerated [7] past the integer band test [8] past the noise radius (exact tests) [9] rays through the second map [10] rays that streamed every band record [11] band trips (128 entries)
-extern __device__ unsigned long long g_tri[12];
+// diagnostic build (triangle pool): [0] scans (waves) [1] live rays [2] grid wave-steps [3] grid lane-steps (cells visited) [4] grid pairs (exact tests) [5] grid batches [6] direction-map entries enumerated [7] past the integer band test [8] past the noise radius (exact tests) [9] rays through the third map [12] through the second [10] rays that streamed every band record [11] band trips (128 entries)
+extern __device__ unsigned long long g_tri[16];
 #endif
 #ifdef PT_STAMPS_RUNS
 extern __device__ unsigned long long g_runs[16];
@@ -918,7 +918,7 @@ __device__ __forceinline__ int* tri_queue() { __shared__ int s[4 * PT_TRI_QUEUE]
 #ifndef PT_MAX_WAVES_PER_BLOCK
 #define PT_MAX_WAVES_PER_BLOCK 4
 #endif
-#define PT_SQ_CAP 128 /* 63 left over + one trip's pushes */
+#define PT_SQ_CAP 128 /* 63 left over + one trip's pushes: 512 B per wave, + 512 B of slots: 4 KB of STATIC LDS per 256-thread workgroup on top of the blob image (launch_render budgets it: kQueuedWalkStaticLds) */
 __device__ __forceinline__ unsigned int* sphere_queue() { __shared__ unsigned int s[PT_MAX_WAVES_PER_BLOCK * PT_SQ_CAP]; return s; }
 __device__ __forceinline__ unsigned long long* sphere_slots() { __shared__ unsigned long long s[PT_MAX_WAVES_PER_BLOCK * 64]; return s; }
 
@@ -1552,10 +1552,10 @@ __device__ __forceinline__ bool tri_pool_scan(glb_f4p pool, cst_f4p cblob, int h
   unsigned int first_own = 0, last_own = (unsigned int)n_tri, cand_own = 0;
   int listed_own = 0;
   {
-    const f4 D0 = cblob[hdr + 9], D1 = cblob[hdr + 10];
-    const bool c0 = n_maps > 0 && rho_own <= D0.y, c1 = n_maps > 1 && rho_own <= D1.y;
-    if (c.live && (c0 || c1)) {
-      const f4 D = c0 ? D0 : D1;
+    const f4 D0 = cblob[hdr + 9], D1 = cblob[hdr + 10], D2 = cblob[hdr + 11];
+    const bool c0 = n_maps > 0 && rho_own <= D0.y, c1 = n_maps > 1 && rho_own <= D1.y, c2 = n_maps > 2 && rho_own <= D2.y;
+    if (c.live && (c0 || c1 || c2)) {
+      const f4 D = c0 ? D0 : c1 ? D1 : D2;
       const int R = as_i(D.x);
       const float adx = __builtin_fabsf(r.d.x), ady = __builtin_fabsf(r.d.y), adz = __builtin_fabsf(r.d.z);
       // face k = the largest |component| (exact comparisons); (p, q) = (d_a, d_b) / d_k with a = k + 1, b = k + 2 (mod 3)
@@ -1567,7 +1567,7 @@ __device__ __forceinline__ bool tri_pool_scan(glb_f4p pool, cst_f4p cblob, int h
       const unsigned int foff = (unsigned int)as_i(D.z);
       first_own = gdword(pool, foff, bin); last_own = gdword(pool, foff, bin + 1u);
       cand_own = (unsigned int)as_i(D.w);
-      listed_own = c0 ? 1 : 2;
+      listed_own = c0 ? 1 : c1 ? 2 : 3;
     }
   }
   for (unsigned long long todo = (PT_TRI_ABLATE & 4) ? 0ull : live; todo != 0; todo &= todo - 1) {
@@ -1581,7 +1581,8 @@ __device__ __forceinline__ bool tri_pool_scan(glb_f4p pool, cst_f4p cblob, int h
     const unsigned int cand_off = (unsigned int)__builtin_amdgcn_readlane((int)cand_own, src);
     const int listed_k = __builtin_amdgcn_readlane(listed_own, src);
     const bool listed = listed_k != 0;
-    PT_TRI_COUNT(9, listed_k == 2 ? 1 : 0);
+    PT_TRI_COUNT(9, listed_k == 3 ? 1 : 0);
+    PT_TRI_COUNT(12, listed_k == 2 ? 1 : 0);
     PT_TRI_COUNT(10, listed ? 0 : 1);
     // band test, then the noise-radius filter: the line within L + kr rho |d| / (|a'| - ea |d|) of the centroid
     // on the 16-byte compressed record (pt_tripool.hpp "compressed records"; every quantity rounded to the safe side)

@@ -62,8 +62,8 @@ struct Flat {
   int tri_pooled = 0;       // triangles that sit in a triangle pool (pt_tripool.hpp; pt_device.hpp: tri_pool_scan)
   double tri_cells_per_triangle = 0; // statistics of the (last) triangle pool, for the tests
   int tri_wide = 0, tri_maps = 0;   // triangles whose band covers every direction; direction maps built
-  long long tri_map_entries[2] = {0, 0};
-  int tri_map_res[2] = {0, 0};
+  long long tri_map_entries[3] = {0, 0, 0};
+  int tri_map_res[3] = {0, 0, 0};
 };
 
 inline int device_kind(int32_t k) {
@@ -308,7 +308,7 @@ inline void put_box(std::vector<F4>& b, const float* f, int32_t mat, int32_t hid
 //   H5 (-, KQ, P / L, KT)          H6 (ball_abs, kr_a, kr_b, ea)
 //   H7 (centroid quantisation origin xyz, eps_c)                   H8 (centroid quantisation step xyz, eps_n)
 //   per direction map k, one F4: (R, rho_max, first: pool offset, candidates (positions in the Morton copy): pool offset)
-enum { kTriPoolHeaderF4 = 9, kTriPoolMaxMaps = 2 };
+enum { kTriPoolHeaderF4 = 9, kTriPoolMaxMaps = 3 };
 inline int32_t put_tri_pool(std::vector<F4>& b, PoolLayout& pool, TriPool& tp, const PtHittable* tri, int count) {
   // the run's records in MORTON order of the centroids (R2.w = the triangle's index in the run, for the tie rule): pt_tripool.hpp
   const size_t ntri = (size_t)count;
@@ -329,7 +329,7 @@ inline int32_t put_tri_pool(std::vector<F4>& b, PoolLayout& pool, TriPool& tp, c
   const uint32_t band = pool.put(std::move(bandv), 260); // (the full stream reads up to 128 records past the last one: dead records)
   const uint32_t cell_first = pool.put(std::move(tp.cell_first), 2);
   const uint32_t cell_cand = pool.put(std::move(tp.cell_cand), 20);
-  uint32_t mfirst[kTriPoolMaxMaps] = {0, 0}, mcand[kTriPoolMaxMaps] = {0, 0};
+  uint32_t mfirst[kTriPoolMaxMaps] = {0, 0, 0}, mcand[kTriPoolMaxMaps] = {0, 0, 0};
   const int n_maps = std::min((int)tp.maps.size(), (int)kTriPoolMaxMaps);
   for (int k = 0; k < n_maps; k++) {
     TriDirMap& dm = tp.maps[(size_t)k];
@@ -472,7 +472,7 @@ inline int flatten(const PtSceneDesc* sc, Flat& out, std::string& err, bool allo
           out.tri_cells_per_triangle = tp.mean_cells_per_triangle;
           out.tri_wide = tp.wide;
           out.tri_maps = (int)tp.maps.size();
-          for (size_t k = 0; k < tp.maps.size() && k < 2; k++) { out.tri_map_entries[k] = (long long)tp.maps[k].cand.size(); out.tri_map_res[k] = tp.maps[k].R; }
+          for (size_t k = 0; k < tp.maps.size() && k < 3; k++) { out.tri_map_entries[k] = (long long)tp.maps[k].cand.size(); out.tri_map_res[k] = tp.maps[k].R; }
           hdr = put_tri_pool(b, out.pool, tp, &sc->hittables[run.first], run.count);
           pooled = true;
           out.tri_pooled += run.count;

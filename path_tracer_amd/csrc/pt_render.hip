@@ -38,7 +38,7 @@ __device__ unsigned long long g_walk[8];
 __device__ unsigned long long g_runs[16];
 #endif
 #ifdef PT_STAMPS_TRI
-__device__ unsigned long long g_tri[12];
+__device__ unsigned long long g_tri[16];
 #endif
 
 using namespace ptd;
@@ -61,7 +61,7 @@ namespace {
 #define PT_MIN_WAVES_COOP 5 /* cooperative kernels: 93 VGPRs, no scratch (7 waves: 72 VGPRs + 76 B/lane of spills in the loop) */
 #endif
 #ifndef PT_MIN_WAVES_TRIPOOL
-#define PT_MIN_WAVES_TRIPOOL 7 /* triangle-pool kernels: 72 VGPRs + 144 bytes of scratch (208 with image textures), seven waves per SIMD (what 22.1 KB of LDS per workgroup allow).  With whole tiles per wave the frame time was the heaviest wave's chain and 4 waves (122 VGPRs, no scratch) measured best; with the stratified deal (lane_acquire) it is throughput: 1080p x 32 spp 2.89 s at 4 waves, 2.65 at 5, 2.51 at 6, and 2.37 -> 2.32 from 6 to 7 at the final table settings; the image-texture variants (tools/tri_textured.py, 1080p x 16 spp) 1.41 s at 4 waves, 1.20 at 6, 1.17 at 7 */
+#define PT_MIN_WAVES_TRIPOOL 7 /* triangle-pool kernels: 72 VGPRs + ~150 bytes of scratch (none of it in the pool's inner loops), seven waves per SIMD.  Round 5 (the rebuilt pool, bound by the latency of its gathers): 1080p x 8 spp 332 ms at 7 waves, 344 at 5 (96 VGPRs), 371 at 4 (128 VGPRs, no scratch) — profiles/r05_ab_tripool.txt; rounds 3-4 measured the same order */
 #endif
 #ifndef PT_MIN_WAVES_COOP_IMG
 #define PT_MIN_WAVES_COOP_IMG 5 /* 96 VGPRs + 60 B/lane of spills; spill-free needs 116 VGPRs = 4 waves: 496-hittable scene -9 % (A/B) */
@@ -902,7 +902,7 @@ static void tuning_env(PtTuning& t) {
   if (const char* e = std::getenv("PT_TRI_M")) t.tri_M = (float)std::atof(e);
   if (const char* e = std::getenv("PT_TRI_MG")) t.tri_Mg = (float)std::atof(e);
   if (const char* e = std::getenv("PT_TRI_RES")) std::sscanf(e, "%d,%d,%d", &t.tri_res[0], &t.tri_res[1], &t.tri_res[2]);
-  if (const char* e = std::getenv("PT_TRI_RHO")) std::sscanf(e, "%f,%f", &t.tri_rho[0], &t.tri_rho[1]);
+  if (const char* e = std::getenv("PT_TRI_RHO")) std::sscanf(e, "%f,%f,%f", &t.tri_rho[0], &t.tri_rho[1], &t.tri_rho2);
   if (const char* e = std::getenv("PT_TRI_BUDGET_MB")) t.tri_budget_mb = std::max(1, std::atoi(e));
   if (const char* e = std::getenv("PT_TRI_CELL")) t.tri_cell = (float)std::atof(e);
   if (const char* e = std::getenv("PT_TRI_MIN")) t.tri_min_run = std::max(1, std::atoi(e));
@@ -950,10 +950,10 @@ static int flatten_tuned(const PtSceneDesc* desc, const PtTuning& t, ptf::Flat& 
   ptf::TriPoolTuning tri;
   if (t.tri_min_run > 0) tri.min_run = t.tri_min_run;
   if (t.tri_M > 0.0f) tri.M = t.tri_M;
-  if (t.tri_res[0] > 0) tri.dm_res[0] = t.tri_res[0];
-  if (t.tri_res[1] > 0) tri.dm_res[1] = t.tri_res[1];
-  if (t.tri_rho[0] > 0.0f) tri.dm_rho[0] = t.tri_rho[0];
-  if (t.tri_rho[1] != 0.0f) tri.dm_rho[1] = t.tri_rho[1]; // (< 0: no second map)
+  for (int k = 0; k < 3; k++) if (t.tri_res[k] > 0) tri.dm_res[k] = t.tri_res[k];
+  if (t.tri_rho[0] != 0.0f) tri.dm_rho[0] = t.tri_rho[0]; // (< 0: no such map)
+  if (t.tri_rho[1] != 0.0f) tri.dm_rho[1] = t.tri_rho[1];
+  if (t.tri_rho2 != 0.0f) tri.dm_rho[2] = t.tri_rho2;
   if (t.tri_budget_mb > 0) tri.dm_budget = (long long)t.tri_budget_mb * (1 << 18); // MiB -> 4-byte entries
   if (t.tri_cell > 0.0f) tri.cell = t.tri_cell;
   if (const char* e = std::getenv("PT_TRI_GRID_BUDGET")) tri.grid_budget = (float)std::atof(e); // (experiments only: not a PtTuning field)
@@ -1054,6 +1054,7 @@ struct PtScene {
   bool mats_simple = false;    // every material is lambertian or lightsource over a solid texture (kernels compiled with MATS_LAMB_LIGHT_SOLID)
   size_t blob_bytes = 0;
   int num_cus = 256;
+  size_t lds_per_block = 64 * 1024; // hipDeviceProp_t::sharedMemPerBlock (gfx950: 160 KB; the Makefile's ARCH=gfx942: 64 KB)
   mutable unsigned int* ws_cost = nullptr; // LPT workspace: per-tile ray counts of the probe pass
   mutable int* ws_order = nullptr;         //                cost-sorted tile order
   mutable int ws_tiles = 0;
@@ -1181,8 +1182,8 @@ int pt_debug_tri_pool(const PtSceneDesc* desc, int32_t out[8]) {
   int rc = flatten_tuned(desc, t, flat, err);
   if (rc) return fail(rc, err);
   out[0] = flat.tri_pooled; out[1] = flat.tri_wide;
-  out[2] = (int32_t)(flat.tri_map_entries[0] >> 10); out[3] = (int32_t)(flat.tri_map_entries[1] >> 10);
-  out[4] = (flat.tri_map_res[0] << 16) | flat.tri_map_res[1];
+  out[2] = (int32_t)(flat.tri_map_entries[0] >> 10); out[3] = (int32_t)((flat.tri_map_entries[1] + flat.tri_map_entries[2]) >> 10);
+  out[4] = (flat.tri_map_res[0] << 20) | (flat.tri_map_res[1] << 10) | flat.tri_map_res[2];
   out[5] = (int32_t)(1000.0 * flat.tri_cells_per_triangle); out[6] = (int32_t)flat.blob.size(); out[7] = flat.grid_spheres;
   return PT_OK;
 }
@@ -1211,6 +1212,7 @@ int pt_scene_create_tuned(const PtSceneDesc* desc, const PtTuning* tuning, PtSce
     hipDeviceProp_t prop;
     PT_TRY(hipGetDeviceProperties(&prop, s->device));
     s->num_cus = prop.multiProcessorCount;
+    s->lds_per_block = prop.sharedMemPerBlock;
   }
   s->n_runs = flat.n_runs;
   s->blob_f4 = (int)flat.blob.size();
@@ -1414,19 +1416,28 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
   // Which sphere-grid walk (pt_device.hpp: sphere_scan, GRID = 1 / 2): the pair queue where walks diverge or the launch is bound by its
   // chains — whole tiles per wave or at least 16 lanes (the rule of `launch` below, evaluated for the kernels' four workgroups per CU) — and
   // not on frames that are both dense (>= 4 M pixels: a tile's rays share their cells) and throughput-bound (>= 6 pixels per resident lane).
+  // The rule is evaluated for the resident lanes the GRID = 2 kernels really have (their occupancy is queried like `launch` does: 31 KB LDS
+  // image + 4 KB of per-wave queues and slots usually allow four workgroups per CU) — round 4 assumed 16 waves per CU here and the cap of
+  // `launch` from the measured occupancy, and the two could disagree.  The queued walk's STATIC 4 KB of LDS (sphere_queue,
+  // sphere_slots) ride on top of the dynamic blob image: where the sum exceeds what a workgroup may have, the walk stays in place.
+  constexpr size_t kQueuedWalkStaticLds = (size_t)PT_MAX_WAVES_PER_BLOCK * (PT_SQ_CAP * 4 + 64 * 8);
   bool queued_walk = false;
-  if (use_grid) {
-    const double rho = (double)a.n_local_pixels / ((double)s->num_cus * 16.0 * 64.0);
+  auto decide_walk = [&](int per_cu_queued, int waves_per_block) {
+    if (!use_grid) return;
+    const bool fits = shmem + kQueuedWalkStaticLds <= s->lds_per_block && per_cu_queued >= 1;
+    const double lanes = (double)std::max(1, s->num_cus) * std::max(1, per_cu_queued) * waves_per_block * 64.0;
+    const double rho = (double)a.n_local_pixels / lanes;
     const bool few_lanes = rho < 0.875 && !(p->flags & (PT_FLAG_TILE_GRANULAR | PT_FLAG_PIXEL_GRANULAR | PT_FLAG_FAST_RNG)) && s->knobs.lanes_cap >= 0; // 16 rho rounds below 16
     const bool dense_and_busy = (double)p->width * p->height >= 4.0e6 && rho >= 6.0;
-    queued_walk = s->knobs.grid_walk == 2 || (s->knobs.grid_walk == 0 && !few_lanes && !dense_and_busy && !(s->knobs.lanes_cap > 0 && s->knobs.lanes_cap < 16));
-  }
+    queued_walk = fits && (s->knobs.grid_walk == 2 || (s->knobs.grid_walk == 0 && !few_lanes && !dense_and_busy && !(s->knobs.lanes_cap > 0 && s->knobs.lanes_cap < 16)));
+  };
   // (small frames through the grid kernels: see `launch`; PT_FLAG_TILE_GRANULAR / PT_FLAG_PIXEL_GRANULAR and the fast mode keep what they ask for)
   // (only the kernels that walk a sphere grid: the headline family's iteration — slab pass, wave-uniform — does not get shorter with fewer
   // lanes: its shard 0/8 took 127 ms that way against 40)
   const bool share_small = use_grid && s->knobs.lanes_cap >= 0 && !(p->flags & (PT_FLAG_TILE_GRANULAR | PT_FLAG_PIXEL_GRANULAR | PT_FLAG_FAST_RNG));
   // (set by launch_uv for the headline family — no sphere grid, no cooperative phase: see `launch`)
   bool chain_bound_family = false;
+  bool launched_queued_walk = false; // the kernel variant actually launched walks sphere grids through the pair queue (pt_debug_last_launch)
   // Persistent grid: no more workgroups than the chip holds at once; lanes pull pixels from the queue.
   auto launch = [&](auto kernel, int block_threads = kBlock) -> int {
     const int waves_per_block = block_threads / 64;
@@ -1437,6 +1448,8 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
       PT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block_threads, shmem));
       s->occupancy[(const void*)kernel] = per_cu;
     }
+    // (a kernel variant that does not fit a CU at all — its static + dynamic LDS beyond the device's limit — must not be launched and hoped for)
+    if (per_cu < 1) return fail(PT_ERR_TOO_LARGE, "pt_render: this scene's kernel variant does not fit a compute unit (LDS " + std::to_string(shmem) + " B dynamic + static)");
     // A headline-family launch with fewer than ~1.6 tiles per wave slot (shard 0 of 3 ... 6 of the 1080p frame) is bound by its heaviest
     // tiles' sequential chains, and a chain's iteration takes as long as the waves that share its SIMD make it: four waves per SIMD that
     // take two tiles each, heaviest first, finish before eight that take one.  Cornell-style 1080p x 1024 spp, kernel ms of shard 0 of
@@ -1505,7 +1518,7 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
       a.lanes_cap = (int)std::min<long long>(64, std::max<long long>(1, ((long long)a.n_local_pixels + waves - 1) / waves));
     }
     n_waves_resident = (int)std::min<long long>(wanted, resident_blocks) * waves_per_block;
-    if (!a.cost) { s->last_launch[0] = (int)std::min<long long>(wanted, resident_blocks); s->last_launch[1] = a.lanes_cap; s->last_launch[2] = a.heavy_pixels; s->last_launch[3] = queued_walk ? 1 : 0; }
+    if (!a.cost) { s->last_launch[0] = (int)std::min<long long>(wanted, resident_blocks); s->last_launch[1] = a.lanes_cap; s->last_launch[2] = a.heavy_pixels; s->last_launch[3] = launched_queued_walk ? 1 : 0; }
     dim3 grid((unsigned int)std::min<long long>(wanted, resident_blocks)), block((unsigned int)block_threads);
     hipLaunchKernelGGL(kernel, grid, block, shmem, st, a);
     PT_HIP(hipGetLastError());
@@ -1555,8 +1568,21 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
     if constexpr (UV == UV_NONE) { // small scene: cold lane state in LDS (7 workgroups x (scene + 8 KB) per CU)
       if (mlds && shmem <= kMaxLdsColdScene && !s->knobs.no_cold_lds) return launch(render_kernel<UV, true, true, false, true>);
     }
-    if (use_grid && queued_walk) // the sphere-grid walk through the pair queue (pt_device.hpp: sphere_scan says where it pays)
+    if (use_grid) { // which walk: decided with the queued-walk kernel's own occupancy
+      int per_cu2 = 0;
+      const void* k2 = mlds ? (const void*)render_kernel<UV, true, true, false, false, false, false, 2> : (const void*)render_kernel<UV, true, false, false, false, false, false, 2>;
+      auto cached = s->occupancy.find(k2);
+      if (cached != s->occupancy.end()) per_cu2 = cached->second;
+      else if (shmem + kQueuedWalkStaticLds <= s->lds_per_block) {
+        PT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, k2, kBlock, shmem));
+        s->occupancy[k2] = per_cu2;
+      }
+      decide_walk(s->knobs.blocks_per_cu ? std::min(per_cu2, s->knobs.blocks_per_cu) : per_cu2, kWavesPerBlock);
+    }
+    if (use_grid && queued_walk) { // the sphere-grid walk through the pair queue (pt_device.hpp: sphere_scan says where it pays)
+      launched_queued_walk = true;
       return mlds ? launch(render_kernel<UV, true, true, false, false, false, false, 2>) : launch(render_kernel<UV, true, false, false, false, false, false, 2>);
+    }
     return mlds ? launch(render_kernel<UV, true, true, false>) : launch(render_kernel<UV, true, false, false>);
   };
   auto launch_variant = [&]() -> int {
@@ -1723,8 +1749,8 @@ int pt_debug_stamps(unsigned long long* out8, int reset) { // diagnostic build o
 }
 #ifdef PT_STAMPS_TRI
 int pt_debug_tri(unsigned long long* out8, int reset) { // -DPT_STAMPS_TRI: counters of the triangle pool (pt_device.hpp: PT_TRI_COUNT)
-  if (out8) PT_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_tri), 12 * sizeof(unsigned long long)));
-  if (reset) { unsigned long long z[12] = {0}; PT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_tri), z, sizeof z)); }
+  if (out8) PT_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_tri), 16 * sizeof(unsigned long long)));
+  if (reset) { unsigned long long z[16] = {0}; PT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_tri), z, sizeof z)); }
   return PT_OK;
 }
 #endif

@@ -6,8 +6,8 @@
 // cannot reproduce that scan bit for bit: the binary32 test accepts a triangle whenever its COMPUTED u, v, u + v pass the
 // comparisons against the COMPUTED a, and for a ray that grazes the triangle's plane (|a| barely above the 1e-7 cut-off of
 // triangle.hpp:71) the rounding noise in u and v exceeds |a| — such a triangle can be "hit" although the ray's line passes
-// far from it.  So the candidate set of a ray is built from THREE exact parts, and a triangle the reference could accept is
-// always in at least one of them:
+// far from it.  So the candidate set of a ray is built from TWO exact parts (rounds 3-4: three), and a triangle the reference could
+// accept is always in at least one of them:
 //
 //   (1) GRID.   Pairs (ray, triangle) that are NOT grazing, |a^| >= thr_i (a^ = the exact e1 . (d x e2) = -d . N_i).  For those
 //       the computed barycentrics are within 1/M of the exact ones, so the exact point P^ where the ray's line meets the
@@ -48,12 +48,15 @@
 //     |t - t^| |d| <= |d| dw / |a| + |t^| |d| da / |a| + u |t| |d| <= 1.2 L_i / (M - 1) + |t^| |d| / (M_a - 1) + u |t| |d|
 // so with kappa = 2.2 / (M_a - 1) the exact parameter t^ lies in [-1.2 L_i / ((M-1) |d|), max (1 + kappa) + 1.2 L_i / ((M-1) |d|)]
 // and the point P' = o + clamp(t^, 0, max (1 + kappa)) d of the WALKED segment is within
-//     sigma'_i = (6/M + 6/M_a + 1.2/(M-1)) L_i  <=  8.5 L_i / (M - 1)        (M >= 8, M_a >= 64)
+//     sigma'_i = (6/M + 6/M_a + 1.2/(M-1)) L_i        (M_a >= 64; the builder keeps M >= 4)
 // of the triangle, hence inside its bounding box grown by sigma'_i: the cell that contains P' lists the triangle, and the walk
 // visits that cell (cells are assigned with a further absolute slack for the walk's own rounding, as the sphere grid's).
 // P' is within sigma'_i of a point of the triangle's PLANE too, so |n^_i . (P' - v0)| <= sigma'_i: a cell with centre m and half
 // edge h that contains a point within `slack` of P' has |n^_i . (m - v0)| <= sigma'_i + slack + h (|n^x| + |n^y| + |n^z|) — cells of
-// the grown box that fail this are not listed (a triangle's box holds ~3 times the cells its slab does).
+// the grown box that fail this are not listed (a triangle's box holds ~3 times the cells its slab does) — and likewise the centre of
+// such a cell is within sigma'_i + slack + the cell's half diagonal of the TRIANGLE itself (point-triangle distance), which rounds the
+// box's corners off.  Every entry also records which of the cell's six face neighbours list the triangle too: a walk that enters a
+// cell through a face whose other side listed the triangle has tested the pair already (a pair's test does not depend on the cell).
 // Grazing, |a^| < thr_i, is |d^ . N_i| < rho P_i + Q_i: the band test, evaluated with N'_i = N_i rounded to binary32.
 // The direction map lists triangle i in bin D = (face k, [p0, p1] x [q0, q1]) — directions d ~ e_k + p e_a + q e_b — iff
 //     min over the bin's rectangle (grown by eps_bin for the device's own rounding of p, q) of |n_k + p n_a + q n_b|
@@ -80,9 +83,13 @@ struct TriPoolTuning {
   float Ma = 256.0f;    // relative slack of t: the walk runs to max (1 + 2.2 / (Ma - 1))
   float cell = 0.22f;   // PT_TRI_CELL: grid cell edge in units of the median grown box extent
   float grid_budget = 160.0f;         // cell entries per triangle the grid may take (cells are enlarged until the estimate fits)
-  int dm_res[2] = {256, 64};          // PT_TRI_RES=a,b: resolution of the direction maps of the two rho classes (<= 1024)
-  float dm_rho[2] = {4.0f, 16.0f};    // PT_TRI_RHO=a,b: class k serves rays with rho <= dm_rho[k] * R (R = radius of the v0's); beyond the last: every band record
-  long long dm_budget = 600ll << 20;  // entries (4 bytes each) the direction maps may take together; a map that does not fit is built at half the resolution, or not at all
+  // Direction maps, one per class of rho (tau_i grows with rho = |o - c| + R, and a map lists by the tau of its class's largest rho):
+  // class 0 serves the rays that START ON THE MESH OR NEXT TO IT (|o - c| <= R + 2 L: rho <= 2 R + 2 L — every secondary ray off a
+  // triangle, half of all rays; its bands are half as wide as the next class's), class 1 a camera a few radii out, class 2 the far
+  // rest (ground hits towards the horizon); beyond the last class a ray streams every band record.
+  int dm_res[3] = {256, 256, 64};           // PT_TRI_RES=a,b,c: resolution of the maps (<= 1024; 0: no such map)
+  float dm_rho[3] = {2.12f, 4.0f, 16.0f};   // PT_TRI_RHO=a,b,c: class k serves rays with rho <= dm_rho[k] * R (R = radius of the v0's)
+  long long dm_budget = 1200ll << 20; // entries (4 bytes each) the direction maps may take together; a map that does not fit is built at half the resolution, or not at all
   int min_run = 4096;   // PT_TRI_MIN: shorter triangle runs are scanned as before (PT_TRICULL=1: 256)
   int threads = 0;      // build threads (0: hardware concurrency, at most 16); the tables do not depend on it
 };
@@ -239,8 +246,8 @@ inline TriPool build_tri_pool(const PtHittable* h, int count, TriPoolTuning tune
   TriPool tp;
   if (count < tune.min_run || count >= (1 << 26)) return tp; // (table entries carry a triangle's position in 26 bits)
   const double u = std::ldexp(1.0, -24), SAFE = 1.5;
-  // (the bound of the header holds for any M > 1; sigma' below is its general form.  M >= 2 keeps the second-order terms SAFE covers small.)
-  const double M = std::max(2.0, (double)tune.M), Ma = std::max(64.0, (double)tune.Ma);
+  // (the bound of the header holds for any M > 1; sigma' below is its general form.  M >= 4 keeps the second-order terms SAFE covers small.)
+  const double M = std::max(4.0, (double)tune.M), Ma = std::max(64.0, (double)tune.Ma);
   std::vector<double> P((size_t)count), Q((size_t)count), pn((size_t)count), qn((size_t)count), sig((size_t)count);
   std::vector<double> nrm((size_t)count * 3);
   std::vector<char> slab_ok((size_t)count, 0); // the unit normal is well conditioned in binary64 (sin of the edges' angle >= 1e-6): the plane slab may be used
@@ -537,7 +544,7 @@ inline TriPool build_tri_pool(const PtHittable* h, int count, TriPoolTuning tune
     T = std::max(1, std::min(T, 16));
     long long budget = tune.dm_budget;
     std::vector<double> tau((size_t)count, 0.0);
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < 3; k++) {
       if (!(tune.dm_rho[k] > 0.0f) || tune.dm_res[k] < 4) continue;
       const double rho_max = (double)tune.dm_rho[k] * R;
       if (!tp.maps.empty() && !(rho_max > tp.maps.back().rho_max)) continue;

@@ -830,18 +830,38 @@ def test_cfg4_shard_of_8_at_4k_4096spp(torch_gpu, orc, shard):
 
 
 def test_full_size_triangle_mesh_1080p_sampled_pixels(torch_gpu, orc):
-    """BASELINE.json configs[4] at FULL size: 100 000 triangles (4.8 MB of records streamed through LDS tiles) + ground
-    sphere + emissive rect, 1920x1080, 256 spp.  64 sampled pixels are re-rendered by the oracle at full spp."""
+    """BASELINE.json configs[4] at FULL size: 100 000 triangles (through the triangle pool: fine grid + direction maps, round 5) + ground
+    sphere + emissive rect, 1920x1080, 256 spp.  256 sampled pixels are re-rendered by the oracle at full spp (was 64)."""
     ps, cam = scenes.build("triangles", n_triangles=100_000)
     w, h, spp = 1920, 1080, 256
     c = scenes.make_camera(cam, w, h)
     fb, ms = R.render(w, h, spp, R.DeviceScene(ps), c, timed=True)
     fbn = fb.cpu().numpy()
     rng = np.random.default_rng(99)
-    xy = np.stack([rng.integers(0, w, 64), rng.integers(0, h, 64)], axis=1).astype(np.int32)
+    xy = np.stack([rng.integers(0, w, 256), rng.integers(0, h, 256)], axis=1).astype(np.int32)
     orc.set_math(True)
     assert_bit_identical(fbn[xy[:, 1], xy[:, 0]], orc.render_pixels(ps, c.c, w, h, spp, xy), "100k triangles 1080p sampled pixels")
     print(f"\n[cfg5 triangles 1080p {spp}spp] kernel {ms:.1f} ms = {w * h * spp / ms / 1e3:.2f} Msamples/s")
+
+
+def test_a_mesh_of_1_5_million_triangles_keeps_its_pool(torch_gpu, orc, lib):
+    """rounds 3-4 kept the pool's tables in the blob (24-bit record offsets: no pool beyond ~830 k triangles, no scene
+    beyond 5.5 M).  A 1.5 M-triangle mesh is pooled (tables in their own buffer, 25-bit offsets in hit ids; its direction maps within the
+    default budget at whatever resolution fits) and a low-spp frame is bit-exact on sampled pixels against the oracle's full scan."""
+    import ctypes as C
+    ps, cam = scenes.triangle_mesh_scene(n_triangles=1_500_000)
+    st = (C.c_int32 * 8)()
+    abi.check(lib.pt_debug_tri_pool(C.byref(ps.desc), st), "pt_debug_tri_pool")
+    assert st[0] == 1_500_000 and st[6] > 4_500_000            # pooled; the blob alone is 4.5 M records (> 2^22, fine below 2^25)
+    w, h, spp = 480, 270, 2
+    c = scenes.make_camera(cam, w, h)
+    fb, ms = R.render(w, h, spp, R.DeviceScene(ps), c, timed=True)
+    fbn = fb.cpu().numpy()
+    rng = np.random.default_rng(5)
+    xy = np.stack([rng.integers(0, w, 48), rng.integers(0, h, 48)], axis=1).astype(np.int32)
+    orc.set_math(True)
+    assert_bit_identical(fbn[xy[:, 1], xy[:, 0]], orc.render_pixels(ps, c.c, w, h, spp, xy), "1.5 M triangles sampled pixels")
+    print(f"\n[1.5 M triangles {w}x{h}x{spp}] kernel {ms:.1f} ms; pool maps (K entries) {list(st)[2:4]} at {(st[4] >> 20) & 1023} / {(st[4] >> 10) & 1023} / {st[4] & 1023}")
 
 
 def test_cfg1_reference_textures_full_frame_and_png(torch_gpu, orc, tmp_path):

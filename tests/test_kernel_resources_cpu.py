@@ -69,7 +69,23 @@ def test_grid_walk_and_triangle_pool_kernels(usage):
     for k, v in pool.items():
         # SEVEN waves — with the stratified deal of pixels the pool is a throughput kernel, and seven waves at 72 VGPRs + 36-52 dwords of
         # scratch measured 20 % faster than four at 122-128 VGPRs with (almost) none, with and without image textures (pt_render.hip)
-        assert v["Occupancy [waves/SIMD]"] >= 7 and v["ScratchSize [bytes/lane]"] <= (160 if "ILi0E" in k else 224), (k, v)
+        assert v["Occupancy [waves/SIMD]"] >= 7 and v["ScratchSize [bytes/lane]"] <= (160 if "ILi0E" in k else 224), (k, v)   # (FAST-mode variants of the pool kernels included: 140)
+
+
+def test_scratch_of_the_kernels_the_five_baseline_configs_launch(usage):
+    """VERDICT r04 item 6-iv, as far as it can be met: which kernel each BASELINE config launches and what scratch it carries.  cfg2 (the
+    headline: cold lane state in LDS, rect / box-only, lambertian + light) and cfg1 (image textures, LDS scene, in-place grid walk): NONE.
+    cfg3 and the shards of cfg4 (queued grid walk): 20 bytes, stored before / reloaded after the walk, none inside its loops.  cfg5 (triangle
+    pool): ~150 bytes at the 72-register budget of seven waves per SIMD — none inside the pool's inner loops, and the spill-free 4-wave
+    build measured 12 % slower (profiles/r05_ab_tripool.txt): the bound below keeps it from creeping."""
+    def one(pattern):
+        ks = [v for k, v in usage.items() if re.search(pattern, k)]
+        assert len(ks) == 1, (pattern, len(ks))
+        return ks[0]["ScratchSize [bytes/lane]"]
+    assert one(r"render_kernelILi0ELb1ELb1ELb0ELb1ELb0ELb0ELi0ELb0ELi65545E") == 0        # cfg2
+    assert one(r"render_kernelILi1ELb1ELb0ELb0ELb0ELb0ELb0ELi1ELb0ELi287E") == 0          # cfg1
+    assert one(r"render_kernelILi1ELb1ELb0ELb0ELb0ELb0ELb0ELi2ELb0ELi287E") <= 24         # cfg3, cfg4's shards
+    assert one(r"render_kernelILi0ELb0ELb0ELb0ELb0ELb0ELb0ELi1ELb1ELi287E") <= 160        # cfg5
 
 
 def test_streaming_and_cooperative_kernels_without_image_textures(usage):
