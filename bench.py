@@ -151,7 +151,7 @@ def ops_per_sample_culled_tri(ctr: dict, pool: dict) -> float:
 
 
 # recorded like ALGORITHMIC_OPS_PER_SAMPLE (the N = 1 cpu_baseline leg re-derives them live): the culled algorithms' figures
-ALGORITHMIC_OPS_PER_SAMPLE_CULLED = {"smoke": 2116.7, "triangles": 402477.1}
+ALGORITHMIC_OPS_PER_SAMPLE_CULLED = {"smoke": 2116.7, "triangles": 205133.7}  # (triangles: round 5's pool — profiles/r05_tripool_counters.json; rounds 3-4: 402 k)
 
 
 def ops_per_sample(ctr: dict) -> float:
@@ -185,6 +185,23 @@ def kernels_sha16(root=None):
     for name in KERNEL_SOURCES:
         hsh.update(((Path(root) if root else ROOT) / "path_tracer_amd" / "csrc" / name).read_bytes())
     return hsh.hexdigest()[:16]
+
+
+def cgroup_cpu_max():
+    """The container's CPU quota in cores (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited / unreadable: a box that shows 256
+    CPUs may let this process use a dozen — which is what a thread-scaling efficiency of 0.08 on 128 OpenMP threads then means."""
+    try:
+        txt = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if txt and txt[0] != "max":
+            return round(int(txt[0]) / int(txt[1]), 2)
+        return None
+    except Exception:  # noqa: BLE001
+        try:
+            q = int(Path("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read_text())
+            p = int(Path("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read_text())
+            return round(q / p, 2) if q > 0 else None
+        except Exception:  # noqa: BLE001
+            return None
 
 
 def pmc_traffic(scene: str, w: int, h: int, spp: int, profiles_dir=None):
@@ -443,20 +460,28 @@ def main() -> None:
             orc.render(packed, bcam.c, bw, bh, gs, DEPTH)
             dtg = time.perf_counter() - t1
             orc.set_math(True)
-            # one thread on its own, on a slice of the same sample (~3 s): what a "core" of this host is worth, and how the
-            # OpenMP run scales over the threads it used (row-dynamic schedule)
+            # one thread on its own, on a slice of the same workload sized for ~3 s (a smaller frame of the same camera where even one
+            # sample per pixel of the sample's frame would take longer: the 100 k-triangle mesh does ~40 samples/s per thread): what a
+            # "core" of this host is worth, and how the OpenMP run scales over the threads it used (row-dynamic schedule)
             nthreads = orc.load().orc_max_threads()
+            per_thread_guess = bw * bh * bs / dt / max(nthreads, 1)              # samples / s / thread if the scaling were perfect
+            want = max(64.0, 3.0 * per_thread_guess)                             # samples for ~3 s (a thread alone is at least that fast)
+            s1 = int(max(1, min(bs, want // (bw * bh))))
+            w1, h1 = bw, bh
+            if want < bw * bh:                                                   # fewer samples than pixels: shrink the frame
+                k = (want / (bw * bh)) ** 0.5
+                w1, h1 = max(8, int(bw * k)), max(8, int(bh * k))
+            cam1 = scenes.make_camera(cam_args, w1, h1)
             orc.load().orc_set_threads(1)
-            s1 = max(1, int(round(bs * 3.0 / max(dt, 1e-3) / max(nthreads, 1))))
             t1 = time.perf_counter()
-            orc.render(packed, bcam.c, bw, bh, s1, DEPTH)
+            orc.render(packed, cam1.c, w1, h1, s1, DEPTH)
             dt1 = time.perf_counter() - t1
             orc.load().orc_set_threads(nthreads)
-            one_thread = bw * bh * s1 / dt1 / 1e6
+            one_thread = w1 * h1 * s1 / dt1 / 1e6
             cpu_line = {"value": round(bw * bh * bs / dt / 1e6, 3), "unit": "Msamples/s",
                         "cores": nthreads, "kind": "port",
-                        "affinity_cpus": len(os.sched_getaffinity(0)), "os_cpu_count": os.cpu_count(),
-                        "one_thread_value": round(one_thread, 4), "one_thread_sample": f"{bw}x{bh}, {s1} spp ({dt1:.1f} s), 1 OpenMP thread",
+                        "affinity_cpus": len(os.sched_getaffinity(0)), "os_cpu_count": os.cpu_count(), "cgroup_cpu_max": cgroup_cpu_max(),
+                        "one_thread_value": round(one_thread, 4), "one_thread_sample": f"{w1}x{h1}, {s1} spp ({dt1:.1f} s), 1 OpenMP thread",
                         "thread_scaling_efficiency": round(bw * bh * bs / dt / 1e6 / (one_thread * max(nthreads, 1)), 3),
                         "sample": f"same scene, {bw}x{bh}, {bs} spp, depth {DEPTH} ({bw * bh * bs / 1e6:.1f} Msamples, {dt:.1f} s), OpenMP CPU oracle, portable math",
                         "value_glibc_math": round(bw * bh * gs / dtg / 1e6, 3),
