@@ -482,6 +482,25 @@ def test_triangle_pool_thresholds_and_small_runs(orc, lib, monkeypatch):
             assert_bit_identical(R.render_host(45, 27, 12, ds, c, flags=flags), ref, f"PT_TRI_MIN=4 seed {seed} flags {flags}")
 
 
+@pytest.mark.parametrize("knobs", [dict(tri_M=4.0), dict(tri_M=48.0), dict(tri_cell=0.6), dict(tri_cell=0.1), dict(tri_res=(32, 16, 16)),
+                                   dict(tri_rho=(1.2, 2.5), tri_rho2=3.0),        # rays fall through all three classes ...
+                                   dict(tri_rho=(-1.0, -1.0), tri_rho2=-1.0),     # ... or there is no map at all: every ray streams every band record
+                                   dict(tri_budget_mb=1)])                          # maps over budget: built coarser or dropped
+def test_triangle_pool_knobs_change_no_bit(orc, lib, knobs):
+    """PtTuning's triangle-pool fields are performance-only (include/pt_render.h): the grid's slack 1 / M and cell size, the direction
+    maps' resolutions, rho classes and memory budget — including the settings that leave rays without a map (they stream every band record)
+    — give the image of the oracle's full scan, on a field with slivers, duplicates and degenerate triangles and from a camera inside it."""
+    orc.set_math(True)
+    for seed in (8001, 8004):
+        ps, cam = random_triangle_field(seed)
+        w, h, spp = 48, 27, 6
+        c = scenes.make_camera(cam, w, h)
+        ref = orc.render(ps, c.c, w, h, spp)
+        t = abi.tuning(tri_min_run=256, **knobs)
+        ds = R.DeviceScene(ps, t)
+        assert_bit_identical(R.render_host(w, h, spp, ds, c), ref, f"triangle field {seed} with {knobs}")
+
+
 def test_rays_that_graze_triangles(orc, lib):
     """Ray-level check aimed at the band: rays that lie ALMOST IN THE PLANE of a triangle of the 100 k-triangle mesh (tilted out of
     it by 1e-8 ... 1e-2) and pass near it — the rays for which the reference's binary32 test accepts triangles by rounding
