@@ -264,7 +264,10 @@ void pt_scene_destroy(PtScene* scene);
  *                      (64 pairs per batch); 0: the launcher's rule (PT_GRID_WALK)
  *   heavy_tiles        sphere-grid kernels on launches bound by their heaviest tiles' chains (1.5 ... 6 pixels per resident lane): the first
  *                      n tiles of the cost-sorted order are handed out 16 pixels at a time, a quarter tile per wave (PT_HEAVY_TILES=n;
- *                      0: one tile per SIMD of the chip in that range, none outside; -1: never)                                              */
+ *                      0: one tile per SIMD of the chip in that range, none outside; -1: never)
+ *   probe_resume       the cost probe's samples are the frame's first samples — the frame launch starts every pixel from the radiance sum and
+ *                      the generator state the probe left (same stream, same order of additions) — 0: yes; -1: the probe's samples are
+ *                      thrown away and rendered again, as before round 5 (PT_NO_PROBE_RESUME; the A/B)                                        */
 typedef struct PtTuning {
   int32_t struct_size; /* sizeof(PtTuning) of the caller's header */
   int32_t sphere_grid;
@@ -282,7 +285,7 @@ typedef struct PtTuning {
   float tri_rho[2];      /* (round 5; these four took the place of reserved words: the struct's size is unchanged) */
   int32_t tri_budget_mb;
   float tri_rho2;
-  int32_t reserved[1];
+  int32_t probe_resume;  /* (round 5, the last reserved word) */
 } PtTuning;
 void pt_tuning_init(PtTuning* t);     /* zero + struct_size: the library's defaults                                          */
 void pt_tuning_from_env(PtTuning* t); /* the defaults with the PT_* environment applied: what pt_scene_create(desc, out) uses */

@@ -96,7 +96,12 @@ struct KArgs {
   int tiles_x, n_tiles;
   int n_local_pixels;  // 64 x the tiles this shard owns (incl. padding pixels of edge tiles)
   unsigned int* queue; // per-launch dequeue counter, zeroed on the stream before the kernel
-  unsigned int* cost;  // non-NULL: cost-probe pass, per local tile ray counts (nothing is written to fb)
+  unsigned int* cost;  // non-NULL: cost-probe pass, per local tile ray counts
+  // The probe's samples are the frame's FIRST samples: with resume_rng the probe leaves every pixel's plain radiance sum in fb and its
+  // generator's state in resume_rng[local pixel]; the frame launch (resume_spp = what the probe rendered) starts every pixel from both, at
+  // sample resume_spp — the same stream, the same order of additions (render.hpp:95-101), and no sample is rendered twice.
+  unsigned int* resume_rng;
+  int resume_spp;
   int cost_max;        // probe: 1 = keep the tile's HEAVIEST pixel (x 64) instead of the sum over its pixels
   const int* order;    // non-NULL: queue position -> local tile, heaviest first
   const int* n_split;  // non-NULL (COOP kernels): [0] how many leading tiles of `order` go through the wide phase, [1] log2 G
@@ -133,6 +138,7 @@ template <> struct Cold<false> {
   unsigned int iters;
   __device__ __forceinline__ void init(lds_fp) { acc = mk(0.0f, 0.0f, 0.0f); s = 0; pix = -1; x = 0; y = 0; iters = 0; }
   __device__ __forceinline__ void begin(int pix_, int x_, int y_, int s0 = 0) { acc = mk(0.0f, 0.0f, 0.0f); s = s0; iters = 0; pix = pix_; x = x_; y = y_; }
+  __device__ __forceinline__ void resume(V3 acc_, int s0) { acc = acc_; s = s0; }
   __device__ __forceinline__ int add_sample(V3 o) { acc = acc + o; return ++s; }
   __device__ __forceinline__ void count_ray() { iters++; }
   __device__ __forceinline__ V3 get_acc() const { return acc; }
@@ -149,6 +155,7 @@ template <> struct Cold<true> {
     p[3 * kBlock] = __int_as_float(s0); p[4 * kBlock] = __int_as_float(pix_); p[5 * kBlock] = __int_as_float(x_);
     p[6 * kBlock] = __int_as_float(y_); p[7 * kBlock] = __int_as_float(0);
   }
+  __device__ __forceinline__ void resume(V3 acc_, int s0) { p[0] = acc_.x; p[kBlock] = acc_.y; p[2 * kBlock] = acc_.z; p[3 * kBlock] = __int_as_float(s0); }
   __device__ __forceinline__ int add_sample(V3 o) {
     p[0] = p[0] + o.x; p[kBlock] = p[kBlock] + o.y; p[2 * kBlock] = p[2 * kBlock] + o.z;
     const int s = __float_as_int(p[3 * kBlock]) + 1;
@@ -207,6 +214,8 @@ __host__ __device__ __forceinline__ uint32_t fast_seed(uint32_t pixel, uint32_t 
 #else
 #define PT_COLD_ARGS(name, a) const KArgs& name = a
 #endif
+
+struct __attribute__((packed, aligned(4))) Rgb12 { float r, g, b; }; // a pixel of the framebuffer: global_{load,store}_dwordx3 need dword alignment only
 
 // Wave-aggregated dequeue: one atomicAdd per wave for all lanes that need a pixel (ballot + prefix count),
 // pixels handed out in tile order so a fresh wave starts on one coherent 8x8 tile.
@@ -309,6 +318,13 @@ __device__ __forceinline__ void lane_acquire(Lane& L, const KArgs& a) {
   } else {
     L.cold.begin(l * PT_TILE_PIXELS + in_tile, x, y);
     L.rng = id;
+    if (k.resume_spp > 0) { // the probe pass rendered this pixel's first samples (KArgs.resume_rng): carry on where it stopped
+      const int pix = l * PT_TILE_PIXELS + in_tile;
+      const long long at = k.shard_count == 1 ? ((long long)y * k.width + x) * 3 : (long long)pix * 3;
+      const Rgb12 part = *(const Rgb12*)(k.fb + at);
+      L.cold.resume(mk(part.r, part.g, part.b), k.resume_spp);
+      L.rng = k.resume_rng[pix];
+    }
   }
   L.live = true;
   L.need_new = true;
@@ -320,7 +336,6 @@ __device__ __forceinline__ void lane_acquire(Lane& L, const KArgs& a) {
 // summary took each counter's maximum over the two launches: tools/pmc_summary.py now reads the frame launch only.  Deferring
 // the stores until a wave's whole tile is done — eight lanes writing 96 contiguous bytes — was tried and changes nothing:
 // 26.26 MB.)
-struct __attribute__((packed, aligned(4))) Rgb12 { float r, g, b; };
 __device__ __forceinline__ void store_rgb(float* p, V3 c) { *(Rgb12*)p = Rgb12{c.x, c.y, c.z}; }
 
 template <bool FAST = false, typename Lane>
@@ -333,6 +348,11 @@ __device__ __forceinline__ void lane_store(Lane& L, const KArgs& a) {
     // kernels' model also needs the lane time, i.e. the sum
     if (k.cost_max) atomicMax(&k.cost[L.cold.get_pix() >> 6], L.cold.get_iters() * PT_TILE_PIXELS);
     else atomicAdd(&k.cost[L.cold.get_pix() >> 6], L.cold.get_iters());
+    if (k.resume_rng) { // ... and, where the frame launch resumes from it, the pixel's state after these samples (KArgs.resume_rng)
+      const long long at = k.shard_count == 1 ? ((long long)L.cold.get_y() * k.width + L.cold.get_x()) * 3 : (long long)L.cold.get_pix() * 3;
+      store_rgb(k.fb + at, L.cold.get_acc());
+      k.resume_rng[L.cold.get_pix()] = L.rng;
+    }
     return;
   }
   long long idx;
@@ -913,6 +933,7 @@ static void tuning_env(PtTuning& t) {
   if (const char* e = std::getenv("PT_SPLIT_TILES")) { t.split_tiles_mode = 1; t.split_tiles = std::atoi(e); }
   if (const char* e = std::getenv("PT_LPT_MAX")) t.lpt_by_max = std::atoi(e) != 0 ? 1 : -1;
   if (const char* e = std::getenv("PT_PROBE_SPP_MAX")) t.probe_spp_max = std::max(1, std::atoi(e));
+  if (has("PT_NO_PROBE_RESUME")) t.probe_resume = -1;
   if (const char* e = std::getenv("PT_GRID_MIN_TILES")) t.grid_min_tiles = std::max(0, std::atoi(e));
   if (const char* e = std::getenv("PT_MODEL_FIXED")) t.model_fixed = (float)std::atof(e);
   if (const char* e = std::getenv("PT_MODEL_CHAIN")) t.model_chain = (float)std::atof(e);
@@ -995,6 +1016,7 @@ struct Knobs {
   bool generic_materials = false;
   int grid_walk = 0;       // PtTuning.grid_walk: 0 the launcher's rule, 1 the wave-synchronous walk, 2 the queued walk
   int lanes_cap = 0;       // PtTuning.lanes_cap: grid kernels on small frames (launch): 0 the rule, -1 whole tiles always, n forced
+  bool no_resume = false;  // PtTuning.probe_resume = -1: the probe's samples are rendered again by the frame launch
   int heavy_tiles = 0;     // PtTuning.heavy_tiles: tiles at the head of the cost-sorted order that are handed out 16 pixels at a time: 0 the rule, -1 never, n forced
   Knobs() {}
   explicit Knobs(const PtTuning& t) {
@@ -1013,6 +1035,7 @@ struct Knobs {
     lanes_cap = t.lanes_cap < 0 ? -1 : std::min(64, t.lanes_cap);
     grid_walk = (t.grid_walk == 1 || t.grid_walk == 2) ? t.grid_walk : 0;
     heavy_tiles = t.heavy_tiles < 0 ? -1 : t.heavy_tiles;
+    no_resume = t.probe_resume < 0;
   }
 };
 
@@ -1056,6 +1079,7 @@ struct PtScene {
   int num_cus = 256;
   size_t lds_per_block = 64 * 1024; // hipDeviceProp_t::sharedMemPerBlock (gfx950: 160 KB; the Makefile's ARCH=gfx942: 64 KB)
   mutable unsigned int* ws_cost = nullptr; // LPT workspace: per-tile ray counts of the probe pass
+  mutable unsigned int* ws_rng = nullptr;  // per local pixel: the generator's state after the probe's samples (KArgs.resume_rng)
   mutable int* ws_order = nullptr;         //                cost-sorted tile order
   mutable int ws_tiles = 0;
   int* ws_nsplit = nullptr;                //                number of leading tiles to split (device scalar)
@@ -1067,7 +1091,7 @@ struct PtScene {
   int device = 0;
   // Scheduling state above marked `mutable` (queue ring cursor, LPT workspace, last-launch info) changes per launch although
   // the scene DATA is immutable: launches on one scene from several host threads serialise their ENQUEUE on this mutex.
-  // The per-scene workspaces (ws_cost / ws_order / ws_nsplit / ws_partial) are shared by every launch on the scene, so
+  // The per-scene workspaces (ws_cost / ws_order / ws_rng / ws_nsplit / ws_partial) are shared by every launch on the scene, so
   // renders on ONE scene must also be stream-ordered (include/pt_render.h): callers that render one scene from several
   // streams create one PtScene per stream (path_tracer_amd/render.py keys its cache by (device, stream)).
   mutable std::mutex sched;
@@ -1281,6 +1305,7 @@ void pt_scene_destroy(PtScene* s) {
   for (hipEvent_t e : s->ring_done) if (e) (void)hipEventDestroy(e);
   if (s->ws_cost) (void)hipFree(s->ws_cost);
   if (s->ws_order) (void)hipFree(s->ws_order);
+  if (s->ws_rng) (void)hipFree(s->ws_rng);
   if (s->ws_nsplit) (void)hipFree(s->ws_nsplit);
   if (s->ws_partial) (void)hipFree(s->ws_partial);
   delete s;
@@ -1321,9 +1346,11 @@ static int reserve_tiles(const PtScene* s, int local_tiles) {
   if (s->ws_tiles >= local_tiles) return PT_OK;
   if (s->ws_cost) (void)hipFree(s->ws_cost);
   if (s->ws_order) (void)hipFree(s->ws_order);
-  s->ws_cost = nullptr; s->ws_order = nullptr; s->ws_tiles = 0;
+  if (s->ws_rng) (void)hipFree(s->ws_rng);
+  s->ws_cost = nullptr; s->ws_order = nullptr; s->ws_rng = nullptr; s->ws_tiles = 0;
   PT_HIP(hipMalloc((void**)&s->ws_cost, (size_t)local_tiles * sizeof(unsigned int)));
   PT_HIP(hipMalloc((void**)&s->ws_order, (size_t)local_tiles * sizeof(int)));
+  PT_HIP(hipMalloc((void**)&s->ws_rng, (size_t)local_tiles * PT_TILE_PIXELS * sizeof(unsigned int)));
   s->ws_tiles = local_tiles;
   return PT_OK;
 }
@@ -1395,6 +1422,7 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
   set_scatter();
   a.cost = nullptr;
   a.cost_max = 0;
+  a.resume_rng = nullptr; a.resume_spp = 0;
   a.order = nullptr;
   const bool mlds = lds && blob_bytes + (size_t)s->mats_f4 * 16 <= kMaxLdsWithMaterials;
   const size_t shmem = lds ? blob_bytes + (mlds ? (size_t)s->mats_f4 * 16 : 0) : 0;
@@ -1594,7 +1622,9 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
   int probe_spp = std::min(4, p->samples / 16);
   // Tiles are ordered by their ray count — or, where a wave holds a tile until its last pixel is done and pixels differ
   // widely (the sphere-field scenes the grid kernels run: a few glass / mirror pixels per tile), by 64 x their heaviest
-  // pixel's, from a deeper probe: 496-hittable scene +3-6 % (same box), Cornell-style -0.8 % (kept on the sum).
+  // pixel's, from a deeper probe: 496-hittable scene +3-6 % (same box), Cornell-style -0.8 % (kept on the sum).  (Round 5, with the
+  // probe's samples kept: still samples / 64 up to 16 — 1080p x 1024 spp 448 / 409 / 395 / 375 ms at depths 2 / 4 / 8 / 16 and 379 / 387 /
+  // 406 at 32 / 64 / 128: an unordered launch runs at half the ordered one's pace; profiles/r05_ab_probe_resume.txt.)
   const bool cost_by_max = s->knobs.lpt_max >= 0 ? s->knobs.lpt_max != 0 : use_grid;
   if (cost_by_max) probe_spp = std::min(std::max(probe_spp, p->samples / 64), s->knobs.probe_spp_max);
   // (the triangle-pool kernels deal every wave a stratified sample of the frame's tiles — lane_acquire, scatter_p — which balances the
@@ -1607,6 +1637,9 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
     a.cost = s->ws_cost;
     a.cost_max = (cost_by_max && !coop) ? 1 : 0;
     a.samples = probe_spp;
+    // the probe's samples are kept (KArgs.resume_rng) — not in the opt-in fast mode, whose chunks are streams of their own
+    const bool resume = !(p->flags & PT_FLAG_FAST_RNG) && !s->knobs.no_resume;
+    a.resume_rng = resume ? s->ws_rng : nullptr;
     int rc = launch_variant();
     if (rc) return rc;
     // rough per-iteration instruction counts: traversal (splittable) vs shading + camera + cooperative overhead (not)
@@ -1623,6 +1656,7 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
       }
     }
     a = main_args;
+    if (resume) { a.resume_rng = s->ws_rng; a.resume_spp = probe_spp; }
     a.order = s->ws_order;
     a.n_split = (coop && !(p->flags & PT_FLAG_NO_SPLIT)) ? s->ws_nsplit : nullptr;
   }

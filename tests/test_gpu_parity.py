@@ -1065,6 +1065,31 @@ def test_heaviest_tiles_in_narrow_pieces_change_nothing(orc, torch_gpu):
     assert torch.equal(a.view(torch.int32), b.view(torch.int32))
 
 
+def test_the_cost_probes_samples_are_the_frames_first_samples(orc, torch_gpu):
+    """Round 5 (pt_render.hip: KArgs.resume_rng): the probe pass that orders the tiles leaves every pixel's radiance sum in the framebuffer
+    and its generator state in a workspace, and the frame launch carries on from both at sample `probe_spp` — the reference's single
+    stream per pixel and its order of additions (render.hpp:95-101), no sample rendered twice.  The frame must equal the one that throws
+    the probe away (PtTuning.probe_resume = -1), the one without a probe (PT_FLAG_NO_LPT) and the oracle's, bit for bit: whole frames,
+    shards (compact tile buffers), the three kernel families (slab pools with LDS-resident cold state, sphere grid, cooperative lists)."""
+    import torch
+    orc.set_math(True)
+    cases = [("cornell", scenes.build("cornell"), 256, 192, 64),   # headline family: cold lane state in LDS
+             ("field", S.sphere_field_scene(), 640, 400, 32),        # grid kernels: the probe keeps the heaviest pixel, 4 000 tiles
+             ("mixed", (S.mixed_scene()[0], S.mixed_scene()[1]), 192, 128, 48)]
+    for name, (ps, cam), W, H, spp in cases:
+        c = scenes.make_camera(cam, W, H)
+        kept = R.render(W, H, spp, R.DeviceScene(ps), c)
+        again = R.render(W, H, spp, R.DeviceScene(ps, tuning=abi.tuning(probe_resume=-1)), c)
+        plain = R.render(W, H, spp, R.DeviceScene(ps), c, flags=abi.PT_FLAG_NO_LPT)
+        assert torch.equal(kept.view(torch.int32), again.view(torch.int32)), name
+        assert torch.equal(kept.view(torch.int32), plain.view(torch.int32)), name
+        xy = np.stack([np.random.default_rng(11).integers(0, W, 300), np.random.default_rng(12).integers(0, H, 300)], axis=1).astype(np.int32)
+        assert_bit_identical(kept.cpu().numpy()[xy[:, 1], xy[:, 0]], orc.render_pixels(ps, c.c, W, H, spp, xy), f"{name}: resumed frame against the oracle")
+        a = R.render(W, H, spp, R.DeviceScene(ps), c, shard_index=1, shard_count=3)
+        b = R.render(W, H, spp, R.DeviceScene(ps, tuning=abi.tuning(probe_resume=-1)), c, shard_index=1, shard_count=3)
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32)), name
+
+
 def test_launcher_rules_for_chain_bound_launches(torch_gpu):
     """What launch_render decides, read back through pt_debug_last_launch: the headline family keeps four workgroups per CU when a launch
     has fewer than 1.6 tiles per wave slot (a shard of 3 - 6 of the 1080p frame) and its full occupancy otherwise; the 496-hittable scene's
