@@ -301,7 +301,7 @@ uint32_t pt_fast_seed(uint32_t pixel, uint32_t chunk);
 
 int32_t pt_shard_tiles(const PtRenderParams* p); /* ceil(n_tiles / shard_count) */
 
-/* Optional: size the scene's per-launch workspaces (tile cost / order arrays of the heaviest-first schedule; the fast
+/* Optional: size the scene's per-launch workspaces (tile cost / order arrays and per-pixel generator states of the heaviest-first schedule; the fast
  * mode's partial sums) for these parameters NOW, so that no later pt_render() with parameters that need no more
  * allocates or frees device memory (hipMalloc / hipFree synchronise the device; without this call the first render at
  * a new size does it).  Call it with the scene's device current.                                                     */
@@ -309,9 +309,13 @@ int pt_scene_reserve(const PtScene* scene, const PtRenderParams* params);
 
 /* The hot path.  Asynchronous on `stream` (a hipStream_t, or NULL for the
  * default stream) like queue.submit (render.hpp:151); fb_device is device
- * memory, fully overwritten (discard_write, render.hpp:152).  The first render
- * of a scene at a new frame size grows the scene's workspaces (hipMalloc, which
- * synchronises); call pt_scene_reserve first where that matters.                */
+ * memory, fully overwritten (discard_write, render.hpp:152) — and READ BACK
+ * while the render runs: the cost-probe pass leaves every pixel's radiance sum
+ * of its first samples there and the frame launch carries on from it
+ * (PtTuning.probe_resume), so the buffer must be ordinary readable device memory
+ * and holds intermediate sums until the stream has passed the call.  The first
+ * render of a scene at a new frame size grows the scene's workspaces (hipMalloc,
+ * which synchronises); call pt_scene_reserve first where that matters.          */
 int pt_render(const PtScene* scene, const PtCamera* cam, const PtRenderParams* p,
               float* fb_device, void* stream);
 
