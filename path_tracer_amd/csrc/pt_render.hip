@@ -40,6 +40,10 @@ __device__ unsigned long long g_runs[16];
 #ifdef PT_STAMPS_TRI
 __device__ unsigned long long g_tri[16];
 #endif
+#ifdef PT_STAMPS_BLOCKS /* diagnostic build (make variant NAME=libpt_blocks.so EXTRA=-DPT_STAMPS_BLOCKS; tools/block_residency.py): per workgroup of the
+                           frame launch where it ran (XCC_ID << 32 | HW_ID) and when it started / ended (s_memrealtime, 100 MHz) */
+__device__ unsigned long long g_blocks[3 * 8192];
+#endif
 
 using namespace ptd;
 
@@ -499,6 +503,14 @@ void render_kernel(KArgs a) {
   if (threadIdx.x < 8) walk_ctr()[threadIdx.x] = 0;
   __syncthreads();
 #endif
+#ifdef PT_STAMPS_BLOCKS
+  if (threadIdx.x == 0 && !a.cost && blockIdx.x < 8192) {
+    const unsigned long long where = ((unsigned long long)__builtin_amdgcn_s_getreg(0x1814) << 32) | (unsigned int)__builtin_amdgcn_s_getreg(0xF804); // XCC_ID, HW_ID
+    g_blocks[3 * blockIdx.x] = where;
+    g_blocks[3 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+  }
+  struct BlockEnd { bool on; unsigned int b; __device__ ~BlockEnd() { if (on) g_blocks[3 * b + 2] = __builtin_amdgcn_s_memrealtime(); } } block_end{threadIdx.x == 0 && !a.cost && blockIdx.x < 8192, blockIdx.x};
+#endif
   Lane L;
   lane_reset(L, (lds_fp)cold_slots);
   if (COOP && a.n_split) {
@@ -676,7 +688,7 @@ __global__ __launch_bounds__(64) void render_single_stream_kernel(KArgs a) {
 // A pixel cannot be split (one sequential RNG stream), so the frame's makespan is bounded below by its heaviest
 // tile, and a heavy tile picked up LAST adds its whole duration to the tail (measured on the 496-hittable scene:
 // mean 2.4 of 5 resident waves per SIMD over the launch).  A probe pass renders the first few samples of every
-// pixel and counts rays per tile (same seeds, results discarded: < 0.5 % extra work); this kernel buckets the tiles
+// pixel and counts rays per tile (same seeds; since round 5 the frame launch resumes from those samples — KArgs.resume_rng); this kernel buckets the tiles
 // into 32 classes of ratio 2^(1/4) below the maximum and emits them heaviest class first.  The order only decides
 // WHEN a pixel is rendered, never its value, so the (atomic, run-to-run varying) order inside a class is harmless.
 constexpr int kLptClasses = 32;
@@ -1655,6 +1667,12 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
         PT_HIP(hipMemcpyAsync(s->ws_nsplit, &s->nsplit_override, sizeof(int), hipMemcpyHostToDevice, st));
       }
     }
+    // (Why one launch in five of the 496-hittable frame takes 407 instead of 376 ms — every workgroup resident from the first microsecond,
+    // one of them 40 ms longer than the rest, tools/block_residency.py: the probe's estimate, a tile's heaviest pixel over 16 samples, is
+    // noisy, a tile whose estimate came out too light sits at a run-to-run varying place of its class (lpt_order_kernel), and when that
+    // place is among the last dequeues its chain is the frame's tail.  A second, ORDERED probe stage of samples / 8 that keeps counting
+    // removes the slow mode — 1080p x 1024 spp 375 / 407 -> 380.8 +- 1.5, x 256 spp 103 / 115 -> 100.1 — at the price of the fast one and of
+    // 4 % on chain-bound shards: not kept, profiles/r05_ab_probe_resume.txt.)
     a = main_args;
     if (resume) { a.resume_rng = s->ws_rng; a.resume_spp = probe_spp; }
     a.order = s->ws_order;
@@ -1775,6 +1793,12 @@ int pt_tonemap_rgb8(const float* fb_device, int32_t width, int32_t height, uint8
   return PT_OK;
 }
 
+#ifdef PT_STAMPS_BLOCKS
+extern "C" int pt_debug_blocks(unsigned long long* out, int n_blocks) { // -DPT_STAMPS_BLOCKS: (where, start, end) of the last frame launch's workgroups
+  PT_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_blocks), (size_t)std::min(n_blocks, 8192) * 3 * sizeof(unsigned long long)));
+  return PT_OK;
+}
+#endif
 #ifdef PT_STAMPS
 int pt_debug_stamps(unsigned long long* out8, int reset) { // diagnostic build only; not part of include/pt_render.h
   if (out8) PT_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_stamps), 8 * sizeof(unsigned long long)));
