@@ -691,6 +691,30 @@ __global__ __launch_bounds__(64) void render_single_stream_kernel(KArgs a) {
 // pixel and counts rays per tile (same seeds; since round 5 the frame launch resumes from those samples — KArgs.resume_rng); this kernel buckets the tiles
 // into 32 classes of ratio 2^(1/4) below the maximum and emits them heaviest class first.  The order only decides
 // WHEN a pixel is rendered, never its value, so the (atomic, run-to-run varying) order inside a class is harmless.
+// A tile's estimate is its heaviest pixel over a few samples — a noisy number for exactly the pixels that matter (an isolated glass or smoke
+// pixel takes 3 rays or 50 per sample), and the two ways of being wrong are not alike: a tile that starts too early costs nothing, a heavy
+// tile that starts late is the frame's tail.  So, for whole frames, a tile is ranked by the largest estimate among itself and its eight
+// neighbours (a dilation of the cost map): heavy pixels lie along silhouettes that run through neighbouring tiles.  What it removes: one
+// launch in five of the 496-hittable 1080p frame took 407 instead of 376 ms — every workgroup resident from the first microsecond, ONE of them
+// 40 ms longer than the rest (tools/block_residency.py) — because a tile whose estimate had come out too light sits at a run-to-run varying
+// place of its class, and sometimes that place is among the last dequeues.  1080p x 1024 spp 383 - 388 (373 ... 409) -> 375.2 +- 1.5 ms over
+// 40 launches, x 256 spp 108 -> 102, 4K x 256 spp 332 (323 ... 352) -> 310 +- 1; neighbours weighted 0.25 / 0.5 / 0.75 / 1.5 or two rings of
+// them bring the slow launches back in part (a neighbour ranked above the heavy tile itself, or too many tiles in the top classes);
+// averaging a pixel with its neighbours instead — nine times the samples — made it WORSE (404 ms: the heavy pixels are isolated ones).
+// profiles/r05_launch_spread_smoke.txt.
+__global__ __launch_bounds__(256) void tile_dilate_kernel(const unsigned int* __restrict__ cost, int tiles_x, int tiles_y, unsigned int* __restrict__ out) {
+  const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (t >= tiles_x * tiles_y) return;
+  const int tx = t % tiles_x, ty = t / tiles_x;
+  unsigned int m = 0;
+  for (int dy = -1; dy <= 1; dy++)
+    for (int dx = -1; dx <= 1; dx++) {
+      const int x = tx + dx, y = ty + dy;
+      if (x >= 0 && x < tiles_x && y >= 0 && y < tiles_y) m = max(m, cost[y * tiles_x + x]);
+    }
+  out[t] = m;
+}
+
 constexpr int kLptClasses = 32;
 __global__ __launch_bounds__(1024) void lpt_order_kernel(const unsigned int* __restrict__ cost, int n, int* __restrict__ order,
                                                         int n_waves, float trav_cost, float fixed_cost, float s_chain, int forced_logG,
@@ -1091,6 +1115,7 @@ struct PtScene {
   int num_cus = 256;
   size_t lds_per_block = 64 * 1024; // hipDeviceProp_t::sharedMemPerBlock (gfx950: 160 KB; the Makefile's ARCH=gfx942: 64 KB)
   mutable unsigned int* ws_cost = nullptr; // LPT workspace: per-tile ray counts of the probe pass
+  mutable unsigned int* ws_rank = nullptr; // per local tile: the cost a tile is ranked by (tile_dilate_kernel)
   mutable unsigned int* ws_rng = nullptr;  // per local pixel: the generator's state after the probe's samples (KArgs.resume_rng)
   mutable int* ws_order = nullptr;         //                cost-sorted tile order
   mutable int ws_tiles = 0;
@@ -1318,6 +1343,7 @@ void pt_scene_destroy(PtScene* s) {
   if (s->ws_cost) (void)hipFree(s->ws_cost);
   if (s->ws_order) (void)hipFree(s->ws_order);
   if (s->ws_rng) (void)hipFree(s->ws_rng);
+  if (s->ws_rank) (void)hipFree(s->ws_rank);
   if (s->ws_nsplit) (void)hipFree(s->ws_nsplit);
   if (s->ws_partial) (void)hipFree(s->ws_partial);
   delete s;
@@ -1359,10 +1385,12 @@ static int reserve_tiles(const PtScene* s, int local_tiles) {
   if (s->ws_cost) (void)hipFree(s->ws_cost);
   if (s->ws_order) (void)hipFree(s->ws_order);
   if (s->ws_rng) (void)hipFree(s->ws_rng);
-  s->ws_cost = nullptr; s->ws_order = nullptr; s->ws_rng = nullptr; s->ws_tiles = 0;
+  if (s->ws_rank) (void)hipFree(s->ws_rank);
+  s->ws_cost = nullptr; s->ws_order = nullptr; s->ws_rng = nullptr; s->ws_rank = nullptr; s->ws_tiles = 0;
   PT_HIP(hipMalloc((void**)&s->ws_cost, (size_t)local_tiles * sizeof(unsigned int)));
   PT_HIP(hipMalloc((void**)&s->ws_order, (size_t)local_tiles * sizeof(int)));
   PT_HIP(hipMalloc((void**)&s->ws_rng, (size_t)local_tiles * PT_TILE_PIXELS * sizeof(unsigned int)));
+  PT_HIP(hipMalloc((void**)&s->ws_rank, (size_t)local_tiles * sizeof(unsigned int)));
   s->ws_tiles = local_tiles;
   return PT_OK;
 }
@@ -1656,8 +1684,14 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
     if (rc) return rc;
     // rough per-iteration instruction counts: traversal (splittable) vs shading + camera + cooperative overhead (not)
     const int forced_logG = s->knobs.wide_logG; // 0: the model picks the group size of the wide phase
+    const unsigned int* ranked = s->ws_cost;
+    if (a.cost_max && p->shard_count == 1 && !coop) { // tile_dilate_kernel (a shard's neighbours are other ranks' tiles: its own estimates)
+      hipLaunchKernelGGL(tile_dilate_kernel, dim3((unsigned int)((local_tiles + 255) / 256)), dim3(256), 0, st, s->ws_cost, a.tiles_x, (int)(a.n_tiles / a.tiles_x), s->ws_rank);
+      PT_HIP(hipGetLastError());
+      ranked = s->ws_rank;
+    }
     // rough per-iteration instruction counts: traversal (splittable) vs shading + camera (not)
-    hipLaunchKernelGGL(lpt_order_kernel, dim3(1), dim3(1024), 0, st, s->ws_cost, local_tiles, s->ws_order, n_waves_resident,
+    hipLaunchKernelGGL(lpt_order_kernel, dim3(1), dim3(1024), 0, st, ranked, local_tiles, s->ws_order, n_waves_resident,
                        std::max(1.0f, s->traversal_cost), s->knobs.model_fixed, s->knobs.model_chain, forced_logG, coop ? s->ws_nsplit : nullptr);
     PT_HIP(hipGetLastError());
     if (s->knobs.has_split_tiles) { // tuning knob: fixed number of split tiles (< 0: all)
@@ -1667,12 +1701,8 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
         PT_HIP(hipMemcpyAsync(s->ws_nsplit, &s->nsplit_override, sizeof(int), hipMemcpyHostToDevice, st));
       }
     }
-    // (Why one launch in five of the 496-hittable frame takes 407 instead of 376 ms — every workgroup resident from the first microsecond,
-    // one of them 40 ms longer than the rest, tools/block_residency.py: the probe's estimate, a tile's heaviest pixel over 16 samples, is
-    // noisy, a tile whose estimate came out too light sits at a run-to-run varying place of its class (lpt_order_kernel), and when that
-    // place is among the last dequeues its chain is the frame's tail.  A second, ORDERED probe stage of samples / 8 that keeps counting
-    // removes the slow mode — 1080p x 1024 spp 375 / 407 -> 380.8 +- 1.5, x 256 spp 103 / 115 -> 100.1 — at the price of the fast one and of
-    // 4 % on chain-bound shards: not kept, profiles/r05_ab_probe_resume.txt.)
+    // (A second, ORDERED probe stage of samples / 8 that keeps counting also removes the slow launches tile_dilate_kernel is there for — 1080p x
+    // 1024 spp 375 / 407 -> 380.8 +- 1.5 — at the price of the fast ones and of 4 % on chain-bound shards: not kept.)
     a = main_args;
     if (resume) { a.resume_rng = s->ws_rng; a.resume_spp = probe_spp; }
     a.order = s->ws_order;
