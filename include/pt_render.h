@@ -267,7 +267,10 @@ void pt_scene_destroy(PtScene* scene);
  *                      0: one tile per SIMD of the chip in that range, none outside; -1: never)
  *   probe_resume       the cost probe's samples are the frame's first samples — the frame launch starts every pixel from the radiance sum and
  *                      the generator state the probe left (same stream, same order of additions) — 0: yes; -1: the probe's samples are
- *                      thrown away and rendered again, as before round 5 (PT_NO_PROBE_RESUME; the A/B)                                        */
+ *                      thrown away and rendered again, as before round 5 (PT_NO_PROBE_RESUME; the A/B)
+ *   chain_priority     headline-family frame launches (no sphere grid, no cooperative phase): from the middle of the tile queue on, a wave
+ *                      raises its issue priority by the samples its slowest pixel still has to render — the longest remaining chain first;
+ *                      changes no value, only when a pixel is rendered — 0: yes; -1: never (PT_NO_CHAIN_PRIO; the A/B)                        */
 typedef struct PtTuning {
   int32_t struct_size; /* sizeof(PtTuning) of the caller's header */
   int32_t sphere_grid;
@@ -286,6 +289,7 @@ typedef struct PtTuning {
   int32_t tri_budget_mb;
   float tri_rho2;
   int32_t probe_resume;  /* (round 5, the last reserved word) */
+  int32_t chain_priority; /* (round 5: appended — a caller built against the shorter struct passes its own struct_size and gets the default) */
 } PtTuning;
 void pt_tuning_init(PtTuning* t);     /* zero + struct_size: the library's defaults                                          */
 void pt_tuning_from_env(PtTuning* t); /* the defaults with the PT_* environment applied: what pt_scene_create(desc, out) uses */

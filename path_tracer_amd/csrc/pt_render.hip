@@ -106,6 +106,10 @@ struct KArgs {
   // sample resume_spp — the same stream, the same order of additions (render.hpp:95-101), and no sample is rendered twice.
   unsigned int* resume_rng;
   int resume_spp;
+  // Headline-family launches (launch_render): once prio_onset queue positions are taken, a wave sets its issue priority — every 64
+  // iterations — by the samples its slowest pixel still has to render: >= prio_t3 -> 3, >= prio_t2 -> 2, >= prio_t1 -> 1, else 0 (render_kernel).
+  // prio_t1 = 0: never.
+  int prio_onset, prio_t1, prio_t2, prio_t3;
   int cost_max;        // probe: 1 = keep the tile's HEAVIEST pixel (x 64) instead of the sum over its pixels
   const int* order;    // non-NULL: queue position -> local tile, heaviest first
   const int* n_split;  // non-NULL (COOP kernels): [0] how many leading tiles of `order` go through the wide phase, [1] log2 G
@@ -146,6 +150,7 @@ template <> struct Cold<false> {
   __device__ __forceinline__ int add_sample(V3 o) { acc = acc + o; return ++s; }
   __device__ __forceinline__ void count_ray() { iters++; }
   __device__ __forceinline__ V3 get_acc() const { return acc; }
+  __device__ __forceinline__ int get_s() const { return s; }
   __device__ __forceinline__ int get_pix() const { return pix; }
   __device__ __forceinline__ int get_x() const { return x; }
   __device__ __forceinline__ int get_y() const { return y; }
@@ -168,6 +173,7 @@ template <> struct Cold<true> {
   }
   __device__ __forceinline__ void count_ray() { p[7 * kBlock] = __int_as_float(__float_as_int(p[7 * kBlock]) + 1); }
   __device__ __forceinline__ V3 get_acc() const { return mk(p[0], p[kBlock], p[2 * kBlock]); }
+  __device__ __forceinline__ int get_s() const { return __float_as_int(p[3 * kBlock]); }
   __device__ __forceinline__ int get_pix() const { return __float_as_int(p[4 * kBlock]); }
   __device__ __forceinline__ int get_x() const { return __float_as_int(p[5 * kBlock]); }
   __device__ __forceinline__ int get_y() const { return __float_as_int(p[6 * kBlock]); }
@@ -521,10 +527,39 @@ void render_kernel(KArgs a) {
 #ifdef PT_STAMPS
   unsigned long long s_prep = 0, s_trav = 0, s_shade = 0, s_iters = 0;
 #endif
+  unsigned int prio_it = 0; // (headline family) iterations of this wave, for the priority poll below
   for (;;) {
 #ifdef PT_STAMPS
     PT_STAMP(t0);
 #endif
+    // LONGEST REMAINING CHAIN FIRST, from mid-frame on (headline family only: kernels without a grid walk, a cooperative phase or a pool).
+    // All resident waves take the heaviest tiles at t = 0, and a third of them never take another: their tile runs for the whole frame,
+    // at 3.5 x a lone wave's iteration because six other waves share the SIMD's issue slots — and the frame ends with the longest of those
+    // chains, ~10 ms after its work would be done if it could be spread (profiles/r05_wave_tail_cornell.txt).  A pixel's chain cannot be
+    // cut, but its wave can be given the slots: once half the queue is taken, every wave tells the SIMD's arbiter how much its slowest
+    // pixel still has to do — more than 1/2, 1/4, 1/8 of the samples: priority 3, 2, 1 (s_setprio; polled every 64 iterations: one scalar
+    // compare per iteration, ~25 instructions per poll).  Waves on light tiles lose slots they had to spare; the long chains end earlier:
+    // Cornell-style 1080p x 1024 spp 139.5 -> 128.2 ms, x 256 spp 37.8 -> 34.9, shard 0 of 4 / 8: 51.9 / 41.6 -> 45.6 / 40.3
+    // (profiles/r05_ab_chain_priority.txt; ladders 2.5-5-10, 3-6-12, 2-4-16 and onsets 7/16 ... 9/16 within 1 %; from the start of the
+    // frame, or by the PROBE's estimate of a tile's heaviest pixel: worse than none — what a wave knows about its own progress is exact, what the
+    // probe guessed is not).  The grid kernels lose 5 % with it (latency-bound at four waves per SIMD) and do not carry it.
+    if constexpr (GRID == 0 && !COOP && !FAST && !TRIPOOL && LDS) {
+      if (a.prio_t1 > 0 && ((++prio_it) & 63u) == 0u) {
+        PT_COLD_ARGS(k, a);
+        unsigned int head = 0;
+        if ((threadIdx.x & 63) == 0) head = __hip_atomic_load(k.queue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        head = __builtin_amdgcn_readfirstlane(head);
+        if (head >= (unsigned int)k.prio_onset) {
+          int rem = L.live ? k.samples - L.cold.get_s() : 0;
+#pragma unroll
+          for (int st = 32; st >= 1; st >>= 1) rem = max(rem, __shfl_xor(rem, st, 64));
+          if (rem >= k.prio_t3) __builtin_amdgcn_s_setprio(3);
+          else if (rem >= k.prio_t2) __builtin_amdgcn_s_setprio(2);
+          else if (rem >= k.prio_t1) __builtin_amdgcn_s_setprio(1);
+          else __builtin_amdgcn_s_setprio(0);
+        }
+      }
+    }
     lane_prepare<FAST>(L, a);
     if (__builtin_amdgcn_ballot_w64(L.live) == 0) {
       if (__builtin_amdgcn_ballot_w64(!L.retired) == 0) break; // queue drained for the whole wave
@@ -970,6 +1005,7 @@ static void tuning_env(PtTuning& t) {
   if (const char* e = std::getenv("PT_LPT_MAX")) t.lpt_by_max = std::atoi(e) != 0 ? 1 : -1;
   if (const char* e = std::getenv("PT_PROBE_SPP_MAX")) t.probe_spp_max = std::max(1, std::atoi(e));
   if (has("PT_NO_PROBE_RESUME")) t.probe_resume = -1;
+  if (has("PT_NO_CHAIN_PRIO")) t.chain_priority = -1;
   if (const char* e = std::getenv("PT_GRID_MIN_TILES")) t.grid_min_tiles = std::max(0, std::atoi(e));
   if (const char* e = std::getenv("PT_MODEL_FIXED")) t.model_fixed = (float)std::atof(e);
   if (const char* e = std::getenv("PT_MODEL_CHAIN")) t.model_chain = (float)std::atof(e);
@@ -1052,6 +1088,7 @@ struct Knobs {
   bool generic_materials = false;
   int grid_walk = 0;       // PtTuning.grid_walk: 0 the launcher's rule, 1 the wave-synchronous walk, 2 the queued walk
   int lanes_cap = 0;       // PtTuning.lanes_cap: grid kernels on small frames (launch): 0 the rule, -1 whole tiles always, n forced
+  bool no_chain_prio = false; // PtTuning.chain_priority = -1: no issue priorities in the headline family's frame launches
   bool no_resume = false;  // PtTuning.probe_resume = -1: the probe's samples are rendered again by the frame launch
   int heavy_tiles = 0;     // PtTuning.heavy_tiles: tiles at the head of the cost-sorted order that are handed out 16 pixels at a time: 0 the rule, -1 never, n forced
   Knobs() {}
@@ -1072,6 +1109,7 @@ struct Knobs {
     grid_walk = (t.grid_walk == 1 || t.grid_walk == 2) ? t.grid_walk : 0;
     heavy_tiles = t.heavy_tiles < 0 ? -1 : t.heavy_tiles;
     no_resume = t.probe_resume < 0;
+    no_chain_prio = t.chain_priority < 0;
   }
 };
 
@@ -1463,6 +1501,7 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
   a.cost = nullptr;
   a.cost_max = 0;
   a.resume_rng = nullptr; a.resume_spp = 0;
+  a.prio_onset = 0; a.prio_t1 = a.prio_t2 = a.prio_t3 = 0;
   a.order = nullptr;
   const bool mlds = lds && blob_bytes + (size_t)s->mats_f4 * 16 <= kMaxLdsWithMaterials;
   const size_t shmem = lds ? blob_bytes + (mlds ? (size_t)s->mats_f4 * 16 : 0) : 0;
@@ -1528,6 +1567,12 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
         (double)launch_units < 1.6 * (double)per_cu * waves_per_block * std::max(1, s->num_cus))
       per_cu = std::min(per_cu, 4);
     if (s->knobs.blocks_per_cu) per_cu = std::min(per_cu, s->knobs.blocks_per_cu); // tuning knob
+    // longest remaining chain first (render_kernel): the headline family's frame launches in parity mode, from the middle of the queue on
+    a.prio_onset = 0; a.prio_t1 = a.prio_t2 = a.prio_t3 = 0;
+    if (chain_bound_family && !a.cost && !a.fast_chunks && a.tile_granular && !s->knobs.no_chain_prio && p->samples >= 16) {
+      a.prio_onset = a.n_local_pixels / 2;
+      a.prio_t3 = p->samples / 2; a.prio_t2 = p->samples / 4; a.prio_t1 = p->samples / 8;
+    }
     const int resident_blocks = std::max(1, per_cu) * std::max(1, s->num_cus);
     // Queue counters come from a ring of kQueueRing slots.  A slot is reused only after the launch that last used it has
     // finished (more than kQueueRing launches in flight on one scene would otherwise share a dequeue counter and lose or

@@ -1090,6 +1090,25 @@ def test_the_cost_probes_samples_are_the_frames_first_samples(orc, torch_gpu):
         assert torch.equal(a.view(torch.int32), b.view(torch.int32)), name
 
 
+def test_longest_remaining_chain_first_changes_no_value(orc, torch_gpu):
+    """Round 5 (pt_render.hip: render_kernel, KArgs.prio_*): from the middle of the tile queue on, the headline family's waves set their issue
+    priority by the samples their slowest pixel still has to render.  Only WHEN a pixel is rendered changes: the frame must equal the one
+    rendered without priorities (PtTuning.chain_priority = -1) and the oracle's, bit for bit — whole frames and shards, long enough for the
+    rule to act (more than 64 iterations per wave after half the queue is taken)."""
+    import torch
+    orc.set_math(True)
+    ps, cam = scenes.build("cornell")
+    for W, H, spp, shard in ((512, 384, 128, None), (640, 360, 64, (1, 3))):
+        c = scenes.make_camera(cam, W, H)
+        kw = dict(shard_index=shard[0], shard_count=shard[1]) if shard else {}
+        on = R.render(W, H, spp, R.DeviceScene(ps), c, **kw)
+        off = R.render(W, H, spp, R.DeviceScene(ps, tuning=abi.tuning(chain_priority=-1)), c, **kw)
+        assert torch.equal(on.view(torch.int32), off.view(torch.int32)), (W, H, spp, shard)
+        if not shard:
+            xy = np.stack([np.random.default_rng(21).integers(0, W, 200), np.random.default_rng(22).integers(0, H, 200)], axis=1).astype(np.int32)
+            assert_bit_identical(on.cpu().numpy()[xy[:, 1], xy[:, 0]], orc.render_pixels(ps, c.c, W, H, spp, xy), "priorities on, against the oracle")
+
+
 def test_launcher_rules_for_chain_bound_launches(torch_gpu):
     """What launch_render decides, read back through pt_debug_last_launch: the headline family keeps four workgroups per CU when a launch
     has fewer than 1.6 tiles per wave slot (a shard of 3 - 6 of the 1080p frame) and its full occupancy otherwise; the 496-hittable scene's
