@@ -1557,14 +1557,16 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
     }
     // (a kernel variant that does not fit a CU at all — its static + dynamic LDS beyond the device's limit — must not be launched and hoped for)
     if (per_cu < 1) return fail(PT_ERR_TOO_LARGE, "pt_render: this scene's kernel variant does not fit a compute unit (LDS " + std::to_string(shmem) + " B dynamic + static)");
-    // A headline-family launch with fewer than ~1.6 tiles per wave slot (shard 0 of 3 ... 6 of the 1080p frame) is bound by its heaviest
+    // A headline-family launch with fewer than ~1.15 tiles per wave slot (shard 0 of 4 ... 6 of the 1080p frame) is bound by its heaviest
     // tiles' sequential chains, and a chain's iteration takes as long as the waves that share its SIMD make it: four waves per SIMD that
     // take two tiles each, heaviest first, finish before eight that take one.  Cornell-style 1080p x 1024 spp, kernel ms of shard 0 of
     // N = 3 / 4 / 6 at 8 and at 4 workgroups per CU: 63.3 / 57.8 / 43.4 and 60.3 / 51.1 / 42.8 (profiles/r04_blocks_sweep.txt); whole frames
     // and halves (>= 2 tiles per slot) keep the full occupancy, and a launch with half a tile per slot takes four per CU by itself.
     // (Grid and triangle-pool kernels: their own occupancy is the best at every shard count — same file.)
+    // (Round 5, with the chain priorities of render_kernel: shard 0 of 3 — 1.3 tiles per slot — 61.2 ms at four workgroups per CU, 54.4 / 57.1 at
+    // six / eight; shard 0 of 4 — 1.0 — 45.2 / 47.3 / 48.7: the bound moved from 1.6 to 1.15; profiles/r05_ab_chain_priority.txt.)
     if (chain_bound_family && !s->knobs.blocks_per_cu && a.n_split == 0 && a.scatter_p == 0 &&
-        (double)launch_units < 1.6 * (double)per_cu * waves_per_block * std::max(1, s->num_cus))
+        (double)launch_units < 1.15 * (double)per_cu * waves_per_block * std::max(1, s->num_cus))
       per_cu = std::min(per_cu, 4);
     if (s->knobs.blocks_per_cu) per_cu = std::min(per_cu, s->knobs.blocks_per_cu); // tuning knob
     // longest remaining chain first (render_kernel): the headline family's frame launches in parity mode, from the middle of the queue on
