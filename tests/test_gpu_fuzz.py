@@ -582,3 +582,30 @@ def test_path_rays_on_the_baseline_scenes(orc, lib, name, n, gens):
     with tri_pools() if name == "triangles" else contextlib.nullcontext():  # the 100 k-triangle mesh through its triangle pool
         checked, bad = follow_paths(lib, orc, ps, c.c, w, h, n, gens, 7)
     assert checked >= 1.5 * n and not bad, f"{len(bad)} of {checked} rays differ: " + " | ".join(bad[:3])
+
+
+@pytest.mark.gpu
+def test_scheduling_paths_change_no_frame():
+    """Round 5's scheduling — the cost probe whose samples are kept, the dilated cost map, the heaviest-first order, the issue priorities of the
+    headline family — decides only WHEN a pixel is rendered.  Random (scene, frame size, samples, shard): the default path's framebuffer must
+    equal, bit for bit, the one rendered with none of it (PT_FLAG_NO_LPT; PtTuning.chain_priority = probe_resume = -1).  The short form of
+    tools/soak_scheduling.py (profiles/r05_soak_scheduling.log: 300 frames); the parity tests compare the default path with the oracle."""
+    import torch
+    import scenes_small as S
+    rng = np.random.default_rng(17)
+    pool = {"cornell": scenes.build("cornell"), "smoke": scenes.build("smoke"), "field": S.sphere_field_scene(), "mixed": S.mixed_scene()}
+    plain = abi.tuning(chain_priority=-1, probe_resume=-1)
+    made = {}
+    for case in range(28):
+        name = list(pool)[case % 4]
+        ps, cam_args = pool[name]
+        W, H = int(rng.integers(64, 800)), int(rng.integers(64, 500))
+        spp = int(rng.choice([16, 17, 32, 48, 96]))
+        n = int(rng.choice([1, 1, 2, 3]))
+        idx = int(rng.integers(0, n))
+        cam = scenes.make_camera(cam_args, W, H)
+        if name not in made:
+            made[name] = (R.DeviceScene(ps), R.DeviceScene(ps, tuning=plain))
+        a = R.render(W, H, spp, made[name][0], cam, shard_index=idx, shard_count=n)
+        b = R.render(W, H, spp, made[name][1], cam, shard_index=idx, shard_count=n, flags=abi.PT_FLAG_NO_LPT)
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (name, W, H, spp, idx, n)
