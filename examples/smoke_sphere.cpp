@@ -1,6 +1,6 @@
 // examples/smoke_sphere.cpp — the reference's src/main.cpp:61-197 rewritten against the C++20 facade: same scene literal
-// (the RNG calls inside one expression are evaluated left to right here; the reference leaves that order to the
-// compiler, main.cpp:83,87,92), same camera, same output stage (gamma 2, clamp, x256, rows flipped) into out.png (main.cpp:33-59)
+// (main.cpp:83 leaves the order of the two RNG calls among its constructor arguments to the compiler; here it is DEFINED
+// as last-to-first, g++'s order, which reproduces the counters the SURVEY recorded from the reference's own build), same camera, same output stage (gamma 2, clamp, x256, rows flipped) into out.png (main.cpp:33-59)
 // or, for any other file name, a binary PPM (main.cpp:17-31).  stb is not a dependency: pt/image_io.hpp decodes and writes.  The two
 // image textures are loaded like main.cpp:133,145 does, through image_texture::image_texture_factory, from <images_dir>/Xilinx.jpg and
 // <images_dir>/SYCL.png (default "../images" as in the reference; a directory holding the decoded-pixel exports Xilinx.ppm / SYCL.ppm
@@ -69,8 +69,10 @@ int main(int argc, char** argv) {
   for (int a = -11; a < 11; a++) {
     for (int b = -11; b < 11; b++) {
       float choose_mat = rng.float_t();
-      float cx = a + 0.9f * rng.float_t();
+      // main.cpp:83 leaves the order of its two draws unspecified; g++ evaluates the constructor's arguments last to
+      // first, and that order reproduces the SURVEY's recorded counters of the reference: z first (scenes.py "rtl")
       float cz = b + 0.9f * rng.float_t();
+      float cx = a + 0.9f * rng.float_t();
       point center(cx, 0.2f, cz);
       float dx = cx - 4.0f, dy = 0.2f - 0.2f, dz = cz - 0.0f;
       if (std::sqrt(dx * dx + dy * dy + dz * dz) > 0.9f) {

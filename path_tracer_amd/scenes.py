@@ -106,12 +106,16 @@ def _procedural_image(w: int, h: int, seed: int) -> np.ndarray:
 
 
 def smoke_sphere_scene(atlas: TextureAtlas | None = None, xilinx_rgb: np.ndarray | None = None,
-                       sycl_rgb: np.ndarray | None = None, textures: str = "reference"):
+                       sycl_rgb: np.ndarray | None = None, textures: str = "reference", arg_order: str = "rtl"):
     """The default scene of /root/reference/src/main.cpp:67-161 ("SmokeSphere").
 
-    main.cpp:83,87,92 leave the order of the rng calls inside one expression unspecified, so the
-    reference's exact scene depends on its compiler; here the order is DEFINED left-to-right.  The
-    result has the same population (≈490 small spheres: 40 % lambertian, 40 % moving lambertian,
+    main.cpp:83 leaves the order of the two rng calls among a constructor's arguments unspecified (:87,:92 multiply
+    two vec_t() draws elementwise: commutative, the order cannot show), so the reference's exact scene depends on
+    its compiler.  Here the order is DEFINED and selectable: arg_order="rtl" (default, round 6) draws the z
+    displacement before the x displacement, which is what g++ does — with it the oracle reproduces every printed
+    digit of the counters SURVEY.md §3.3 recorded from the reference's own g++ 11.4 build
+    (tests/test_survey_counters_anchor.py); "ltr" is rounds 1-5's scene (the same population, another draw).  The
+    result has the population (≈490 small spheres: 40 % lambertian, 40 % moving lambertian,
     15 % metal, 5 % glass; pyramid; light; image-textured rect + sphere; glass, lambertian and metal
     big spheres; logo sphere; metal monolith; smoke ball).  The atlas follows texture.hpp:113-114,157: the {0,0,1}
     fallback texel, then Xilinx.jpg's texels at offset 1, then SYCL.png's at 1 + 1024*512.
@@ -119,6 +123,8 @@ def smoke_sphere_scene(atlas: TextureAtlas | None = None, xilinx_rgb: np.ndarray
     stand-ins; explicit xilinx_rgb / sycl_rgb arrays override either.  Returns (hittables, camera_args, atlas)."""
     if textures not in ("reference", "procedural"):
         raise ValueError("textures must be 'reference' or 'procedural'")
+    if arg_order not in ("ltr", "rtl"):
+        raise ValueError("arg_order must be 'ltr' or 'rtl'")
     if textures == "reference" and (xilinx_rgb is None or sycl_rgb is None):
         rx, rs = reference_textures()
         xilinx_rgb = rx if xilinx_rgb is None else xilinx_rgb
@@ -131,8 +137,12 @@ def smoke_sphere_scene(atlas: TextureAtlas | None = None, xilinx_rgb: np.ndarray
     for a in range(-11, 11):
         for b in range(-11, 11):
             choose_mat = rng.float_t()
-            cx = f32(a) + f32(0.9) * rng.float_t()
-            cz = f32(b) + f32(0.9) * rng.float_t()
+            if arg_order == "rtl":  # main.cpp:83's constructor arguments evaluated last to first (what g++ does)
+                cz = f32(b) + f32(0.9) * rng.float_t()
+                cx = f32(a) + f32(0.9) * rng.float_t()
+            else:
+                cx = f32(a) + f32(0.9) * rng.float_t()
+                cz = f32(b) + f32(0.9) * rng.float_t()
             center = np.array([cx, f32(0.2), cz], dtype=f32)
             d = center - np.array([4, 0.2, 0], dtype=f32)
             if np.sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]) > f32(0.9):
