@@ -242,7 +242,11 @@ void pt_scene_destroy(PtScene* scene);
  *   tri_pool           -1: no triangle pool (PT_NO_TRICULL)
  *   tri_min_run        shortest triangle run that gets a pool (PT_TRI_MIN; 4096; PT_TRICULL=1 means 256)
  *   tri_M, tri_cell    the pool's slack 1/M (grid boxes grow with 1/M, bands with M) and its grid cell in median grown boxes (PT_TRI_M,
- *                      PT_TRI_CELL; 12, 0.22).  tri_Mg: ignored since round 5 (the two-radius filter of rounds 3-4 is gone)
+ *                      PT_TRI_CELL; 12, 0.22)
+ *   tri_binned         scenes with ONE pooled triangle run render in GENERATIONS (round 6; csrc/pt_binned.hpp): every live pixel traces one
+ *                      ray per generation and the rays are sorted by direction bin, so that a bin's list of grazing candidates is read once
+ *                      for 64 rays — 0: yes; -1: the persistent kernel takes each ray through its own list (PT_TRI_UNBINNED; the A/B).
+ *                      Such renders have returned only when the frame is done (the number of generations is known on the device only)
  *   tri_res[0..2], tri_rho[0..1] + tri_rho2   the pool's direction maps: resolution per cube-map face and the largest rho / R a map
  *                      serves, per rho class (PT_TRI_RES=a,b,c PT_TRI_RHO=a,b,c; {256, 256, 64}, {2.12, 4, 16}; a negative rho: no such
  *                      map; rays with rho beyond the last class stream every band record)
@@ -277,7 +281,9 @@ typedef struct PtTuning {
   float grid_margin, grid_cell;
   int32_t slab_pools;
   int32_t tri_pool, tri_min_run;
-  float tri_M, tri_Mg, tri_cell;
+  float tri_M;
+  int32_t tri_binned; /* (round 6: took the place of tri_Mg, dead since round 5) */
+  float tri_cell;
   int32_t tri_res[3];
   int32_t generic_materials;
   int32_t blocks_per_cu, cold_state, wide_log2_group, split_tiles_mode, split_tiles, lpt_by_max, probe_spp_max, grid_min_tiles;

@@ -84,7 +84,7 @@ class PtTuning(C.Structure):
     """include/pt_render.h PtTuning: performance-only knobs (same image under all of them).  Zero = the library's default."""
     _fields_ = [("struct_size", C.c_int32), ("sphere_grid", C.c_int32), ("grid_margin", C.c_float), ("grid_cell", C.c_float),
                 ("slab_pools", C.c_int32), ("tri_pool", C.c_int32), ("tri_min_run", C.c_int32),
-                ("tri_M", C.c_float), ("tri_Mg", C.c_float), ("tri_cell", C.c_float), ("tri_res", C.c_int32 * 3),
+                ("tri_M", C.c_float), ("tri_binned", C.c_int32), ("tri_cell", C.c_float), ("tri_res", C.c_int32 * 3),
                 ("generic_materials", C.c_int32), ("blocks_per_cu", C.c_int32), ("cold_state", C.c_int32),
                 ("wide_log2_group", C.c_int32), ("split_tiles_mode", C.c_int32), ("split_tiles", C.c_int32),
                 ("lpt_by_max", C.c_int32), ("probe_spp_max", C.c_int32), ("grid_min_tiles", C.c_int32),

@@ -913,7 +913,7 @@ __device__ __forceinline__ unsigned long long* tri_slots() { __shared__ unsigned
 #ifndef PT_TRI_ABLATE
 #define PT_TRI_ABLATE 0 /* timing experiments only: 1 no grid, 2 no direction maps (every ray streams every band record), 4 no band stage at all (wrong images) */
 #endif
-#define PT_TRI_QUEUE 192 /* >= 63 left over + one trip's 64 pushes (the grid's pairs; the band stage's survivors), and >= PT_SQ_CAP */
+#define PT_TRI_QUEUE 192 /* >= 64 PT_TRI_PAIRS - 1 left over + one trip's 64 pushes (the grid's pairs; the band stage's survivors), and >= PT_SQ_CAP */
 __device__ __forceinline__ int* tri_queue() { __shared__ int s[4 * PT_TRI_QUEUE]; return s; } // per wave: what waits for the exact test
 #ifndef PT_MAX_WAVES_PER_BLOCK
 #define PT_MAX_WAVES_PER_BLOCK 4
@@ -1385,13 +1385,191 @@ __device__ __forceinline__ bool tri_param(f4 R0, f4 R1, f4 R2, const Ray& r, flo
 }
 __device__ __forceinline__ float rl_f(float v, int src) { return as_f(__builtin_amdgcn_readlane(as_i(v), src)); }
 
+// the bin of a direction in a direction map of R bins per face edge (pt_tripool.hpp: build_dir_map lists by exactly this rule)
+__device__ __forceinline__ unsigned int tri_dir_bin(V3 d, int R) {
+  const float adx = __builtin_fabsf(d.x), ady = __builtin_fabsf(d.y), adz = __builtin_fabsf(d.z);
+  // face k = the largest |component| (exact comparisons); (p, q) = (d_a, d_b) / d_k with a = k + 1, b = k + 2 (mod 3)
+  const int k = (adx >= ady && adx >= adz) ? 0 : (ady >= adz ? 1 : 2);
+  const float dk = k == 0 ? d.x : k == 1 ? d.y : d.z, da = k == 0 ? d.y : k == 1 ? d.z : d.x, db = k == 0 ? d.z : k == 1 ? d.x : d.y;
+  const float rk = __builtin_amdgcn_rcpf(dk), halfR = 0.5f * (float)R;
+  const int ci = min(max((int)__builtin_floorf((da * rk + 1.0f) * halfR), 0), R - 1), cj = min(max((int)__builtin_floorf((db * rk + 1.0f) * halfR), 0), R - 1);
+  return (unsigned int)((k * R + cj) * R + ci);
+}
+
 // centroid of a compressed band record: lo + k step per axis, one multiplication and one addition each, NOT fused — the host measures
 // the deviation eps_c of exactly this decode (pt_tripool.hpp "compressed records")
 __device__ __forceinline__ V3 tri_centroid(unsigned int kx, unsigned int ky, unsigned int kz, f4 H7, f4 H8) {
   return mk(H7.x + (float)kx * H8.x, H7.y + (float)ky * H8.y, H7.z + (float)kz * H8.z);
 }
 
-__device__ __forceinline__ bool tri_pool_scan(glb_f4p pool, cst_f4p cblob, int hdr, int goff, const RayCtx& c, HitState& h) {
+// ONE RAY (wave-uniform: in scalar operands) through one list of a direction map, the list's entries across the 64 lanes: stage 1 (the band
+// test in integers on the gathered compressed records), stage 2 (the noise-radius filter, 64 queued survivors at a time), then the
+// reference's test, 64 at a time; on_hit(key) receives every accepted candidate's tri_key.  Called by tri_pool_scan for each of a wave's
+// rays in turn, and (round 6) by the binned band stage for the rays of packets too small to share a list (pt_binned.hpp).
+struct TriBandCtx {
+  f4 H5, H6, H7, H8;
+  unsigned int band_rec, tri_sorted;
+  int n_tri, goff;
+};
+template <typename HitFn>
+__device__ __forceinline__ void tri_band_one_ray(glb_f4p pool, const TriBandCtx& K, const Ray& ur, float ua, float rho, float dn, unsigned int first,
+                                                 unsigned int last, unsigned int cand_off, bool listed, HitFn&& on_hit) {
+#ifndef PT_NO_FILTER_FMA
+#pragma clang fp contract(fast) /* filter arithmetic: see tri_pool_scan */
+#endif
+  const f4 H5 = K.H5, H6 = K.H6, H7 = K.H7, H8 = K.H8;
+  const unsigned int band_rec = K.band_rec, tri_sorted = K.tri_sorted;
+  const int n_tri = K.n_tri, goff = K.goff;
+  const int lane = threadIdx.x & 63;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  int* const tq = tri_queue() + (threadIdx.x >> 6) * PT_TRI_QUEUE; // per wave: what waits for the exact test
+  int qn = 0; // entries queued for the exact test (uniform)
+  auto push = [&](bool p, int e) {
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(p);
+    if (p) tq[qn + __builtin_popcountll(m & below)] = e;
+    qn += __builtin_popcountll(m);
+  };
+  // the reference's test for the top min(64, qn) entries and the (uniform) ray; a hit goes to on_hit
+  auto drain = [&](int keep) {
+    __builtin_amdgcn_wave_barrier();
+    while (qn > keep) {
+      const int n = min(qn, 64);
+      if (lane < n) {
+        const unsigned int o = tri_sorted + 3u * (unsigned int)tq[qn - n + lane];
+        const f4 R0 = pool[o], R1 = pool[o + 1], R2 = pool[o + 2];
+        float t;
+        if (tri_param(R0, R1, R2, ur, t) && !(t < PT_TMIN)) on_hit(tri_key(t, goff + 3 * as_i(R2.w)));
+      }
+      qn -= n;
+    }
+    __builtin_amdgcn_wave_barrier();
+  };
+  // band test, then the noise-radius filter: the line within L + kr rho |d| / (|a'| - ea |d|) of the centroid
+  // on the 16-byte compressed record (pt_tripool.hpp "compressed records"; every quantity rounded to the safe side)
+  auto near_line = [&](V3 C, float rad) { // does the ray's LINE pass within `rad` of the point C?
+    const V3 x = cross(C - ur.o, ur.d);
+    return dot(x, x) <= rad * rad * ua * 1.00001f;
+  };
+  auto band_pass = [&](f4 Q) {
+    const unsigned int w0 = (unsigned int)as_i(Q.x), w1 = (unsigned int)as_i(Q.y), w2 = (unsigned int)as_i(Q.z), w3 = (unsigned int)as_i(Q.w);
+    const float nx = (float)((int)(w0 << 16) >> 16), ny = (float)((int)w0 >> 16), nz = (float)((int)(w1 << 16) >> 16);
+    const float pn = as_f((int)(w1 & 0xffff0000u)), L = as_f((int)(w3 & 0xffff0000u));
+    const float dq = __builtin_fabsf(ur.d.x * nx + ur.d.y * ny + ur.d.z * nz) * 3.0518509e-5f; // |d . n~|, n~ = (nx, ny, nz) / 32767
+    const float rL = __builtin_amdgcn_rcpf(L) * 1.00001f;
+    if (!(dq <= dn * (pn * (rho + H5.y * L + H5.w * rL) + H8.w) * 1.00001f)) return false;
+    const float L2 = L * L;
+    const float nlow = 0.98f * H5.z * L * __builtin_amdgcn_rcpf(pn);          // <= |N|
+    const float a1 = (dq - dn * H8.w) * nlow - H6.w * L2 * dn;                 // <= |a'| - ea |d|
+    const float rr = (H6.y + H6.z * L) * L2 * rho * dn * __builtin_amdgcn_rcpf(a1) * 1.001f; // >= the noise radius; a1 <= 0: no bound
+    const V3 C = tri_centroid(w2 & 0xffffu, w2 >> 16, w3 & 0xffffu, H7, H8);
+    return !(a1 > 0.0f) || near_line(C, L + rr + H6.x + H7.w);
+  };
+  const V3 dh = __builtin_amdgcn_rsqf(ua) * ur.d; // unit direction (a few ulp: covered by the integer test's absolute slack)
+  // Two stages.  Stage 1, on every enumerated candidate: the band test alone, in INTEGERS — the record's normal is three 16-bit
+  // integers k / 32767, the ray's unit direction is rounded to the same grid once per ray, and two v_dot2_i32_i16 give
+  // S = kn . kd exactly (|S| <= 32767^2 (1 + 1e-4): no overflow); |d^ . n^| <= |S| / 32767^2 + eps_n + eps_d with
+  // eps_d = sqrt(3) / (2 * 32767) + 1e-6 (the rounding of the direction and of rsq), so the test below passes whenever the band
+  // test of pt_tripool.hpp does.  Its survivors are queued and run the full filter 64 at a time (stage 2).
+  const int kdx = (int)__builtin_rintf(dh.x * 32767.0f), kdy = (int)__builtin_rintf(dh.y * 32767.0f), kdz = (int)__builtin_rintf(dh.z * 32767.0f);
+  short2_t dxy, dz0;
+  { const unsigned int a = ((unsigned int)kdx & 0xffffu) | ((unsigned int)kdy << 16), b = (unsigned int)kdz & 0xffffu; __builtin_memcpy(&dxy, &a, 4); __builtin_memcpy(&dz0, &b, 4); }
+  const float e1s = H8.w + 2.75e-5f;
+  auto band_stage1 = [&](f4 Q) {
+    const unsigned int w0 = (unsigned int)as_i(Q.x), w1 = (unsigned int)as_i(Q.y), w3 = (unsigned int)as_i(Q.w);
+    short2_t nxy, nzp;
+    __builtin_memcpy(&nxy, &w0, 4); __builtin_memcpy(&nzp, &w1, 4); // (nzp's high half is pn's bits: multiplied by dz0's zero)
+    const int S = __builtin_amdgcn_sdot2(nzp, dz0, __builtin_amdgcn_sdot2(nxy, dxy, 0, false), false);
+    const float sa = (float)(S < 0 ? -S : S);
+    const float pn = as_f((int)(w1 & 0xffff0000u)), L = as_f((int)(w3 & 0xffff0000u));
+    const float rL = __builtin_amdgcn_rcpf(L) * 1.00001f;
+    return sa <= (pn * (rho + H5.y * L + H5.w * rL) + e1s) * 1.0737e9f; // 32767^2 (1 + 2e-5)
+  };
+  f4* const bq = tri_bqueue() + (threadIdx.x >> 6) * PT_TRI_BQUEUE;
+  int* const bqi = tri_bqueue_idx() + (threadIdx.x >> 6) * PT_TRI_BQUEUE;
+  int bn = 0;
+  auto bpush = [&](bool p, int e, f4 Q) {
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(p);
+    if (p) { const int at = bn + __builtin_popcountll(m & below); bq[at] = Q; bqi[at] = e; }
+    bn += __builtin_popcountll(m);
+  };
+  auto drain_band = [&](int keep) {
+    __builtin_amdgcn_wave_barrier();
+    while (bn > keep) {
+      const int n = min(bn, 64);
+      bool pass = false;
+      int e = 0;
+      if (lane < n) { e = bqi[bn - n + lane]; pass = band_pass(bq[bn - n + lane]); }
+      bn -= n;
+      PT_TRI_COUNT(8, __builtin_popcountll(__builtin_amdgcn_ballot_w64(pass)));
+      push(pass, e);
+      drain(63);
+    }
+    __builtin_amdgcn_wave_barrier();
+  };
+  // 128 entries per trip: lane l takes entries base + l, base + 64 + l.  The loop is a two-stage software pipeline — while the records
+  // of trip i are tested, the records of trip i + 1 are being gathered and the indices of trip i + 2 loaded — because a ray's turn is a
+  // chain of dependent loads (index -> record, a microsecond each from beyond L2) and ~20 trips long: un-pipelined, that latency was
+  // what a wave waited for (both arrays carry spare entries behind their end: no clamping; what lies beyond `last` is masked).
+  constexpr int PER = 2;
+  auto load_idx = [&](unsigned int base, int (&idx)[PER]) {
+#pragma unroll
+    for (int j = 0; j < PER; j++) { const unsigned int k = base + 64u * (unsigned int)j + (unsigned int)lane; idx[j] = listed ? (int)gdword_stream(pool, cand_off, k) : (int)k; }
+  };
+  auto load_rec = [&](const int (&idx)[PER], f4 (&Q)[PER]) {
+#pragma unroll
+    for (int j = 0; j < PER; j++) Q[j] = pool[band_rec + (unsigned int)idx[j]];
+  };
+  int idxA[PER], idxB[PER], idxC[PER];
+  f4 QA[PER], QB[PER];
+  // (indices past `last` read spare or foreign entries: clamp what they point at to a valid record)
+  auto clamp_idx = [&](int (&idx)[PER]) {
+#pragma unroll
+    for (int j = 0; j < PER; j++) idx[j] = min(max(idx[j], 0), n_tri + 127);
+  };
+  load_idx(first, idxA); clamp_idx(idxA);
+  load_idx(first + 64u * PER, idxB);
+  load_rec(idxA, QA);
+  for (unsigned int base = first; base < last; base += 64u * PER) {
+    PT_TRI_COUNT(11, 1);
+    load_idx(base + 128u * PER, idxC); // two trips ahead
+    clamp_idx(idxB);
+    load_rec(idxB, QB);                // one trip ahead
+#ifdef PT_BAND_ONE_STAGE /* A/B: the whole filter on the gathered record at once (no integer stage, no LDS queue of records) */
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+      const bool pass = base + 64u * (unsigned int)j + (unsigned int)lane < last && band_pass(QA[j]);
+      push(pass, idxA[j]);
+      drain(63);
+    }
+    PT_TRI_COUNT(6, min(64u * PER, last - base));
+#else
+    unsigned int passmask = 0;
+#pragma unroll
+    for (int j = 0; j < PER; j++) passmask |= (base + 64u * (unsigned int)j + (unsigned int)lane < last && band_stage1(QA[j])) ? (1u << j) : 0u;
+    PT_TRI_COUNT(6, min(64u * PER, last - base));
+    PT_TRI_COUNT(7, PT_TRI_WAVE_BITS(passmask));
+#pragma unroll
+    for (int j = 0; j < PER; j++) bpush((passmask >> j) & 1u, idxA[j], QA[j]);
+    drain_band(63);
+#endif
+#pragma unroll
+    for (int j = 0; j < PER; j++) { idxA[j] = idxB[j]; QA[j] = QB[j]; idxB[j] = idxC[j]; }
+  }
+  drain_band(0);
+  drain(0);
+}
+
+// What a ray asks of the BINNED band stage (round 6; pt_render.hip: band_kernel): tri_pool_scan<true> runs the grid part in place and,
+// instead of taking the wave's rays through their direction-map lists one at a time, says which list a ray needs — key = the bin of its
+// direction in the map of its rho class, numbered across the maps (the last key: every band record) — so that the launcher can bring
+// the rays of one bin together from all over the frame.  key < 0: no request (a dead lane, or the run was scanned in full).
+struct TriDefer {
+  int key;
+  float rho;
+};
+
+template <bool DEFER = false>
+__device__ __forceinline__ bool tri_pool_scan(glb_f4p pool, cst_f4p cblob, int hdr, int goff, const RayCtx& c, HitState& h, TriDefer* dfr = nullptr) {
 #ifndef PT_NO_FILTER_FMA
   // Everything written in this function is FILTER arithmetic — necessary conditions with explicit slack against exact mathematics
   // (pt_tripool.hpp), and the walk whose rounding the cells' absolute slack covers — so a product may fuse with the sum that
@@ -1403,13 +1581,17 @@ __device__ __forceinline__ bool tri_pool_scan(glb_f4p pool, cst_f4p cblob, int h
   const f4 H7 = cblob[hdr + 7], H8 = cblob[hdr + 8]; // the quantisation of the compressed band records (pt_tripool.hpp)
   const V3 oc_own = c.r.o - xyz(H2);
   const float oc2_own = dot(oc_own, oc_own);
-  if (__builtin_amdgcn_ballot_w64(c.live && !(c.reg && oc2_own <= H3.x)) != 0) return false;
+  const bool in_domain = c.reg && oc2_own <= H3.x;
+  // (the persistent kernels: one ray outside the pool's domain and the whole wave scans the run; the binned renderer — DEFER — takes such
+  // a ray out of the walk and files it under the key "every triangle, exactly": a full scan inside a generation would hold up the frame)
+  if (!DEFER && __builtin_amdgcn_ballot_w64(c.live && !in_domain) != 0) return false;
+  const bool c_live = c.live && (!DEFER || in_domain);
   const unsigned int cell_first = (unsigned int)as_i(H4.x), cell_cand = (unsigned int)as_i(H4.y), tri_sorted = (unsigned int)as_i(H4.z), band_rec = (unsigned int)as_i(H4.w);
   const int lane = threadIdx.x & 63;
   unsigned long long* const slot = tri_slots() + (threadIdx.x & ~63); // this wave's 64 slots
   const unsigned long long key0 = h.hit >= 0 ? tri_key(h.closest, hit_off(h.hit)) : ((unsigned long long)0x7f800000u << 32);
   slot[lane] = key0;
-  const unsigned long long live = __builtin_amdgcn_ballot_w64(c.live);
+  const unsigned long long live = __builtin_amdgcn_ballot_w64(c_live);
   PT_TRI_COUNT(0, 1);
   PT_TRI_COUNT(1, __builtin_popcountll(live));
   int* const tq = tri_queue() + (threadIdx.x >> 6) * PT_TRI_QUEUE; // per wave: what waits for the exact test
@@ -1431,7 +1613,7 @@ __device__ __forceinline__ bool tri_pool_scan(glb_f4p pool, cst_f4p cblob, int h
     float closest = h.closest; // the slot's t as last read back
     // closest (1 + kappa) — closest lowered by every hit so far — then the walk's own slack (relative 1e-4)
     auto limit = [&]() { const float m = __builtin_fminf(t_out, closest + closest * kappa); return m + (__builtin_fabsf(m) * 1e-4f + 1e-4f); };
-    bool active = c.live && t0 <= limit();
+    bool active = c_live && t0 <= limit();
     const float px = gx + t0 * (r.d.x * inv), py = gy + t0 * (r.d.y * inv), pz = gz + t0 * (r.d.z * inv);
     int ix = min(max((int)__builtin_floorf(px), 0), nx - 1);
     int iy = min(max((int)__builtin_floorf(py), 0), ny - 1);
@@ -1450,25 +1632,45 @@ __device__ __forceinline__ bool tri_pool_scan(glb_f4p pool, cst_f4p cblob, int h
     // (The first version let every lane loop over ITS cell's list: a wave-step took as many trips as its fullest cell has candidates,
     // most of them at a handful of lanes — 1 844 ms at 1080p x 8 spp against 568 ms of round 4's kernel.)
     int qn = 0; // pairs queued (wave-uniform)
-    auto test_batch = [&]() { // 64 pairs (the top of the queue) through the reference's test
+    // up to PT_TRI_PAIRS x 64 pairs (the top of the queue) through the reference's test: the records of all of them are requested before
+    // the first is tested (round 6: a batch is a chain LDS -> three gathers -> test, and a wave-step queues ten of them: one batch at a
+    // time, the wave waited a memory latency per batch)
+#ifndef PT_TRI_PAIRS
+#define PT_TRI_PAIRS 2
+#endif
+    constexpr int NP = DEFER ? PT_TRI_PAIRS : 1; // (the persistent kernels, at seven waves per SIMD, spill with more than one)
+    auto test_batch = [&]() {
       __builtin_amdgcn_wave_barrier();
-      const int n = min(qn, 64);
-      const bool on = lane < n;
-      const unsigned int e = (unsigned int)tq[qn - n + (on ? lane : 0)];
-      const int src = (int)(e >> 26);
-      PT_TRI_COUNT(5, 1);
-      PT_TRI_COUNT(4, n);
-      Ray r2; // the pair's ray, from its owner's registers
-      r2.o = mk(__shfl(r.o.x, src, 64), __shfl(r.o.y, src, 64), __shfl(r.o.z, src, 64));
-      r2.d = mk(__shfl(r.d.x, src, 64), __shfl(r.d.y, src, 64), __shfl(r.d.z, src, 64));
-      r2.tm = 0.0f;
-      if (on) {
-        const unsigned int o = tri_sorted + 3u * (e & 0x3ffffffu);
-        const f4 R0 = pool[o], R1 = pool[o + 1], R2 = pool[o + 2];
-        float t;
-        if (tri_param(R0, R1, R2, r2, t) && !(t < PT_TMIN)) atomicMin(&slot[src], tri_key(t, goff + 3 * as_i(R2.w)));
+      int nb[NP], srcs[NP];
+      f4 R0[NP], R1[NP], R2[NP];
+      int left = qn;
+#pragma unroll
+      for (int k = 0; k < NP; k++) {
+        const int n = min(left, 64);
+        nb[k] = n;
+        const bool on = lane < n;
+        const unsigned int e = (unsigned int)tq[left - n + (on ? lane : 0)];
+        srcs[k] = (int)(e >> 26);
+        const unsigned int o = tri_sorted + 3u * (on ? (e & 0x3ffffffu) : 0u);
+        R0[k] = pool[o]; R1[k] = pool[o + 1]; R2[k] = pool[o + 2];
+        left -= n;
       }
-      qn -= n;
+#pragma unroll
+      for (int k = 0; k < NP; k++) {
+        if (nb[k] == 0) continue; // (wave-uniform)
+        PT_TRI_COUNT(5, 1);
+        PT_TRI_COUNT(4, nb[k]);
+        const int src = srcs[k];
+        Ray r2; // the pair's ray, from its owner's registers
+        r2.o = mk(__shfl(r.o.x, src, 64), __shfl(r.o.y, src, 64), __shfl(r.o.z, src, 64));
+        r2.d = mk(__shfl(r.d.x, src, 64), __shfl(r.d.y, src, 64), __shfl(r.d.z, src, 64));
+        r2.tm = 0.0f;
+        if (lane < nb[k]) {
+          float t;
+          if (tri_param(R0[k], R1[k], R2[k], r2, t) && !(t < PT_TMIN)) atomicMin(&slot[src], tri_key(t, goff + 3 * as_i(R2[k].w)));
+        }
+      }
+      qn = left;
       __builtin_amdgcn_wave_barrier();
     };
     unsigned int k0 = 0, k1 = 0; // this cell's candidate range
@@ -1490,26 +1692,43 @@ __device__ __forceinline__ bool tri_pool_scan(glb_f4p pool, cst_f4p cblob, int h
       const int T = __builtin_amdgcn_readlane(incl, 63);
       const int kbase = (int)k1 - incl; // candidate index of position p for this lane's range: kbase + p
       const unsigned int skip_bit = came < 6 ? (1u << (26 + came)) : 0u;
-      for (int base = 0; base < T; base += 64) {
-        const int p = base + lane;
-        const bool on = p < T;
-        // owner: the first lane whose inclusive count exceeds p (lanes without candidates repeat their predecessor's count and are never first)
-        int lo = 0;
+      // (round 6: PT_TRI_TRIPS trips' entries are requested before the first is looked at — a trip was a chain owner search -> load -> ballot,
+      // and a wave-step of 64 lanes has ten of them: one at a time, the wave waited a memory latency per trip)
+#ifndef PT_TRI_TRIPS
+#define PT_TRI_TRIPS 4
+#endif
+      constexpr int NT = DEFER ? PT_TRI_TRIPS : 1;
+      for (int base = 0; base < T; base += 64 * NT) {
+        unsigned int es[NT], sbs[NT];
+        int srcs[NT];
 #pragma unroll
-        for (int st = 32; st >= 1; st >>= 1) { const int v = __shfl(incl, lo + st - 1, 64); lo += v <= p ? st : 0; }
-        const int src = on ? lo : lane;
-        const int kb = __shfl(kbase, src, 64);
-        const unsigned int sb = (unsigned int)__shfl((int)skip_bit, src, 64);
-        bool keep = false;
-        unsigned int e = 0;
-        if (on) { e = gdword_stream(pool, cell_cand, (unsigned int)(kb + p)); keep = (e & sb) == 0u; }
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
-        if (keep) tq[qn + __builtin_popcountll(m & below)] = (int)(((unsigned int)src << 26) | (e & 0x3ffffffu));
-        qn += __builtin_popcountll(m);
-        if (qn >= 64) test_batch();
+        for (int k = 0; k < NT; k++) {
+          const int p = base + 64 * k + lane;
+          const bool on = p < T;
+          // owner: the first lane whose inclusive count exceeds p (lanes without candidates repeat their predecessor's count and are never first)
+          int lo = 0;
+#pragma unroll
+          for (int st = 32; st >= 1; st >>= 1) { const int v = __shfl(incl, lo + st - 1, 64); lo += v <= p ? st : 0; }
+          const int src = on ? lo : lane;
+          const int kb = __shfl(kbase, src, 64);
+          sbs[k] = on ? (unsigned int)__shfl((int)skip_bit, src, 64) : 0xffffffffu; // (off: every entry "skipped")
+          srcs[k] = src;
+          es[k] = 0xffffffffu;
+          if (on) es[k] = gdword_stream(pool, cell_cand, (unsigned int)(kb + p));
+          if (base + 64 * (k + 1) >= T) break; // (wave-uniform: no trip behind this one)
+        }
+#pragma unroll
+        for (int k = 0; k < NT; k++) {
+          const bool keep = (es[k] & sbs[k]) == 0u;
+          const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+          if (keep) tq[qn + __builtin_popcountll(m & below)] = (int)(((unsigned int)srcs[k] << 26) | (es[k] & 0x3ffffffu));
+          qn += __builtin_popcountll(m);
+          if (qn >= 64 * NP) test_batch();
+          if (base + 64 * (k + 1) >= T) break;
+        }
       }
       if (T > 0) { // (the limit below looks at the nearest hit so far: everything queued is tested first)
-        if (qn > 0) test_batch();
+        while (qn > 0) test_batch();
         closest = as_f((int)(unsigned int)(slot[lane] >> 32));
       }
       // step: the walk ends where the next cell lies outside the grid or begins beyond the nearest hit so far
@@ -1526,27 +1745,8 @@ __device__ __forceinline__ bool tri_pool_scan(glb_f4p pool, cst_f4p cblob, int h
   const float rho_own = (__builtin_amdgcn_sqrtf(oc2_own) + H2.w) * 1.000002f;
   const float dn_own = __builtin_amdgcn_sqrtf(c.a) * 1.000002f;
   const int n_tri = as_i(H3.z), n_maps = (PT_TRI_ABLATE & 2) ? 0 : as_i(H3.w);
-  int qn = 0; // entries queued for the exact test (uniform)
-  auto push = [&](bool p, int e) {
-    const unsigned long long m = __builtin_amdgcn_ballot_w64(p);
-    if (p) tq[qn + __builtin_popcountll(m & below)] = e;
-    qn += __builtin_popcountll(m);
-  };
-  // the reference's test for the top min(64, qn) entries and the (uniform) ray of lane src; a hit goes to that ray's slot
-  auto drain = [&](int keep, const Ray& ur, int src) {
-    __builtin_amdgcn_wave_barrier();
-    while (qn > keep) {
-      const int n = min(qn, 64);
-      if (lane < n) {
-        const unsigned int o = tri_sorted + 3u * (unsigned int)tq[qn - n + lane];
-        const f4 R0 = pool[o], R1 = pool[o + 1], R2 = pool[o + 2];
-        float t;
-        if (tri_param(R0, R1, R2, ur, t) && !(t < PT_TMIN)) atomicMin(&slot[src], tri_key(t, goff + 3 * as_i(R2.w)));
-      }
-      qn -= n;
-    }
-    __builtin_amdgcn_wave_barrier();
-  };
+  TriBandCtx bctx;
+  bctx.H5 = H5; bctx.H6 = H6; bctx.H7 = H7; bctx.H8 = H8; bctx.band_rec = band_rec; bctx.tri_sorted = tri_sorted; bctx.n_tri = n_tri; bctx.goff = goff;
   // Every lane looks up ITS ray's list first (the bin of its direction in the map of its rho class — or, beyond the last class, every
   // triangle): two gathers for the whole wave instead of two dependent scalar loads at the head of every ray's turn.
   unsigned int first_own = 0, last_own = (unsigned int)n_tri, cand_own = 0;
@@ -1554,16 +1754,23 @@ __device__ __forceinline__ bool tri_pool_scan(glb_f4p pool, cst_f4p cblob, int h
   {
     const f4 D0 = cblob[hdr + 9], D1 = cblob[hdr + 10], D2 = cblob[hdr + 11];
     const bool c0 = n_maps > 0 && rho_own <= D0.y, c1 = n_maps > 1 && rho_own <= D1.y, c2 = n_maps > 2 && rho_own <= D2.y;
-    if (c.live && (c0 || c1 || c2)) {
+    if constexpr (DEFER) {
+      // the binned band stage: hand the request out (keys: map 0's bins, then map 1's, then map 2's, then "every record")
+      const unsigned long long kf = slot[lane];
+      if (kf != key0) { h.closest = as_f((int)(unsigned int)(kf >> 32)); h.hit = hit_pack(DK_TRI, 0, (int)(0xffffffffu - (unsigned int)(kf & 0xffffffffull))); }
+      const int R0 = n_maps > 0 ? as_i(D0.x) : 0, R1 = n_maps > 1 ? as_i(D1.x) : 0, R2 = n_maps > 2 ? as_i(D2.x) : 0;
+      const int base1 = 3 * R0 * R0, base2 = base1 + 3 * R1 * R1, base_all = base2 + 3 * R2 * R2;
+      dfr->rho = rho_own;
+      dfr->key = c_live ? base_all : c.live ? base_all + 1 : -1; // (base_all: every band record; base_all + 1: every triangle, exactly)
+      if (c_live && (c0 || c1 || c2)) {
+        const f4 D = c0 ? D0 : c1 ? D1 : D2;
+        dfr->key = (c0 ? 0 : c1 ? base1 : base2) + (int)tri_dir_bin(r.d, as_i(D.x));
+      }
+      return true;
+    }
+    if (c_live && (c0 || c1 || c2)) {
       const f4 D = c0 ? D0 : c1 ? D1 : D2;
-      const int R = as_i(D.x);
-      const float adx = __builtin_fabsf(r.d.x), ady = __builtin_fabsf(r.d.y), adz = __builtin_fabsf(r.d.z);
-      // face k = the largest |component| (exact comparisons); (p, q) = (d_a, d_b) / d_k with a = k + 1, b = k + 2 (mod 3)
-      const int k = (adx >= ady && adx >= adz) ? 0 : (ady >= adz ? 1 : 2);
-      const float dk = k == 0 ? r.d.x : k == 1 ? r.d.y : r.d.z, da = k == 0 ? r.d.y : k == 1 ? r.d.z : r.d.x, db = k == 0 ? r.d.z : k == 1 ? r.d.x : r.d.y;
-      const float rk = __builtin_amdgcn_rcpf(dk), halfR = 0.5f * (float)R;
-      const int ci = min(max((int)__builtin_floorf((da * rk + 1.0f) * halfR), 0), R - 1), cj = min(max((int)__builtin_floorf((db * rk + 1.0f) * halfR), 0), R - 1);
-      const unsigned int bin = (unsigned int)((k * R + cj) * R + ci);
+      const unsigned int bin = tri_dir_bin(r.d, as_i(D.x));
       const unsigned int foff = (unsigned int)as_i(D.z);
       first_own = gdword(pool, foff, bin); last_own = gdword(pool, foff, bin + 1u);
       cand_own = (unsigned int)as_i(D.w);
@@ -1584,109 +1791,7 @@ __device__ __forceinline__ bool tri_pool_scan(glb_f4p pool, cst_f4p cblob, int h
     PT_TRI_COUNT(9, listed_k == 3 ? 1 : 0);
     PT_TRI_COUNT(12, listed_k == 2 ? 1 : 0);
     PT_TRI_COUNT(10, listed ? 0 : 1);
-    // band test, then the noise-radius filter: the line within L + kr rho |d| / (|a'| - ea |d|) of the centroid
-    // on the 16-byte compressed record (pt_tripool.hpp "compressed records"; every quantity rounded to the safe side)
-    auto near_line = [&](V3 C, float rad) { // does the ray's LINE pass within `rad` of the point C?
-      const V3 x = cross(C - ur.o, ur.d);
-      return dot(x, x) <= rad * rad * ua * 1.00001f;
-    };
-    auto band_pass = [&](f4 Q) {
-      const unsigned int w0 = (unsigned int)as_i(Q.x), w1 = (unsigned int)as_i(Q.y), w2 = (unsigned int)as_i(Q.z), w3 = (unsigned int)as_i(Q.w);
-      const float nx = (float)((int)(w0 << 16) >> 16), ny = (float)((int)w0 >> 16), nz = (float)((int)(w1 << 16) >> 16);
-      const float pn = as_f((int)(w1 & 0xffff0000u)), L = as_f((int)(w3 & 0xffff0000u));
-      const float dq = __builtin_fabsf(ur.d.x * nx + ur.d.y * ny + ur.d.z * nz) * 3.0518509e-5f; // |d . n~|, n~ = (nx, ny, nz) / 32767
-      const float rL = __builtin_amdgcn_rcpf(L) * 1.00001f;
-      if (!(dq <= dn * (pn * (rho + H5.y * L + H5.w * rL) + H8.w) * 1.00001f)) return false;
-      const float L2 = L * L;
-      const float nlow = 0.98f * H5.z * L * __builtin_amdgcn_rcpf(pn);          // <= |N|
-      const float a1 = (dq - dn * H8.w) * nlow - H6.w * L2 * dn;                 // <= |a'| - ea |d|
-      const float rr = (H6.y + H6.z * L) * L2 * rho * dn * __builtin_amdgcn_rcpf(a1) * 1.001f; // >= the noise radius; a1 <= 0: no bound
-      const V3 C = tri_centroid(w2 & 0xffffu, w2 >> 16, w3 & 0xffffu, H7, H8);
-      return !(a1 > 0.0f) || near_line(C, L + rr + H6.x + H7.w);
-    };
-    const V3 dh = __builtin_amdgcn_rsqf(ua) * ur.d; // unit direction (a few ulp: covered by the integer test's absolute slack)
-    // Two stages.  Stage 1, on every enumerated candidate: the band test alone, in INTEGERS — the record's normal is three 16-bit
-    // integers k / 32767, the ray's unit direction is rounded to the same grid once per ray, and two v_dot2_i32_i16 give
-    // S = kn . kd exactly (|S| <= 32767^2 (1 + 1e-4): no overflow); |d^ . n^| <= |S| / 32767^2 + eps_n + eps_d with
-    // eps_d = sqrt(3) / (2 * 32767) + 1e-6 (the rounding of the direction and of rsq), so the test below passes whenever the band
-    // test of pt_tripool.hpp does.  Its survivors are queued and run the full filter 64 at a time (stage 2).
-    const int kdx = (int)__builtin_rintf(dh.x * 32767.0f), kdy = (int)__builtin_rintf(dh.y * 32767.0f), kdz = (int)__builtin_rintf(dh.z * 32767.0f);
-    short2_t dxy, dz0;
-    { const unsigned int a = ((unsigned int)kdx & 0xffffu) | ((unsigned int)kdy << 16), b = (unsigned int)kdz & 0xffffu; __builtin_memcpy(&dxy, &a, 4); __builtin_memcpy(&dz0, &b, 4); }
-    const float e1s = H8.w + 2.75e-5f;
-    auto band_stage1 = [&](f4 Q) {
-      const unsigned int w0 = (unsigned int)as_i(Q.x), w1 = (unsigned int)as_i(Q.y), w3 = (unsigned int)as_i(Q.w);
-      short2_t nxy, nzp;
-      __builtin_memcpy(&nxy, &w0, 4); __builtin_memcpy(&nzp, &w1, 4); // (nzp's high half is pn's bits: multiplied by dz0's zero)
-      const int S = __builtin_amdgcn_sdot2(nzp, dz0, __builtin_amdgcn_sdot2(nxy, dxy, 0, false), false);
-      const float sa = (float)(S < 0 ? -S : S);
-      const float pn = as_f((int)(w1 & 0xffff0000u)), L = as_f((int)(w3 & 0xffff0000u));
-      const float rL = __builtin_amdgcn_rcpf(L) * 1.00001f;
-      return sa <= (pn * (rho + H5.y * L + H5.w * rL) + e1s) * 1.0737e9f; // 32767^2 (1 + 2e-5)
-    };
-    f4* const bq = tri_bqueue() + (threadIdx.x >> 6) * PT_TRI_BQUEUE;
-    int* const bqi = tri_bqueue_idx() + (threadIdx.x >> 6) * PT_TRI_BQUEUE;
-    int bn = 0;
-    auto bpush = [&](bool p, int e, f4 Q) {
-      const unsigned long long m = __builtin_amdgcn_ballot_w64(p);
-      if (p) { const int at = bn + __builtin_popcountll(m & below); bq[at] = Q; bqi[at] = e; }
-      bn += __builtin_popcountll(m);
-    };
-    auto drain_band = [&](int keep) {
-      __builtin_amdgcn_wave_barrier();
-      while (bn > keep) {
-        const int n = min(bn, 64);
-        bool pass = false;
-        int e = 0;
-        if (lane < n) { e = bqi[bn - n + lane]; pass = band_pass(bq[bn - n + lane]); }
-        bn -= n;
-        PT_TRI_COUNT(8, __builtin_popcountll(__builtin_amdgcn_ballot_w64(pass)));
-        push(pass, e);
-        drain(63, ur, src);
-      }
-      __builtin_amdgcn_wave_barrier();
-    };
-    // 128 entries per trip: lane l takes entries base + l, base + 64 + l.  The loop is a two-stage software pipeline — while the records
-    // of trip i are tested, the records of trip i + 1 are being gathered and the indices of trip i + 2 loaded — because a ray's turn is a
-    // chain of dependent loads (index -> record, a microsecond each from beyond L2) and ~20 trips long: un-pipelined, that latency was
-    // what a wave waited for (both arrays carry spare entries behind their end: no clamping; what lies beyond `last` is masked).
-    constexpr int PER = 2;
-    auto load_idx = [&](unsigned int base, int (&idx)[PER]) {
-#pragma unroll
-      for (int j = 0; j < PER; j++) { const unsigned int k = base + 64u * (unsigned int)j + (unsigned int)lane; idx[j] = listed ? (int)gdword_stream(pool, cand_off, k) : (int)k; }
-    };
-    auto load_rec = [&](const int (&idx)[PER], f4 (&Q)[PER]) {
-#pragma unroll
-      for (int j = 0; j < PER; j++) Q[j] = pool[band_rec + (unsigned int)idx[j]];
-    };
-    int idxA[PER], idxB[PER], idxC[PER];
-    f4 QA[PER], QB[PER];
-    // (indices past `last` read spare or foreign entries: clamp what they point at to a valid record)
-    auto clamp_idx = [&](int (&idx)[PER]) {
-#pragma unroll
-      for (int j = 0; j < PER; j++) idx[j] = min(max(idx[j], 0), n_tri + 127);
-    };
-    load_idx(first, idxA); clamp_idx(idxA);
-    load_idx(first + 64u * PER, idxB);
-    load_rec(idxA, QA);
-    for (unsigned int base = first; base < last; base += 64u * PER) {
-      PT_TRI_COUNT(11, 1);
-      load_idx(base + 128u * PER, idxC); // two trips ahead
-      clamp_idx(idxB);
-      load_rec(idxB, QB);                // one trip ahead
-      unsigned int passmask = 0;
-#pragma unroll
-      for (int j = 0; j < PER; j++) passmask |= (base + 64u * (unsigned int)j + (unsigned int)lane < last && band_stage1(QA[j])) ? (1u << j) : 0u;
-      PT_TRI_COUNT(6, min(64u * PER, last - base));
-      PT_TRI_COUNT(7, PT_TRI_WAVE_BITS(passmask));
-#pragma unroll
-      for (int j = 0; j < PER; j++) bpush((passmask >> j) & 1u, idxA[j], QA[j]);
-      drain_band(63);
-#pragma unroll
-      for (int j = 0; j < PER; j++) { idxA[j] = idxB[j]; QA[j] = QB[j]; idxB[j] = idxC[j]; }
-    }
-    drain_band(0);
-    drain(0, ur, src);
+    tri_band_one_ray(pool, bctx, ur, ua, rho, dn, first, last, cand_off, listed, [&](unsigned long long key) { atomicMin(&slot[src], key); });
   }
   // each lane reads its own ray's slot back: changed = some triangle of this run is the nearest hit so far
   const unsigned long long kf = slot[lane];
@@ -1696,9 +1801,9 @@ __device__ __forceinline__ bool tri_pool_scan(glb_f4p pool, cst_f4p cblob, int h
 
 // RECTBOX: the scene holds rects and boxes only (MATS_RECTBOX_ONLY kernels): the sphere / triangle / medium loops are not compiled in —
 // less code, and nothing of theirs (the medium's sqrt(d.d), say) can be hoisted into the per-iteration prologue of a kernel that never runs it.
-template <bool IMG, int TRIP = 1, int TTRIP = TRIP, bool WHOLE = true, bool BADOUEL = false, int GRID = 1, bool TRIPOOL = false, bool RECTBOX = false, typename P>
+template <bool IMG, int TRIP = 1, int TTRIP = TRIP, bool WHOLE = true, bool BADOUEL = false, int GRID = 1, bool TRIPOOL = false, bool RECTBOX = false, bool DEFER = false, typename P>
 __device__ __forceinline__ void hit_records(P recs, cst_f4p cblob, int kind, int n, int goff,
-                                            const RayCtx& c, bool fast, uint32_t& rng, HitState& h, glb_f4p pool = nullptr) {
+                                            const RayCtx& c, bool fast, uint32_t& rng, HitState& h, glb_f4p pool = nullptr, TriDefer* dfr = nullptr) {
   const Ray& r = c.r;
   int off = 0;
   if (!RECTBOX && kind == DK_SPHERE) {
@@ -1737,8 +1842,8 @@ __device__ __forceinline__ void hit_records(P recs, cst_f4p cblob, int kind, int
   } else if (!RECTBOX && kind == DK_TRI) {
     if constexpr (TRIPOOL && WHOLE) { // a long run with a triangle pool (flag + header offset in the run's aux record)
       const f4 aux = cblob[goff - 1];
-      if (as_i(aux.x) != 0 && fast) {
-        if (tri_pool_scan(pool, cblob, as_i(aux.y), goff, c, h)) return;
+      if (as_i(aux.x) != 0 && (fast || DEFER)) { // (DEFER: irregular rays are taken out lane by lane, inside)
+        if (tri_pool_scan<DEFER>(pool, cblob, as_i(aux.y), goff, c, h, dfr)) return;
       }
     }
     auto accept_at = [&](int o) { return [&h, goff, o](float t) { h.closest = t; h.hit = hit_pack(DK_TRI, 0, goff + o); }; };
@@ -1909,10 +2014,13 @@ __device__ __forceinline__ int record_size(int kind) {
 // kernel constants: an s_load lands in SGPRs directly, no LDS round trip + v_readfirstlane per run) and the records from LDS.
 // `cblob`: the blob in global memory through the scalar cache (run headers, sphere-run masks); `blob`: where the records are
 // read from (LDS copy, or the same global blob).
-template <bool IMG, bool BADOUEL = false, int GRID = 1, bool TRIPOOL = false, bool RECTBOX = false, typename P>
-__device__ __forceinline__ void hit_world(P blob, cst_f4p cblob, int n_runs, const RayCtx& c, bool fast, uint32_t& rng, HitState& h, const f4* pool = nullptr) {
-  hit_begin(h);
-  for (int ri = 0; ri < n_runs; ++ri) {
+// hit_world_range: the runs [ri0, ri1) of the list, on top of the hit h already holds (hit_world = the whole list from nothing).
+// DEFER (the binned triangle-pool renderer, pt_render.hip: bin_step_kernel): a pooled triangle run does its grid part and leaves
+// its direction-map part as a request in *dfr (tri_pool_scan<true>).
+template <bool IMG, bool BADOUEL = false, int GRID = 1, bool TRIPOOL = false, bool RECTBOX = false, bool DEFER = false, typename P>
+__device__ __forceinline__ void hit_world_range(P blob, cst_f4p cblob, int ri0, int ri1, const RayCtx& c, bool fast, uint32_t& rng, HitState& h, const f4* pool = nullptr,
+                                                TriDefer* dfr = nullptr) {
+  for (int ri = ri0; ri < ri1; ++ri) {
 #ifdef PT_STAMPS_RUNS /* diagnostic build: cycles per run of the list (wave leader's clock), g_runs[min(ri, 15)] */
     const unsigned long long run_t0 = __builtin_amdgcn_s_memtime();
     __builtin_amdgcn_sched_barrier(0);
@@ -1931,8 +2039,13 @@ __device__ __forceinline__ void hit_world(P blob, cst_f4p cblob, int n_runs, con
         }
       }
     }
-    hit_records<IMG, 1, 1, true, BADOUEL, GRID, TRIPOOL, RECTBOX>(blob + off, cblob, kind, as_i(runf.z), off, c, fast, rng, h, (glb_f4p)pool);
+    hit_records<IMG, 1, 1, true, BADOUEL, GRID, TRIPOOL, RECTBOX, DEFER>(blob + off, cblob, kind, as_i(runf.z), off, c, fast, rng, h, (glb_f4p)pool, dfr);
   }
+}
+template <bool IMG, bool BADOUEL = false, int GRID = 1, bool TRIPOOL = false, bool RECTBOX = false, typename P>
+__device__ __forceinline__ void hit_world(P blob, cst_f4p cblob, int n_runs, const RayCtx& c, bool fast, uint32_t& rng, HitState& h, const f4* pool = nullptr) {
+  hit_begin(h);
+  hit_world_range<IMG, BADOUEL, GRID, TRIPOOL, RECTBOX, false>(blob, cblob, 0, n_runs, c, fast, rng, h, pool);
 }
 
 // Wave-uniform switch: the straight-line rect/box path is used only when every live lane's ray is regular.

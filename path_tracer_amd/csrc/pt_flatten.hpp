@@ -64,6 +64,8 @@ struct Flat {
   int tri_wide = 0, tri_maps = 0;   // triangles whose band covers every direction; direction maps built
   long long tri_map_entries[3] = {0, 0, 0};
   int tri_map_res[3] = {0, 0, 0};
+  int tri_pool_runs = 0;            // runs that got a pool; the binned renderer (pt_render.hip: launch_binned) serves scenes with exactly one
+  int tri_pool_run = -1, tri_pool_hdr = 0, tri_pool_goff = 0, tri_pool_count = 0; // that run: its index, its pool header and first record in the blob, its triangles
 };
 
 inline int device_kind(int32_t k) {
@@ -327,6 +329,10 @@ inline int32_t put_tri_pool(std::vector<F4>& b, PoolLayout& pool, TriPool& tp, c
   bandv.reserve(4 * ntri);
   for (uint32_t i : order) bandv.insert(bandv.end(), &tp.band_q[4 * (size_t)i], &tp.band_q[4 * (size_t)i] + 4);
   const uint32_t band = pool.put(std::move(bandv), 260); // (the full stream reads up to 128 records past the last one: dead records)
+  std::vector<uint32_t> readyv; // the ready band records, in the same (Morton) order: three F4 per triangle
+  readyv.reserve(12 * ntri);
+  for (uint32_t i : order) for (int k = 0; k < 12; k++) readyv.push_back(bits(tp.band_ready[12 * (size_t)i + (size_t)k]));
+  const uint32_t ready = pool.put(std::move(readyv), 192); // (a trip gathers 64 records; indices past a list's end are clamped to the table)
   const uint32_t cell_first = pool.put(std::move(tp.cell_first), 2);
   const uint32_t cell_cand = pool.put(std::move(tp.cell_cand), 20);
   uint32_t mfirst[kTriPoolMaxMaps] = {0, 0, 0}, mcand[kTriPoolMaxMaps] = {0, 0, 0};
@@ -350,6 +356,7 @@ inline int32_t put_tri_pool(std::vector<F4>& b, PoolLayout& pool, TriPool& tp, c
     if (k < n_maps) b.push_back({as_f(tp.maps[(size_t)k].R), tp.maps[(size_t)k].rho_max, as_f((int32_t)mfirst[k]), as_f((int32_t)mcand[k])});
     else b.push_back({as_f(0), -1.0f, as_f(0), as_f(0)});
   }
+  b.push_back({as_f((int32_t)ready), 0.0f, 0.0f, 0.0f}); // hdr + 12: the ready band records (pt_render.hip: band_kernel)
   return hdr;
 }
 
@@ -476,6 +483,8 @@ inline int flatten(const PtSceneDesc* sc, Flat& out, std::string& err, bool allo
           hdr = put_tri_pool(b, out.pool, tp, &sc->hittables[run.first], run.count);
           pooled = true;
           out.tri_pooled += run.count;
+          out.tri_pool_runs++;
+          out.tri_pool_run = (int)ri; out.tri_pool_hdr = hdr; out.tri_pool_goff = (int32_t)b.size() + 1; out.tri_pool_count = run.count;
         }
       }
       b.push_back({as_f(pooled ? 1 : 0), as_f(hdr), 0, 0});

@@ -67,6 +67,9 @@ namespace {
 #ifndef PT_MIN_WAVES_TRIPOOL
 #define PT_MIN_WAVES_TRIPOOL 7 /* triangle-pool kernels: 72 VGPRs + ~150 bytes of scratch (none of it in the pool's inner loops), seven waves per SIMD.  Round 5 (the rebuilt pool, bound by the latency of its gathers): 1080p x 8 spp 332 ms at 7 waves, 344 at 5 (96 VGPRs), 371 at 4 (128 VGPRs, no scratch) — profiles/r05_ab_tripool.txt; rounds 3-4 measured the same order */
 #endif
+#ifndef PT_MIN_WAVES_BINSTEP
+#define PT_MIN_WAVES_BINSTEP 4 /* bin_step_kernel (pt_binned.hpp): 128 VGPRs, no scratch (6 waves: 80 VGPRs + 236 B of scratch with the pipelined trips) */
+#endif
 #ifndef PT_MIN_WAVES_COOP_IMG
 #define PT_MIN_WAVES_COOP_IMG 5 /* 96 VGPRs + 60 B/lane of spills; spill-free needs 116 VGPRs = 4 waves: 496-hittable scene -9 % (A/B) */
 #endif
@@ -719,6 +722,8 @@ __global__ __launch_bounds__(64) void render_single_stream_kernel(KArgs a) {
     }
 }
 
+#include "pt_binned.hpp"
+
 // ---- longest-processing-time-first tile order -------------------------------------------------------------
 // A pixel cannot be split (one sequential RNG stream), so the frame's makespan is bounded below by its heaviest
 // tile, and a heavy tile picked up LAST adds its whole duration to the tail (measured on the 496-hittable scene:
@@ -991,7 +996,7 @@ static void tuning_env(PtTuning& t) {
   if (has("PT_NO_TRICULL")) t.tri_pool = -1;
   if (has("PT_TRICULL")) t.tri_min_run = 256;
   if (const char* e = std::getenv("PT_TRI_M")) t.tri_M = (float)std::atof(e);
-  if (const char* e = std::getenv("PT_TRI_MG")) t.tri_Mg = (float)std::atof(e);
+  if (has("PT_TRI_UNBINNED")) t.tri_binned = -1;
   if (const char* e = std::getenv("PT_TRI_RES")) std::sscanf(e, "%d,%d,%d", &t.tri_res[0], &t.tri_res[1], &t.tri_res[2]);
   if (const char* e = std::getenv("PT_TRI_RHO")) std::sscanf(e, "%f,%f,%f", &t.tri_rho[0], &t.tri_rho[1], &t.tri_rho2);
   if (const char* e = std::getenv("PT_TRI_BUDGET_MB")) t.tri_budget_mb = std::max(1, std::atoi(e));
@@ -1160,6 +1165,12 @@ struct PtScene {
   int* ws_nsplit = nullptr;                //                number of leading tiles to split (device scalar)
   mutable float* ws_partial = nullptr;     // PT_FLAG_FAST_RNG: per-chunk partial sums (grow-only)
   mutable size_t ws_partial_floats = 0;
+  // the binned triangle-pool renderer (pt_binned.hpp): the pooled run, the key space of its direction maps, and a grow-only workspace
+  int bin_run = -1, bin_hdr = 0, bin_goff = 0, bin_keys = 0, bin_full_slices = 1, bin_base1 = 0;
+  bool binned = false;          // this scene's parity-mode renders go through it
+  mutable void* ws_bin = nullptr; // per-pixel state, requests and slots for ws_bin_pixels local pixels; the sort's tables
+  mutable size_t ws_bin_pixels = 0;
+  mutable int last_generations = 0; // generations of the last binned render (pt_debug_last_launch)
   unsigned int* queues = nullptr; // ring of per-launch pixel-queue counters
   mutable unsigned int next_queue = 0;
   mutable hipEvent_t ring_done[kQueueRing] = {}; // recorded behind the launch that uses a slot: a wrapped ring waits for it
@@ -1346,6 +1357,16 @@ int pt_scene_create_tuned(const PtSceneDesc* desc, const PtTuning* tuning, PtSce
     if ((m.kind != PT_MAT_LAMBERTIAN && m.kind != PT_MAT_LIGHTSOURCE) || desc->textures[m.texture].kind != PT_TEX_SOLID) s->mats_simple = false;
   }
   s->tri_pooled = flat.has_badouel ? 0 : flat.tri_pooled; // (scenes with Badouel-strategy triangles keep the round-2 kernels)
+  // The binned renderer serves scenes with ONE pooled run whose stale u, v need no tracking (pt_binned.hpp); PtTuning.tri_binned = -1: never.
+  if (s->tri_pooled > 0 && flat.tri_pool_runs == 1 && !s->track_uv && tun.tri_binned >= 0) {
+    s->binned = true;
+    s->bin_run = flat.tri_pool_run; s->bin_hdr = flat.tri_pool_hdr; s->bin_goff = flat.tri_pool_goff;
+    s->bin_full_slices = std::min(64, std::max(1, (flat.tri_pool_count + 2047) / 2048));
+    long long keys = 2; // ... + "every band record" + "every triangle, exactly" (pt_device.hpp: tri_pool_scan<true>)
+    for (int k = 0; k < flat.tri_maps && k < 3; k++) keys += 3ll * flat.tri_map_res[k] * flat.tri_map_res[k];
+    s->bin_keys = (int)keys;
+    s->bin_base1 = flat.tri_maps > 0 ? 3 * flat.tri_map_res[0] * flat.tri_map_res[0] : 0;
+  }
   s->blob_bytes = flat.blob.size() * 16;
   s->mats_f4 = (int)flat.mats.size();
   // one buffer: [blob records][material table] so a kernel can stage both with one contiguous copy
@@ -1384,6 +1405,7 @@ void pt_scene_destroy(PtScene* s) {
   if (s->ws_rank) (void)hipFree(s->ws_rank);
   if (s->ws_nsplit) (void)hipFree(s->ws_nsplit);
   if (s->ws_partial) (void)hipFree(s->ws_partial);
+  if (s->ws_bin) (void)hipFree(s->ws_bin);
   delete s;
 }
 
@@ -1441,6 +1463,129 @@ static int reserve_partial(const PtScene* s, size_t floats) {
   return PT_OK;
 }
 
+// The binned triangle-pool renderer (pt_binned.hpp): generations of { step, sort the requests by direction bin, band stage }, until no pixel
+// is live.  How many generations a frame takes is known only on the device (the heaviest pixel's ray count), so the host reads the live
+// count back every few generations: unlike the persistent kernels' launches this render has returned only when the frame is done.
+static int reserve_binned(const PtScene* s, size_t n_pixels, size_t n_keys, size_t& bytes_out);
+static int launch_binned(const PtScene* s, KArgs a, const PtRenderParams* p, int local_tiles, hipStream_t st) {
+  if (p->depth <= 0) return PT_OK; // every sample black (render.hpp:58,91): the frame is pre-zeroed
+  a.n_local_pixels = local_tiles * PT_TILE_PIXELS;
+  a.cost = nullptr; a.cost_max = 0; a.resume_rng = nullptr; a.resume_spp = 0; a.order = nullptr; a.n_split = nullptr;
+  a.prio_onset = a.prio_t1 = a.prio_t2 = a.prio_t3 = 0;
+  a.tile_granular = 1; a.heavy_pixels = 0; a.heavy_lanes = 64; a.scatter_p = 0; a.scatter_log = 0; a.lanes_cap = 64;
+  a.fast_chunks = 0; a.samples_total = p->samples; a.fast_stride = 0; a.queue = nullptr; a.coop_prefix = -1;
+  const size_t N = (size_t)a.n_local_pixels, K = (size_t)s->bin_keys;
+  size_t bytes = 0;
+  if (int rc = reserve_binned(s, N, K, bytes)) return rc;
+  // carve the workspace (every array 256-byte aligned)
+  char* base = (char*)s->ws_bin;
+  size_t at = 0;
+  auto take = [&](size_t n) { char* q = base + at; at += (n + 255) & ~(size_t)255; return q; };
+  const size_t n_blocks = (K + 1023) / 1024, max_packets = (N / 64 + 1) * (size_t)s->bin_full_slices + std::min(K, N) + 1;
+  BinArgs ba;
+  ba.k = a;
+  ba.A0 = (f4*)take(N * 16); ba.A1 = (f4*)take(N * 16); ba.A2 = (f4*)take(N * 16); ba.A3 = (f4*)take(N * 16);
+  ba.A4 = (int4*)take(N * 16); ba.A5 = (f4*)take(N * 16);
+  ba.slot = (unsigned long long*)take(N * 8);
+  SortArgs sa;
+  sa.hist = (unsigned int*)take(K * 4);
+  sa.offs = (unsigned int*)take((K + 1) * 4);
+  sa.block_tot = (uint2*)take(n_blocks * 8);
+  sa.packets = (int2*)take(max_packets * 8);
+  sa.ctl = (unsigned int*)take(64);
+  unsigned int* sorted = (unsigned int*)take(N * 4);
+  unsigned int* live_list[2] = {(unsigned int*)take(N * 4), (unsigned int*)take(N * 4)};
+  sa.n_keys = (int)K; sa.n_blocks = (int)n_blocks; sa.full_slices = s->bin_full_slices;
+  ba.hist = sa.hist; ba.ctl = sa.ctl; ba.pool_run = s->bin_run;
+  ba.scatter_p = 0; ba.dbg_base1 = s->bin_base1;
+  if (!s->knobs.no_scatter) {
+    const unsigned int nt = (unsigned int)local_tiles;
+    unsigned int P = nt / 64 > 1 ? nt / 64 : 1;
+    auto gcd = [](unsigned int x, unsigned int y) { while (y) { const unsigned int t = x % y; x = y; y = t; } return x; };
+    while (gcd(P, nt) != 1) ++P;
+    ba.scatter_p = (int)P;
+  }
+  BandArgs bd;
+  bd.pool = s->pool; bd.blob = s->blob; bd.hdr = s->bin_hdr; bd.goff = s->bin_goff;
+  bd.A0 = ba.A0; bd.A1 = ba.A1; bd.A5 = ba.A5; bd.slot = ba.slot; bd.offs = sa.offs; bd.packets = sa.packets; bd.ctl = sa.ctl; bd.sorted = sorted;
+  bd.dense_min = 16; bd.full_slices = s->bin_full_slices;
+  if (const char* e = std::getenv("PT_BAND_DENSE_MIN")) bd.dense_min = std::max(1, std::atoi(e)); // (experiments only)
+  PT_HIP(hipMemsetAsync(sa.hist, 0, K * 4, st));
+  PT_HIP(hipMemsetAsync(sa.ctl, 0, 64, st));
+  const dim3 step_grid((unsigned int)((N + kBlock - 1) / kBlock)), step_block(kBlock);
+  const int band_blocks = std::max(1, s->num_cus) * 6;
+  auto step = [&](int gen) -> int {
+    ba.gen = gen;
+    ba.live_in = live_list[gen & 1]; ba.live_out = live_list[(gen + 1) & 1];
+    if (s->has_image) {
+      if (s->mats_simple) hipLaunchKernelGGL((bin_step_kernel<UV_WINNER, MATS_LAMB_LIGHT_SOLID>), step_grid, step_block, 0, st, ba);
+      else hipLaunchKernelGGL((bin_step_kernel<UV_WINNER, MATS_ALL>), step_grid, step_block, 0, st, ba);
+    } else {
+      if (s->mats_simple) hipLaunchKernelGGL((bin_step_kernel<UV_NONE, MATS_LAMB_LIGHT_SOLID>), step_grid, step_block, 0, st, ba);
+      else hipLaunchKernelGGL((bin_step_kernel<UV_NONE, MATS_ALL>), step_grid, step_block, 0, st, ba);
+    }
+    PT_HIP(hipGetLastError());
+    hipLaunchKernelGGL(bin_count_kernel, dim3((unsigned int)n_blocks), dim3(1024), 0, st, sa);
+    hipLaunchKernelGGL(bin_prefix_kernel, dim3(1), dim3(64), 0, st, sa);
+    hipLaunchKernelGGL(bin_offsets_kernel, dim3((unsigned int)n_blocks), dim3(1024), 0, st, sa);
+    hipLaunchKernelGGL(bin_scatter_kernel, dim3((unsigned int)((N + 255) / 256)), dim3(256), 0, st, ba.A4, ba.A5, sa.offs, sorted, ba.live_out, sa.ctl);
+    hipLaunchKernelGGL(band_kernel, dim3((unsigned int)band_blocks), dim3(64 * kBandWaves), 0, st, bd);
+    PT_HIP(hipGetLastError());
+    return PT_OK;
+  };
+  // Generations while they pay: the host reads the live count back every 8 generations (the first time after min(samples, 8)) and, once
+  // fewer than `tail_frac` of the pixels are live, hands them to bin_finish_kernel.
+  int gen = 0;
+  unsigned int live = (unsigned int)N;
+  const long long max_gen = (long long)p->samples * std::max(1, p->depth) + 2;
+  double tail_frac = 0.25;
+  if (const char* e = std::getenv("PT_BIN_TAIL")) tail_frac = std::atof(e); // (experiments only; 0: generations to the end)
+  const unsigned int tail_at = (unsigned int)(tail_frac * (double)N);
+  while (live != 0 && live >= tail_at && gen <= max_gen) {
+    const int until = gen + 8;
+    for (; gen < until; gen++) if (int rc = step(gen)) return rc;
+    PT_HIP(hipMemcpyAsync(&live, sa.ctl + 3, sizeof live, hipMemcpyDeviceToHost, st));
+    PT_HIP(hipStreamSynchronize(st));
+  }
+  if (live != 0 && gen <= max_gen) { // the tail: persistent waves finish what is left (ctl[3] live pixels in the list the last step wrote)
+    ba.gen = gen; ba.live_in = live_list[gen & 1]; ba.live_out = live_list[(gen + 1) & 1];
+    PT_HIP(hipMemsetAsync(sa.ctl + 5, 0, 4, st));
+    int per_cu = 0;
+    const void* fk = s->has_image ? (s->mats_simple ? (const void*)bin_finish_kernel<UV_WINNER, MATS_LAMB_LIGHT_SOLID> : (const void*)bin_finish_kernel<UV_WINNER, MATS_ALL>)
+                                  : (s->mats_simple ? (const void*)bin_finish_kernel<UV_NONE, MATS_LAMB_LIGHT_SOLID> : (const void*)bin_finish_kernel<UV_NONE, MATS_ALL>);
+    auto cached = s->occupancy.find(fk);
+    if (cached != s->occupancy.end()) per_cu = cached->second;
+    else { PT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fk, kBlock, 0)); s->occupancy[fk] = per_cu; }
+    const unsigned int blocks = (unsigned int)std::min<long long>((long long)std::max(1, per_cu) * std::max(1, s->num_cus), ((long long)live + kBlock - 1) / kBlock * 64);
+    const dim3 fgrid(std::max(1u, blocks)), fblock(kBlock);
+    if (s->has_image) {
+      if (s->mats_simple) hipLaunchKernelGGL((bin_finish_kernel<UV_WINNER, MATS_LAMB_LIGHT_SOLID>), fgrid, fblock, 0, st, ba);
+      else hipLaunchKernelGGL((bin_finish_kernel<UV_WINNER, MATS_ALL>), fgrid, fblock, 0, st, ba);
+    } else {
+      if (s->mats_simple) hipLaunchKernelGGL((bin_finish_kernel<UV_NONE, MATS_LAMB_LIGHT_SOLID>), fgrid, fblock, 0, st, ba);
+      else hipLaunchKernelGGL((bin_finish_kernel<UV_NONE, MATS_ALL>), fgrid, fblock, 0, st, ba);
+    }
+    PT_HIP(hipGetLastError());
+    live = 0;
+  }
+  s->last_generations = gen;
+  s->last_launch[0] = (int)step_grid.x; s->last_launch[1] = 64; s->last_launch[2] = 0; s->last_launch[3] = 0;
+  if (live != 0) return fail(PT_ERR_HIP, "pt_render: the binned renderer did not finish within samples x depth generations");
+  return PT_OK;
+}
+
+static int reserve_binned(const PtScene* s, size_t N, size_t K, size_t& bytes) {
+  const size_t n_blocks = (K + 1023) / 1024, max_packets = (N / 64 + 1) * (size_t)s->bin_full_slices + std::min(K, N) + 1;
+  auto r = [](size_t n) { return (n + 255) & ~(size_t)255; };
+  bytes = 6 * r(N * 16) + r(N * 8) + r(K * 4) + r((K + 1) * 4) + r(n_blocks * 8) + r(max_packets * 8) + r(64) + 3 * r(N * 4);
+  if (s->ws_bin && s->ws_bin_pixels >= N) return PT_OK;
+  if (s->ws_bin) (void)hipFree(s->ws_bin);
+  s->ws_bin = nullptr; s->ws_bin_pixels = 0;
+  PT_HIP(hipMalloc(&s->ws_bin, bytes));
+  s->ws_bin_pixels = N;
+  return PT_OK;
+}
+
 static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderParams* p, float* fb, hipStream_t st) {
   int cur = -1;
   PT_HIP(hipGetDevice(&cur));
@@ -1472,6 +1617,7 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
     return PT_OK;
   }
   a.coop_prefix = (s->coop_ok && a.fast_ok && !(p->flags & PT_FLAG_NO_COOP)) ? s->coop_prefix : -1;
+  if (s->binned && !(p->flags & (PT_FLAG_FORCE_STREAM | PT_FLAG_FAST_RNG))) return launch_binned(s, a, p, local_tiles, st);
   const size_t blob_bytes = (size_t)s->blob_f4 * 16;
   // a scene with a triangle pool is queried through per-lane loads from the global blob: the scalar-cache resident kernels,
   // whatever its size (PT_FLAG_FORCE_STREAM: the streaming kernel, which scans every triangle, as the A/B)
@@ -1870,6 +2016,12 @@ int pt_tonemap_rgb8(const float* fb_device, int32_t width, int32_t height, uint8
   return PT_OK;
 }
 
+#ifdef PT_BIN_DEBUG
+extern "C" int pt_debug_bin_fallbacks(unsigned int* out) { // -DPT_BIN_DEBUG: per generation (rays, waves) that scanned the pooled run in full
+  PT_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bin_fb), 4096 * sizeof(unsigned int)));
+  return PT_OK;
+}
+#endif
 #ifdef PT_STAMPS_BLOCKS
 extern "C" int pt_debug_blocks(unsigned long long* out, int n_blocks) { // -DPT_STAMPS_BLOCKS: (where, start, end) of the last frame launch's workgroups
   PT_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_blocks), (size_t)std::min(n_blocks, 8192) * 3 * sizeof(unsigned long long)));

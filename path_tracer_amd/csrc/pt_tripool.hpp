@@ -117,6 +117,11 @@ struct TriPool {
   // still exact — see "compressed records" in build_tri_pool): 4 dwords per triangle
   float cq_lo[3] = {0, 0, 0}, cq_step[3] = {0, 0, 0}, eps_c = 0, eps_n = 0, kq = 0, kt = 0;
   std::vector<uint32_t> band_q; // (nq.x | nq.y << 16) (nq.z | bf16(pn) << 16) (cq.x | cq.y << 16) (cq.z | bf16(L) << 16)
+  // READY band records (round 6; what the binned band stage reads, pt_render.hip: band_kernel — one record serves the 64 rays of a packet, so
+  // it is stored decoded, 12 floats per triangle): (nq.x, nq.y, nq.z, pn~) (C~.x, C~.y, C~.z, L~ + ball_abs + eps_c) (G, nlow, E2, KR) with
+  // the per-triangle sub-expressions of the compressed record's filter precomputed from the SAME decoded values, each rounded to the side
+  // that relaxes the filter: see "ready records" in build_tri_pool
+  std::vector<float> band_ready;
   // statistics for the tests / DESIGN
   double mean_cells_per_triangle = 0;
   int wide = 0; // triangles whose band at the first map's rho_max covers every direction (tau >= 1, or no normal at all)
@@ -536,6 +541,37 @@ inline TriPool build_tri_pool(const PtHittable* h, int count, TriPoolTuning tune
       if (!(pnv < 1e30 && Lv < 1e30 && qn[(size_t)i] * (1 + 8 * u) <= pnv * ((double)tp.kq * Lv + (double)tp.kt / Lv))) return tp;
     }
     tp.eps_n = (float)(dev_n * (1 + 1e-6) + 3e-6); // + the binary32 rounding of d . (kx, ky, kz) / 32767 and of N'/|N'| against N/|N|
+    // ---- ready records -------------------------------------------------------------------------------------------------------
+    // The filter of a compressed record (pt_device.hpp: tri_pool_scan, band_pass), on the record's decoded values n~ = (kx, ky, kz) / 32767,
+    // pn~, L~, C~ (the device's own decode, operation by operation):
+    //     band    |d . n~| <= |d| (pn~ (rho + kq L~ + kt / L~) + eps_n)
+    //     radius  a1 = (|d . n~| - |d| eps_n) nlow - ea L~^2 |d|,  nlow = 0.98 p_per_L L~ / pn~;  a1 <= 0, or the ray's line within
+    //             L~ + ball_abs + eps_c + (kr_a + kr_b L~) L~^2 rho |d| / a1 of C~
+    // The binned band stage evaluates the same two conditions from G = pn~ (kq L~ + kt / L~) + eps_n, nlow, E2 = ea L~^2,
+    // KR = (kr_a + kr_b L~) L~^2 and Lr = L~ + ball_abs + eps_c, computed HERE in binary64 and rounded to binary32 on the side that makes
+    // the condition easier to pass (G, E2, KR, Lr up, nlow down; a relative 4e-6 on top, and the device keeps band_pass's own factors
+    // 1.00001 / 1.001): every pair band_pass lets through, the ready record lets through — a necessary condition stays one.
+    {
+      auto up = [](double x) { return std::nextafter((float)(x * (1 + 4e-6)), INFINITY); };
+      auto down = [](double x) { return std::max(0.0f, std::nextafter((float)(x * (1 - 4e-6)), -INFINITY)); };
+      tp.band_ready.assign((size_t)count * 12, 0.0f);
+      for (int i = 0; i < count; i++) {
+        float* r = &tp.band_ready[(size_t)i * 12];
+        if (dead[(size_t)i]) { r[8] = -1.0f; continue; } // n~ = 0 and G < 0: |d . n~| = 0 <= |d| (0 rho - 1) never holds
+        const uint32_t* q = &tp.band_q[(size_t)i * 4];
+        const int16_t kx = (int16_t)(q[0] & 0xffffu), ky = (int16_t)(q[0] >> 16), kz = (int16_t)(q[1] & 0xffffu);
+        const double pnv = bf16_val(q[1] >> 16), Lv = bf16_val(q[3] >> 16);
+        const uint32_t ck[3] = {q[2] & 0xffffu, q[2] >> 16, q[3] & 0xffffu};
+        r[0] = (float)kx; r[1] = (float)ky; r[2] = (float)kz; r[3] = (float)pnv;
+        for (int k = 0; k < 3; k++) { const float prod = (float)ck[k] * tp.cq_step[k]; r[4 + k] = tp.cq_lo[k] + prod; } // the device's decode (tri_centroid)
+        r[7] = up(Lv + (double)tp.ball_abs + (double)tp.eps_c);
+        const double g = pnv * ((double)tp.kq * Lv + (double)tp.kt / Lv * 1.00002) + (double)tp.eps_n;
+        r[8] = g < 3e38 ? up(g) : INFINITY;
+        r[9] = down(0.98 * (double)tp.p_per_L * Lv / pnv);
+        r[10] = up((double)tp.ea * Lv * Lv);
+        r[11] = up(((double)tp.kr_a + (double)tp.kr_b * Lv) * Lv * Lv);
+      }
+    }
   }
   // ---- (2) the direction maps ------------------------------------------------------------------------------------------------
   // class k: rays with rho <= rho_max_k; triangle i is listed by tau_i = rho_max_k pn_i + qn_i (what the real band test admits for such a ray)

@@ -386,7 +386,7 @@ def test_tuning_struct_and_environment_give_identical_blobs(lib, monkeypatch):
         ({"PT_GRID_M": "0.75", "PT_GRID_CELL": "3.43"}, dict(grid_margin=0.75, grid_cell=3.43), smoke),
         ({"PT_TRICULL": "1"}, dict(tri_min_run=256), tri),
         ({"PT_TRI_MIN": "1000", "PT_TRI_M": "20", "PT_TRI_MG": "48", "PT_TRI_CELL": "1.0", "PT_TRI_RES": "64,32,16"},
-         dict(tri_min_run=1000, tri_M=20.0, tri_Mg=48.0, tri_cell=1.0, tri_res=(64, 32, 16)), tri),
+         dict(tri_min_run=1000, tri_M=20.0, tri_binned=-1, tri_cell=1.0, tri_res=(64, 32, 16)), tri),
         ({"PT_TRICULL": "1", "PT_NO_TRICULL": "1"}, dict(tri_min_run=256, tri_pool=-1), tri),
         ({"PT_POOL_ALWAYS": "1"}, dict(slab_pools=1), mixed),
         ({"PT_NO_BOXCULL": "1"}, dict(slab_pools=-1), scenes.build("cornell")[0]),

@@ -12,4 +12,5 @@ packed, cam_args = scenes.build("triangles", n_triangles=100_000)
 cam = scenes.make_camera(cam_args, W, H)
 ds = R.DeviceScene(packed)
 fb, ms = R.render(W, H, SPP, ds, cam, flags=abi.PT_FLAG_NO_LPT, timed=True)
+fb, ms = R.render(W, H, SPP, ds, cam, flags=abi.PT_FLAG_NO_LPT, timed=True)  # (second render: workspaces allocated, tables warm)
 print(f"{W}x{H}x{SPP}: {ms:.1f} ms = {W * H * SPP / ms / 1e3:.3f} Msamples/s", flush=True)
