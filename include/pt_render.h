@@ -245,8 +245,11 @@ void pt_scene_destroy(PtScene* scene);
  *                      PT_TRI_CELL; 12, 0.22)
  *   tri_binned         scenes with ONE pooled triangle run render in GENERATIONS (round 6; csrc/pt_binned.hpp): every live pixel traces one
  *                      ray per generation and the rays are sorted by direction bin, so that a bin's list of grazing candidates is read once
- *                      for 64 rays — 0: yes; -1: the persistent kernel takes each ray through its own list (PT_TRI_UNBINNED; the A/B).
+ *                      for 64 rays — 1: on (PT_TRI_BINNED); 0: off: measured, it does not beat the persistent kernel yet (docs/EXPERIMENTS.md).
  *                      Such renders have returned only when the frame is done (the number of generations is known on the device only)
+ *   tri_cache          triangle-pool kernels, pinhole cameras: a lane keeps the grazing candidates of its pixel's camera rays (built by the
+ *                      pixel's first sample with the filters widened to the pixel's footprint) and every later camera ray of the pixel tests
+ *                      those instead of enumerating its direction-map list — 0: yes; -1: no (PT_NO_TRI_CACHE; the A/B)
  *   tri_res[0..2], tri_rho[0..1] + tri_rho2   the pool's direction maps: resolution per cube-map face and the largest rho / R a map
  *                      serves, per rho class (PT_TRI_RES=a,b,c PT_TRI_RHO=a,b,c; {256, 256, 64}, {2.12, 4, 16}; a negative rho: no such
  *                      map; rays with rho beyond the last class stream every band record)
@@ -296,6 +299,7 @@ typedef struct PtTuning {
   float tri_rho2;
   int32_t probe_resume;  /* (round 5, the last reserved word) */
   int32_t chain_priority; /* (round 5: appended — a caller built against the shorter struct passes its own struct_size and gets the default) */
+  int32_t tri_cache;      /* (round 6: appended) */
 } PtTuning;
 void pt_tuning_init(PtTuning* t);     /* zero + struct_size: the library's defaults                                          */
 void pt_tuning_from_env(PtTuning* t); /* the defaults with the PT_* environment applied: what pt_scene_create(desc, out) uses */

@@ -1386,13 +1386,18 @@ __device__ __forceinline__ bool tri_param(f4 R0, f4 R1, f4 R2, const Ray& r, flo
 __device__ __forceinline__ float rl_f(float v, int src) { return as_f(__builtin_amdgcn_readlane(as_i(v), src)); }
 
 // the bin of a direction in a direction map of R bins per face edge (pt_tripool.hpp: build_dir_map lists by exactly this rule)
-__device__ __forceinline__ unsigned int tri_dir_bin(V3 d, int R) {
+__device__ __forceinline__ void tri_dir_cell(V3 d, int R, int& k, int& ci, int& cj) {
   const float adx = __builtin_fabsf(d.x), ady = __builtin_fabsf(d.y), adz = __builtin_fabsf(d.z);
   // face k = the largest |component| (exact comparisons); (p, q) = (d_a, d_b) / d_k with a = k + 1, b = k + 2 (mod 3)
-  const int k = (adx >= ady && adx >= adz) ? 0 : (ady >= adz ? 1 : 2);
+  k = (adx >= ady && adx >= adz) ? 0 : (ady >= adz ? 1 : 2);
   const float dk = k == 0 ? d.x : k == 1 ? d.y : d.z, da = k == 0 ? d.y : k == 1 ? d.z : d.x, db = k == 0 ? d.z : k == 1 ? d.x : d.y;
   const float rk = __builtin_amdgcn_rcpf(dk), halfR = 0.5f * (float)R;
-  const int ci = min(max((int)__builtin_floorf((da * rk + 1.0f) * halfR), 0), R - 1), cj = min(max((int)__builtin_floorf((db * rk + 1.0f) * halfR), 0), R - 1);
+  ci = min(max((int)__builtin_floorf((da * rk + 1.0f) * halfR), 0), R - 1);
+  cj = min(max((int)__builtin_floorf((db * rk + 1.0f) * halfR), 0), R - 1);
+}
+__device__ __forceinline__ unsigned int tri_dir_bin(V3 d, int R) {
+  int k, ci, cj;
+  tri_dir_cell(d, R, k, ci, cj);
   return (unsigned int)((k * R + cj) * R + ci);
 }
 
@@ -1411,9 +1416,16 @@ struct TriBandCtx {
   unsigned int band_rec, tri_sorted;
   int n_tri, goff;
 };
-template <typename HitFn>
+// BUILD (round 6, the camera rays' candidate cache — tri_pool_scan): `ur` is the ray through a pixel's CENTRE and `dd` bounds |d - d_c| over
+// every ray of the pixel (same origin: a pinhole camera); the two filters are evaluated in the form that holds for ALL of those rays at once
+//     band    |d . n~| >= |d_c . n~| - dd |n~|  and  |d| <= |d_c| + dd:   |d_c . n~| - dd <= (|d_c| + dd) (pn (rho + ...) + eps_n)
+//     radius  a1 >= (|d_c . n~| - dd - (|d_c| + dd) eps_n) nlow - ea L^2 (|d_c| + dd), the noise radius <= its value at that a1 and at |d_c| + dd,
+//             and |(C - o) x d| >= |(C - o) x d_c| - |C - o| dd:   |(C - o) x d_c| <= rad (|d_c| + dd) + |C - o| dd
+// — each a consequence of the pair's own condition, so what passes for some ray of the pixel passes here — and the survivors are not tested
+// but handed to on_hit as the pixel's candidate list (on_hit(position), lanes below the returned count... see the caller).
+template <bool BUILD = false, typename HitFn>
 __device__ __forceinline__ void tri_band_one_ray(glb_f4p pool, const TriBandCtx& K, const Ray& ur, float ua, float rho, float dn, unsigned int first,
-                                                 unsigned int last, unsigned int cand_off, bool listed, HitFn&& on_hit) {
+                                                 unsigned int last, unsigned int cand_off, bool listed, HitFn&& on_hit, float dd = 0.0f) {
 #ifndef PT_NO_FILTER_FMA
 #pragma clang fp contract(fast) /* filter arithmetic: see tri_pool_scan */
 #endif
@@ -1434,7 +1446,8 @@ __device__ __forceinline__ void tri_band_one_ray(glb_f4p pool, const TriBandCtx&
     __builtin_amdgcn_wave_barrier();
     while (qn > keep) {
       const int n = min(qn, 64);
-      if (lane < n) {
+      if constexpr (BUILD) on_hit(lane < n ? tq[qn - n + lane] : -1, n); // (wave-wide: n survivors, one per lane)
+      else if (lane < n) {
         const unsigned int o = tri_sorted + 3u * (unsigned int)tq[qn - n + lane];
         const f4 R0 = pool[o], R1 = pool[o + 1], R2 = pool[o + 2];
         float t;
@@ -1444,23 +1457,30 @@ __device__ __forceinline__ void tri_band_one_ray(glb_f4p pool, const TriBandCtx&
     }
     __builtin_amdgcn_wave_barrier();
   };
+  const float dn_hi = dn + dd * 1.0001f; // (BUILD: >= |d| for every ray of the pixel)
   // band test, then the noise-radius filter: the line within L + kr rho |d| / (|a'| - ea |d|) of the centroid
   // on the 16-byte compressed record (pt_tripool.hpp "compressed records"; every quantity rounded to the safe side)
   auto near_line = [&](V3 C, float rad) { // does the ray's LINE pass within `rad` of the point C?
     const V3 x = cross(C - ur.o, ur.d);
+    if constexpr (BUILD) {
+      const V3 co = C - ur.o;
+      const float lim = rad * dn_hi + __builtin_amdgcn_sqrtf(dot(co, co)) * dd * 1.0001f;
+      return dot(x, x) <= lim * lim * 1.00002f;
+    }
     return dot(x, x) <= rad * rad * ua * 1.00001f;
   };
   auto band_pass = [&](f4 Q) {
     const unsigned int w0 = (unsigned int)as_i(Q.x), w1 = (unsigned int)as_i(Q.y), w2 = (unsigned int)as_i(Q.z), w3 = (unsigned int)as_i(Q.w);
     const float nx = (float)((int)(w0 << 16) >> 16), ny = (float)((int)w0 >> 16), nz = (float)((int)(w1 << 16) >> 16);
     const float pn = as_f((int)(w1 & 0xffff0000u)), L = as_f((int)(w3 & 0xffff0000u));
-    const float dq = __builtin_fabsf(ur.d.x * nx + ur.d.y * ny + ur.d.z * nz) * 3.0518509e-5f; // |d . n~|, n~ = (nx, ny, nz) / 32767
+    float dq = __builtin_fabsf(ur.d.x * nx + ur.d.y * ny + ur.d.z * nz) * 3.0518509e-5f; // |d . n~|, n~ = (nx, ny, nz) / 32767
+    if constexpr (BUILD) dq = __builtin_fmaxf(dq - dd * 1.0002f, 0.0f);                  // (a lower bound over the pixel's rays; |n~| <= 1 + 1e-4)
     const float rL = __builtin_amdgcn_rcpf(L) * 1.00001f;
-    if (!(dq <= dn * (pn * (rho + H5.y * L + H5.w * rL) + H8.w) * 1.00001f)) return false;
+    if (!(dq <= dn_hi * (pn * (rho + H5.y * L + H5.w * rL) + H8.w) * 1.00001f)) return false;
     const float L2 = L * L;
     const float nlow = 0.98f * H5.z * L * __builtin_amdgcn_rcpf(pn);          // <= |N|
-    const float a1 = (dq - dn * H8.w) * nlow - H6.w * L2 * dn;                 // <= |a'| - ea |d|
-    const float rr = (H6.y + H6.z * L) * L2 * rho * dn * __builtin_amdgcn_rcpf(a1) * 1.001f; // >= the noise radius; a1 <= 0: no bound
+    const float a1 = (dq - dn_hi * H8.w) * nlow - H6.w * L2 * dn_hi;           // <= |a'| - ea |d|
+    const float rr = (H6.y + H6.z * L) * L2 * rho * dn_hi * __builtin_amdgcn_rcpf(a1) * 1.001f; // >= the noise radius; a1 <= 0: no bound
     const V3 C = tri_centroid(w2 & 0xffffu, w2 >> 16, w3 & 0xffffu, H7, H8);
     return !(a1 > 0.0f) || near_line(C, L + rr + H6.x + H7.w);
   };
@@ -1473,7 +1493,8 @@ __device__ __forceinline__ void tri_band_one_ray(glb_f4p pool, const TriBandCtx&
   const int kdx = (int)__builtin_rintf(dh.x * 32767.0f), kdy = (int)__builtin_rintf(dh.y * 32767.0f), kdz = (int)__builtin_rintf(dh.z * 32767.0f);
   short2_t dxy, dz0;
   { const unsigned int a = ((unsigned int)kdx & 0xffffu) | ((unsigned int)kdy << 16), b = (unsigned int)kdz & 0xffffu; __builtin_memcpy(&dxy, &a, 4); __builtin_memcpy(&dz0, &b, 4); }
-  const float e1s = H8.w + 2.75e-5f;
+  // (BUILD: |d^ - d^_c| <= 2 dd / |d_c| for the unit directions of the pixel's rays)
+  const float e1s = H8.w + 2.75e-5f + (BUILD ? 2.02f * dd * __builtin_amdgcn_rcpf(dn) : 0.0f);
   auto band_stage1 = [&](f4 Q) {
     const unsigned int w0 = (unsigned int)as_i(Q.x), w1 = (unsigned int)as_i(Q.y), w3 = (unsigned int)as_i(Q.w);
     short2_t nxy, nzp;
@@ -1568,8 +1589,27 @@ struct TriDefer {
   float rho;
 };
 
+// The camera rays' candidate cache (round 6).  Every sample of a pixel starts with a camera ray, and for a pinhole camera those rays share
+// their origin and differ in direction by less than a pixel: the few dozen entries of the direction-map lists that survive the two filters
+// are nearly the same for all of them.  A lane holds ONE pixel for all its samples (pt_render.hip), so it keeps that pixel's list: the first
+// camera ray builds it — the bins the pixel's footprint touches, the filters in the form that holds for every ray of the pixel
+// (tri_band_one_ray<true>) — and every camera ray of the pixel, that one included, runs the reference's test on the cached candidates
+// instead of enumerating 2 300 map entries.  A superset of each ray's own candidate set: testing more triangles changes nothing.
+//   cache line of a lane: [0] the pixel it belongs to (the kernel's pixel id), [1] entries (-1: this pixel gets no cache — footprint over a
+//   face edge of the cube map, beyond the last rho class, or more than PT_TRI_CACHE_CAP survivors), [2 ...] positions in the Morton-ordered copy
+#define PT_TRI_CACHE_WORDS 256
+#define PT_TRI_CACHE_CAP (PT_TRI_CACHE_WORDS - 2)
+struct TriPrimCtx {
+  bool prim;  // per lane: this ray is a camera ray (the first of its sample) of a pinhole camera
+  int xy;     // per lane: pixel x | y << 16
+  int pix;    // per lane: the pixel's id in this render (the cache tag)
+  const __attribute__((address_space(4))) float* foot; // uniform: (llc - origin) xyz, hor / W xyz, ver / H xyz, dd  (the kernel arguments' KArgs::foot)
+  unsigned int* cache; // all lanes' cache lines; NULL: no cache
+};
+
 template <bool DEFER = false>
-__device__ __forceinline__ bool tri_pool_scan(glb_f4p pool, cst_f4p cblob, int hdr, int goff, const RayCtx& c, HitState& h, TriDefer* dfr = nullptr) {
+__device__ __forceinline__ bool tri_pool_scan(glb_f4p pool, cst_f4p cblob, int hdr, int goff, const RayCtx& c, HitState& h, TriDefer* dfr = nullptr,
+                                              const TriPrimCtx* pc = nullptr) {
 #ifndef PT_NO_FILTER_FMA
   // Everything written in this function is FILTER arithmetic — necessary conditions with explicit slack against exact mathematics
   // (pt_tripool.hpp), and the walk whose rounding the cells' absolute slack covers — so a product may fuse with the sum that
@@ -1791,6 +1831,68 @@ __device__ __forceinline__ bool tri_pool_scan(glb_f4p pool, cst_f4p cblob, int h
     PT_TRI_COUNT(9, listed_k == 3 ? 1 : 0);
     PT_TRI_COUNT(12, listed_k == 2 ? 1 : 0);
     PT_TRI_COUNT(10, listed ? 0 : 1);
+    if (pc != nullptr && pc->cache != nullptr && __builtin_amdgcn_readlane((int)pc->prim, src) != 0) { // a camera ray: its pixel's cached candidates
+      unsigned int* const cs = pc->cache + (size_t)(blockIdx.x * blockDim.x + (threadIdx.x & ~63u) + (unsigned int)src) * PT_TRI_CACHE_WORDS;
+      const int pix = __builtin_amdgcn_readlane(pc->pix, src);
+      int n = -1;
+      if (__builtin_amdgcn_readfirstlane((int)cs[0]) == pix) n = __builtin_amdgcn_readfirstlane((int)cs[1]);
+      else {
+        // build: the centre ray of the pixel, the bins its footprint touches
+        const int xy = __builtin_amdgcn_readlane(pc->xy, src);
+        const float sc = ((float)(xy & 0xffff) + 0.5f), tc = ((float)(xy >> 16) + 0.5f);
+        const V3 fb = mk(pc->foot[0], pc->foot[1], pc->foot[2]), fh = mk(pc->foot[3], pc->foot[4], pc->foot[5]), fv = mk(pc->foot[6], pc->foot[7], pc->foot[8]);
+        const float dd = pc->foot[9];
+        Ray cr;
+        cr.o = ur.o; cr.tm = 0.0f;
+        cr.d = fb + sc * fh + tc * fv;
+        const float cua = dot(cr.d, cr.d), cdn = __builtin_amdgcn_sqrtf(cua) * 1.000002f;
+        n = 0;
+        if (!listed) n = -1; // (beyond the last rho class: such a ray streams every record anyway)
+        else {
+          const f4 D = cblob[hdr + 8 + listed_k];
+          const int R = as_i(D.x);
+          int k0 = 0, i0 = R, i1 = -1, j0 = R, j1 = -1;
+          bool one_face = true;
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const V3 dq4 = cr.d + ((q & 1) ? 0.5f : -0.5f) * fh + ((q & 2) ? 0.5f : -0.5f) * fv;
+            int k, ci, cj;
+            tri_dir_cell(dq4, R, k, ci, cj);
+            if (q == 0) k0 = k;
+            one_face = one_face && k == k0;
+            i0 = min(i0, ci); i1 = max(i1, ci); j0 = min(j0, cj); j1 = max(j1, cj);
+          }
+          if (!one_face || (i1 - i0 + 1) * (j1 - j0 + 1) > 4) n = -1;
+          const unsigned int foff = (unsigned int)as_i(D.z);
+          for (int cj = j0; cj <= j1 && n >= 0; cj++)
+            for (int ci = i0; ci <= i1 && n >= 0; ci++) {
+              const unsigned int bin = (unsigned int)((k0 * R + cj) * R + ci);
+              const unsigned int bf = (unsigned int)__builtin_amdgcn_readfirstlane((int)gdword(pool, foff, bin)), bl = (unsigned int)__builtin_amdgcn_readfirstlane((int)gdword(pool, foff, bin + 1u));
+              tri_band_one_ray<true>(pool, bctx, cr, cua, rho, cdn, bf, bl, (unsigned int)as_i(D.w), true,
+                                     [&](int e, int cnt) {
+                                       if (n >= 0 && n + cnt <= PT_TRI_CACHE_CAP) { if (lane < cnt) cs[2 + n + lane] = (unsigned int)e; n += cnt; }
+                                       else n = -1;
+                                     }, dd);
+            }
+        }
+        if (lane == 0) { cs[0] = (unsigned int)pix; cs[1] = (unsigned int)n; }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); // (the list is read back by other lanes of this wave, now and for the pixel's later samples)
+        __builtin_amdgcn_wave_barrier();
+      }
+      if (n >= 0) {
+        PT_TRI_COUNT(13, 1);
+        PT_TRI_COUNT(14, n);
+        for (int base = 0; base < n; base += 64) {
+          if (base + lane < n) {
+            const unsigned int o = tri_sorted + 3u * cs[2 + base + lane];
+            const f4 R0 = pool[o], R1 = pool[o + 1], R2 = pool[o + 2];
+            float t;
+            if (tri_param(R0, R1, R2, ur, t) && !(t < PT_TMIN)) atomicMin(&slot[src], tri_key(t, goff + 3 * as_i(R2.w)));
+          }
+        }
+        continue;
+      }
+    }
     tri_band_one_ray(pool, bctx, ur, ua, rho, dn, first, last, cand_off, listed, [&](unsigned long long key) { atomicMin(&slot[src], key); });
   }
   // each lane reads its own ray's slot back: changed = some triangle of this run is the nearest hit so far
@@ -1803,7 +1905,8 @@ __device__ __forceinline__ bool tri_pool_scan(glb_f4p pool, cst_f4p cblob, int h
 // less code, and nothing of theirs (the medium's sqrt(d.d), say) can be hoisted into the per-iteration prologue of a kernel that never runs it.
 template <bool IMG, int TRIP = 1, int TTRIP = TRIP, bool WHOLE = true, bool BADOUEL = false, int GRID = 1, bool TRIPOOL = false, bool RECTBOX = false, bool DEFER = false, typename P>
 __device__ __forceinline__ void hit_records(P recs, cst_f4p cblob, int kind, int n, int goff,
-                                            const RayCtx& c, bool fast, uint32_t& rng, HitState& h, glb_f4p pool = nullptr, TriDefer* dfr = nullptr) {
+                                            const RayCtx& c, bool fast, uint32_t& rng, HitState& h, glb_f4p pool = nullptr, TriDefer* dfr = nullptr,
+                                            const TriPrimCtx* pc = nullptr) {
   const Ray& r = c.r;
   int off = 0;
   if (!RECTBOX && kind == DK_SPHERE) {
@@ -1843,7 +1946,7 @@ __device__ __forceinline__ void hit_records(P recs, cst_f4p cblob, int kind, int
     if constexpr (TRIPOOL && WHOLE) { // a long run with a triangle pool (flag + header offset in the run's aux record)
       const f4 aux = cblob[goff - 1];
       if (as_i(aux.x) != 0 && (fast || DEFER)) { // (DEFER: irregular rays are taken out lane by lane, inside)
-        if (tri_pool_scan<DEFER>(pool, cblob, as_i(aux.y), goff, c, h, dfr)) return;
+        if (tri_pool_scan<DEFER>(pool, cblob, as_i(aux.y), goff, c, h, dfr, pc)) return;
       }
     }
     auto accept_at = [&](int o) { return [&h, goff, o](float t) { h.closest = t; h.hit = hit_pack(DK_TRI, 0, goff + o); }; };
@@ -2019,7 +2122,7 @@ __device__ __forceinline__ int record_size(int kind) {
 // its direction-map part as a request in *dfr (tri_pool_scan<true>).
 template <bool IMG, bool BADOUEL = false, int GRID = 1, bool TRIPOOL = false, bool RECTBOX = false, bool DEFER = false, typename P>
 __device__ __forceinline__ void hit_world_range(P blob, cst_f4p cblob, int ri0, int ri1, const RayCtx& c, bool fast, uint32_t& rng, HitState& h, const f4* pool = nullptr,
-                                                TriDefer* dfr = nullptr) {
+                                                TriDefer* dfr = nullptr, const TriPrimCtx* pc = nullptr) {
   for (int ri = ri0; ri < ri1; ++ri) {
 #ifdef PT_STAMPS_RUNS /* diagnostic build: cycles per run of the list (wave leader's clock), g_runs[min(ri, 15)] */
     const unsigned long long run_t0 = __builtin_amdgcn_s_memtime();
@@ -2039,13 +2142,14 @@ __device__ __forceinline__ void hit_world_range(P blob, cst_f4p cblob, int ri0, 
         }
       }
     }
-    hit_records<IMG, 1, 1, true, BADOUEL, GRID, TRIPOOL, RECTBOX, DEFER>(blob + off, cblob, kind, as_i(runf.z), off, c, fast, rng, h, (glb_f4p)pool, dfr);
+    hit_records<IMG, 1, 1, true, BADOUEL, GRID, TRIPOOL, RECTBOX, DEFER>(blob + off, cblob, kind, as_i(runf.z), off, c, fast, rng, h, (glb_f4p)pool, dfr, pc);
   }
 }
 template <bool IMG, bool BADOUEL = false, int GRID = 1, bool TRIPOOL = false, bool RECTBOX = false, typename P>
-__device__ __forceinline__ void hit_world(P blob, cst_f4p cblob, int n_runs, const RayCtx& c, bool fast, uint32_t& rng, HitState& h, const f4* pool = nullptr) {
+__device__ __forceinline__ void hit_world(P blob, cst_f4p cblob, int n_runs, const RayCtx& c, bool fast, uint32_t& rng, HitState& h, const f4* pool = nullptr,
+                                          const TriPrimCtx* pc = nullptr) {
   hit_begin(h);
-  hit_world_range<IMG, BADOUEL, GRID, TRIPOOL, RECTBOX, false>(blob, cblob, 0, n_runs, c, fast, rng, h, pool);
+  hit_world_range<IMG, BADOUEL, GRID, TRIPOOL, RECTBOX, false>(blob, cblob, 0, n_runs, c, fast, rng, h, pool, nullptr, pc);
 }
 
 // Wave-uniform switch: the straight-line rect/box path is used only when every live lane's ray is regular.

@@ -65,7 +65,7 @@ namespace {
 #define PT_MIN_WAVES_COOP 5 /* cooperative kernels: 93 VGPRs, no scratch (7 waves: 72 VGPRs + 76 B/lane of spills in the loop) */
 #endif
 #ifndef PT_MIN_WAVES_TRIPOOL
-#define PT_MIN_WAVES_TRIPOOL 7 /* triangle-pool kernels: 72 VGPRs + ~150 bytes of scratch (none of it in the pool's inner loops), seven waves per SIMD.  Round 5 (the rebuilt pool, bound by the latency of its gathers): 1080p x 8 spp 332 ms at 7 waves, 344 at 5 (96 VGPRs), 371 at 4 (128 VGPRs, no scratch) — profiles/r05_ab_tripool.txt; rounds 3-4 measured the same order */
+#define PT_MIN_WAVES_TRIPOOL 6 /* triangle-pool kernels: 80 VGPRs + scratch.  Round 6 (with the camera rays' candidate cache): 1080p x 32 spp 1 116 ms at 7 waves (72 VGPRs, 228 B of scratch), 986 at 6, 978 at 5 — profiles/r06_ab_tri_cache.txt; rounds 3-5, without the cache, measured 7 best */
 #endif
 #ifndef PT_MIN_WAVES_BINSTEP
 #define PT_MIN_WAVES_BINSTEP 4 /* bin_step_kernel (pt_binned.hpp): 128 VGPRs, no scratch (6 waves: 80 VGPRs + 236 B of scratch with the pipelined trips) */
@@ -130,6 +130,9 @@ struct KArgs {
   // [chunk][framebuffer layout] (fast_reduce_kernel adds the chunks in order and divides).  0 = the reference's single stream.
   int fast_chunks, samples_total;
   long long fast_stride; // floats per chunk plane of the workspace
+  // the camera rays' candidate cache of the triangle-pool kernels (pt_device.hpp: TriPrimCtx): one line per resident lane; NULL: none
+  unsigned int* tri_cache;
+  float foot[10];        // (llc - origin) xyz, hor / W xyz, ver / H xyz, the bound dd on |d - d_centre| over a pixel's camera rays
 };
 
 // Per-lane state of the persistent loop.  A lane owns ONE pixel at a time, for all of its samples (the
@@ -600,6 +603,19 @@ void render_kernel(KArgs a) {
       RayCtx c = make_ctx(L.ray, a.fast_ok != 0);
       c.live = L.live;
       const bool fast = wave_all_regular(c, L.live);
+      if constexpr (TRIPOOL) {
+        TriPrimCtx pc;
+        pc.cache = a.tri_cache;
+        pc.prim = L.live && L.b == 0;
+        pc.xy = L.cold.get_x() | (L.cold.get_y() << 16);
+        pc.pix = L.cold.get_pix();
+#ifdef __HIP_DEVICE_COMPILE__
+        pc.foot = (const __attribute__((address_space(4))) float*)((unsigned long long)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(KArgs, foot));
+#else
+        pc.foot = nullptr;
+#endif
+        hit_world<IMG, BADOUEL, GRID, TRIPOOL, (MATS & MATS_RECTBOX_ONLY) != 0>((cst_f4p)a.blob, (cst_f4p)a.blob, a.n_runs, c, fast, L.rng, h, a.pool, &pc);
+      } else
       hit_world<IMG, BADOUEL, GRID, TRIPOOL, (MATS & MATS_RECTBOX_ONLY) != 0>((cst_f4p)a.blob, (cst_f4p)a.blob, a.n_runs, c, fast, L.rng, h, a.pool);
       lane_shade<UV, FAST, MATS>(L, a, h, a.blob, a.mats, fast);
     }
@@ -996,7 +1012,8 @@ static void tuning_env(PtTuning& t) {
   if (has("PT_NO_TRICULL")) t.tri_pool = -1;
   if (has("PT_TRICULL")) t.tri_min_run = 256;
   if (const char* e = std::getenv("PT_TRI_M")) t.tri_M = (float)std::atof(e);
-  if (has("PT_TRI_UNBINNED")) t.tri_binned = -1;
+  if (has("PT_TRI_BINNED")) t.tri_binned = 1;
+  if (has("PT_NO_TRI_CACHE")) t.tri_cache = -1;
   if (const char* e = std::getenv("PT_TRI_RES")) std::sscanf(e, "%d,%d,%d", &t.tri_res[0], &t.tri_res[1], &t.tri_res[2]);
   if (const char* e = std::getenv("PT_TRI_RHO")) std::sscanf(e, "%f,%f,%f", &t.tri_rho[0], &t.tri_rho[1], &t.tri_rho2);
   if (const char* e = std::getenv("PT_TRI_BUDGET_MB")) t.tri_budget_mb = std::max(1, std::atoi(e));
@@ -1093,6 +1110,7 @@ struct Knobs {
   bool generic_materials = false;
   int grid_walk = 0;       // PtTuning.grid_walk: 0 the launcher's rule, 1 the wave-synchronous walk, 2 the queued walk
   int lanes_cap = 0;       // PtTuning.lanes_cap: grid kernels on small frames (launch): 0 the rule, -1 whole tiles always, n forced
+  bool no_tri_cache = false;  // PtTuning.tri_cache = -1: camera rays enumerate their direction-map list like every other ray
   bool no_chain_prio = false; // PtTuning.chain_priority = -1: no issue priorities in the headline family's frame launches
   bool no_resume = false;  // PtTuning.probe_resume = -1: the probe's samples are rendered again by the frame launch
   int heavy_tiles = 0;     // PtTuning.heavy_tiles: tiles at the head of the cost-sorted order that are handed out 16 pixels at a time: 0 the rule, -1 never, n forced
@@ -1115,6 +1133,7 @@ struct Knobs {
     heavy_tiles = t.heavy_tiles < 0 ? -1 : t.heavy_tiles;
     no_resume = t.probe_resume < 0;
     no_chain_prio = t.chain_priority < 0;
+    no_tri_cache = t.tri_cache < 0;
   }
 };
 
@@ -1168,6 +1187,8 @@ struct PtScene {
   // the binned triangle-pool renderer (pt_binned.hpp): the pooled run, the key space of its direction maps, and a grow-only workspace
   int bin_run = -1, bin_hdr = 0, bin_goff = 0, bin_keys = 0, bin_full_slices = 1, bin_base1 = 0;
   bool binned = false;          // this scene's parity-mode renders go through it
+  mutable unsigned int* ws_tricache = nullptr; // the camera rays' candidate cache: one line per resident lane of the triangle-pool kernels
+  mutable size_t ws_tricache_lanes = 0;
   mutable void* ws_bin = nullptr; // per-pixel state, requests and slots for ws_bin_pixels local pixels; the sort's tables
   mutable size_t ws_bin_pixels = 0;
   mutable int last_generations = 0; // generations of the last binned render (pt_debug_last_launch)
@@ -1357,8 +1378,8 @@ int pt_scene_create_tuned(const PtSceneDesc* desc, const PtTuning* tuning, PtSce
     if ((m.kind != PT_MAT_LAMBERTIAN && m.kind != PT_MAT_LIGHTSOURCE) || desc->textures[m.texture].kind != PT_TEX_SOLID) s->mats_simple = false;
   }
   s->tri_pooled = flat.has_badouel ? 0 : flat.tri_pooled; // (scenes with Badouel-strategy triangles keep the round-2 kernels)
-  // The binned renderer serves scenes with ONE pooled run whose stale u, v need no tracking (pt_binned.hpp); PtTuning.tri_binned = -1: never.
-  if (s->tri_pooled > 0 && flat.tri_pool_runs == 1 && !s->track_uv && tun.tri_binned >= 0) {
+  // The binned renderer serves scenes with ONE pooled run whose stale u, v need no tracking (pt_binned.hpp); PtTuning.tri_binned = 1 (measured: it does not pay yet — docs/EXPERIMENTS.md — so it is opt-in).
+  if (s->tri_pooled > 0 && flat.tri_pool_runs == 1 && !s->track_uv && tun.tri_binned > 0) {
     s->binned = true;
     s->bin_run = flat.tri_pool_run; s->bin_hdr = flat.tri_pool_hdr; s->bin_goff = flat.tri_pool_goff;
     s->bin_full_slices = std::min(64, std::max(1, (flat.tri_pool_count + 2047) / 2048));
@@ -1406,6 +1427,7 @@ void pt_scene_destroy(PtScene* s) {
   if (s->ws_nsplit) (void)hipFree(s->ws_nsplit);
   if (s->ws_partial) (void)hipFree(s->ws_partial);
   if (s->ws_bin) (void)hipFree(s->ws_bin);
+  if (s->ws_tricache) (void)hipFree(s->ws_tricache);
   delete s;
 }
 
@@ -1646,6 +1668,8 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
   set_scatter();
   a.cost = nullptr;
   a.cost_max = 0;
+  a.tri_cache = nullptr;
+  for (float& f : a.foot) f = 0.0f;
   a.resume_rng = nullptr; a.resume_spp = 0;
   a.prio_onset = 0; a.prio_t1 = a.prio_t2 = a.prio_t3 = 0;
   a.order = nullptr;
@@ -1781,6 +1805,33 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
     n_waves_resident = (int)std::min<long long>(wanted, resident_blocks) * waves_per_block;
     if (!a.cost) { s->last_launch[0] = (int)std::min<long long>(wanted, resident_blocks); s->last_launch[1] = a.lanes_cap; s->last_launch[2] = a.heavy_pixels; s->last_launch[3] = launched_queued_walk ? 1 : 0; }
     dim3 grid((unsigned int)std::min<long long>(wanted, resident_blocks)), block((unsigned int)block_threads);
+    // The camera rays' candidate cache (pt_device.hpp: TriPrimCtx): triangle-pool kernels, a pinhole camera (the rays of a pixel share
+    // their origin), pixel coordinates that fit 16 bits.  One 1 KB line per lane of the launch; every line starts out belonging to no pixel.
+    a.tri_cache = nullptr;
+    if (tri_pool && a.cam.lens_radius == 0.0f && !s->knobs.no_tri_cache && p->width <= 65535 && p->height <= 65535) {
+      const size_t lanes = (size_t)grid.x * block.x;
+      if (s->ws_tricache_lanes < lanes) {
+        if (s->ws_tricache) (void)hipFree(s->ws_tricache);
+        s->ws_tricache = nullptr; s->ws_tricache_lanes = 0;
+        PT_HIP(hipMalloc((void**)&s->ws_tricache, lanes * PT_TRI_CACHE_WORDS * 4));
+        s->ws_tricache_lanes = lanes;
+      }
+      PT_HIP(hipMemsetAsync(s->ws_tricache, 0xff, lanes * PT_TRI_CACHE_WORDS * 4, st));
+      a.tri_cache = s->ws_tricache;
+      // the footprint of a pixel in direction space (camera.hpp:93-100 with lens_radius 0: d = llc + s hor + t ver - origin, s in [x / W, (x + 1) / W])
+      const Cam& cm = a.cam;
+      float base[3], hw[3], vh[3];
+      double dmax = 0, lh = 0, lv = 0;
+      for (int k = 0; k < 3; k++) {
+        base[k] = cm.llc[k] - cm.origin[k]; hw[k] = cm.horizontal[k] * a.inv_w; vh[k] = cm.vertical[k] * a.inv_h;
+        a.foot[k] = base[k]; a.foot[3 + k] = hw[k]; a.foot[6 + k] = vh[k];
+        lh += (double)hw[k] * hw[k]; lv += (double)vh[k] * vh[k];
+        dmax += std::fabs((double)cm.llc[k]) + std::fabs((double)cm.origin[k]) + std::fabs((double)cm.horizontal[k]) + std::fabs((double)cm.vertical[k]);
+      }
+      lh = std::sqrt(lh); lv = std::sqrt(lv);
+      // half a pixel each way (the jitter may round to the pixel's far edge), + the binary32 rounding of the camera's own arithmetic and of the centre ray
+      a.foot[9] = (float)((0.5 * (lh + lv)) * 1.001 + 1e-5 * dmax);
+    }
     hipLaunchKernelGGL(kernel, grid, block, shmem, st, a);
     PT_HIP(hipGetLastError());
     PT_HIP(hipEventRecord(s->ring_done[slot], st));

@@ -30,13 +30,15 @@ print(f"{W}x{H}x{spp}: {ms:.1f} ms = {W*H*spp/ms/1e3:.2f} Msamples/s; wave scans
 print(f"grid, per ray: cells visited {o[3]/rays:.1f}, exact tests {o[4]/rays:.1f}; per scan: wave-steps {o[2]/scans:.1f} (lanes per step {o[3]/max(o[2],1):.1f}), batches {o[5]/scans:.1f} (pairs per batch {o[4]/max(o[5],1):.1f})")
 print(f"direction map, per ray: entries enumerated {o[6]/rays:.1f} in {o[11]/rays:.1f} trips, past the integer band test {o[7]/rays:.1f}, past the noise radius (exact tests) {o[8]/rays:.1f}")
 print(f"rays through the second map {o[12]/rays:.4f}, through the third {o[9]/rays:.4f}, rays that streamed every record {o[10]/rays:.4f}")
+# [13] camera rays served by their pixel's cached candidate list, [14] cached candidates they tested (round 6)
+print(f"camera rays served from their pixel's cache: {o[13]/rays:.4f} of all rays, {o[14]/max(o[13],1):.1f} cached candidates (exact tests) each")
 
 if os.environ.get("PT_TRI_JSON"):  # the record bench.py prices the culled algorithm with (profiles/<tag>_tripool_counters.json)
     import json
     final = {"final": True, "round": int(os.environ["PT_FINAL_ROUND"])} if os.environ.get("PT_FINAL_ROUND") else {}
     json.dump({**final, "scene": "triangles", "workload": f"{W}x{H}x{spp}",
                "note": "in-kernel counters of the triangle pool, diagnostic build (make -C path_tracer_amd/csrc stamps EXTRA=-DPT_STAMPS_TRI), tools/tri_counters.py",
-               "per_ray": {"exact_tests": (o[4] + o[8]) / rays, "grid_filter_tests": 0.0, "band_tests": o[6] / rays,
+               "per_ray": {"exact_tests": (o[4] + o[8] + o[14]) / rays, "cached_ray_share": o[13] / rays, "cached_exact_tests": o[14] / rays, "grid_filter_tests": 0.0, "band_tests": o[6] / rays,
                            "always_tests": 0.0, "noise_radius_tests": o[7] / rays, "grid_cells": o[3] / rays,
                            "grid_exact_tests": o[4] / rays, "band_exact_tests": o[8] / rays, "second_map_share": o[12] / rays, "third_map_share": o[9] / rays, "full_stream_share": o[10] / rays},
                "pool": {"triangles": st[0], "wide": st[1], "map_entries_k": list(st)[2:4], "map_res": [(st[4] >> 20) & 1023, (st[4] >> 10) & 1023, st[4] & 1023], "blob_bytes": st[6] * 16}},
