@@ -251,9 +251,9 @@ void pt_scene_destroy(PtScene* scene);
  *                      pixel's first sample with the filters widened to the pixel's footprint) and every later camera ray of the pixel tests
  *                      those instead of enumerating its direction-map list — 0: yes; -1: no (PT_NO_TRI_CACHE; the A/B)
  *   tri_res[0..2], tri_rho[0..1] + tri_rho2   the pool's direction maps: resolution per cube-map face and the largest rho / R a map
- *                      serves, per rho class (PT_TRI_RES=a,b,c PT_TRI_RHO=a,b,c; {256, 256, 64}, {2.12, 4, 16}; a negative rho: no such
+ *                      serves, per rho class (PT_TRI_RES=a,b,c PT_TRI_RHO=a,b,c; {128, 64, 32} since round 6 — camera rays take their candidates from the pixel's cache: tri_cache —, {2.12, 4, 16}; a negative rho: no such
  *                      map; rays with rho beyond the last class stream every band record)
- *   tri_budget_mb      MiB the direction maps may take together (PT_TRI_BUDGET_MB; 4800): a map over budget is built coarser or not at all
+ *   tri_budget_mb      MiB the direction maps may take together (PT_TRI_BUDGET_MB; 1600, for all of a scene's pooled runs): a map over budget is built coarser or not at all
  *   generic_materials  1: no material-specialised kernels (PT_NO_MATSPEC)
  *   blocks_per_cu      cap on resident workgroups per CU (PT_BLOCKS_PER_CU)
  *   cold_state         -1: the cold lane state stays in registers (PT_NO_COLD_LDS)

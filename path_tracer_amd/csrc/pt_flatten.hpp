@@ -36,7 +36,7 @@ struct PoolLayout {
   std::vector<PoolSegment> segments;
   uint64_t size_f4 = 0;
   uint32_t put(std::vector<uint32_t>&& v, int spare_f4) { // returns the segment's offset; `spare_f4` zeroed records follow it (the scans may load a whole chunk without clamping)
-    const uint64_t at = size_f4;
+    const uint64_t at = size_f4; // (< 2^31: flatten() checks a pool's whole size before it puts any of its tables)
     size_f4 += (v.size() + 3) / 4 + (uint64_t)spare_f4;
     segments.push_back(PoolSegment{at, std::move(v)});
     return (uint32_t)at;
@@ -475,7 +475,10 @@ inline int flatten(const PtSceneDesc* sc, Flat& out, std::string& err, bool allo
       bool pooled = false;
       if (allow_tri_pool) {
         TriPool tp = build_tri_pool(&sc->hittables[run.first], run.count, tri_tune);
-        if (tp.ok && out.pool.size_f4 + 8ull * (size_t)run.count + tp.cell_cand.size() / 4 < (1ull << 31)) {
+        unsigned long long map_f4 = 0; // (the maps count too — a pool's tables are addressed by 32-bit F4 offsets)
+        for (const TriDirMap& dm : tp.maps) { map_f4 += (dm.cand.size() + dm.first.size()) / 4 + 140; tri_tune.dm_budget -= (long long)dm.cand.size(); } // the next run gets what is left of the budget
+        tri_tune.dm_budget = std::max(0ll, tri_tune.dm_budget);
+        if (tp.ok && out.pool.size_f4 + 12ull * (size_t)run.count + tp.cell_cand.size() / 4 + tp.cell_first.size() / 4 + map_f4 + 1024 < (1ull << 31)) {
           out.tri_cells_per_triangle = tp.mean_cells_per_triangle;
           out.tri_wide = tp.wide;
           out.tri_maps = (int)tp.maps.size();

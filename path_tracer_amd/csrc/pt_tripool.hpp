@@ -68,7 +68,10 @@
 // grazing rays); the GPU suite checks the walked structure against the oracle's brute-force scan, bit for bit.
 #pragma once
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstdint>
 #include <cstring>
 #include <thread>
@@ -79,7 +82,7 @@
 namespace ptf {
 
 struct TriPoolTuning {
-  float M = 12.0f;      // PT_TRI_M (swept 6 ... 48 on cfg5, round 5: profiles/r05_tripool_sweep.txt): barycentric slack 1/M — the grid's boxes grow with 1/M (sigma'), the bands with M.  Round 5: the grid is walked per lane and costs little, the band candidates are the expensive ones: the optimum moved from 12 towards smaller M
+  float M = 12.0f;      // PT_TRI_M: barycentric slack 1/M — the grid's boxes grow with 1/M (sigma'), the bands with M.  Swept on cfg5 in rounds 5 and 6 (docs/EXPERIMENTS.md; profiles/r06_tri_sweep.txt: 1080p x 32 spp 1 126 / 963 / 941 / 1 000 ms at M = 8 / 12 / 16 / 24): flat between 12 and 16, kept at 12
   float Ma = 256.0f;    // relative slack of t: the walk runs to max (1 + 2.2 / (Ma - 1))
   float cell = 0.22f;   // PT_TRI_CELL: grid cell edge in units of the median grown box extent
   float grid_budget = 160.0f;         // cell entries per triangle the grid may take (cells are enlarged until the estimate fits)
@@ -87,9 +90,12 @@ struct TriPoolTuning {
   // class 0 serves the rays that START ON THE MESH OR NEXT TO IT (|o - c| <= R + 2 L: rho <= 2 R + 2 L — every secondary ray off a
   // triangle, half of all rays; its bands are half as wide as the next class's), class 1 a camera a few radii out, class 2 the far
   // rest (ground hits towards the horizon); beyond the last class a ray streams every band record.
-  int dm_res[3] = {256, 256, 64};           // PT_TRI_RES=a,b,c: resolution of the maps (<= 1024; 0: no such map)
+  // Round 6: {256, 256, 64} -> {128, 64, 32}.  Camera rays take their candidates from their pixel's cache (pt_device.hpp: TriPrimCtx), so the
+  // class they fall into is enumerated once per pixel, not once per sample, and the maps' size stopped paying for itself: 1080p x 32 spp 953 ms
+  // with 3.0 GB of tables built in 2.1 s, 979 ms with 0.62 GB built in 0.9 s (profiles/r06_tri_map_res_sweep.txt).
+  int dm_res[3] = {128, 64, 32};            // PT_TRI_RES=a,b,c: resolution of the maps (<= 1024; 0: no such map)
   float dm_rho[3] = {2.12f, 4.0f, 16.0f};   // PT_TRI_RHO=a,b,c: class k serves rays with rho <= dm_rho[k] * R (R = radius of the v0's)
-  long long dm_budget = 1200ll << 20; // entries (4 bytes each) the direction maps may take together; a map that does not fit is built at half the resolution, or not at all
+  long long dm_budget = 400ll << 20;  // entries (4 bytes each) the direction maps may take together (all pooled runs of a scene: the flattener hands the rest on); a map that does not fit is built at half the resolution, or not at all
   int min_run = 4096;   // PT_TRI_MIN: shorter triangle runs are scanned as before (PT_TRICULL=1: 256)
   int threads = 0;      // build threads (0: hardware concurrency, at most 16); the tables do not depend on it
 };
@@ -249,6 +255,14 @@ inline bool build_dir_map(TriDirMap& dm, int R, const std::vector<double>& nrm, 
 
 inline TriPool build_tri_pool(const PtHittable* h, int count, TriPoolTuning tune = TriPoolTuning()) {
   TriPool tp;
+  const bool timing = std::getenv("PT_TRI_TIMING") != nullptr; // (diagnostics: stage times on stderr)
+  auto t_prev = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!timing) return;
+    const auto t = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "build_tri_pool: %-28s %.3f s\n", what, std::chrono::duration<double>(t - t_prev).count());
+    t_prev = t;
+  };
   if (count < tune.min_run || count >= (1 << 26)) return tp; // (table entries carry a triangle's position in 26 bits)
   const double u = std::ldexp(1.0, -24), SAFE = 1.5;
   // (the bound of the header holds for any M > 1; sigma' below is its general form.  M >= 4 keeps the second-order terms SAFE covers small.)
@@ -306,6 +320,7 @@ inline TriPool build_tri_pool(const PtHittable* h, int count, TriPoolTuning tune
   }
   if (n_live < tune.min_run) return tp;
   R *= 1.0 + 8 * u;
+  lap("per-triangle constants");
   // ---- (1) the grid -----------------------------------------------------------------------------------------------------
   std::nth_element(ext.begin(), ext.begin() + ext.size() / 2, ext.end());
   double cell = std::max(1e-6, (double)tune.cell * ext[ext.size() / 2]);
@@ -435,45 +450,76 @@ inline TriPool build_tri_pool(const PtHittable* h, int count, TriPoolTuning tune
     for (int i = 0; i < count; i++) tp.order[(size_t)i] = (uint32_t)i;
     std::stable_sort(tp.order.begin(), tp.order.end(), [&](uint32_t x, uint32_t y) { return code[x] < code[y]; });
   }
-  std::vector<uint32_t> cnt(ncell + 1, 0);
-  size_t total_entries = 0;
-  for (int i = 0; i < count; i++) {
-    if (dead[(size_t)i]) continue;
-    for_cells(i, [&](size_t ci) { cnt[ci]++; total_entries++; });
+  lap("grid sizing + Morton order");
+  // Two passes over the triangles in Morton order, each thread its own contiguous slice (pass 0 counts per (thread, cell), pass 1 writes):
+  // a cell's candidates ascend, and the table is the single-threaded one whatever the number of threads (round 6: this was one thread,
+  // a third of the scene's build time).
+  int GT = tune.threads > 0 ? tune.threads : (int)std::thread::hardware_concurrency();
+  GT = std::max(1, std::min(GT, 16));
+  if (ncell * (size_t)GT > (64u << 20)) GT = std::max(1, (int)((64u << 20) / ncell)); // (per-thread counters: at most 256 MB)
+  auto gslice = [&](int t, int& p0, int& p1) { p0 = (int)((long long)count * t / GT); p1 = (int)((long long)count * (t + 1) / GT); };
+  std::vector<std::vector<uint32_t>> gcnt((size_t)GT);
+  {
+    std::vector<std::thread> th;
+    for (int t = 0; t < GT; t++)
+      th.emplace_back([&, t]() {
+        gcnt[(size_t)t].assign(ncell, 0);
+        int p0, p1;
+        gslice(t, p0, p1);
+        uint32_t* const cn = gcnt[(size_t)t].data();
+        for (int p = p0; p < p1; p++) {
+          const int i = (int)tp.order[(size_t)p];
+          if (!dead[(size_t)i]) for_cells(i, [&](size_t ci) { cn[ci]++; });
+        }
+      });
+    for (auto& x : th) x.join();
   }
-  if (total_entries >= (1u << 30)) return tp;
+  size_t total_entries = 0;
   tp.cell_first.assign(ncell + 1, 0);
-  for (size_t k = 0; k < ncell; k++) tp.cell_first[k + 1] = tp.cell_first[k] + cnt[k];
+  for (size_t k = 0; k < ncell; k++) {
+    tp.cell_first[k] = (uint32_t)total_entries;
+    for (int t = 0; t < GT; t++) { const uint32_t c = gcnt[(size_t)t][k]; gcnt[(size_t)t][k] = (uint32_t)total_entries; total_entries += c; } // -> this thread's cursor in the cell
+    if (total_entries >= (1u << 30)) return tp;
+  }
+  tp.cell_first[ncell] = (uint32_t)total_entries;
   tp.cell_cand.assign(total_entries, 0);
   {
-    std::vector<uint32_t> cur(tp.cell_first.begin(), tp.cell_first.end() - 1);
     // Each entry also says in which of the cell's six face neighbours the triangle is listed as well (bits 26 ... 31: -x +x -y +y -z +z):
     // a walk steps from cell to cell through faces, and a triangle that the cell it comes from lists has been tested there already
     // (or where that cell's predecessor listed it, and so on back to the first cell of the chain) — a (ray, triangle) pair's test does
     // not depend on the cell it is made in, so the device skips it (tri_pool_scan).  2^26 positions: build_tri_pool's caller checks the count.
-    std::vector<uint32_t> own; // the cells of one triangle, sorted
     const long long sx = 1, sy = tp.n[0], sz = (long long)tp.n[0] * tp.n[1];
-    for (int p = 0; p < count; p++) { // in Morton order: a cell's candidates ascend
-      const int i = (int)tp.order[(size_t)p];
-      if (dead[(size_t)i]) continue;
-      own.clear();
-      for_cells(i, [&](size_t ci) { own.push_back((uint32_t)ci); });
-      std::sort(own.begin(), own.end());
-      for (uint32_t ci : own) {
-        const int x = (int)(ci % (uint32_t)tp.n[0]), y = (int)((ci / (uint32_t)tp.n[0]) % (uint32_t)tp.n[1]), z = (int)(ci / (uint32_t)(tp.n[0] * tp.n[1]));
-        auto has = [&](bool in_grid, long long c2) { return in_grid && std::binary_search(own.begin(), own.end(), (uint32_t)c2); };
-        uint32_t bits = 0;
-        bits |= has(x > 0, (long long)ci - sx) ? 1u : 0u;
-        bits |= has(x + 1 < tp.n[0], (long long)ci + sx) ? 2u : 0u;
-        bits |= has(y > 0, (long long)ci - sy) ? 4u : 0u;
-        bits |= has(y + 1 < tp.n[1], (long long)ci + sy) ? 8u : 0u;
-        bits |= has(z > 0, (long long)ci - sz) ? 16u : 0u;
-        bits |= has(z + 1 < tp.n[2], (long long)ci + sz) ? 32u : 0u;
-        tp.cell_cand[cur[ci]++] = (uint32_t)p | (bits << 26);
-      }
-    }
+    std::vector<std::thread> th;
+    for (int t = 0; t < GT; t++)
+      th.emplace_back([&, t]() {
+        int p0, p1;
+        gslice(t, p0, p1);
+        uint32_t* const cur = gcnt[(size_t)t].data();
+        std::vector<uint32_t> own; // the cells of one triangle, sorted
+        for (int p = p0; p < p1; p++) { // in Morton order: a cell's candidates ascend
+          const int i = (int)tp.order[(size_t)p];
+          if (dead[(size_t)i]) continue;
+          own.clear();
+          for_cells(i, [&](size_t ci) { own.push_back((uint32_t)ci); });
+          std::sort(own.begin(), own.end());
+          for (uint32_t ci : own) {
+            const int x = (int)(ci % (uint32_t)tp.n[0]), y = (int)((ci / (uint32_t)tp.n[0]) % (uint32_t)tp.n[1]), z = (int)(ci / (uint32_t)(tp.n[0] * tp.n[1]));
+            auto has = [&](bool in_grid, long long c2) { return in_grid && std::binary_search(own.begin(), own.end(), (uint32_t)c2); };
+            uint32_t bits = 0;
+            bits |= has(x > 0, (long long)ci - sx) ? 1u : 0u;
+            bits |= has(x + 1 < tp.n[0], (long long)ci + sx) ? 2u : 0u;
+            bits |= has(y > 0, (long long)ci - sy) ? 4u : 0u;
+            bits |= has(y + 1 < tp.n[1], (long long)ci + sy) ? 8u : 0u;
+            bits |= has(z > 0, (long long)ci - sz) ? 16u : 0u;
+            bits |= has(z + 1 < tp.n[2], (long long)ci + sz) ? 32u : 0u;
+            tp.cell_cand[cur[ci]++] = (uint32_t)p | (bits << 26);
+          }
+        }
+      });
+    for (auto& x : th) x.join();
   }
   tp.mean_cells_per_triangle = (double)total_entries / std::max(1, n_live);
+  lap("grid cells (count + fill)");
   // ---- compressed records --------------------------------------------------------------------------------------------------
   // Both band filters are NECESSARY conditions of an acceptance: any relaxation keeps the pool exact.  So the device reads them
   // from quantised records, every quantity rounded to the safe side:
@@ -573,6 +619,7 @@ inline TriPool build_tri_pool(const PtHittable* h, int count, TriPoolTuning tune
       }
     }
   }
+  lap("compressed + ready records");
   // ---- (2) the direction maps ------------------------------------------------------------------------------------------------
   // class k: rays with rho <= rho_max_k; triangle i is listed by tau_i = rho_max_k pn_i + qn_i (what the real band test admits for such a ray)
   {
@@ -604,6 +651,7 @@ inline TriPool build_tri_pool(const PtHittable* h, int count, TriPoolTuning tune
       }
     }
   }
+  lap("direction maps");
   tp.ok = true;
   return tp;
 }

@@ -457,6 +457,53 @@ def test_random_triangle_fields_through_the_triangle_pool(orc, lib, seed):
     assert_bit_identical(R.render_host(w, h, 70, ds, c, flags=F), orc.render(ps, c.c, w, h, 70, flags=F), f"triangle field seed {seed} fast mode")
 
 
+@pytest.mark.parametrize("seed,tail", [(8000, "0"), (8001, "0.4"), (8003, "0"), (8004, "0.9"), (8006, "0.2"), (8009, "0"), (8012, "0.5")])
+def test_binned_triangle_pool_renderer(orc, lib, seed, tail, monkeypatch):
+    """PtTuning.tri_binned = 1 (csrc/pt_binned.hpp, opt-in): the frame in GENERATIONS — every live pixel one ray per generation, the rays' band
+    stage brought together by direction bin (dense packets: 64 rays share a streamed list; sparse packets: the persistent kernel's own
+    one-ray routine; rays outside the pool's domain: sliced full scans) — to the end of the frame (PT_BIN_TAIL=0) or with the tail handed to
+    persistent waves at several points: the oracle's frame bit for bit, whole frames and shards, every ray irregular (PT_FLAG_NO_FASTDIV), and
+    with packets forced dense (PT_BAND_DENSE_MIN=1) or sparse (=65)."""
+    ps, cam = random_triangle_field(seed)
+    w, h, spp = 40, 24, 8
+    c = scenes.make_camera(cam, w, h)
+    orc.set_math(True)
+    ref = orc.render(ps, c.c, w, h, spp)
+    monkeypatch.setenv("PT_BIN_TAIL", tail)
+    ds = R.DeviceScene(ps, abi.tuning(tri_min_run=256, tri_binned=1))
+    for dense_min in (None, "1", "65"):
+        if dense_min is not None:
+            monkeypatch.setenv("PT_BAND_DENSE_MIN", dense_min)
+        assert_bit_identical(R.render_host(w, h, spp, ds, c), ref, f"binned renderer, field {seed}, tail {tail}, dense_min {dense_min}")
+    monkeypatch.delenv("PT_BAND_DENSE_MIN")
+    assert_bit_identical(R.render_host(w, h, spp, ds, c, flags=abi.PT_FLAG_NO_FASTDIV), ref, f"binned renderer, field {seed}: every ray outside the pool's domain")
+    for k in range(3):
+        assert_bit_identical(R.render_host(w, h, spp, ds, c, shard_index=k, shard_count=3),
+                             orc.render(ps, c.c, w, h, spp, shard_index=k, shard_count=3), f"binned renderer, field {seed}, shard {k}/3")
+
+
+@pytest.mark.parametrize("seed", [8000, 8002, 8005, 8011])
+def test_camera_ray_candidate_cache_changes_no_bit(orc, lib, seed):
+    """PtTuning.tri_cache (round 6): a lane keeps the grazing candidates of its pixel's camera rays — built once per pixel with the filters
+    widened to the pixel's footprint — instead of enumerating the direction map for every sample.  With and without it, at frame sizes
+    whose pixels are wide (every list overflows: no cache) and narrow (lists cached), many samples per pixel, whole frames and shards,
+    and with a lens (the rays of a pixel no longer share their origin: no cache): the oracle's frame."""
+    ps, cam = random_triangle_field(seed)
+    orc.set_math(True)
+    for (w, h, spp) in ((24, 16, 24), (320, 180, 3)):
+        c = scenes.make_camera(cam, w, h)
+        ref = orc.render(ps, c.c, w, h, spp)
+        for cache in (0, -1):
+            ds = R.DeviceScene(ps, abi.tuning(tri_min_run=256, tri_cache=cache))
+            assert_bit_identical(R.render_host(w, h, spp, ds, c), ref, f"field {seed} {w}x{h}x{spp} tri_cache {cache}")
+            if w == 24:
+                assert_bit_identical(R.render_host(w, h, spp, ds, c, shard_index=1, shard_count=2),
+                                     orc.render(ps, c.c, w, h, spp, shard_index=1, shard_count=2), f"field {seed} shard 1/2 tri_cache {cache}")
+    lens = dict(cam, aperture=0.05)
+    c = scenes.make_camera(lens, 64, 36)
+    assert_bit_identical(R.render_host(64, 36, 6, R.DeviceScene(ps, abi.tuning(tri_min_run=256)), c), orc.render(ps, c.c, 64, 36, 6), f"field {seed} with a lens")
+
+
 def test_triangle_pool_thresholds_and_small_runs(orc, lib, monkeypatch):
     """By default only runs of >= 4096 triangles get a pool (the fuzz fields do not: full scan); PT_TRICULL=1 lowers the threshold
     to 256; PT_NO_TRICULL overrides everything; PT_TRI_MIN=4 puts pools into the small mixed scenes (triangle runs of a handful,

@@ -10,7 +10,11 @@ from path_tracer_amd import render as R
 W, H, SPP = (int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (480, 270, 4)
 packed, cam_args = scenes.build("triangles", n_triangles=100_000)
 cam = scenes.make_camera(cam_args, W, H)
+import time
+_t0 = time.time()
 ds = R.DeviceScene(packed)
+torch.cuda.synchronize()
+print(f"scene create {time.time() - _t0:.2f} s", flush=True)
 fb, ms = R.render(W, H, SPP, ds, cam, flags=abi.PT_FLAG_NO_LPT, timed=True)
 fb, ms = R.render(W, H, SPP, ds, cam, flags=abi.PT_FLAG_NO_LPT, timed=True)  # (second render: workspaces allocated, tables warm)
 print(f"{W}x{H}x{SPP}: {ms:.1f} ms = {W * H * SPP / ms / 1e3:.3f} Msamples/s", flush=True)
