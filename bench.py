@@ -173,7 +173,7 @@ def ops_per_sample(ctr: dict) -> float:
     return total / n
 
 
-KERNEL_SOURCES = ("pt_render.hip", "pt_device.hpp", "pt_math.hpp", "pt_flatten.hpp", "pt_tripool.hpp")
+KERNEL_SOURCES = ("pt_render.hip", "pt_device.hpp", "pt_math.hpp", "pt_flatten.hpp", "pt_tripool.hpp", "pt_binned.hpp")  # csrc/Makefile: KSRC, same order
 
 
 def kernels_sha16(root=None):
@@ -349,7 +349,16 @@ def main() -> None:
     scene_name, W1, H1, SPP, DEPTH = cfg["scene"], cfg["width"], cfg["height"], cfg["spp"], args.depth
     kw = {"n_triangles": 100_000} if scene_name == "triangles" else {}
     packed, cam_args = scenes.build(scene_name, **kw)
-    ds = R.DeviceScene(packed)  # scene resident in HBM before the timed region
+    # The scene is resident in HBM before the timed region — what that costs is on the line all the same (cfg5's 3 s of host
+    # work and 2.9 GB of tables were invisible): pt_scene_create = validate + flatten + build the culling structures + upload.
+    torch.cuda.synchronize()
+    t_build = time.perf_counter()
+    ds = R.DeviceScene(packed)
+    torch.cuda.synchronize()
+    scene_build_s = time.perf_counter() - t_build
+    from path_tracer_amd import abi as _abi
+    scene_device_bytes = int(_abi.load_library().pt_scene_device_bytes(ds.handle))
+    library_build_id = _abi.load_library().pt_build_id().decode()
 
     def barrier():
         if dist_path:
@@ -434,7 +443,7 @@ def main() -> None:
             # --- cpu_baseline leg: the only place bench.py touches oracle/ (test infrastructure) ---------------
             from oracle import binding as orc
             orc.set_math(True)
-            cw, ch, cs = (480, 270, 4) if scene_name != "triangles" else (96, 54, 1)
+            cw, ch, cs = (480, 270, 2) if scene_name != "triangles" else (64, 36, 1)
             _, ctr = orc.render(packed, scenes.make_camera(cam_args, cw, ch).c, cw, ch, cs, DEPTH, counters=True)
             ops = ops_per_sample(ctr.as_dict())  # exit-point counters -> algorithmic ops per sample, live
             if GRID_WALK.get(scene_name) and grid_culled:
@@ -442,30 +451,33 @@ def main() -> None:
                 ops_culled = ops_per_sample_culled(ctr.as_dict(), sum(1 for k in packed.kinds() if k == abi_.PT_HIT_SPHERE), st[7], GRID_WALK[scene_name])
             if TRI_POOL.get(scene_name) and tri_culled:
                 ops_culled = ops_per_sample_culled_tri(ctr.as_dict(), TRI_POOL[scene_name])
-            # bounded sample of the same workload, sized for ~15 s of CPU work from a 1-spp probe
-            bw, bh = (W, H) if scene_name != "triangles" else (240, 135)
+            # bounded sample of the same workload.  Round 6: ~3 s of OpenMP work, ~1 s each for the glibc-math and the
+            # one-thread legs — the whole CPU leg now costs about what the GPU region does (it was 22 s against 3: the driver's gpu_busy
+            # sampler saw an idle device on all of its samples).  The rate does not depend on the sample's size (Msamples/s is resolution-
+            # independent: SURVEY.md §8d), only its noise does.
+            bw, bh = (W // 2, H // 2) if scene_name != "triangles" else (160, 90)
             bcam = scenes.make_camera(cam_args, bw, bh)
             t1 = time.perf_counter()
             orc.render(packed, bcam.c, bw, bh, 1, DEPTH)
             probe = time.perf_counter() - t1
-            bs = int(max(1, min(SPP, round(15.0 / max(probe, 1e-3)))))
+            bs = int(max(1, min(SPP, round(3.0 / max(probe, 1e-3)))))
             t1 = time.perf_counter()
             orc.render(packed, bcam.c, bw, bh, bs, DEPTH)
             dt = time.perf_counter() - t1
             # the same sample with glibc's float libm (the reference's own libm semantics; transcendental-free scenes such as
             # the Cornell-style one give the same image either way), half the sample: it rides beside, it is not `value`
             orc.set_math(False)
-            gs = max(1, bs // 2)
+            gs = max(1, bs // 3)
             t1 = time.perf_counter()
             orc.render(packed, bcam.c, bw, bh, gs, DEPTH)
             dtg = time.perf_counter() - t1
             orc.set_math(True)
-            # one thread on its own, on a slice of the same workload sized for ~3 s (a smaller frame of the same camera where even one
+            # one thread on its own, on a slice of the same workload sized for ~1 s (a smaller frame of the same camera where even one
             # sample per pixel of the sample's frame would take longer: the 100 k-triangle mesh does ~40 samples/s per thread): what a
             # "core" of this host is worth, and how the OpenMP run scales over the threads it used (row-dynamic schedule)
             nthreads = orc.load().orc_max_threads()
             per_thread_guess = bw * bh * bs / dt / max(nthreads, 1)              # samples / s / thread if the scaling were perfect
-            want = max(64.0, 3.0 * per_thread_guess)                             # samples for ~3 s (a thread alone is at least that fast)
+            want = max(64.0, 1.0 * per_thread_guess)                             # samples for ~1 s (a thread alone is at least that fast)
             s1 = int(max(1, min(bs, want // (bw * bh))))
             w1, h1 = bw, bh
             if want < bw * bh:                                                   # fewer samples than pixels: shrink the frame
@@ -506,7 +518,9 @@ def main() -> None:
         # ... and they are RECORDINGS: they describe the build they were recorded on.  A recording of another build (its kernel-source hash
         # differs from this tree's) is not reported as if it were this run's: every PMC-derived field is nulled, the line says which
         # recording was refused.  (tools/pmc_summary.py stamps kernels_sha16 / recorded_at_head; older summaries carry neither = stale.)
-        kernels_now = kernels_sha16()
+        # "this build" is the LIBRARY that ran (pt_build_id: the hash of the kernel sources it was compiled from, csrc/Makefile), not the
+        # tree beside it (a stale .so or a PT_RENDER_LIB override would otherwise pass for the tree's build)
+        kernels_now = library_build_id
         pmc_record = {"file": pmc[1], "kernels_sha16": pmc[3], "recorded_at_head": pmc[4], "matches_this_build": pmc[3] == kernels_now} if pmc else None
         if pmc and pmc[3] != kernels_now:
             pmc = None
@@ -536,6 +550,9 @@ def main() -> None:
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic", "frame": f"{W}x{H}",
+            # outside the timed region, and therefore said: seconds of pt_scene_create (flatten + culling structures + upload) and the
+            # device bytes of the scene's data (records, materials, triangle-pool tables, atlas)
+            "scene_build_s": round(scene_build_s, 3), "scene_device_bytes": scene_device_bytes,
             "config": {"workload": f"{scene_name}: {SCENE_TEXT[scene_name]}, {W}x{H}, {SPP} spp, depth {DEPTH}, "
                                    + ("seed = pixel linear id" if args.mode == "parity" else "FAST MODE: one RNG stream per (pixel, sample)"),
                        "baseline_config": args.config, "hittables": packed.n_hittables, "mode": args.mode,
@@ -559,7 +576,7 @@ def main() -> None:
                          "algorithmic_ops_per_sample_reference": round(ops_reference, 1),
                          "traffic": pmc[0] if pmc else None, "traffic_source": pmc[1] if pmc else None,
                          # which recording the PMC-derived fields (traffic, hbm, *_pmc, executed_over_algorithmic) come from; nulled when stale
-                         "pmc_recording": pmc_record, "kernels_sha16": kernels_now, "recorded_at_head": pmc_record["recorded_at_head"] if pmc_record else None,
+                         "pmc_recording": pmc_record, "kernels_sha16": kernels_now, "tree_kernels_sha16": kernels_sha16(), "recorded_at_head": pmc_record["recorded_at_head"] if pmc_record else None,
                          # north-star evidence: HBM is not the limiter, VALU issue is busy (PMC of the committed profile)
                          "hbm": {"achieved_gbs": round(pmc[0] / (kern_ms * 1e-3) / 1e9, 3), "peak_gbs": 8000.0,
                                  "frac": round(mem_frac, 6), "traffic_over_algorithmic": round(pmc[0] / algorithmic_bytes, 2)} if pmc else None,
@@ -580,7 +597,10 @@ def main() -> None:
             # and (parity mode) the shard's own chain floor as measured on ONE GPU — where strong scaling must flatten
             line["distributed"] = dict(dist_detail or {}, backend=dist.get_backend(), world_size=dist.get_world_size(),
                                        rccl_version=".".join(str(v) for v in torch.cuda.nccl.version()),
-                                       exchange="one ncclGather of float tiles to rank 0 + device un-interleave (pt_unshard_tiles)",
+                                       # what THIS path issues (render.py: gather_frame): torch.distributed.gather, which the NCCL backend runs as
+                                       # grouped point-to-point sends / receives — every peer -> root transfer on its own xGMI link, like the one
+                                       # ncclGather the C ABI's pt_dist_gather_frame issues (csrc/pt_dist.cpp), which this Python path does not call
+                                       exchange="torch.distributed.gather of float tiles to rank 0 (NCCL backend: RCCL grouped send / recv) + device un-interleave (pt_unshard_tiles)",
                                        bytes_gathered_per_rank=int(((W + 7) // 8) * ((H + 7) // 8) + world - 1) // world * 64 * 12)
             if args.mode == "parity":
                 floor = predicted_chain_floor_ms(scene_name, W1, H1, SPP, world)

@@ -37,7 +37,10 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 1
+/* 2 (round 6): PtTuning's word 9 is tri_binned (was tri_Mg, dead since round 5), tri_cache appended; pt_scene_device_bytes, pt_build_id.
+ * The table structs (PtHittable / PtMaterial / PtTexture / PtCamera / PtRenderParams) are those of version 1: scene fixtures written
+ * under version 1 load unchanged (path_tracer_amd/scene_io.py).                                                                    */
+#define PT_ABI_VERSION 2
 
 /* ---- tags: same numbering as the reference's variant alternatives ---------- */
 
@@ -227,6 +230,12 @@ int pt_camera_init(PtCamera* cam, const float look_from[3], const float look_at[
  * (render.hpp:146-148).  Unlike freeze() it may be called any number of times. */
 int pt_scene_create(const PtSceneDesc* desc, PtScene** out_scene);
 void pt_scene_destroy(PtScene* scene);
+/* Device memory the scene's DATA occupies: record blob + material table + the triangle pools' tables + texture atlas
+ * (launch workspaces — tile orders, candidate caches — come on top and are sized by the frame).  -1 for NULL.      */
+int64_t pt_scene_device_bytes(const PtScene* scene);
+/* Which kernels this library was built from: the first 16 hex digits of the sha256 over its kernel sources
+ * (csrc/Makefile) — what bench.py and tools/pmc_summary.py stamp PMC recordings with.                               */
+const char* pt_build_id(void);
 
 /* ---- tuning --------------------------------------------------------------------------------------------------------------
  * PERFORMANCE-ONLY knobs: every setting gives the same image bit for bit (tests/test_abi_cpu.py, the GPU parity suite runs

@@ -13,7 +13,7 @@ import ctypes as C
 import os
 from pathlib import Path
 
-PT_ABI_VERSION = 1
+PT_ABI_VERSION = 2  # (1: rounds 1-5; the table structs did not change: scene_io loads both)
 
 # tags — same numbering as the reference's std::variant alternatives
 PT_HIT_SPHERE, PT_HIT_XY_RECT, PT_HIT_TRIANGLE, PT_HIT_BOX, PT_HIT_CONSTANT_MEDIUM = 0, 1, 2, 3, 4
@@ -143,6 +143,8 @@ SIGNATURES = {
     "pt_debug_flatten_tuned": (C.c_int, [C.POINTER(PtSceneDesc), C.POINTER(PtTuning), _FP, C.c_int64, C.POINTER(C.c_int32),
                                          C.POINTER(C.c_int32), _FP, C.c_int64, C.POINTER(C.c_int32)]),
     "pt_scene_destroy": (None, [_SCENE_P]),
+    "pt_scene_device_bytes": (C.c_int64, [_SCENE_P]),
+    "pt_build_id": (C.c_char_p, []),
     "pt_scene_reserve": (C.c_int, [_SCENE_P, C.POINTER(PtRenderParams)]),
     "pt_fast_seed": (C.c_uint32, [C.c_uint32, C.c_uint32]),
     "pt_framebuffer_floats": (C.c_int64, [C.POINTER(PtRenderParams)]),

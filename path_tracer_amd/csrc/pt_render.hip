@@ -1173,7 +1173,7 @@ struct PtScene {
   int tri_pooled = 0;          // triangles that sit in a triangle pool (the TRIPOOL kernels query it)
   bool rectbox_only = false;   // every hittable is a rect or a box (kernels compiled with MATS_RECTBOX_ONLY: resolve_hit)
   bool mats_simple = false;    // every material is lambertian or lightsource over a solid texture (kernels compiled with MATS_LAMB_LIGHT_SOLID)
-  size_t blob_bytes = 0;
+  size_t blob_bytes = 0, atlas_bytes = 0;
   int num_cus = 256;
   size_t lds_per_block = 64 * 1024; // hipDeviceProp_t::sharedMemPerBlock (gfx950: 160 KB; the Makefile's ARCH=gfx942: 64 KB)
   mutable unsigned int* ws_cost = nullptr; // LPT workspace: per-tile ray counts of the probe pass
@@ -1404,6 +1404,7 @@ int pt_scene_create_tuned(const PtSceneDesc* desc, const PtTuning* tuning, PtSce
       if (!sg.dwords.empty()) PT_TRY(hipMemcpy(s->pool + sg.at_f4, sg.dwords.data(), sg.dwords.size() * 4, hipMemcpyHostToDevice));
   }
   size_t atlas_bytes = flat.has_image ? (size_t)desc->atlas_bytes : 0;
+  s->atlas_bytes = atlas_bytes;
   PT_TRY(hipMalloc((void**)&s->atlas, std::max<size_t>(atlas_bytes, 16)));
   if (atlas_bytes) PT_TRY(hipMemcpy(s->atlas, desc->atlas, atlas_bytes, hipMemcpyHostToDevice));
   PT_TRY(hipMalloc((void**)&s->queues, 2 * kQueueRing * sizeof(unsigned int)));
@@ -1412,6 +1413,16 @@ int pt_scene_create_tuned(const PtSceneDesc* desc, const PtTuning* tuning, PtSce
   *out_scene = s;
   return PT_OK;
 }
+
+int64_t pt_scene_device_bytes(const PtScene* s) {
+  if (!s) return -1;
+  return (int64_t)s->blob_bytes + (int64_t)s->mats_f4 * 16 + (int64_t)s->pool_bytes + (int64_t)s->atlas_bytes;
+}
+
+#ifndef PT_BUILD_ID
+#define PT_BUILD_ID "unknown"
+#endif
+const char* pt_build_id(void) { return PT_BUILD_ID; }
 
 void pt_scene_destroy(PtScene* s) {
   if (!s) return;

@@ -29,8 +29,8 @@ def save_scene(path: str, scene: PackedScene, camera_args: dict | None = None) -
 def load_scene(path: str):
     """Returns (PackedScene, camera_args dict)."""
     z = np.load(path, allow_pickle=False)
-    if int(z["abi_version"]) != abi.PT_ABI_VERSION:
-        raise ValueError(f"{path}: ABI version {int(z['abi_version'])} != {abi.PT_ABI_VERSION}")
+    if int(z["abi_version"]) not in (1, abi.PT_ABI_VERSION):  # (version 2 changed PtTuning and added entry points: the tables are version 1's)
+        raise ValueError(f"{path}: ABI version {int(z['abi_version'])} is not one this build reads (1, {abi.PT_ABI_VERSION})")
     mats = (abi.PtMaterial * max(1, len(z["materials"]))).from_buffer_copy(z["materials"].tobytes() or bytes(32))
     texs = (abi.PtTexture * max(1, len(z["textures"]))).from_buffer_copy(z["textures"].tobytes() or bytes(48))
     ps = pack_tables(z["hittables"], [mats[i] for i in range(len(z["materials"]))],

@@ -73,6 +73,13 @@ def test_peak_and_defaults():
         assert d["roofline"]["bound"] in ("valu", "hbm") and d["roofline"]["frac"] > 0
         # > 1 only where the kernel provably skips the reference's tests (the sphere culling grid: DESIGN.md §3)
         assert d["roofline"]["frac"] < 1 or "smoke" in d["config"]["workload"]
+        # round 6 on: what the scene cost to build and what it occupies on the device are on the line, although the
+        # timed region starts with the scene resident
+        if int(f.name[1:3]) >= 6:
+            assert d["scene_build_s"] > 0 and d["scene_device_bytes"] > 0, f.name
+            if "triangles" in d["config"]["workload"]:
+                assert d["scene_build_s"] < 1.5 and d["scene_device_bytes"] < 1.0e9, (f.name, d["scene_build_s"], d["scene_device_bytes"])
+    assert '"scene_build_s"' in text and '"scene_device_bytes"' in text
 
 
 def test_exit_point_pricing_follows_survey_8d():

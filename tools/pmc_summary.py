@@ -15,7 +15,7 @@ import sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
-KERNEL_SOURCES = ("pt_render.hip", "pt_device.hpp", "pt_math.hpp", "pt_flatten.hpp", "pt_tripool.hpp")
+KERNEL_SOURCES = ("pt_render.hip", "pt_device.hpp", "pt_math.hpp", "pt_flatten.hpp", "pt_tripool.hpp", "pt_binned.hpp")  # csrc/Makefile: KSRC
 
 
 def kernels_sha16(root=ROOT):

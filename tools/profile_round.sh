@@ -12,7 +12,7 @@ ARGS="$@"
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-python3 -c "import bench; print(bench.kernels_sha16())" > $OUT/kernels_sha16.txt   # which build the counters below belong to (tools/pmc_summary.py)
+python3 -c "from path_tracer_amd import abi; print(abi.load_library().pt_build_id().decode())" > $OUT/kernels_sha16.txt   # which build the counters below belong to: the LIBRARY that runs (pt_build_id), tools/pmc_summary.py
 python bench.py --steps $STEPS --warmup $WARMUP $ARGS > $OUT/bench_n1.json 2> $OUT/bench_n1.err
 cat $OUT/bench_n1.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 bench.py --steps $STEPS --warmup $WARMUP --no-cpu-baseline $ARGS > $OUT/kt.log 2>&1
