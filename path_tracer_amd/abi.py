@@ -217,7 +217,8 @@ def load_library() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the library does not export what the header declares
         fn.restype = res
         fn.argtypes = args
-    if lib.pt_abi_version() != PT_ABI_VERSION:
+    older_ok = bool(os.environ.get("PT_RENDER_LIB")) and os.environ.get("PT_RENDER_LIB_ALLOW_OLDER") == "1"  # (A/B tooling: an older build beside this tree)
+    if lib.pt_abi_version() != PT_ABI_VERSION and not (older_ok and lib.pt_abi_version() == 1):
         raise ImportError(f"{path}: ABI version {lib.pt_abi_version()} != {PT_ABI_VERSION}")
     _lib = lib
     return lib

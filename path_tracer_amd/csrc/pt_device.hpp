@@ -1660,7 +1660,6 @@ __device__ __forceinline__ bool tri_pool_scan(glb_f4p pool, cst_f4p cblob, int h
     int iz = min(max((int)__builtin_floorf(pz), 0), nz - 1);
     const bool fx = r.d.x > 0.0f, fy = r.d.y > 0.0f, fz = r.d.z > 0.0f;
     float tmx = ((float)(ix + (fx ? 1 : 0)) - gx) * rx, tmy = ((float)(iy + (fy ? 1 : 0)) - gy) * ry, tmz = ((float)(iz + (fz ? 1 : 0)) - gz) * rz;
-    const float dtx = __builtin_fabsf(rx), dty = __builtin_fabsf(ry), dtz = __builtin_fabsf(rz);
     const int stx = fx ? 1 : -1, sty = fy ? 1 : -1, stz = fz ? 1 : -1;
     // The cells' candidate ranges are EXPANDED over the wave: an inclusive scan of the lanes' counts gives every (lane, candidate) entry of
     // this wave-step a position p in [0, T); trip by trip the 64 lanes take positions p = base + lane, find the entry's owner (the lane
@@ -1775,7 +1774,12 @@ __device__ __forceinline__ bool tri_pool_scan(glb_f4p pool, cst_f4p cblob, int h
       active = active & inside & !(tn > limit());
       came = sx ? (fx ? 0 : 1) : sy ? (fy ? 2 : 3) : (fz ? 4 : 5); // stepped +x: entered through the new cell's -x face, ...
       ix = jx; iy = jy; iz = jz;
-      tmx += sx ? dtx : 0.0f; tmy += sy ? dty : 0.0f; tmz += sz ? dtz : 0.0f;
+      // the stepped axis' next boundary, from the cell INDEX (round 6): t = (boundary - g) r carries ~2 u (|g| + |t d|) of rounding
+      // whatever the number of steps — what the cells' slack is sized for (pt_tripool.hpp: rlimit) — where the running sum tmx += dtx of
+      // rounds 3-5 added a rounding per step (k steps at D cells from the origin: ~k u D cells, beyond the slack for k D > 10^5)
+      tmx = sx ? ((float)(ix + (fx ? 1 : 0)) - gx) * rx : tmx;
+      tmy = sy ? ((float)(iy + (fy ? 1 : 0)) - gy) * ry : tmy;
+      tmz = sz ? ((float)(iz + (fz ? 1 : 0)) - gz) * rz : tmz;
       k0 = active ? n0 : 0u; k1 = active ? n1 : 0u;
     }
   }

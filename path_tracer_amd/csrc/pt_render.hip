@@ -117,6 +117,7 @@ struct KArgs {
   const int* order;    // non-NULL: queue position -> local tile, heaviest first
   const int* n_split;  // non-NULL (COOP kernels): [0] how many leading tiles of `order` go through the wide phase, [1] log2 G
   int tile_granular;   // PT_FLAG_TILE_GRANULAR
+  int tile_group;      // tile-granular launches: lanes of a wave that take pixels together (64: the whole wave = a tile; 32 / 16: half / quarter tiles)
   int heavy_pixels;    // > 0 (tile-granular grid kernels, chain-bound launches): the first heavy_pixels queue positions — the heaviest tiles of the
   int heavy_lanes;     //   cost-sorted order — are taken heavy_lanes pixels at a time, by the first heavy_lanes lanes of a wave (lane_acquire)
   int scatter_p;       // > 0 (triangle-pool kernels): queue positions are dealt to tiles in runs of 2^scatter_log pixels with this stride (lane_acquire)
@@ -273,8 +274,21 @@ __device__ __forceinline__ void lane_acquire(Lane& L, const KArgs& a) {
     else if (!got) return;                 // (groups that got a pixel go on to set it up)
   }
   if (!L.wide) {
-    // tile-granular mode: a wave takes its next 64 pixels only when all of its lanes are idle
-    if (k.tile_granular && __builtin_amdgcn_ballot_w64(L.live) != 0) return;
+    // tile-granular mode: a wave takes its next 64 pixels only when all of its lanes are idle — or (round 6, tile_group = 32 / 16) an aligned
+    // GROUP of its lanes takes the next half / quarter tile as soon as that group is idle: a wave's iteration costs the same whether 64 or 40
+    // of its lanes are live, and a tile's lanes idle from their own last sample to the tile's (lane utilisation 0.78 on the headline frame)
+    unsigned long long mask2 = mask;
+    if (k.tile_granular) {
+      const unsigned long long live_m = __builtin_amdgcn_ballot_w64(L.live);
+      if (k.tile_group >= 64) { if (live_m != 0) return; }
+      else {
+        const int g0 = lane & ~(k.tile_group - 1);
+        const unsigned long long gm = ((k.tile_group == 32 ? 0xffffffffull : 0xffffull) << g0);
+        const bool group_idle = (live_m & gm) == 0;
+        mask2 = __builtin_amdgcn_ballot_w64(want && group_idle);
+        if (mask2 == 0) return;
+      }
+    }
     // The heaviest tiles in narrower waves.  A tile's time is its heaviest pixel's sequential chain times the wave's iteration, and an
     // iteration of a wave that steps 16 pixels together is shorter than one that steps 64 (the longest grid walk, the largest candidate
     // count, every material among them): the 4K frame's heaviest tiles alone take 55 / 48 / 43 ms at 64 / 32 / 16 lanes.  A launch that is
@@ -283,18 +297,21 @@ __device__ __forceinline__ void lane_acquire(Lane& L, const KArgs& a) {
     // other waves' takes: a wave may take a narrow piece just behind the head, or a whole tile just inside it; both are merely other
     // partitions of the same pixels.  At launch every resident wave peeks an untouched queue, so the head is never shorter than one piece per
     // wave — a quarter of the resident waves in tiles, which is the rule's own length; shorter forced heads measure the same.)
-    unsigned int take = (unsigned int)__builtin_popcountll(mask);
+    const bool want2 = want && ((mask2 >> lane) & 1ull);
+    const int leader2 = __builtin_ctzll(mask2);
+    const unsigned int rank2 = __builtin_amdgcn_mbcnt_hi((unsigned int)(mask2 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mask2, 0u));
+    unsigned int take = (unsigned int)__builtin_popcountll(mask2);
     if (k.heavy_pixels > 0 && k.tile_granular) {
       unsigned int cur = 0;
-      if (lane == leader) cur = __hip_atomic_load(k.queue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      cur = __builtin_amdgcn_readlane(cur, leader);
+      if (lane == leader2) cur = __hip_atomic_load(k.queue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      cur = __builtin_amdgcn_readlane(cur, leader2);
       if (cur < (unsigned int)k.heavy_pixels) take = min(take, (unsigned int)k.heavy_lanes);
     }
     unsigned int base = 0;
-    if (lane == leader) base = atomicAdd(k.queue, take);
-    base = __builtin_amdgcn_readlane(base, leader);
-    if (!want || rank >= take) return;
-    i = split_pixels + base + rank;
+    if (lane == leader2) base = atomicAdd(k.queue, take);
+    base = __builtin_amdgcn_readlane(base, leader2);
+    if (!want2 || rank2 >= take) return;
+    i = split_pixels + base + rank2;
   }
   if (i >= (unsigned int)k.n_local_pixels) { L.retired = true; return; }
   // fast mode: the queue hands out (tile, chunk) units, a tile's chunks back to back
@@ -1505,7 +1522,7 @@ static int launch_binned(const PtScene* s, KArgs a, const PtRenderParams* p, int
   a.n_local_pixels = local_tiles * PT_TILE_PIXELS;
   a.cost = nullptr; a.cost_max = 0; a.resume_rng = nullptr; a.resume_spp = 0; a.order = nullptr; a.n_split = nullptr;
   a.prio_onset = a.prio_t1 = a.prio_t2 = a.prio_t3 = 0;
-  a.tile_granular = 1; a.heavy_pixels = 0; a.heavy_lanes = 64; a.scatter_p = 0; a.scatter_log = 0; a.lanes_cap = 64;
+  a.tile_granular = 1; a.tile_group = 64; a.heavy_pixels = 0; a.heavy_lanes = 64; a.scatter_p = 0; a.scatter_log = 0; a.lanes_cap = 64;
   a.fast_chunks = 0; a.samples_total = p->samples; a.fast_stride = 0; a.queue = nullptr; a.coop_prefix = -1;
   const size_t N = (size_t)a.n_local_pixels, K = (size_t)s->bin_keys;
   size_t bytes = 0;
@@ -1664,6 +1681,8 @@ static int launch_render(const PtScene* s, const PtCamera* cam, const PtRenderPa
   // streaming kernel (a workgroup waits for its slowest lane); either can be forced
   // (the triangle-pool kernels' iterations are long and per-lane: single pixels, like the streaming kernel)
   a.heavy_pixels = 0; a.heavy_lanes = 64;
+  a.tile_group = 64;
+  if (const char* e = std::getenv("PT_TILE_GROUP")) { const int g = std::atoi(e); if (g == 16 || g == 32) a.tile_group = g; } // (experiment)
   a.tile_granular = (p->flags & PT_FLAG_TILE_GRANULAR) ? 1 : (p->flags & PT_FLAG_PIXEL_GRANULAR) ? 0 : ((resident && !tri_pool) ? 1 : 0);
   a.scatter_p = 0; a.scatter_log = 0;
   auto set_scatter = [&]() { // (after a.n_local_pixels is final: fast mode multiplies it by the chunks per pixel)
