@@ -387,7 +387,7 @@ constexpr int kBandWaves = 4; // waves per workgroup of band_kernel
 
 __global__ __launch_bounds__(64 * kBandWaves, 4) void band_kernel(BandArgs b) {
 #pragma clang fp contract(fast) /* filter arithmetic only (see tri_pool_scan): the reference's test — tri_param — is a function of its own, compiled as written */
-  static_assert(kBandWaves * 64 == kBlock && PT_TRI_BQUEUE == 64 * 3 && PT_TRI_QUEUE >= 128, "band_kernel borrows tri_pool_scan's per-wave LDS queues");
+  static_assert(kBandWaves * 64 == kBlock && PT_TRI_BQUEUE >= 64 * 3 && PT_TRI_QUEUE >= 128, "band_kernel borrows tri_pool_scan's per-wave LDS queues");
   __shared__ f4 rays[kBandWaves][64 * 2];
   __shared__ int pix[kBandWaves][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;

@@ -1360,7 +1360,10 @@ __device__ __forceinline__ unsigned int sdword(glb_f4p pool, unsigned int base_f
 //       time, and what survives that is queued again and runs the reference's test 64 at a time, into the same slots.
 //       The grid goes first: the nearest hit it finds is nearly always the final one, and nothing here depends on that.
 typedef short short2_t __attribute__((ext_vector_type(2)));
-#define PT_TRI_BQUEUE 192
+#ifndef PT_BAND_PER
+#define PT_BAND_PER 2 /* entries a lane takes per trip of the direction-map loop (tri_band_one_ray) */
+#endif
+#define PT_TRI_BQUEUE (64 + 64 * PT_BAND_PER)
 // per wave (63 + 128 entries are needed): band candidates past the integer band test — the compressed record itself (stage 2 reads it from
 // here: a second gather of the record cost a TA cycle per lane, and this kernel is bound by those) and the candidate's position
 __device__ __forceinline__ f4* tri_bqueue() { __shared__ f4 s[4 * PT_TRI_BQUEUE]; return s; }
@@ -1531,7 +1534,7 @@ __device__ __forceinline__ void tri_band_one_ray(glb_f4p pool, const TriBandCtx&
   // of trip i are tested, the records of trip i + 1 are being gathered and the indices of trip i + 2 loaded — because a ray's turn is a
   // chain of dependent loads (index -> record, a microsecond each from beyond L2) and ~20 trips long: un-pipelined, that latency was
   // what a wave waited for (both arrays carry spare entries behind their end: no clamping; what lies beyond `last` is masked).
-  constexpr int PER = 2;
+  constexpr int PER = PT_BAND_PER;
   auto load_idx = [&](unsigned int base, int (&idx)[PER]) {
 #pragma unroll
     for (int j = 0; j < PER; j++) { const unsigned int k = base + 64u * (unsigned int)j + (unsigned int)lane; idx[j] = listed ? (int)gdword_stream(pool, cand_off, k) : (int)k; }
@@ -1545,7 +1548,7 @@ __device__ __forceinline__ void tri_band_one_ray(glb_f4p pool, const TriBandCtx&
   // (indices past `last` read spare or foreign entries: clamp what they point at to a valid record)
   auto clamp_idx = [&](int (&idx)[PER]) {
 #pragma unroll
-    for (int j = 0; j < PER; j++) idx[j] = min(max(idx[j], 0), n_tri + 127);
+    for (int j = 0; j < PER; j++) idx[j] = min(max(idx[j], 0), n_tri + 127); // (the record tables carry >= 128 spare records)
   };
   load_idx(first, idxA); clamp_idx(idxA);
   load_idx(first + 64u * PER, idxB);

@@ -340,7 +340,7 @@ inline int32_t put_tri_pool(std::vector<F4>& b, PoolLayout& pool, TriPool& tp, c
   for (int k = 0; k < n_maps; k++) {
     TriDirMap& dm = tp.maps[(size_t)k];
     mfirst[k] = pool.put(std::move(dm.first), 2);
-    mcand[k] = pool.put(std::move(dm.cand), 132); // (the pipelined scan loads indices up to three trips of 128 past a list's end)
+    mcand[k] = pool.put(std::move(dm.cand), 200); // (the pipelined scan loads indices up to three trips of 64 PT_BAND_PER (<= 4) past a list's end)
   }
   const int32_t hdr = (int32_t)b.size();
   b.push_back({tp.origin[0], tp.origin[1], tp.origin[2], tp.inv_cell});

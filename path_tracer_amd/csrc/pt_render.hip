@@ -1346,8 +1346,17 @@ int pt_scene_create_tuned(const PtSceneDesc* desc, const PtTuning* tuning, PtSce
   PtTuning tun;
   int rc = resolve_tuning(tuning, tun, err);
   if (rc) return fail(rc, err);
+  const bool timing = std::getenv("PT_TRI_TIMING") != nullptr; // (diagnostics: stage times on stderr, like build_tri_pool's)
+  auto t_prev = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!timing) return;
+    const auto t = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "pt_scene_create: %-27s %.3f s\n", what, std::chrono::duration<double>(t - t_prev).count());
+    t_prev = t;
+  };
   rc = flatten_tuned(desc, tun, flat, err);
   if (rc) return fail(rc, err);
+  lap("flatten (+ culling tables)");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(PT_ERR_NO_DEVICE, "no HIP device visible");
   PtScene* s = new PtScene();
@@ -1417,9 +1426,19 @@ int pt_scene_create_tuned(const PtSceneDesc* desc, const PtTuning* tuning, PtSce
     s->pool_bytes = (size_t)flat.pool.size_f4 * 16;
     PT_TRY(hipMalloc((void**)&s->pool, s->pool_bytes));
     PT_TRY(hipMemset(s->pool, 0, s->pool_bytes));
-    for (const ptf::PoolSegment& sg : flat.pool.segments)
-      if (!sg.dwords.empty()) PT_TRY(hipMemcpy(s->pool + sg.at_f4, sg.dwords.data(), sg.dwords.size() * 4, hipMemcpyHostToDevice));
+    if (timing) { (void)hipDeviceSynchronize(); lap("blob upload, pool malloc + memset"); }
+    // (the big tables — hundreds of megabytes of direction-map lists — are pinned in place for their copy: a pageable hipMemcpy
+    // staged them at ~3 GB/s, a third of the scene's build time in round 6)
+    for (const ptf::PoolSegment& sg : flat.pool.segments) {
+      if (sg.dwords.empty()) continue;
+      const size_t bytes = sg.dwords.size() * 4;
+      const bool pin = bytes >= (8u << 20) && hipHostRegister((void*)sg.dwords.data(), bytes, hipHostRegisterDefault) == hipSuccess;
+      e = hipMemcpy(s->pool + sg.at_f4, sg.dwords.data(), bytes, hipMemcpyHostToDevice);
+      if (pin) (void)hipHostUnregister((void*)sg.dwords.data());
+      if (e != hipSuccess) { cleanup(); return fail(PT_ERR_HIP, std::string("hipMemcpy of a pool table: ") + hipGetErrorString(e)); }
+    }
   }
+  lap("upload blob + pool");
   size_t atlas_bytes = flat.has_image ? (size_t)desc->atlas_bytes : 0;
   s->atlas_bytes = atlas_bytes;
   PT_TRY(hipMalloc((void**)&s->atlas, std::max<size_t>(atlas_bytes, 16)));
