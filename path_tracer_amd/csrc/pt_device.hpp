@@ -1680,7 +1680,7 @@ __device__ __forceinline__ bool tri_pool_scan(glb_f4p pool, cst_f4p cblob, int h
 #ifndef PT_TRI_PAIRS
 #define PT_TRI_PAIRS 2
 #endif
-    constexpr int NP = DEFER ? PT_TRI_PAIRS : 1; // (the persistent kernels, at seven waves per SIMD, spill with more than one)
+    constexpr int NP = PT_TRI_PAIRS; // (the persistent kernels: two in flight at five waves per SIMD, 96 VGPRs — 1080p x 32 spp 1 009 -> 979 ms; at six waves / 80 VGPRs the same code spills and loses 10 %: profiles/r06_ab_tri_pipe.txt)
     auto test_batch = [&]() {
       __builtin_amdgcn_wave_barrier();
       int nb[NP], srcs[NP];
@@ -1739,7 +1739,7 @@ __device__ __forceinline__ bool tri_pool_scan(glb_f4p pool, cst_f4p cblob, int h
 #ifndef PT_TRI_TRIPS
 #define PT_TRI_TRIPS 4
 #endif
-      constexpr int NT = DEFER ? PT_TRI_TRIPS : 1;
+      constexpr int NT = DEFER ? PT_TRI_TRIPS : 2; // (the binned step kernel has 128 VGPRs: four; the persistent kernels two)
       for (int base = 0; base < T; base += 64 * NT) {
         unsigned int es[NT], sbs[NT];
         int srcs[NT];
@@ -1757,7 +1757,6 @@ __device__ __forceinline__ bool tri_pool_scan(glb_f4p pool, cst_f4p cblob, int h
           srcs[k] = src;
           es[k] = 0xffffffffu;
           if (on) es[k] = gdword_stream(pool, cell_cand, (unsigned int)(kb + p));
-          if (base + 64 * (k + 1) >= T) break; // (wave-uniform: no trip behind this one)
         }
 #pragma unroll
         for (int k = 0; k < NT; k++) {
@@ -1766,7 +1765,6 @@ __device__ __forceinline__ bool tri_pool_scan(glb_f4p pool, cst_f4p cblob, int h
           if (keep) tq[qn + __builtin_popcountll(m & below)] = (int)(((unsigned int)srcs[k] << 26) | (es[k] & 0x3ffffffu));
           qn += __builtin_popcountll(m);
           if (qn >= 64 * NP) test_batch();
-          if (base + 64 * (k + 1) >= T) break;
         }
       }
       if (T > 0) { // (the limit below looks at the nearest hit so far: everything queued is tested first)

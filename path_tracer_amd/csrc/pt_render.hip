@@ -65,7 +65,7 @@ namespace {
 #define PT_MIN_WAVES_COOP 5 /* cooperative kernels: 93 VGPRs, no scratch (7 waves: 72 VGPRs + 76 B/lane of spills in the loop) */
 #endif
 #ifndef PT_MIN_WAVES_TRIPOOL
-#define PT_MIN_WAVES_TRIPOOL 6 /* triangle-pool kernels: 80 VGPRs + scratch.  Round 6 (with the camera rays' candidate cache): 1080p x 32 spp 1 116 ms at 7 waves (72 VGPRs, 228 B of scratch), 986 at 6, 978 at 5 — profiles/r06_ab_tri_cache.txt; rounds 3-5, without the cache, measured 7 best */
+#define PT_MIN_WAVES_TRIPOOL 5 /* triangle-pool kernels: 96 VGPRs.  Round 6, with the camera rays' candidate cache and two pair batches / two expansion trips in flight in the grid walk: 1080p x 32 spp 1 116 ms at 7 waves (72 VGPRs + 228 B of scratch), 986 at 6 (80 VGPRs), 978 at 5; with the pipelined walk 1 116 at 6, 979 at 5 — profiles/r06_ab_tri_cache.txt, r06_ab_tri_pipe.txt; rounds 3-5 (no cache, no pipelining) measured 7 best */
 #endif
 #ifndef PT_MIN_WAVES_BINSTEP
 #define PT_MIN_WAVES_BINSTEP 4 /* bin_step_kernel (pt_binned.hpp): 128 VGPRs, no scratch (6 waves: 80 VGPRs + 236 B of scratch with the pipelined trips) */
