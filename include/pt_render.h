@@ -256,6 +256,9 @@ const char* pt_build_id(void);
  *                      ray per generation and the rays are sorted by direction bin, so that a bin's list of grazing candidates is read once
  *                      for 64 rays — 1: on (PT_TRI_BINNED); 0: off: measured, it does not beat the persistent kernel yet (docs/EXPERIMENTS.md).
  *                      Such renders have returned only when the frame is done (the number of generations is known on the device only)
+ *   sphere_merge       a sphere run of more than two spheres also tests, through its lists, the static spheres of later short sphere runs
+ *                      that only rect / box / short triangle runs separate it from (the resident kernels then skip those runs: a short run
+ *                      costs ~600 cycles per sphere, a list entry ~100) — 0: yes; -1: every run where it stands (PT_NO_SPHERE_MERGE; the A/B)
  *   tri_cache          triangle-pool kernels, pinhole cameras: a lane keeps the grazing candidates of its pixel's camera rays (built by the
  *                      pixel's first sample with the filters widened to the pixel's footprint) and every later camera ray of the pixel tests
  *                      those instead of enumerating its direction-map list — 0: yes; -1: no (PT_NO_TRI_CACHE; the A/B)
@@ -309,6 +312,7 @@ typedef struct PtTuning {
   int32_t probe_resume;  /* (round 5, the last reserved word) */
   int32_t chain_priority; /* (round 5: appended — a caller built against the shorter struct passes its own struct_size and gets the default) */
   int32_t tri_cache;      /* (round 6: appended) */
+  int32_t sphere_merge;   /* (round 6: appended) */
 } PtTuning;
 void pt_tuning_init(PtTuning* t);     /* zero + struct_size: the library's defaults                                          */
 void pt_tuning_from_env(PtTuning* t); /* the defaults with the PT_* environment applied: what pt_scene_create(desc, out) uses */

@@ -90,7 +90,7 @@ class PtTuning(C.Structure):
                 ("lpt_by_max", C.c_int32), ("probe_spp_max", C.c_int32), ("grid_min_tiles", C.c_int32),
                 ("model_fixed", C.c_float), ("model_chain", C.c_float), ("scatter_log", C.c_int32), ("scatter_mode", C.c_int32),
                 ("lanes_cap", C.c_int32), ("grid_walk", C.c_int32), ("heavy_tiles", C.c_int32),
-                ("tri_rho", C.c_float * 2), ("tri_budget_mb", C.c_int32), ("tri_rho2", C.c_float), ("probe_resume", C.c_int32), ("chain_priority", C.c_int32), ("tri_cache", C.c_int32)]
+                ("tri_rho", C.c_float * 2), ("tri_budget_mb", C.c_int32), ("tri_rho2", C.c_float), ("probe_resume", C.c_int32), ("chain_priority", C.c_int32), ("tri_cache", C.c_int32), ("sphere_merge", C.c_int32)]
 
 
 def tuning(**fields) -> "PtTuning":

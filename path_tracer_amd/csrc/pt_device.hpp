@@ -54,7 +54,8 @@ typedef const __attribute__((address_space(4))) f4* cst_f4p; // global blob via 
 typedef const __attribute__((address_space(1))) f4* glb_f4p; // the same blob for per-lane (VMEM) loads: the triangle pool
 
 // device kinds of a run / hit id (not the ABI tags: the three rect axes share one kind)
-enum { DK_SPHERE = 0, DK_RECT = 1, DK_TRI = 2, DK_BOX = 3, DK_MEDIUM = 4, DK_TRI_B = 5 /* Badouel-strategy triangles */ };
+enum { DK_SPHERE = 0, DK_RECT = 1, DK_TRI = 2, DK_BOX = 3, DK_MEDIUM = 4, DK_TRI_B = 5 /* Badouel-strategy triangles */,
+       DK_ABSORBED = 8 /* flag in a run header's kind: pt_flatten.hpp "absorbed sphere runs" */ };
 
 // record sizes in f4 units
 enum { SZ_SPHERE = 3, SZ_RECT = 2, SZ_TRI = 3, SZ_BOX = 2, SZ_MEDIUM = 4, SZ_MATERIAL = 4 };
@@ -1033,7 +1034,8 @@ __device__ __forceinline__ void sphere_grid_walk_queued(P recs, P cells, P cand,
 template <int K, int GRID, bool TRIPOOL, typename P, typename AcceptAt>
 __device__ __forceinline__ void sphere_scan(P recs, cst_f4p cblob, int n, int goff, const RayCtx& c, HitState& h, AcceptAt accept_at) {
   const f4 aux = cblob[goff - 1];
-  const int flags = as_i(aux.w), ns = as_i(aux.z), nm = n - ns;
+  // (aux.z: entries of the static list, the absorbed spheres of later runs — flags >> 8 of them — included: pt_flatten.hpp "absorbed sphere runs")
+  const int flags = as_i(aux.w), ns = as_i(aux.z), nm = n - (ns - (flags >> 8));
   if (!(flags & 1)) { // moving spheres with different shutter intervals: one sphere at a time in list order, fraction memoised
     TimeFrac tf = time_frac_none();
     for (int i = 0, off = 0; i < n; ++i, off += SZ_SPHERE) sphere_roots(recs, off, c, PT_TMIN, h.closest, true, tf, accept_at(off));
@@ -1266,7 +1268,9 @@ __device__ __forceinline__ bool slab_chunk_pass(P xrecs, P slrecs, cst_f4p srecs
     if (active) {
       const unsigned long long exec_now = __builtin_amdgcn_ballot_w64(true);
       int hit_base = as_i(X0.w);
-      const bool holder_later = (h.hit >= 0) & (hit_off(h.hit) > hit_off(hit_base));
+      // (a later holder that is a SPHERE — an absorbed run's, tested through an earlier run's lists — is strict itself: in list order this
+      // hittable takes an equal t first and the sphere then fails t < max, so the candidate keeps the non-strict comparison)
+      const bool holder_later = ((h.hit >= 0) & (hit_off(h.hit) > hit_off(hit_base))) && hit_kind(h.hit) != DK_SPHERE;
       float cl = holder_later ? as_f(as_i(h.closest) - 1) : h.closest;
       int hit_now = h.hit;
       box_cmpx(X0, X1, c, exec_now, hit_base, cl, hit_now);
@@ -2055,7 +2059,7 @@ __device__ __forceinline__ void hit_records_strided(P recs, cst_f4p cblob, int k
       const f4 aux = cblob[goff - 1];
       if (as_i(aux.w) & 1) {
         listed = true;
-        const int ns = as_i(aux.z), nm = cnt - ns, qs = (ns + 3) >> 2, qm = (nm + 3) >> 2;
+        const int ns = as_i(aux.z), nm = cnt - (ns - (as_i(aux.w) >> 8)), qs = (ns + 3) >> 2, qm = (nm + 3) >> 2;
         const P lists = recs - (1 + ((as_i(aux.w) & 4) ? 4 : 0) + qs + qm); // (a grid's four header records sit between the lists and aux)
         auto entry = [&](int e) {
           const f4 v = lists[e];
@@ -2137,6 +2141,7 @@ __device__ __forceinline__ void hit_world_range(P blob, cst_f4p cblob, int ri0, 
 #endif
     f4 runf = cblob[ri];
     const int off = as_i(runf.y), kind = as_i(runf.x);
+    if (kind & DK_ABSORBED) continue; // a sphere run that an earlier run's lists have tested already (pt_flatten.hpp "absorbed sphere runs")
     if constexpr (!IMG) {
       if (fast && (kind == DK_RECT || kind == DK_BOX)) { // head of a slab pool: the pool covers this run and the next span - 1
         const f4 aux = cblob[off - 1];                   // (largest |coordinate|, span, pool offset, entries)
@@ -2314,6 +2319,7 @@ __device__ __forceinline__ void hit_world_lds(P blob, cst_f4p cblob, const CoopS
     if (ri < cs.n_runs) {
       f4 runf = blob[ri];
       kind = as_i(runf.x); off = as_i(runf.y); cnt = as_i(runf.z); first = as_i(runf.w);
+      if (kind & DK_ABSORBED) continue; // (an absorbed sphere run: the absorbing run's lists — which the strided scan splits too — hold its spheres)
     }
     if (!merged && kind == DK_MEDIUM) { // butterfly: afterwards all G lanes hold the group's winner
       merge_stage<IMG, 1>(s);

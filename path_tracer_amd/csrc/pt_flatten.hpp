@@ -24,7 +24,8 @@ static_assert(sizeof(F4) == 16);
 
 inline float as_f(int32_t i) { float f; std::memcpy(&f, &i, 4); return f; }
 
-enum { DK_SPHERE = 0, DK_RECT = 1, DK_TRI = 2, DK_BOX = 3, DK_MEDIUM = 4, DK_TRI_B = 5 /* Badouel-strategy triangles */ };
+enum { DK_SPHERE = 0, DK_RECT = 1, DK_TRI = 2, DK_BOX = 3, DK_MEDIUM = 4, DK_TRI_B = 5 /* Badouel-strategy triangles */,
+       DK_ABSORBED = 8 /* flag in a run header's kind: a sphere run that an earlier run's lists test (flatten: "absorbed sphere runs") */ };
 // hit id (pt_device.hpp: hit_pack): [24:0] record offset in the blob (F4 units), [27:25] box side, [30:28] device kind
 enum { kHitOffBits = 25, kHitSideShift = 25, kHitKindShift = 28 };
 
@@ -64,6 +65,7 @@ struct Flat {
   int tri_wide = 0, tri_maps = 0;   // triangles whose band covers every direction; direction maps built
   long long tri_map_entries[3] = {0, 0, 0};
   int tri_map_res[3] = {0, 0, 0};
+  int absorbed_spheres = 0;         // spheres of short later runs that an earlier run's lists test (flatten: "absorbed sphere runs")
   int tri_pool_runs = 0;            // runs that got a pool; the binned renderer (pt_render.hip: launch_binned) serves scenes with exactly one
   int tri_pool_run = -1, tri_pool_hdr = 0, tri_pool_goff = 0, tri_pool_count = 0; // that run: its index, its pool header and first record in the blob, its triangles
 };
@@ -257,7 +259,11 @@ inline int put_offset_list(std::vector<F4>& b, std::vector<int32_t> l) { // retu
   return (int)(l.size() / 4);
 }
 
-inline int put_sphere_run_aux(std::vector<F4>& b, const PtHittable* h, int count, bool allow_grid, GridTuning tune = GridTuning()) { // returns the spheres in the grid
+// foreign / patch (round 6, "absorbed runs"): static spheres of LATER runs that this run's lists test as well (flatten() says which and
+// why that changes no result); their offsets are known only once the runs between are laid out, so the lists carry the placeholders
+// -(1 + k) of `foreign` and flatten() patches the F4 ranges returned in `patch`.
+inline int put_sphere_run_aux(std::vector<F4>& b, const PtHittable* h, int count, bool allow_grid, GridTuning tune = GridTuning(),
+                              const std::vector<int32_t>* foreign = nullptr, std::vector<std::pair<size_t, size_t>>* patch = nullptr) { // returns the spheres in the grid
   std::vector<int32_t> st, mv;
   bool uniform = true;
   float t0 = 0.0f, t1 = 0.0f;
@@ -269,7 +275,6 @@ inline int put_sphere_run_aux(std::vector<F4>& b, const PtHittable* h, int count
       mv.push_back(i * 3);
     } else st.push_back(i * 3);
   }
-  const int ns = (int)st.size();
   const bool any = !mv.empty();
   SphereGrid g;
   if (allow_grid) g = build_sphere_grid(h, count, uniform && (!any || t0 < t1), tune);
@@ -280,10 +285,14 @@ inline int put_sphere_run_aux(std::vector<F4>& b, const PtHittable* h, int count
     std::vector<uint32_t> packed((g.cand.size() + 1) / 2, 0u);
     for (size_t k = 0; k < g.cand.size(); k++) packed[k / 2] |= (uint32_t)g.cand[k] << (16 * (k & 1));
     put_dwords(b, packed.data(), packed.size());   n_cand_f4 = (int)(b.size() - before);
+    if (foreign && !foreign->empty()) { g.big_st.insert(g.big_st.end(), foreign->begin(), foreign->end()); if (patch) patch->push_back({b.size(), 0}); }
     qbs = put_offset_list(b, g.big_st);
+    if (foreign && !foreign->empty() && patch) patch->back().second = (size_t)qbs;
     qbm = put_offset_list(b, g.big_mv);
   }
-  put_offset_list(b, st);
+  if (foreign && !foreign->empty()) { st.insert(st.end(), foreign->begin(), foreign->end()); if (patch) patch->push_back({b.size(), 0}); }
+  const int qst = put_offset_list(b, st);
+  if (foreign && !foreign->empty() && patch) patch->back().second = (size_t)qst;
   put_offset_list(b, mv);
   if (g.ok) {
     b.push_back({g.origin[0], g.origin[1], g.origin[2], g.inv_cell});
@@ -291,8 +300,10 @@ inline int put_sphere_run_aux(std::vector<F4>& b, const PtHittable* h, int count
     b.push_back({g.center[0], g.center[1], g.center[2], g.rlimit2});
     b.push_back({as_f(n_cell_f4), as_f(n_cand_f4), as_f(qbs), as_f(qbm)});
   }
-  b.push_back({t0, t1, as_f(ns), as_f((uniform ? 1 : 0) | (any ? 2 : 0) | (g.ok ? 4 : 0))});
-  return g.ok ? count - (int)g.big_st.size() - (int)g.big_mv.size() : 0;
+  // aux: (time0, time1, entries of the static list — the run's own static spheres and the absorbed ones —, flags: 1 the moving spheres share
+  // their shutter interval, 2 some sphere moves, 4 the run has a grid, 8 this run is absorbed by an earlier one; bits 8 ...: absorbed spheres in its lists)
+  b.push_back({t0, t1, as_f((int32_t)st.size()), as_f((uniform ? 1 : 0) | (any ? 2 : 0) | (g.ok ? 4 : 0) | ((foreign ? (int32_t)foreign->size() : 0) << 8))});
+  return g.ok ? count + (foreign ? (int)foreign->size() : 0) - (int)g.big_st.size() - (int)g.big_mv.size() : 0;
 }
 inline void put_box(std::vector<F4>& b, const float* f, int32_t mat, int32_t hidx) {
   b.push_back({f[0], f[1], f[2], as_f(mat)});
@@ -361,7 +372,7 @@ inline int32_t put_tri_pool(std::vector<F4>& b, PoolLayout& pool, TriPool& tp, c
 }
 
 inline int flatten(const PtSceneDesc* sc, Flat& out, std::string& err, bool allow_grid = true, int box_cull = 1, GridTuning tune = GridTuning(),
-                   bool allow_tri_pool = true, TriPoolTuning tri_tune = TriPoolTuning()) {
+                   bool allow_tri_pool = true, TriPoolTuning tri_tune = TriPoolTuning(), bool sphere_merge = true) {
   int rc = validate(sc, err);
   if (rc) return rc;
   out = Flat();
@@ -420,9 +431,60 @@ inline int flatten(const PtSceneDesc* sc, Flat& out, std::string& err, bool allo
   b.resize(runs.size());
   size_t pool_at = 0, pool_x = 0;  // the current slab pool: where its table / its exact entries start, its first hittable, its entries
   int pool_first = 0, pool_n = 0;
+  // ---- absorbed sphere runs (round 6) ------------------------------------------------------------------------------------------
+  // The reference's default scene ends with thirteen hittables in six runs behind its 483 spheres (pyramid, light, rect, the big spheres,
+  // monolith, smoke), and a short run costs a resident kernel ~600 cycles per sphere — its header, its aux record and its records are
+  // dependent loads — where a LIST ENTRY of a long run costs ~100.  So a sphere run of more than two spheres also tests, through its lists,
+  // the STATIC spheres of later sphere runs that only rect / box runs and short unpooled triangle runs separate it from; the later run
+  // is flagged (aux flags bit 3) and the resident kernels skip it.  Why no bit changes: records stay where they are (offsets still compare
+  // like list positions), a sphere's t does not depend on the running maximum, and moving a sphere's test EARLIER past kinds that accept
+  // t == max (rectangle.hpp:36, triangle.hpp:91) is what the tie rule already covers — list order [X, S], equal t: X holds, S needs
+  // t < max and fails; evaluated [S, X]: S holds, X accepts t <= max and replaces it — X either way; sphere against sphere is
+  // sphere_finish_unordered's offset rule.  Never past a constant_medium (its draw looks at the running maximum, constant_medium.hpp:52-65),
+  // a pooled triangle run (its slots order equal t by offset) or a Badouel run, and not where stale u, v are tracked.  The slab pool's
+  // own out-of-order rule learnt the one new case: a LATER holder that is a sphere does not make a rect / box candidate strict.
+  std::vector<int> absorbed_by(runs.size(), -1);
+  struct Foreign { int run, idx; };
+  std::vector<std::vector<Foreign>> foreign_of(runs.size());
+  if (sphere_merge && !(out.has_image && !out.coop_ok)) {
+    for (size_t ri = 0; ri < runs.size(); ri++) {
+      if (runs[ri].kind != DK_SPHERE || runs[ri].count <= 2 || absorbed_by[ri] >= 0) continue;
+      { // (a run whose moving spheres have different shutter intervals is scanned sphere by sphere, not through its lists: put_sphere_run_aux)
+        bool uniform = true, any = false;
+        float t0 = 0.0f, t1 = 0.0f;
+        for (int i = 0; i < runs[ri].count; i++) {
+          const float* f = sc->hittables[runs[ri].first + i].f;
+          if (f[7] == f[8]) continue;
+          if (!any) { t0 = f[7]; t1 = f[8]; any = true; }
+          else if (std::memcmp(&t0, &f[7], 4) != 0 || std::memcmp(&t1, &f[8], 4) != 0) uniform = false;
+        }
+        if (!uniform) continue;
+      }
+      for (size_t rj = ri + 1; rj < runs.size(); rj++) {
+        const Run& rr = runs[rj];
+        if (rr.kind == DK_RECT || rr.kind == DK_BOX) continue;
+        if (rr.kind == DK_TRI && rr.count <= 64 && rr.count < tri_tune.min_run) continue;
+        if (rr.kind != DK_SPHERE || absorbed_by[rj] >= 0 || rr.count > 64) break;
+        bool all_static = true;
+        for (int i = 0; i < rr.count; i++) { const float* f = sc->hittables[rr.first + i].f; if (f[7] != f[8]) all_static = false; }
+        if (!all_static) break;
+        absorbed_by[rj] = (int)ri;
+        for (int i = 0; i < rr.count; i++) foreign_of[ri].push_back({(int)rj, i});
+      }
+    }
+  }
+  struct Patch { size_t ri; std::vector<std::pair<size_t, size_t>> ranges; };
+  std::vector<Patch> patches;
   for (size_t ri = 0; ri < runs.size(); ri++) {
     const Run& run = runs[ri];
-    if (run.kind == DK_SPHERE) out.grid_spheres += put_sphere_run_aux(b, &sc->hittables[run.first], run.count, allow_grid, tune);
+    if (run.kind == DK_SPHERE) {
+      std::vector<int32_t> codes;
+      for (size_t k = 0; k < foreign_of[ri].size(); k++) codes.push_back(-(int32_t)(1 + k));
+      Patch pt{ri, {}};
+      out.grid_spheres += put_sphere_run_aux(b, &sc->hittables[run.first], run.count, allow_grid, tune, &codes, &pt.ranges);
+      if (!codes.empty()) patches.push_back(std::move(pt));
+      if (absorbed_by[ri] >= 0) { int32_t fl; std::memcpy(&fl, &b.back().w, 4); b.back().w = as_f(fl | 8); } // aux flags bit 3: absorbed
+    }
     // slab pools (pt_device.hpp: slab_pool): a maximal stretch of consecutive rect / box runs with enough boxes gets a table
     // [n slab entries (lo, -)(hi, -), padded to an even count][n exact entries (lo', hit id)(hi', -)] in front of its first run; every rect / box run
     // carries an aux F4 at its first record - 1: (largest |coordinate| of the pool, runs the pool spans (0: not a pool head),
@@ -492,7 +554,7 @@ inline int flatten(const PtSceneDesc* sc, Flat& out, std::string& err, bool allo
       }
       b.push_back({as_f(pooled ? 1 : 0), as_f(hdr), 0, 0});
     }
-    b[ri] = {as_f(run.kind), as_f((int32_t)b.size()), as_f(run.count), as_f(run.first)};
+    b[ri] = {as_f(run.kind | (absorbed_by[ri] >= 0 ? DK_ABSORBED : 0)), as_f((int32_t)b.size()), as_f(run.count), as_f(run.first)};
     for (int i = run.first; i < run.first + run.count; i++) {
       const PtHittable& h = sc->hittables[i];
       const float* f = h.f;
@@ -523,6 +585,25 @@ inline int flatten(const PtSceneDesc* sc, Flat& out, std::string& err, bool allo
         }
       }
     }
+  }
+  // the absorbed spheres' offsets, now that every run is laid out (relative to the absorbing run's first record, like the run's own)
+  for (const Patch& pt : patches) {
+    int32_t base;
+    std::memcpy(&base, &b[pt.ri].y, 4);
+    for (const auto& rg : pt.ranges)
+      for (size_t q = rg.first; q < rg.first + rg.second; q++) {
+        float* w = &b[q].x;
+        for (int j = 0; j < 4; j++) {
+          int32_t v;
+          std::memcpy(&v, &w[j], 4);
+          if (v >= 0) continue;
+          const Foreign& fo = foreign_of[pt.ri][(size_t)(-v - 1)];
+          int32_t off_j;
+          std::memcpy(&off_j, &b[(size_t)fo.run].y, 4);
+          w[j] = as_f(off_j + 3 * fo.idx - base);
+        }
+      }
+    out.absorbed_spheres += (int)foreign_of[pt.ri].size();
   }
   if (b.size() >= (1u << kHitOffBits)) { err = "scene too large for 25-bit record offsets (33.5 M records of 16 bytes)"; return PT_ERR_TOO_LARGE; }
   return PT_OK;

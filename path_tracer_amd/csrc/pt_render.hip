@@ -696,7 +696,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel_stream(KArgs a) {
     hit_begin(h);
     for (int ri = 0; ri < a.n_runs; ++ri) {
       f4 runf = cblob[ri];
-      const int kind = as_i(runf.x), off = as_i(runf.y), cnt = as_i(runf.z);
+      const int kind = as_i(runf.x) & 7, off = as_i(runf.y), cnt = as_i(runf.z); // (& 7: this kernel scans every run where it stands, absorbed or not — pt_flatten.hpp)
       const int sz = record_size(kind);
       if (cnt * sz <= kSmallRunF4) {
         if (!wave_idle) {
@@ -1031,6 +1031,7 @@ static void tuning_env(PtTuning& t) {
   if (const char* e = std::getenv("PT_TRI_M")) t.tri_M = (float)std::atof(e);
   if (has("PT_TRI_BINNED")) t.tri_binned = 1;
   if (has("PT_NO_TRI_CACHE")) t.tri_cache = -1;
+  if (has("PT_NO_SPHERE_MERGE")) t.sphere_merge = -1;
   if (const char* e = std::getenv("PT_TRI_RES")) std::sscanf(e, "%d,%d,%d", &t.tri_res[0], &t.tri_res[1], &t.tri_res[2]);
   if (const char* e = std::getenv("PT_TRI_RHO")) std::sscanf(e, "%f,%f,%f", &t.tri_rho[0], &t.tri_rho[1], &t.tri_rho2);
   if (const char* e = std::getenv("PT_TRI_BUDGET_MB")) t.tri_budget_mb = std::max(1, std::atoi(e));
@@ -1089,12 +1090,13 @@ static int flatten_tuned(const PtSceneDesc* desc, const PtTuning& t, ptf::Flat& 
   if (t.tri_budget_mb > 0) tri.dm_budget = (long long)t.tri_budget_mb * (1 << 18); // MiB -> 4-byte entries
   if (t.tri_cell > 0.0f) tri.cell = t.tri_cell;
   if (const char* e = std::getenv("PT_TRI_GRID_BUDGET")) tri.grid_budget = (float)std::atof(e); // (experiments only: not a PtTuning field)
-  int rc = ptf::flatten(desc, flat, err, allow_grid, box_cull, tune, allow_tri, tri);
+  const bool merge = t.sphere_merge >= 0;
+  int rc = ptf::flatten(desc, flat, err, allow_grid, box_cull, tune, allow_tri, tri, merge);
   if (rc) return rc;
   if (flat.grid_spheres > 0 && flat.blob.size() * 16 > kMaxLdsBlob) {
     ptf::Flat plain;
     std::string err2;
-    if (flat.tri_pooled == 0 && ptf::flatten(desc, plain, err2, false, box_cull, tune, allow_tri, tri) == PT_OK && plain.blob.size() * 16 <= kMaxLdsBlob) flat = std::move(plain);
+    if (flat.tri_pooled == 0 && ptf::flatten(desc, plain, err2, false, box_cull, tune, allow_tri, tri, merge) == PT_OK && plain.blob.size() * 16 <= kMaxLdsBlob) flat = std::move(plain);
   }
   return PT_OK;
 }

@@ -114,6 +114,36 @@ def sphere_ties_scene():
     return pack(hs), cam
 
 
+def absorbed_ties_scene():
+    """Equal-t ties across ABSORBED sphere runs (round 6, pt_flatten.hpp): run 0 (four spheres: lists) also tests the static spheres of
+    the two later sphere runs that only a rect, three boxes (a slab pool) and a triangle separate it from, i.e. EARLIER than the reference's
+    list order does.  Surfaces are placed so that axis-parallel rays tie exactly (a sphere's pole in a rect's / a box face's / a triangle's
+    plane: t = 2.5 from z = 1) — with a sphere of run 0 (it loses to the later accept-equal kinds), with a sphere of a LATER run only (the
+    rect / box / triangle come first in the list and keep the hit: the device, which tested the sphere first, must let them replace it) —
+    and spheres duplicated across the runs (the first in list order wins)."""
+    red, green, blue, white = (lambertian_material(c) for c in ((0.9, 0.1, 0.1), (0.1, 0.9, 0.1), (0.1, 0.1, 0.9), (0.8, 0.8, 0.8)))
+    light = lightsource_material((3, 3, 3))
+    hs = [
+        sphere((0, -100.5, -2), 100, white),
+        sphere((0, 0, -2), 0.5, blue),                                     # A: its front pole (0, 0, -1.5) lies in the rect's plane
+        sphere((0, 1.1, -2), 0.3, red),
+        sphere((-2.4, 0, -2), 0.5, green),                                 # F: duplicated in the last run
+        xy_rect(-0.3, 0.3, -0.3, 0.3, -1.5, white),                        # ties with A (earlier: the rect wins) and with A' (later: the rect wins)
+        box((0.7, -0.5, -2.5), (1.7, 0.5, -1.5), red),                     # its front face ties with C' (a later run's sphere)
+        box((0.9, 0.5, -2.3), (1.5, 0.9, -1.7), green),
+        box((-3.4, -0.5, -2.5), (-2.9, 0.5, -1.5), blue),
+        sphere((0, 0, -2), 0.5, green),                                    # A': duplicate of A, later: loses to A (and to the rect)
+        sphere((1.2, 0, -2), 0.5, light),                                  # C': front pole (1.2, 0, -1.5) in the box's front face; the box is earlier: wins
+        triangle((-1.6, -0.4, -1.5), (-0.8, -0.4, -1.5), (-1.2, 0.5, -1.5), white),  # ties with B' below (later): the triangle wins
+        sphere((-1.2, 0, -2), 0.5, red),                                   # B': front pole (-1.2, 0, -1.5) in the triangle's plane
+        sphere((-2.4, 0, -2), 0.5, blue),                                  # F': duplicate of F (run 0): F wins
+        sphere((0.3, 0.9, -1.6), 0.2, metal_material((0.8, 0.8, 0.8), 0.1)),
+    ]
+    cam = dict(look_from=(0, 0.3, 1.5), look_at=(0, 0.1, -2), vup=(0, 1, 0), vfov=75.0, aperture=0.0, focus_dist=3.5,
+               time0=0.0, time1=0.0)
+    return pack(hs), cam
+
+
 def badouel_scene():
     """Triangles with the Badouel intersection strategy (triangle.hpp:14-56, `_triangle<badouel_ray_triangle_intersec>`) next to
     Moller-Trumbore ones and other kinds: separate runs in list order, a shared edge, a coplanar duplicate pair (the later
@@ -176,4 +206,4 @@ def cornell_scene():
 
 
 ALL = {"cornell": cornell_scene, "mixed": mixed_scene, "spheres": spheres_scene, "triangles": triangles_scene,
-       "ties": ties_scene, "sphere_ties": sphere_ties_scene, "badouel": badouel_scene, "sphere_field": sphere_field_scene, "empty": empty_scene}
+       "ties": ties_scene, "sphere_ties": sphere_ties_scene, "absorbed_ties": absorbed_ties_scene, "badouel": badouel_scene, "sphere_field": sphere_field_scene, "empty": empty_scene}

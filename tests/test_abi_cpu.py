@@ -159,9 +159,10 @@ def decode_sphere_aux(blob, first, count):
     full static / moving offset lists and, when the run has one, the grid (dims, cell table, candidates, big lists)."""
     aux = blob[first - 1]
     flags, ns = int(aux.view(np.int32)[3]), int(aux.view(np.int32)[2])
-    qs, qm = (ns + 3) // 4, (count - ns + 3) // 4
+    n_foreign, flags = flags >> 8, flags & 255  # (round 6: the static list also names the absorbed spheres of later runs; aux.z counts them in)
+    qs, qm = (ns + 3) // 4, (count - (ns - n_foreign) + 3) // 4
     end = first - 1 - (4 if flags & 4 else 0)
-    out = dict(t0=float(aux[0]), t1=float(aux[1]), ns=ns, flags=flags,
+    out = dict(t0=float(aux[0]), t1=float(aux[1]), ns=ns, flags=flags, n_foreign=n_foreign,
                static=blob[end - qs - qm:end - qm].view(np.int32).reshape(-1), moving=blob[end - qm:end].view(np.int32).reshape(-1))
     if flags & 4:
         g0, g1, g2, g3 = blob[first - 5], blob[first - 4], blob[first - 3], blob[first - 2]
@@ -220,6 +221,20 @@ def test_flatten_sphere_grid(lib):
     assert kind == 0 and count == 483 and first_h == 0
     d = decode_sphere_aux(blob, first, count)
     assert d["flags"] == 7
+    # round 6, absorbed sphere runs: the glowing ball (run 2) and the five big spheres (run 4) sit behind the pyramid / the rect — kinds that
+    # accept t == max — so run 0's lists test them too and the resident kernels skip their runs (kind | 8 in the run header)
+    assert runs[:, 0].tolist() == [0, 2, 0 | 8, 1, 0 | 8, 3, 4] and d["n_foreign"] == 6
+    own = {3 * i for i in range(count)}
+    foreign = {int(runs[2, 1]) - first, *(int(runs[4, 1]) - first + 3 * i for i in range(5))}
+    assert set(d["static"].tolist()) - own == foreign and set(d["big_static"].tolist()) - own == foreign
+    n_f4, n_r = C.c_int32(), C.c_int32()
+    t_off = abi.tuning(sphere_merge=-1)
+    abi.check(lib.pt_debug_flatten_tuned(C.byref(ps.desc), C.byref(t_off), None, 0, C.byref(n_f4), C.byref(n_r), None, 0, None), "pt_debug_flatten_tuned")
+    plain = np.zeros((n_f4.value, 4), np.float32)
+    abi.check(lib.pt_debug_flatten_tuned(C.byref(ps.desc), C.byref(t_off), plain.ctypes.data_as(C.POINTER(C.c_float)), len(plain), None, None, None, 0, None), "pt_debug_flatten_tuned")
+    assert plain[:n_runs].view(np.int32)[:, 0].tolist() == [0, 2, 0, 1, 0, 3, 4]  # PtTuning.sphere_merge = -1: every run where it stands
+    d["static"] = np.array([o for o in d["static"].tolist() if o in own], np.int32)
+    d["big_static"] = np.array([o for o in d["big_static"].tolist() if o in own], np.int32)
     nx, ny, nz = d["dims"]
     assert len(d["cells"]) >= nx * ny * nz and ny == 1 and nx >= 10 and nz >= 10
     assert abs(d["cell"] * d["inv_cell"] - 1) < 1e-6 and abs(d["cell"] - 3.0 * (0.2 + 0.1)) < 1e-4   # margin 0.5 r, cell 3 (r + margin)

@@ -351,7 +351,7 @@ def compare_bounce(got, ref, n, what, has_image):
                                                 ("spheres", (0, 0.5, 0), 5.0), ("triangles", (0, 1.5, 0), 4.0),
                                                 ("ties", (0, 0, -2), 3.0), ("empty", (0, 0, 0), 1.0),
                                                 ("badouel", (0, 0.3, -2), 3.0), ("sphere_ties", (0, 0.2, -2), 3.0),
-                                                ("sphere_field", (0, 0.4, 0), 9.0)])
+                                                ("absorbed_ties", (0, 0.2, -2), 3.5), ("sphere_field", (0, 0.4, 0), 9.0)])
 def test_bounce_bit_exact(lib, orc, name, center, extent):
     """hit_world + emitted + scatter of one ray (render.hpp:58-89): every hit_record field, the scattered
     ray, the attenuation and the RNG state after, for thousands of random rays."""
@@ -368,6 +368,48 @@ def test_bounce_bit_exact(lib, orc, name, center, extent):
     assert len(set(statuses)) >= (1 if name == "empty" else 2), "inputs should exercise hits and misses"
     has_image = any(ps.textures[i].kind == abi.PT_TEX_IMAGE for i in range(ps.n_textures))
     compare_bounce(out, ref, n, name, has_image)
+
+
+def test_ties_across_absorbed_sphere_runs(lib, orc):
+    """pt_flatten.hpp "absorbed sphere runs": a long sphere run's lists also test the static spheres of later short sphere runs, i.e. before
+    the rect / box / triangle runs between them.  Rays aimed at the points where those surfaces tie EXACTLY (a sphere's pole in a plane; the
+    same sphere twice) — straight down the z axis from several distances and with several direction lengths, plus a cloud around each —
+    must resolve as the reference's list-order scan does: the oracle's hittable, t and scattered ray for every one, with the merge and
+    without it (PtTuning.sphere_merge = -1), through the LDS kernels, the scalar-cache kernels and the bounce probe."""
+    ps, cam = S.ALL["absorbed_ties"]()
+    rays = []
+    for (px, py) in ((0.0, 0.0), (1.2, 0.0), (-1.2, 0.0), (-2.4, 0.0), (0.1, 0.1), (1.2, 0.2), (-1.2, 0.1)):
+        for oz in (1.0, 0.5, 2.0, 3.0):
+            for s_ in (1.0, 2.0, 0.5, 4.0):
+                rays.append(((px, py, oz), (0.0, 0.0, -s_)))
+    rng = np.random.default_rng(66)
+    for (px, py) in ((0.0, 0.0), (1.2, 0.0), (-1.2, 0.0), (-2.4, 0.0)):
+        for _ in range(400):
+            o = np.array([px, py, 1.0]) + rng.normal(size=3) * 0.05
+            tgt = np.array([px, py, -1.5]) + rng.normal(size=3) * np.array([0.2, 0.2, 0.0])
+            rays.append((tuple(o), tuple(tgt - o)))
+    n = len(rays)
+    recs = (abi.PtBounceIn * n)()
+    for k, (o, d) in enumerate(rays):
+        recs[k].origin[:] = [float(x) for x in o]; recs[k].dir[:] = [float(x) for x in d]; recs[k].time = 0.0
+        recs[k].rng_state = 12345 + k; recs[k].attenuation[:] = [1.0, 1.0, 1.0]
+    orc.set_math(True)
+    ref = orc.bounce(ps, recs)
+    tied = sum(1 for k in range(112) if ref[k].status != abi.PT_BOUNCE_MISS)
+    assert tied >= 100, "the axis rays should hit the tied surfaces"
+    # what the reference's scan returns at the engineered ties: the rect (hittable 4) over sphere A, the box (5) over C', the triangle (10) over B', F (3) over F'
+    assert {ref[k].hittable for k in range(0, 16)} == {4} and {ref[k].hittable for k in range(16, 32)} == {5}
+    # (the triangle's t comes out of other arithmetic than a plane's: at some distances it is an ulp off the sphere's and B' wins outright)
+    assert {ref[k].hittable for k in range(32, 48)} == {10, 11} and {ref[k].hittable for k in range(48, 64)} == {3}
+    for merge in (0, -1):
+        ds = R.DeviceScene(ps, abi.tuning(sphere_merge=merge))
+        out = (abi.PtBounceOut * n)()
+        abi.check(lib.pt_debug_bounce(ds.handle, recs, out, n), "pt_debug_bounce")
+        compare_bounce(out, ref, n, f"absorbed ties, sphere_merge {merge}", False)
+        c = scenes.make_camera(cam, 96, 54)
+        want = orc.render(ps, c.c, 96, 54, 16)
+        for flags in (0, abi.PT_FLAG_NO_LDS, abi.PT_FLAG_FORCE_COOP, abi.PT_FLAG_FORCE_STREAM, abi.PT_FLAG_PIXEL_GRANULAR):
+            assert_bit_identical(R.render_host(96, 54, 16, ds, c, flags=flags), want, f"absorbed ties frame, sphere_merge {merge}, flags {flags}")
 
 
 @pytest.mark.parametrize("name", list(S.ALL))
@@ -467,7 +509,7 @@ def test_lds_and_scalar_fetch_agree(name):
     assert_bit_identical(a, b, name)
 
 
-@pytest.mark.parametrize("name", ["cornell", "mixed", "triangles", "spheres", "ties", "sphere_ties", "badouel"])
+@pytest.mark.parametrize("name", ["cornell", "mixed", "triangles", "spheres", "ties", "sphere_ties", "badouel", "absorbed_ties"])
 def test_streaming_kernel_agrees(name):
     """The LDS-tile streaming kernel (used when the scene exceeds LDS) gives the resident kernel's frame."""
     ps, cam = S.ALL[name]()
@@ -477,7 +519,7 @@ def test_streaming_kernel_agrees(name):
     assert_bit_identical(a, b, name)
 
 
-@pytest.mark.parametrize("name", ["cornell", "spheres", "triangles", "ties", "mixed", "sphere_ties"])
+@pytest.mark.parametrize("name", ["cornell", "spheres", "triangles", "ties", "mixed", "sphere_ties", "absorbed_ties"])
 @pytest.mark.parametrize("size", [(1, 1), (2, 1), (3, 1), (5, 1), (3, 3), (17, 1), (8, 4), (33, 1), (40, 2)])
 def test_streaming_kernel_cooperative_tail(orc, name, size):
     """The streaming kernel spreads the rays of a wave that is down to <= 32 live lanes over groups of G = 64 >>
@@ -588,7 +630,7 @@ def test_cost_sorted_tile_order_does_not_matter(orc, name, flags):
     assert_bit_identical(a, orc.render(ps, c.c, w, h, spp), name + " vs oracle")
 
 
-@pytest.mark.parametrize("name", ["cornell", "spheres", "triangles", "ties", "mixed", "sphere_ties"])
+@pytest.mark.parametrize("name", ["cornell", "spheres", "triangles", "ties", "mixed", "sphere_ties", "absorbed_ties"])
 @pytest.mark.parametrize("size", [(37, 21), (64, 40), (9, 5)])
 def test_cooperative_traversal_agrees(orc, name, size):
     """Waves with <= 32 live lanes split each ray's list over idle lanes and merge the segment winners with the
@@ -605,7 +647,7 @@ def test_cooperative_traversal_agrees(orc, name, size):
     assert_bit_identical(a, orc.render(ps, c.c, w, h, 24), f"{name} {w}x{h} vs oracle")
 
 
-@pytest.mark.parametrize("name", ["cornell", "spheres", "triangles", "ties", "mixed", "sphere_ties"])
+@pytest.mark.parametrize("name", ["cornell", "spheres", "triangles", "ties", "mixed", "sphere_ties", "absorbed_ties"])
 def test_wide_phase_every_group_size(orc, name, monkeypatch):
     """Heavy tiles are rendered G lanes per pixel: all G lanes hold the same pixel (same seed, same draws), each tests the
     hittables == its lane (mod G), a butterfly merges the partial winners with the scan's own tie rule.  Tuning knobs force
