@@ -59,7 +59,7 @@ OPS = dict(
 # Algorithmic lane-ops per sample of the standard scenes at depth 50: oracle exit-point counters (a 480x270x4 render;
 # 96x54x1 for the mesh) priced with OPS above.  Recorded so that ranks of an N>1 job, where the cpu_baseline leg does
 # not run, need nothing from oracle/; the N=1 cpu_baseline leg re-derives the figure live and reports that.
-ALGORITHMIC_OPS_PER_SAMPLE = {"cornell": 2062.7, "smoke": 39395.4, "triangles": 8220663.0}  # the REFERENCE's algorithm as written (never the culled figures below)
+ALGORITHMIC_OPS_PER_SAMPLE = {"cornell": 2062.7, "smoke": 39448.4, "triangles": 8220663.0}  # (smoke: round 6's scene — main.cpp:83 in g++'s argument order)  # the REFERENCE's algorithm as written (never the culled figures below)
 
 # The 496-hittable scene does NOT run the reference's algorithm as written: 476 of its 489 spheres sit in an exact culling grid
 #  and a ray tests the spheres of the cells it crosses instead of all of them.  Pricing the kernel against the
@@ -151,7 +151,7 @@ def ops_per_sample_culled_tri(ctr: dict, pool: dict) -> float:
 
 
 # recorded like ALGORITHMIC_OPS_PER_SAMPLE (the N = 1 cpu_baseline leg re-derives them live): the culled algorithms' figures
-ALGORITHMIC_OPS_PER_SAMPLE_CULLED = {"smoke": 2116.7, "triangles": 205133.7}  # (triangles: round 5's pool — profiles/r05_tripool_counters.json; rounds 3-4: 402 k)
+ALGORITHMIC_OPS_PER_SAMPLE_CULLED = {"smoke": 2072.8, "triangles": 156643.9}  # (round 6: profiles/r06_smoke_walk_counters.json, r06_tripool_counters.json — camera rays take their grazing candidates from the pixel's cache; round 5: 2 116.7 / 205 k; rounds 3-4: 402 k)
 
 
 def ops_per_sample(ctr: dict) -> float:
@@ -448,7 +448,7 @@ def main() -> None:
             # --- cpu_baseline leg: the only place bench.py touches oracle/ (test infrastructure) ---------------
             from oracle import binding as orc
             orc.set_math(True)
-            cw, ch, cs = (480, 270, 2) if scene_name != "triangles" else (64, 36, 1)
+            cw, ch, cs = (480, 270, 4) if scene_name != "triangles" else (64, 36, 1)
             _, ctr = orc.render(packed, scenes.make_camera(cam_args, cw, ch).c, cw, ch, cs, DEPTH, counters=True)
             ops = ops_per_sample(ctr.as_dict())  # exit-point counters -> algorithmic ops per sample, live
             if GRID_WALK.get(scene_name) and grid_culled:
@@ -557,7 +557,7 @@ def main() -> None:
             "vs_baseline": None, "dtype": "f32", "data": "synthetic", "frame": f"{W}x{H}",
             # outside the timed region, and therefore said: seconds of pt_scene_create (flatten + culling structures + upload) and the
             # device bytes of the scene's data (records, materials, triangle-pool tables, atlas)
-            "scene_build_s": round(scene_build_s, 3), "scene_build_first_in_process_s": round(scene_build_first_s, 3), "scene_device_bytes": scene_device_bytes,
+            "scene_build_s": round(scene_build_s, 4), "scene_build_first_in_process_s": round(scene_build_first_s, 4), "scene_device_bytes": scene_device_bytes,
             "config": {"workload": f"{scene_name}: {SCENE_TEXT[scene_name]}, {W}x{H}, {SPP} spp, depth {DEPTH}, "
                                    + ("seed = pixel linear id" if args.mode == "parity" else "FAST MODE: one RNG stream per (pixel, sample)"),
                        "baseline_config": args.config, "hittables": packed.n_hittables, "mode": args.mode,

@@ -76,7 +76,7 @@ def test_peak_and_defaults():
         # round 6 on: what the scene cost to build and what it occupies on the device are on the line, although the
         # timed region starts with the scene resident
         if int(f.name[1:3]) >= 6:
-            assert d["scene_build_s"] > 0 and d["scene_device_bytes"] > 0, f.name
+            assert d["scene_build_s"] >= 0 and d["scene_build_first_in_process_s"] > 0 and d["scene_device_bytes"] > 0, f.name  # (a 1 KB scene builds in 0.4 ms)
             if "triangles" in d["config"]["workload"]:
                 assert d["scene_build_s"] < 1.5 and d["scene_device_bytes"] < 1.0e9, (f.name, d["scene_build_s"], d["scene_device_bytes"])
     assert '"scene_build_s"' in text and '"scene_device_bytes"' in text
