@@ -434,8 +434,9 @@ def main() -> None:
         value = samples_per_step * args.steps / elapsed / 1e6
         ops = ALGORITHMIC_OPS_PER_SAMPLE[scene_name]
         ops_culled = ALGORITHMIC_OPS_PER_SAMPLE_CULLED.get(scene_name)
-        # which algorithm the kernel runs is read off the SCENE as pt_scene_create flattens it (pt_debug_tri_pool: spheres in a culling grid,
-        # triangles in a pool) — not off the environment: a PtTuning passed by a caller overrides the PT_* variables
+        # which algorithm the kernel runs is read off the scene as pt_scene_create(desc) flattens it — the library's defaults with the PT_*
+        # variables applied, which is how THIS program creates its scene (pt_debug_tri_pool: spheres in a culling grid, triangles in a pool);
+        # a caller that creates scenes with an explicit PtTuning would have to ask pt_debug_flatten_tuned instead
         import ctypes as C_
         from path_tracer_amd import abi as abi_
         st_scene = (C_.c_int32 * 8)()
@@ -537,9 +538,8 @@ def main() -> None:
         # algorithmic HBM bytes of one launch: the frame written once (12 B per pixel of this rank's share) + the scene read once
         # (the flattened blob with its culling tables, the material table, the texture atlas)
         # (the triangle pools' tables are a buffer of their own since round 5: pt_debug_flatten_pool)
-        n_pool_ = C_.c_int64()
-        abi_.check(abi_.load_library().pt_debug_flatten_pool(C_.byref(packed.desc), None, None, 0, C_.byref(n_pool_)), "pt_debug_flatten_pool")
-        scene_bytes = int(st_scene[6]) * 16 + int(n_pool_.value) * 16 + int(packed.desc.n_materials) * 64 + int(packed.desc.atlas_bytes)
+        # (round 6: what the scene occupies on the device, from the scene itself — pt_scene_device_bytes — instead of a second flatten of it)
+        scene_bytes = scene_device_bytes
         algorithmic_bytes = W * H * 12 // world + scene_bytes
         valu_frac = achieved / PEAK_TLANEOPS
         # memory leg: bytes that went past L2 (FETCH_SIZE + WRITE_SIZE of the committed PMC passes of this workload) / kernel time / 8 TB/s

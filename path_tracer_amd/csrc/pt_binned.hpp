@@ -293,7 +293,7 @@ struct SortArgs {
   unsigned int* offs;    // [n_keys + 1]
   uint2* block_tot;      // [n_blocks]: (requests, packets) of a block, then their exclusive prefix
   int2* packets;         // (key, chunk)
-  unsigned int* ctl;     // [0] -, [1] n_packets, [2] band_kernel's packet counter, [3] live pixels of the generation (read by the host), [4] the accumulator bin_step_kernel adds to
+  unsigned int* ctl;     // [0] -, [1] n_packets, [2] band_kernel's packet counter, [3] live pixels of the generation (read by the host), [4] the accumulator bin_step_kernel adds to, [5] bin_finish_kernel's pixel queue
   int n_keys, n_blocks;
   int full_slices;       // a packet of the last key ("every triangle, exactly") is cut into this many slices of the run, one wave each
 };

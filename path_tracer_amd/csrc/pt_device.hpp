@@ -2142,6 +2142,9 @@ __device__ __forceinline__ void hit_world_range(P blob, cst_f4p cblob, int ri0, 
     f4 runf = cblob[ri];
     const int off = as_i(runf.y), kind = as_i(runf.x);
     if (kind & DK_ABSORBED) continue; // a sphere run that an earlier run's lists have tested already (pt_flatten.hpp "absorbed sphere runs")
+#ifdef PT_ABLATE_TAIL /* measurement-only build (a WRONG image): what would the runs behind the first cost if they were free? */
+    if (ri > 0) continue;
+#endif
     if constexpr (!IMG) {
       if (fast && (kind == DK_RECT || kind == DK_BOX)) { // head of a slab pool: the pool covers this run and the next span - 1
         const f4 aux = cblob[off - 1];                   // (largest |coordinate|, span, pool offset, entries)

@@ -30,7 +30,7 @@ enum { DK_SPHERE = 0, DK_RECT = 1, DK_TRI = 2, DK_BOX = 3, DK_MEDIUM = 4, DK_TRI
 enum { kHitOffBits = 25, kHitSideShift = 25, kHitKindShift = 28 };
 
 // The pool buffer is described, not materialised, on the host: a list of segments (offset in F4 units, the dwords that go there), the big
-// ones MOVED out of the TriPool — a copy of the 100 k-triangle mesh's 0.6 GB of maps into one contiguous host vector cost seconds of
+// ones MOVED out of the TriPool — a copy of the 100 k-triangle mesh's maps (0.6 GB at round 6's resolutions, 2.9 GB at round 5's) into one contiguous host vector cost seconds of
 // first-touch page faults.  pt_scene_create uploads segment by segment into a zeroed device buffer; pt_debug_flatten_pool assembles them.
 struct PoolSegment { uint64_t at_f4; std::vector<uint32_t> dwords; };
 struct PoolLayout {
