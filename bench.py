@@ -28,6 +28,7 @@ Extra objects on the JSON line:
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -463,10 +464,21 @@ def main() -> None:
             # independent: SURVEY.md §8d), only its noise does.
             bw, bh = (W // 2, H // 2) if scene_name != "triangles" else (160, 90)
             bcam = scenes.make_camera(cam_args, bw, bh)
+            # threads: what the container may actually run.  A box that shows 256 CPUs under a 16-CPU cgroup quota ran 128 OpenMP threads in
+            # bursts (a one-sample probe at 65 Msamples/s, the sample it sized at 10: 19.6 s instead of 3); the quota, rounded up, is the
+            # thread count now, and the sample is sized from a second, longer probe.
+            quota = cgroup_cpu_max()
+            if quota:
+                orc.load().orc_set_threads(int(max(1, min(orc.load().orc_max_threads(), math.ceil(quota)))))
             t1 = time.perf_counter()
             orc.render(packed, bcam.c, bw, bh, 1, DEPTH)
             probe = time.perf_counter() - t1
-            bs = int(max(1, min(SPP, round(3.0 / max(probe, 1e-3)))))
+            ps = int(max(1, min(SPP, round(0.4 / max(probe, 1e-3)))))
+            if ps > 1:
+                t1 = time.perf_counter()
+                orc.render(packed, bcam.c, bw, bh, ps, DEPTH)
+                probe = (time.perf_counter() - t1) / ps
+            bs = int(max(1, min(SPP, round(2.6 / max(probe, 1e-3)))))
             t1 = time.perf_counter()
             orc.render(packed, bcam.c, bw, bh, bs, DEPTH)
             dt = time.perf_counter() - t1
