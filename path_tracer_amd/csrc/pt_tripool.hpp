@@ -13,8 +13,8 @@
 //       the computed barycentrics are within 1/M of the exact ones, so the exact point P^ where the ray's line meets the
 //       triangle's plane lies within sigma_i of the triangle, and the computed t is within the same distance (along the ray,
 //       plus a relative 1/M_a) of P^'s exact parameter.  The triangle is listed in every cell of a fine uniform grid that meets
-//       its bounding box grown by sigma'_i AND the slab |n^_i . (x - v0)| <= sigma'_i around its plane (every point within
-//       sigma'_i of the triangle is in both); every lane walks ITS ray through the cells of its segment [0, closest (1 + kappa)].
+//       its bounding box grown by sigma'_i AND the slab |n^_i . (x - v0)| <= sigma_t,i around its plane (the point the bound below
+//       speaks of is in both); every lane walks ITS ray through the cells of its segment [0, closest (1 + kappa)].
 //   (2) BAND.   Pairs that ARE grazing, |d^ . n^_i| < tau_i(rho).  Round 5: indexed by the RAY'S DIRECTION, not by the
 //       triangle's normal.  A cube map over unit directions (three faces, antipodes identified: the test is even in d); bin D
 //       lists every triangle i for which SOME direction of D satisfies |d^ . n^_i| <= tau_i(rho_max) — the triangle's band is a
@@ -43,17 +43,24 @@
 // themselves; the 4 u is the cheap test's own a' = fl(d . N'_i) against a^).
 // NOT grazing, |a^| >= thr_i, and accepted by the reference (0 <= u/a <= 1, 0 <= v/a, (u + v)/a <= 1 + u, |a| >= 1e-7,
 // min <= t <= max) implies
-//     |beta - u/a| <= (du + da) / |a^| <= 1/M + 1/M_a, same for gamma: beta, gamma >= -1/M', beta + gamma <= 1 + 2/M' + u
-//     => dist(P^, triangle) <= (6/M + 6/M_a + u) L_i
+//     eb := |beta - u/a| <= (du + da) / |a^|,  eg := |gamma - v/a| <= (dv + da) / |a^|,  and JOINTLY (thr bounds the sum M (du + dv) + M_a da)
+//     eb + eg <= 1/M + 2/M_a,  each <= 1/M + 1/M_a:        beta >= -eb,  gamma >= -eg,  beta + gamma <= 1 + u + eb + eg
+// — a triangle of the (beta, gamma) plane with corners A = (-eb, -eg), B = (1 + u + eb + 2 eg, -eg), C = (-eb, 1 + u + 2 eb + eg).  The
+// distance to the (convex) triangle is a convex function, so over that region it is largest at a corner: at A, |P^ - v0| <= (eb + eg) L;
+// at B, |P^ - v1| = |(u + eb + 2 eg) e1 - eg e2| <= (u + eb + 3 eg) L <= (u + 3/M + 4/M_a) L; C likewise:
+//     => dist(P^, triangle) <= (3/M + 4/M_a + u) L_i
+// (rounds 3-5 bounded every barycentric separately and clamped in two steps: 6/M + 6/M_a — the same structure, twice as fat.)
 //     |t - t^| |d| <= |d| dw / |a| + |t^| |d| da / |a| + u |t| |d| <= 1.2 L_i / (M - 1) + |t^| |d| / (M_a - 1) + u |t| |d|
-// so with kappa = 2.2 / (M_a - 1) the exact parameter t^ lies in [-1.2 L_i / ((M-1) |d|), max (1 + kappa) + 1.2 L_i / ((M-1) |d|)]
+// so with kappa = 2.2 / (M_a - 1) the exact parameter t^ lies in [-1.21 L_i / ((M-1) |d|), max (1 + kappa) + 1.21 L_i / ((M-1) |d|)]
 // and the point P' = o + clamp(t^, 0, max (1 + kappa)) d of the WALKED segment is within
-//     sigma'_i = (6/M + 6/M_a + 1.2/(M-1)) L_i        (M_a >= 64; the builder keeps M >= 4)
+//     sigma_t,i = 1.25 L_i / (M - 1)  of P^ (along the ray),  hence within
+//     sigma'_i  = (3/M + 4/M_a + 1.25/(M-1)) L_i        (M_a >= 64; the builder keeps M >= 4)
 // of the triangle, hence inside its bounding box grown by sigma'_i: the cell that contains P' lists the triangle, and the walk
 // visits that cell (cells are assigned with a further absolute slack for the walk's own rounding, as the sphere grid's).
-// P' is within sigma'_i of a point of the triangle's PLANE too, so |n^_i . (P' - v0)| <= sigma'_i: a cell with centre m and half
-// edge h that contains a point within `slack` of P' has |n^_i . (m - v0)| <= sigma'_i + slack + h (|n^x| + |n^y| + |n^z|) — cells of
-// the grown box that fail this are not listed (a triangle's box holds ~3 times the cells its slab does) — and likewise the centre of
+// P^ lies IN the triangle's plane (it is where the line meets it), so P' is within sigma_t,i of that plane: |n^_i . (P' - v0)| <=
+// sigma_t,i (round 6; rounds 3-5 used sigma'_i here as well, a slab six times as thick at M = 12): a cell with centre m and half
+// edge h that contains a point within `slack` of P' has |n^_i . (m - v0)| <= sigma_t,i + slack + h (|n^x| + |n^y| + |n^z|) — cells of
+// the grown box that fail this are not listed (the slab is what decides most cells) — and likewise the centre of
 // such a cell is within sigma'_i + slack + the cell's half diagonal of the TRIANGLE itself (point-triangle distance), which rounds the
 // box's corners off.  Every entry also records which of the cell's six face neighbours list the triangle too: a walk that enters a
 // cell through a face whose other side listed the triangle has tested the pair already (a pair's test does not depend on the cell).
@@ -285,7 +292,8 @@ inline TriPool build_tri_pool(const PtHittable* h, int count, TriPoolTuning tune
   ext.reserve((size_t)count);
   tp.ball.assign((size_t)count * 4, 0.0f);
   int n_live = 0;
-  const double sig_per_L = 6.0 / M + 6.0 / Ma + 1.2 / (M - 1.0); // sigma'_i / L_i (header: the three terms of the bound)
+  const double sig_t_per_L = 1.25 / (M - 1.0);                  // sigma_t,i / L_i: P' from P^, along the ray (header)
+  const double sig_per_L = 3.0 / M + 4.0 / Ma + sig_t_per_L;    // sigma'_i / L_i: P' from the triangle
   for (int i = 0; i < count; i++) {
     const float* f = h[i].f;
     // the edges as the flattener stores them (binary32 differences: triangle.hpp:65-66)
@@ -398,7 +406,7 @@ inline TriPool build_tri_pool(const PtHittable* h, int count, TriPoolTuning tune
   }
   const double inv = (double)tp.inv_cell; // assign with the float value the device uses
   const size_t ncell = (size_t)tp.n[0] * tp.n[1] * tp.n[2];
-  // a cell of the grown box is listed only if it also meets the slab around the triangle's plane (header): |n^ . (m - v0)| <= sigma' + slack + h |n^|_1
+  // a cell of the grown box is listed only if it also meets the slab around the triangle's plane (header): |n^ . (m - v0)| <= sigma_t + slack + h |n^|_1
   auto for_cells = [&](int i, auto&& emit) {
     double blo[3], bhi[3];
     box_of(i, slack, blo, bhi);
@@ -409,7 +417,8 @@ inline TriPool build_tri_pool(const PtHittable* h, int count, TriPoolTuning tune
     }
     const bool flat = slab_ok[(size_t)i] != 0; // has a normal that binary64 resolves (else: every cell of the box)
     const double* nn = &nrm[(size_t)i * 3];
-    const double hc = 0.5 / inv, reach = sig[(size_t)i] + slack + hc * (std::fabs(nn[0]) + std::fabs(nn[1]) + std::fabs(nn[2])) * (1 + 1e-9) + 1e-9 * cell;
+    const double sig_t = sig[(size_t)i] * (sig_t_per_L / sig_per_L);
+    const double hc = 0.5 / inv, reach = sig_t + slack + hc * (std::fabs(nn[0]) + std::fabs(nn[1]) + std::fabs(nn[2])) * (1 + 1e-9) + 1e-9 * cell;
     const float* f = h[i].f;
     // ... and (round 5) only if its centre is within sigma' + slack + the cell's half diagonal of the TRIANGLE itself: P' is within
     // sigma' of the triangle and within slack of a point of the cell, whose centre is at most half a diagonal from there (the box and the

@@ -5,8 +5,9 @@ for adversarial rays that lie almost in a triangle's plane:
   every (ray, triangle) pair the emulated test accepts is either GRAZING by the pool's own band test
   (|d . N'_i| < |d| (rho P_i + Q_i): it is then listed in the bin of the ray's direction in the direction map of its rho class), or
   NOT grazing and then
-  (a) the exact line-plane point, clamped onto the forward ray, lies inside the triangle's box grown by sigma'_i AND within sigma'_i of
-      its plane (so the grid cell that contains that point lists the triangle), and
+  (a) the exact line-plane point, clamped onto the forward ray, lies within sigma'_i = (3/M + 4/M_a + 1.25/(M-1)) L_i of the triangle (so inside
+      its box grown by sigma'_i) AND within sigma_t,i = 1.25 L_i / (M - 1) of its plane (so the grid cell that contains that point lists the
+      triangle; round 6 tightened both: the joint bound on the two barycentrics' errors, the plane slab by the ray-parameter term alone), and
   (b) the computed t is within kappa (relative) + 1.2 L_i / ((M - 1) |d|) of the exact parameter (so the walk's range
       [0, closest (1 + kappa)] reaches that cell);
   and in every case the ray's LINE passes within the radius the noise filter allows of the centroid.
@@ -25,7 +26,8 @@ from path_tracer_amd.scene import hittable_dtype
 f32 = np.float32
 U = 2.0 ** -24
 M, MA, SAFE = 12.0, 256.0, 1.5   # pt_tripool.hpp: TriPoolTuning defaults and SAFE
-SIG_PER_L = 6 / M + 6 / MA + 1.2 / (M - 1)
+SIG_T_PER_L = 1.25 / (M - 1)               # P' from P^ along the ray: the plane slab's half thickness
+SIG_PER_L = 3 / M + 4 / MA + SIG_T_PER_L   # P' from the triangle: the grown box, the point-triangle distance
 
 
 def cross32(a, b):
@@ -104,6 +106,38 @@ class Pool:
         return self.pu[4 * m["cand"] + fr[0]: 4 * m["cand"] + fr[1]].astype(np.int64)
 
 
+def T_dist2(p, a, e1, e2):
+    """Squared distance from the point p to the triangle (a, a + e1, a + e2): the closest-point regions (vertex / edge / face), binary64."""
+    b, c = a + e1, a + e2
+    ap = p - a
+    d1, d2 = e1 @ ap, e2 @ ap
+    if d1 <= 0 and d2 <= 0:
+        return ap @ ap
+    bp = p - b
+    d3, d4 = e1 @ bp, e2 @ bp
+    if d3 >= 0 and d4 <= d3:
+        return bp @ bp
+    vc = d1 * d4 - d3 * d2
+    if vc <= 0 and d1 >= 0 and d3 <= 0:
+        q = a + e1 * (d1 / (d1 - d3))
+        return (p - q) @ (p - q)
+    cp = p - c
+    d5, d6 = e1 @ cp, e2 @ cp
+    if d6 >= 0 and d5 <= d6:
+        return cp @ cp
+    vb = d5 * d2 - d1 * d6
+    if vb <= 0 and d2 >= 0 and d6 <= 0:
+        q = a + e2 * (d2 / (d2 - d6))
+        return (p - q) @ (p - q)
+    va = d3 * d6 - d5 * d4
+    if va <= 0 and (d4 - d3) >= 0 and (d5 - d6) >= 0:
+        q = b + (c - b) * ((d4 - d3) / ((d4 - d3) + (d5 - d6)))
+        return (p - q) @ (p - q)
+    den = va + vb + vc
+    q = a + e1 * (vb / den) + e2 * (vc / den)
+    return (p - q) @ (p - q)
+
+
 def mesh_arrays(ps):
     h = np.frombuffer(ps.hittables, dtype=hittable_dtype)
     f = h["f"][1:-1].astype(f32)
@@ -179,7 +213,9 @@ def test_accepted_pairs_are_band_or_grid_candidates(lib):
             th = (e2d[i] @ np.cross(od - v0d[i], e1d[i])) / a_
             Pp = od + max(th, 0.0) * dd
             assert np.max(np.maximum(np.maximum(lo[i] - Pp, Pp - hi[i]), 0)) <= sig[i], ("grown box", i)
-            assert abs(nh_all[i] @ (Pp - v0d[i])) <= sig[i], ("plane slab", i)
+            assert abs(nh_all[i] @ (Pp - v0d[i])) <= SIG_T_PER_L * L[i], ("plane slab", i)
+            stats["max_dist_over_L"] = max(stats.get("max_dist_over_L", 0.0), float(np.sqrt(T_dist2(Pp, v0d[i], e1d[i], e2d[i])) / L[i]))
+            assert stats["max_dist_over_L"] <= SIG_PER_L, ("point-triangle distance", i)
             assert abs(float(t[i]) - th) <= 2.2 / (MA - 1) * abs(th) + 1.2 * L[i] / ((M - 1) * dn) + 1e-12, ("t", i)
             # the cell that contains P' lists the triangle
             cxyz = np.floor((Pp - pool.origin) * pool.inv_cell).astype(int)
