@@ -43,22 +43,26 @@
 // themselves; the 4 u is the cheap test's own a' = fl(d . N'_i) against a^).
 // NOT grazing, |a^| >= thr_i, and accepted by the reference (0 <= u/a <= 1, 0 <= v/a, (u + v)/a <= 1 + u, |a| >= 1e-7,
 // min <= t <= max) implies
-//     eb := |beta - u/a| <= (du + da) / |a^|,  eg := |gamma - v/a| <= (dv + da) / |a^|,  and JOINTLY (thr bounds the sum M (du + dv) + M_a da)
-//     eb + eg <= 1/M + 2/M_a,  each <= 1/M + 1/M_a:        beta >= -eb,  gamma >= -eg,  beta + gamma <= 1 + u + eb + eg
+//     eb := |beta - u/a| <= (du + da) / |a^|,  eg := |gamma - v/a| <= (dv + da) / |a^|.
+// thr_i bounds the SUM: M SAFE (du + dv) + M_a SAFE da <= thr_i <= |a^| with du + dv <= 17.5 u |s^| |d| L_i and rho >= |s^|.  SAFE = 1.5 was
+// chosen for the second-order terms of du, dv, da — a relative 10^-5 — so for this side of the split M_g := 1.4 M and M_ag := 1.4 M_a hold
+// with a 7 % reserve for them (round 6; rounds 3-5 let the whole factor go unused here):
+//     eb + eg <= S := 1/M_g + 2/M_ag,  each <= T := 1/M_g + 1/M_ag:        beta >= -eb,  gamma >= -eg,  beta + gamma <= 1 + u + eb + eg
 // — a triangle of the (beta, gamma) plane with corners A = (-eb, -eg), B = (1 + u + eb + 2 eg, -eg), C = (-eb, 1 + u + 2 eb + eg).  The
-// distance to the (convex) triangle is a convex function, so over that region it is largest at a corner: at A, |P^ - v0| <= (eb + eg) L;
-// at B, |P^ - v1| = |(u + eb + 2 eg) e1 - eg e2| <= (u + eb + 3 eg) L <= (u + 3/M + 4/M_a) L; C likewise:
-//     => dist(P^, triangle) <= (3/M + 4/M_a + u) L_i
-// (rounds 3-5 bounded every barycentric separately and clamped in two steps: 6/M + 6/M_a — the same structure, twice as fat.)
-//     |t - t^| |d| <= |d| dw / |a| + |t^| |d| da / |a| + u |t| |d| <= 1.2 L_i / (M - 1) + |t^| |d| / (M_a - 1) + u |t| |d|
-// so with kappa = 2.2 / (M_a - 1) the exact parameter t^ lies in [-1.21 L_i / ((M-1) |d|), max (1 + kappa) + 1.21 L_i / ((M-1) |d|)]
+// distance to the (convex) triangle is a convex function, so over that region it is largest at a corner: at A, |P^ - v0| <= eb |e1| + eg |e2|;
+// at B, |P^ - v1| = |(u + eb + 2 eg) e1 - eg e2| <= (u + eb + eg) |e1| + eg (|e1| + |e2|) <= (u + S) |e1| + T (|e1| + |e2|); C likewise with |e2|:
+//     => dist(P^, triangle) <= sigma_b,i := (S + u) L_i + T (|e1| + |e2|)          (<= (3/M_g + 4/M_ag + u) L_i)
+// (rounds 3-5 bounded every barycentric separately, clamped in two steps and used M itself: (6/M + 6/M_a) L_i — the same structure, three times as fat.)
+//     |t - t^| |d| <= |d| dw / |a| + |t^| |d| da / |a| + u |t| |d|,   |d| dw / |a| <= 9.5 |e1| |e2| / (17.5 M_g L_i (1 - 1/M_ag)) <= 0.545 l_i / M_g
+// with l_i = min(|e1|, |e2|) (|e1| |e2| = l_i L_i), the other two relative: <= |t^| |d| / (M_ag - 1) + u |t| |d|;
+// so with kappa = 2.2 / (M_a - 1) the exact parameter t^ lies in [-0.55 l_i / (M_g |d|), max (1 + kappa) + 0.55 l_i / (M_g |d|)]
 // and the point P' = o + clamp(t^, 0, max (1 + kappa)) d of the WALKED segment is within
-//     sigma_t,i = 1.25 L_i / (M - 1)  of P^ (along the ray),  hence within
-//     sigma'_i  = (3/M + 4/M_a + 1.25/(M-1)) L_i        (M_a >= 64; the builder keeps M >= 4)
+//     sigma_t,i = 0.56 l_i / (M_g - 1)  of P^ (along the ray),  hence within
+//     sigma'_i  = sigma_b,i + sigma_t,i        (0.33 L_i at M = 8 for |e1| = |e2|; M_a >= 64; the builder keeps M >= 4)
 // of the triangle, hence inside its bounding box grown by sigma'_i: the cell that contains P' lists the triangle, and the walk
 // visits that cell (cells are assigned with a further absolute slack for the walk's own rounding, as the sphere grid's).
 // P^ lies IN the triangle's plane (it is where the line meets it), so P' is within sigma_t,i of that plane: |n^_i . (P' - v0)| <=
-// sigma_t,i (round 6; rounds 3-5 used sigma'_i here as well, a slab six times as thick at M = 12): a cell with centre m and half
+// sigma_t,i (round 6; rounds 3-5 used their sigma'_i = 0.63 L_i here as well, where sigma_t,i is 0.055 l_i at M = 8): a cell with centre m and half
 // edge h that contains a point within `slack` of P' has |n^_i . (m - v0)| <= sigma_t,i + slack + h (|n^x| + |n^y| + |n^z|) — cells of
 // the grown box that fail this are not listed (the slab is what decides most cells) — and likewise the centre of
 // such a cell is within sigma'_i + slack + the cell's half diagonal of the TRIANGLE itself (point-triangle distance), which rounds the
@@ -89,9 +93,9 @@
 namespace ptf {
 
 struct TriPoolTuning {
-  float M = 12.0f;      // PT_TRI_M: barycentric slack 1/M — the grid's boxes grow with 1/M (sigma'), the bands with M.  Swept on cfg5 in rounds 5 and 6 (docs/EXPERIMENTS.md; profiles/r06_tri_sweep.txt: 1080p x 32 spp 1 126 / 963 / 941 / 1 000 ms at M = 8 / 12 / 16 / 24): flat between 12 and 16, kept at 12
+  float M = 8.0f;       // PT_TRI_M: barycentric slack 1/M — the grid's boxes grow with 1/M (sigma'), the bands with M.  Swept on cfg5 every round (docs/EXPERIMENTS.md); round 6, after the grid's slack was re-derived (sigma' three times smaller at the same M), the optimum moved from 12 to 6 … 8: 1080p x 32 spp 781 / 751 / 736 / 725 ms at M = 12 / 10 / 8 / 6
   float Ma = 256.0f;    // relative slack of t: the walk runs to max (1 + 2.2 / (Ma - 1))
-  float cell = 0.22f;   // PT_TRI_CELL: grid cell edge in units of the median grown box extent
+  float cell = 0.30f;   // PT_TRI_CELL: grid cell edge in units of the median grown box extent (round 6, M = 8: 746 / 723 / 744 / 768 ms at 0.22 / 0.35 / 0.5 / 0.7)
   float grid_budget = 160.0f;         // cell entries per triangle the grid may take (cells are enlarged until the estimate fits)
   // Direction maps, one per class of rho (tau_i grows with rho = |o - c| + R, and a map lists by the tau of its class's largest rho):
   // class 0 serves the rays that START ON THE MESH OR NEXT TO IT (|o - c| <= R + 2 L: rho <= 2 R + 2 L — every secondary ray off a
@@ -292,8 +296,9 @@ inline TriPool build_tri_pool(const PtHittable* h, int count, TriPoolTuning tune
   ext.reserve((size_t)count);
   tp.ball.assign((size_t)count * 4, 0.0f);
   int n_live = 0;
-  const double sig_t_per_L = 1.25 / (M - 1.0);                  // sigma_t,i / L_i: P' from P^, along the ray (header)
-  const double sig_per_L = 3.0 / M + 4.0 / Ma + sig_t_per_L;    // sigma'_i / L_i: P' from the triangle
+  const double Mg = 1.4 * M, Mag = 1.4 * Ma;                     // what thr_i (with its SAFE = 1.5) gives the grid's side of the split (header)
+  const double bS = 1.0 / Mg + 2.0 / Mag, bT = 1.0 / Mg + 1.0 / Mag;
+  std::vector<double> sigt((size_t)count, 0.0);                  // sigma_t,i: P' from P^, along the ray — the plane slab's half thickness
   for (int i = 0; i < count; i++) {
     const float* f = h[i].f;
     // the edges as the flattener stores them (binary32 differences: triangle.hpp:65-66)
@@ -311,7 +316,8 @@ inline TriPool build_tri_pool(const PtHittable* h, int count, TriPoolTuning tune
     n_live++;
     P[(size_t)i] = M * 17.5 * u * L * SAFE;
     Q[(size_t)i] = (Ma * 7.0 + 4.0) * u * l1 * l2 * SAFE + std::ldexp(1.0, -40);
-    sig[(size_t)i] = sig_per_L * L * (1 + 8 * u);
+    sigt[(size_t)i] = 0.56 * std::min(l1, l2) / (Mg - 1.0) * (1 + 8 * u);
+    sig[(size_t)i] = ((bS + 2 * u) * L + bT * (l1 + l2)) * (1 + 8 * u) + sigt[(size_t)i]; // sigma'_i: P' from the triangle
     if (nN > 0.0) {
       pn[(size_t)i] = P[(size_t)i] / nN; qn[(size_t)i] = Q[(size_t)i] / nN;
       for (int k = 0; k < 3; k++) nrm[(size_t)i * 3 + k] = N[k] / nN;
@@ -417,7 +423,7 @@ inline TriPool build_tri_pool(const PtHittable* h, int count, TriPoolTuning tune
     }
     const bool flat = slab_ok[(size_t)i] != 0; // has a normal that binary64 resolves (else: every cell of the box)
     const double* nn = &nrm[(size_t)i * 3];
-    const double sig_t = sig[(size_t)i] * (sig_t_per_L / sig_per_L);
+    const double sig_t = sigt[(size_t)i];
     const double hc = 0.5 / inv, reach = sig_t + slack + hc * (std::fabs(nn[0]) + std::fabs(nn[1]) + std::fabs(nn[2])) * (1 + 1e-9) + 1e-9 * cell;
     const float* f = h[i].f;
     // ... and (round 5) only if its centre is within sigma' + slack + the cell's half diagonal of the TRIANGLE itself: P' is within

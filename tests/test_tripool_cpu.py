@@ -5,8 +5,8 @@ for adversarial rays that lie almost in a triangle's plane:
   every (ray, triangle) pair the emulated test accepts is either GRAZING by the pool's own band test
   (|d . N'_i| < |d| (rho P_i + Q_i): it is then listed in the bin of the ray's direction in the direction map of its rho class), or
   NOT grazing and then
-  (a) the exact line-plane point, clamped onto the forward ray, lies within sigma'_i = (3/M + 4/M_a + 1.25/(M-1)) L_i of the triangle (so inside
-      its box grown by sigma'_i) AND within sigma_t,i = 1.25 L_i / (M - 1) of its plane (so the grid cell that contains that point lists the
+  (a) the exact line-plane point, clamped onto the forward ray, lies within sigma'_i = sigma_b,i + sigma_t,i of the triangle (so inside
+      its box grown by sigma'_i) AND within sigma_t,i = 0.56 min(|e1|, |e2|) / (1.4 M - 1) of its plane (so the grid cell that contains that point lists the
       triangle; round 6 tightened both: the joint bound on the two barycentrics' errors, the plane slab by the ray-parameter term alone), and
   (b) the computed t is within kappa (relative) + 1.2 L_i / ((M - 1) |d|) of the exact parameter (so the walk's range
       [0, closest (1 + kappa)] reaches that cell);
@@ -25,9 +25,16 @@ from path_tracer_amd.scene import hittable_dtype
 
 f32 = np.float32
 U = 2.0 ** -24
-M, MA, SAFE = 12.0, 256.0, 1.5   # pt_tripool.hpp: TriPoolTuning defaults and SAFE
-SIG_T_PER_L = 1.25 / (M - 1)               # P' from P^ along the ray: the plane slab's half thickness
-SIG_PER_L = 3 / M + 4 / MA + SIG_T_PER_L   # P' from the triangle: the grown box, the point-triangle distance
+M, MA, SAFE = 8.0, 256.0, 1.5   # pt_tripool.hpp: TriPoolTuning defaults and SAFE
+MG, MAG = 1.4 * M, 1.4 * MA                # what the grazing threshold (with its SAFE) gives the grid's side (pt_tripool.hpp header)
+BS, BT = 1 / MG + 2 / MAG, 1 / MG + 1 / MAG
+
+
+def sigmas(l1, l2):
+    """(sigma_t,i, sigma'_i): P' from P^ along the ray (the plane slab's half thickness); P' from the triangle (the grown box, the
+    point-triangle distance)."""
+    sig_t = 0.56 * np.minimum(l1, l2) / (MG - 1)
+    return sig_t, (BS + 2 * U) * np.maximum(l1, l2) + BT * (l1 + l2) + sig_t
 
 
 def cross32(a, b):
@@ -159,7 +166,7 @@ def test_accepted_pairs_are_band_or_grid_candidates(lib):
     L = np.maximum(l1, l2)
     P = M * 17.5 * U * L * SAFE
     Q = (MA * 7 + 4) * U * l1 * l2 * SAFE + 2.0 ** -40
-    sig = SIG_PER_L * L
+    sig_t, sig = sigmas(l1, l2)
     centre = v0d.mean(0)
     R = np.linalg.norm(v0d - centre, axis=1).max()
     assert abs(R / pool.R - 1) < 1e-5 and np.allclose(centre, pool.centre, atol=1e-5)
@@ -213,9 +220,10 @@ def test_accepted_pairs_are_band_or_grid_candidates(lib):
             th = (e2d[i] @ np.cross(od - v0d[i], e1d[i])) / a_
             Pp = od + max(th, 0.0) * dd
             assert np.max(np.maximum(np.maximum(lo[i] - Pp, Pp - hi[i]), 0)) <= sig[i], ("grown box", i)
-            assert abs(nh_all[i] @ (Pp - v0d[i])) <= SIG_T_PER_L * L[i], ("plane slab", i)
-            stats["max_dist_over_L"] = max(stats.get("max_dist_over_L", 0.0), float(np.sqrt(T_dist2(Pp, v0d[i], e1d[i], e2d[i])) / L[i]))
-            assert stats["max_dist_over_L"] <= SIG_PER_L, ("point-triangle distance", i)
+            assert abs(nh_all[i] @ (Pp - v0d[i])) <= sig_t[i], ("plane slab", i)
+            assert np.sqrt(T_dist2(Pp, v0d[i], e1d[i], e2d[i])) <= sig[i], ("point-triangle distance", i)
+            stats["slab_used"] = max(stats.get("slab_used", 0.0), float(abs(nh_all[i] @ (Pp - v0d[i])) / sig_t[i]))
+            stats["dist_used"] = max(stats.get("dist_used", 0.0), float(np.sqrt(T_dist2(Pp, v0d[i], e1d[i], e2d[i])) / sig[i]))
             assert abs(float(t[i]) - th) <= 2.2 / (MA - 1) * abs(th) + 1.2 * L[i] / ((M - 1) * dn) + 1e-12, ("t", i)
             # the cell that contains P' lists the triangle
             cxyz = np.floor((Pp - pool.origin) * pool.inv_cell).astype(int)
@@ -242,6 +250,7 @@ def test_accepted_pairs_are_band_or_grid_candidates(lib):
         t1 = e1d[i] / l1[i]
         d = (t1 + nh * 10 ** rng.uniform(-6, -2)) * rng.uniform(0.3, 2)
         check(cen[i] - d / np.linalg.norm(d) * rng.uniform(15, 90), d)
+    print("accepted pairs:", stats)   # (-s: how much of the two slacks the worst observed pair used)
     assert stats["accepted"] > 3000 and stats["band"] > 20 and stats["grid"] > 2000, stats
 
 
