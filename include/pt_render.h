@@ -251,7 +251,7 @@ const char* pt_build_id(void);
  *   tri_pool           -1: no triangle pool (PT_NO_TRICULL)
  *   tri_min_run        shortest triangle run that gets a pool (PT_TRI_MIN; 4096; PT_TRICULL=1 means 256)
  *   tri_M, tri_cell    the pool's slack 1/M (grid boxes grow with 1/M, bands with M) and its grid cell in median grown boxes (PT_TRI_M,
- *                      PT_TRI_CELL; 8, 0.30 — round 6, after the grid's slack was re-derived; 12, 0.22 before)
+ *                      PT_TRI_CELL; 6, 0.30 — round 6, after the grid's slack was re-derived; 12, 0.22 before)
  *   tri_binned         scenes with ONE pooled triangle run render in GENERATIONS (round 6; csrc/pt_binned.hpp): every live pixel traces one
  *                      ray per generation and the rays are sorted by direction bin, so that a bin's list of grazing candidates is read once
  *                      for 64 rays — 1: on (PT_TRI_BINNED); 0: off: measured, it does not beat the persistent kernel yet (docs/EXPERIMENTS.md).

@@ -58,11 +58,13 @@
 // so with kappa = 2.2 / (M_a - 1) the exact parameter t^ lies in [-0.55 l_i / (M_g |d|), max (1 + kappa) + 0.55 l_i / (M_g |d|)]
 // and the point P' = o + clamp(t^, 0, max (1 + kappa)) d of the WALKED segment is within
 //     sigma_t,i = 0.56 l_i / (M_g - 1)  of P^ (along the ray),  hence within
-//     sigma'_i  = sigma_b,i + sigma_t,i        (0.33 L_i at M = 8 for |e1| = |e2|; M_a >= 64; the builder keeps M >= 4)
-// of the triangle, hence inside its bounding box grown by sigma'_i: the cell that contains P' lists the triangle, and the walk
+//     sigma'_i  = sigma_b,i + sigma_t,i        (0.43 L_i at M = 6 for |e1| = |e2|; M_a >= 64; the builder keeps M >= 4)
+// of the triangle — more precisely P^ lies in the ENLARGED triangle T+_i = { v0 + beta e1 + gamma e2 : beta >= -T, gamma >= -T, beta + gamma <= 1 + u + S }
+// (the union of the regions above over the admissible eb, eg) and P' within sigma_t,i of T+_i, which is what the cells are listed by (build_tri_pool:
+// for_cells) — hence inside its bounding box grown by sigma'_i: the cell that contains P' lists the triangle, and the walk
 // visits that cell (cells are assigned with a further absolute slack for the walk's own rounding, as the sphere grid's).
 // P^ lies IN the triangle's plane (it is where the line meets it), so P' is within sigma_t,i of that plane: |n^_i . (P' - v0)| <=
-// sigma_t,i (round 6; rounds 3-5 used their sigma'_i = 0.63 L_i here as well, where sigma_t,i is 0.055 l_i at M = 8): a cell with centre m and half
+// sigma_t,i (round 6; rounds 3-5 used their sigma'_i = 0.63 L_i here as well, where sigma_t,i is 0.076 l_i at M = 6): a cell with centre m and half
 // edge h that contains a point within `slack` of P' has |n^_i . (m - v0)| <= sigma_t,i + slack + h (|n^x| + |n^y| + |n^z|) — cells of
 // the grown box that fail this are not listed (the slab is what decides most cells) — and likewise the centre of
 // such a cell is within sigma'_i + slack + the cell's half diagonal of the TRIANGLE itself (point-triangle distance), which rounds the
@@ -93,7 +95,7 @@
 namespace ptf {
 
 struct TriPoolTuning {
-  float M = 8.0f;       // PT_TRI_M: barycentric slack 1/M — the grid's boxes grow with 1/M (sigma'), the bands with M.  Swept on cfg5 every round (docs/EXPERIMENTS.md); round 6, after the grid's slack was re-derived (sigma' three times smaller at the same M), the optimum moved from 12 to 6 … 8: 1080p x 32 spp 781 / 751 / 736 / 725 ms at M = 12 / 10 / 8 / 6
+  float M = 6.0f;       // PT_TRI_M: barycentric slack 1/M — the grid's boxes grow with 1/M (sigma'), the bands with M.  Swept on cfg5 every round (docs/EXPERIMENTS.md); round 6, as the grid's slack was re-derived and its listing made exact (three, then five times fewer entries at the same M), the optimum moved from 12 to 8 to 6: 1080p x 32 spp 711 / 680 / 660 ms at M = 10 / 8 / 6
   float Ma = 256.0f;    // relative slack of t: the walk runs to max (1 + 2.2 / (Ma - 1))
   float cell = 0.30f;   // PT_TRI_CELL: grid cell edge in units of the median grown box extent (round 6, M = 8: 746 / 723 / 744 / 768 ms at 0.22 / 0.35 / 0.5 / 0.7)
   float grid_budget = 160.0f;         // cell entries per triangle the grid may take (cells are enlarged until the estimate fits)
@@ -167,6 +169,32 @@ inline double point_triangle_dist2(const double p[3], const double a[3], const d
   const double den = va + vb + vc;
   if (!(den > 0)) return std::min(len2(0, 0), std::min(len2(1, 0), len2(0, 1))); // (degenerate: a vertex is never farther than the true distance + an edge)
   return len2(vb / den, vc / den);                                             // the face
+}
+// Does the axis-aligned box (centre m, half extents hh) meet the triangle (a, b, c)?  Separating axes: the box's three, the triangle's
+// normal, the nine products of a box axis and a triangle edge (Akenine-Moller).  Touching counts as meeting; a degenerate triangle's
+// vanishing axes separate nothing (conservative).
+inline bool tri_box_overlap(const double m[3], const double hh[3], const double a[3], const double b[3], const double c[3]) {
+  double v[3][3];
+  for (int k = 0; k < 3; k++) { v[0][k] = a[k] - m[k]; v[1][k] = b[k] - m[k]; v[2][k] = c[k] - m[k]; }
+  for (int k = 0; k < 3; k++) {
+    const double mn = std::min({v[0][k], v[1][k], v[2][k]}), mx = std::max({v[0][k], v[1][k], v[2][k]});
+    if (mn > hh[k] || mx < -hh[k]) return false;
+  }
+  double f[3][3];
+  for (int k = 0; k < 3; k++) { f[0][k] = v[1][k] - v[0][k]; f[1][k] = v[2][k] - v[1][k]; f[2][k] = v[0][k] - v[2][k]; }
+  const double n[3] = {f[0][1] * f[1][2] - f[0][2] * f[1][1], f[0][2] * f[1][0] - f[0][0] * f[1][2], f[0][0] * f[1][1] - f[0][1] * f[1][0]};
+  if (std::fabs(n[0] * v[0][0] + n[1] * v[0][1] + n[2] * v[0][2]) > hh[0] * std::fabs(n[0]) + hh[1] * std::fabs(n[1]) + hh[2] * std::fabs(n[2])) return false;
+  for (int j = 0; j < 3; j++) {
+    const double ax[3][3] = {{0.0, -f[j][2], f[j][1]}, {f[j][2], 0.0, -f[j][0]}, {-f[j][1], f[j][0], 0.0}}; // e_i x f_j
+    for (int i = 0; i < 3; i++) {
+      const double p0 = ax[i][0] * v[0][0] + ax[i][1] * v[0][1] + ax[i][2] * v[0][2];
+      const double p1 = ax[i][0] * v[1][0] + ax[i][1] * v[1][1] + ax[i][2] * v[1][2];
+      const double p2 = ax[i][0] * v[2][0] + ax[i][1] * v[2][1] + ax[i][2] * v[2][2];
+      const double r = hh[0] * std::fabs(ax[i][0]) + hh[1] * std::fabs(ax[i][1]) + hh[2] * std::fabs(ax[i][2]);
+      if (std::min({p0, p1, p2}) > r || std::max({p0, p1, p2}) < -r) return false;
+    }
+  }
+  return true;
 }
 // f(p, q) = nk + p na + nb q over the rectangle [pl, ph] x [ql, qh]: is min |f| <= W possible, and for which p?  Returns false when no p qualifies.
 inline bool strip_columns(double nk, double na, double nb, double ql, double qh, double W, double& pa, double& pb) {
@@ -412,36 +440,42 @@ inline TriPool build_tri_pool(const PtHittable* h, int count, TriPoolTuning tune
   }
   const double inv = (double)tp.inv_cell; // assign with the float value the device uses
   const size_t ncell = (size_t)tp.n[0] * tp.n[1] * tp.n[2];
-  // a cell of the grown box is listed only if it also meets the slab around the triangle's plane (header): |n^ . (m - v0)| <= sigma_t + slack + h |n^|_1
+  // Which cells list triangle i (header, "the region of P^"): P^ lies in the ENLARGED triangle T+ — the image of beta >= -T, gamma >= -T,
+  // beta + gamma <= 1 + u + S, a copy of the triangle scaled by 1 + u + S + 2 T from the corner v0 - T (e1 + e2) — and P' within r = sigma_t +
+  // slack of it, so a cell is listed iff its box grown by r meets T+ (an exact triangle-box test: no bounding ball around the cell) AND
+  // meets the slab |n^ . (x - v0)| <= sigma_t + slack around the plane.  (Rounds 3-5 and the first half of round 6 listed the cells whose CENTRE
+  // is within sigma' + half a cell diagonal of the triangle: the rounded offset of the triangle by the corners' distance, and a ball around the cell.)
   auto for_cells = [&](int i, auto&& emit) {
-    double blo[3], bhi[3];
-    box_of(i, slack, blo, bhi);
-    int c0[3], c1[3];
-    for (int k = 0; k < 3; k++) {
-      c0[k] = std::max(0, std::min(tp.n[k] - 1, (int)std::floor((blo[k] - tp.origin[k]) * inv)));
-      c1[k] = std::max(0, std::min(tp.n[k] - 1, (int)std::floor((bhi[k] - tp.origin[k]) * inv)));
-    }
-    const bool flat = slab_ok[(size_t)i] != 0; // has a normal that binary64 resolves (else: every cell of the box)
-    const double* nn = &nrm[(size_t)i * 3];
-    const double sig_t = sigt[(size_t)i];
-    const double hc = 0.5 / inv, reach = sig_t + slack + hc * (std::fabs(nn[0]) + std::fabs(nn[1]) + std::fabs(nn[2])) * (1 + 1e-9) + 1e-9 * cell;
     const float* f = h[i].f;
-    // ... and (round 5) only if its centre is within sigma' + slack + the cell's half diagonal of the TRIANGLE itself: P' is within
-    // sigma' of the triangle and within slack of a point of the cell, whose centre is at most half a diagonal from there (the box and the
-    // slab are cheaper to test and cut most cells; this one rounds the grown box's corners and edges off).  Conservative for a
-    // degenerate triangle: the distance to a vertex is used where the face is lost, never more than an edge beyond the truth — such
-    // triangles skip the test (they are slivers of the band's share anyway).
     const double v0d[3] = {f[0], f[1], f[2]};
     const double e1d[3] = {(double)(float)(f[3] - f[0]), (double)(float)(f[4] - f[1]), (double)(float)(f[5] - f[2])};
     const double e2d[3] = {(double)(float)(f[6] - f[0]), (double)(float)(f[7] - f[1]), (double)(float)(f[8] - f[2])};
-    const double rad = sig[(size_t)i] + slack + hc * 1.7320508075688772 * (1 + 1e-9) + 1e-9 * cell, rad2 = rad * rad;
+    const double Tq = bT * (1 + 1e-6), top = (1.0 + 2 * u + bS + bT) * (1 + 1e-6);
+    double A[3], B[3], C[3];
+    for (int k = 0; k < 3; k++) {
+      A[k] = v0d[k] - Tq * e1d[k] - Tq * e2d[k];
+      B[k] = v0d[k] + top * e1d[k] - Tq * e2d[k];
+      C[k] = v0d[k] - Tq * e1d[k] + top * e2d[k];
+    }
+    const double sig_t = sigt[(size_t)i], r = sig_t + slack;
+    int c0[3], c1[3];
+    for (int k = 0; k < 3; k++) {
+      const double blo = std::min({A[k], B[k], C[k]}) - r, bhi = std::max({A[k], B[k], C[k]}) + r;
+      c0[k] = std::max(0, std::min(tp.n[k] - 1, (int)std::floor((blo - tp.origin[k]) * inv - 1e-9)));
+      c1[k] = std::max(0, std::min(tp.n[k] - 1, (int)std::floor((bhi - tp.origin[k]) * inv + 1e-9)));
+    }
+    const bool flat = slab_ok[(size_t)i] != 0; // has a normal that binary64 resolves (else: every cell of T+'s grown box)
+    const double* nn = &nrm[(size_t)i * 3];
+    const double hc = 0.5 / inv, reach = r + hc * (std::fabs(nn[0]) + std::fabs(nn[1]) + std::fabs(nn[2])) * (1 + 1e-9) + 1e-9 * cell;
+    const double hx = hc * (1 + 1e-9) + r + 1e-9 * cell;
+    const double hh[3] = {hx, hx, hx};
     for (int z = c0[2]; z <= c1[2]; z++)
       for (int y = c0[1]; y <= c1[1]; y++)
         for (int x = c0[0]; x <= c1[0]; x++) {
           if (flat) {
             const double m[3] = {tp.origin[0] + (x + 0.5) / inv, tp.origin[1] + (y + 0.5) / inv, tp.origin[2] + (z + 0.5) / inv};
             if (std::fabs(nn[0] * (m[0] - f[0]) + nn[1] * (m[1] - f[1]) + nn[2] * (m[2] - f[2])) > reach) continue;
-            if (detail::point_triangle_dist2(m, v0d, e1d, e2d) > rad2) continue;
+            if (!detail::tri_box_overlap(m, hh, A, B, C)) continue;
           }
           emit(((size_t)z * tp.n[1] + y) * tp.n[0] + x);
         }

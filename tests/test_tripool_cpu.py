@@ -25,7 +25,7 @@ from path_tracer_amd.scene import hittable_dtype
 
 f32 = np.float32
 U = 2.0 ** -24
-M, MA, SAFE = 8.0, 256.0, 1.5   # pt_tripool.hpp: TriPoolTuning defaults and SAFE
+M, MA, SAFE = 6.0, 256.0, 1.5   # pt_tripool.hpp: TriPoolTuning defaults and SAFE
 MG, MAG = 1.4 * M, 1.4 * MA                # what the grazing threshold (with its SAFE) gives the grid's side (pt_tripool.hpp header)
 BS, BT = 1 / MG + 2 / MAG, 1 / MG + 1 / MAG
 
@@ -252,6 +252,42 @@ def test_accepted_pairs_are_band_or_grid_candidates(lib):
         check(cen[i] - d / np.linalg.norm(d) * rng.uniform(15, 90), d)
     print("accepted pairs:", stats)   # (-s: how much of the two slacks the worst observed pair used)
     assert stats["accepted"] > 3000 and stats["band"] > 20 and stats["grid"] > 2000, stats
+
+
+def test_grid_lists_every_cell_the_bound_allows(lib, monkeypatch):
+    """The grid's tables against the REGION the bound speaks of, not only against the points rounding happens to reach: the exact line-plane
+    point of an accepted pair that is not grazing lies in the enlarged triangle T+ (beta >= -T, gamma >= -T, beta + gamma <= 1 + u + S) and
+    the point of the walked segment within sigma_t of it — every cell that contains such a point must list the triangle (corners and edges
+    of T+ included, offsets of the full sigma_t in every direction)."""
+    monkeypatch.setenv("PT_TRICULL", "1")
+    ps, _ = scenes.triangle_mesh_scene(n_triangles=3000, seed=21)
+    pool = Pool(lib, ps)
+    v0, e1, e2 = mesh_arrays(ps)
+    v0d, e1d, e2d = v0.astype(np.float64), e1.astype(np.float64), e2.astype(np.float64)
+    l1, l2 = np.linalg.norm(e1d, axis=1), np.linalg.norm(e2d, axis=1)
+    sig_t, _ = sigmas(l1, l2)
+    rng = np.random.default_rng(9)
+    top = 1 + U + BS
+    checked = 0
+    for _ in range(6000):
+        i = int(rng.integers(len(v0)))
+        kind = rng.integers(5)
+        if kind == 0: b, g = -BT, -BT
+        elif kind == 1: b, g = top + BT, -BT
+        elif kind == 2: b, g = -BT, top + BT
+        elif kind == 3:                                   # on an edge of T+
+            w = rng.uniform()
+            b, g = [(-BT + w * (top + 2 * BT), -BT), (-BT, -BT + w * (top + 2 * BT)), (-BT + w * (top + 2 * BT), top + BT - w * (top + 2 * BT))][int(rng.integers(3))]
+        else:                                             # inside
+            b = rng.uniform(-BT, top + BT); g = rng.uniform(-BT, top - b)
+        ph = v0d[i] + b * e1d[i] + g * e2d[i]
+        off = rng.normal(size=3)
+        pp = ph + off / np.linalg.norm(off) * sig_t[i] * rng.choice([1.0, 1.0, rng.uniform()])
+        cxyz = np.floor((pp - pool.origin) * pool.inv_cell).astype(int)
+        if np.all(cxyz >= 0) and np.all(cxyz < pool.n):
+            assert int(pool.pos_of[i]) in pool.cell_list(*cxyz), (i, kind, b, g)
+            checked += 1
+    assert checked > 5000
 
 
 def test_direction_maps_list_every_triangle_a_direction_can_graze(lib):
