@@ -152,7 +152,7 @@ def ops_per_sample_culled_tri(ctr: dict, pool: dict) -> float:
 
 
 # recorded like ALGORITHMIC_OPS_PER_SAMPLE (the N = 1 cpu_baseline leg re-derives them live): the culled algorithms' figures
-ALGORITHMIC_OPS_PER_SAMPLE_CULLED = {"smoke": 2072.8, "triangles": 104318.0}  # (round 6: profiles/r06_smoke_walk_counters.json, r06_tripool_counters.json — camera rays take their grazing candidates from the pixel's cache, the grid's slack re-derived: 277 -> 223 pair tests per ray after 581; round 5: 2 116.7 / 205 k; rounds 3-4: 402 k)
+ALGORITHMIC_OPS_PER_SAMPLE_CULLED = {"smoke": 2072.8, "triangles": 88771.3}  # (round 6: profiles/r06_smoke_walk_counters.json, r06_tripool_counters.json — camera rays take their grazing candidates from the pixel's cache, the grid's slack re-derived and its cells listed exactly: 185 pair tests per ray after 581; round 5: 2 116.7 / 205 k; rounds 3-4: 402 k)
 
 
 def ops_per_sample(ctr: dict) -> float:
